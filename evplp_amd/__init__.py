@@ -1,0 +1,359 @@
+"""evplp_amd -- Python binding (ctypes) of libevplp_hip.so, the MI355X implementation of evplp's
+radiance-accumulation hot path.
+
+The product is the C-ABI library (include/evplp.h) plus the C++ host side above it
+(evplp_amd/csrc/host); this module only exposes that ABI to tests, bench.py and the multi-GPU
+strip renderer.  It never computes anything itself and has no CPU fallback: if the shared
+library is missing the import fails loudly, and without a HIP device `Context()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libevplp_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+ABI_VERSION = 1
+
+# evplp_status
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_OOM = 0, -1, -2, -3, -4, -5, -6
+# flags (rt/rtcomphoton/rtphotonrecord.h:9-15)
+USABLE_VPL, USABLE_PHOTON, LAMBERT_ONLY, PHONG_ONLY = 1, 2, 4, 8
+# EMis (rtcomphoton.h:64-72, string map :1199-1206)
+MIS_MODES = {"one": 0, "balance": 1, "max": 2, "power2": 3, "geometryClamp": 4, "geometryBrdfClamp": 5}
+BVH_LBVH, BVH_SAH = 0, 1
+(BUF_RECORDS, BUF_GBUF_POSITION, BUF_GBUF_NORMAL, BUF_GBUF_DIFFUSE, BUF_GBUF_PHONG, BUF_LIGHT,
+ BUF_VPL_ACCUM, BUF_PHOTON_ACCUM, BUF_COUNT) = range(9)
+(PASS_PRIMARY, PASS_LIGHT_TRACE, PASS_GATHER_VPL, PASS_GATHER_VSL, PASS_SPLAT, PASS_RESOLVE, PASS_COUNT) = range(7)
+
+RECORD_DTYPE = np.dtype([
+    ("pos", np.float32, 3), ("flags", np.uint32),
+    ("normal", np.float32, 3), ("p_select_lambert", np.float32),
+    ("flux", np.float32, 3), ("pad1", np.float32),
+    ("flux_dir", np.float32, 3), ("pad2", np.float32),
+    ("rho_d", np.float32, 3), ("pad3", np.float32),
+    ("rho_s", np.float32, 3), ("phong_exp", np.float32),
+])
+assert RECORD_DTYPE.itemsize == 96
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("res_x", C.c_int32), ("res_y", C.c_int32),
+                ("strip_rank", C.c_int32), ("strip_count", C.c_int32), ("strip_rows", C.c_int32),
+                ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
+                ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kd", C.c_float * 3), ("ks", C.c_float * 3), ("ns", C.c_float),
+                ("tex_kd", C.c_int32), ("tex_ks", C.c_int32), ("tex_ns", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3),
+                ("fovy", C.c_float), ("aspect", C.c_float)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("camera_pos", C.c_float * 3), ("mis_mode", C.c_uint32), ("pdf_mc", C.c_float),
+                ("clamping_value", C.c_float), ("photon_radius", C.c_float), ("vsl_radius", C.c_float),
+                ("vsl_inv_pi_radius2", C.c_float), ("num_light_paths", C.c_uint32),
+                ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
+                ("do_accumulate", C.c_uint32), ("rng_seed", C.c_uint32), ("jitter", C.c_float * 2)]
+
+
+class PassStats(C.Structure):
+    _fields_ = [("ms", C.c_float), ("pairs", C.c_uint64), ("rays", C.c_uint64), ("usable", C.c_uint64),
+                ("dominant_kernel_ms", C.c_float), ("reserved", C.c_uint32 * 3)]
+
+
+# every symbol include/evplp.h declares: (restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = {
+    "evplp_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "evplp_destroy": (None, [_P]),
+    "evplp_last_error": (C.c_char_p, [_P]),
+    "evplp_abi_version": (C.c_int, []),
+    "evplp_set_stream": (C.c_int, [_P, _P]),
+    "evplp_synchronize": (C.c_int, [_P]),
+    "evplp_add_texture": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "evplp_add_material": (C.c_int, [_P, C.POINTER(Material)]),
+    "evplp_add_mesh": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "evplp_set_arealight": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float * 4)]),
+    "evplp_set_camera": (C.c_int, [_P, C.POINTER(Camera)]),
+    "evplp_build_accel": (C.c_int, [_P]),
+    "evplp_scene_metrics": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "evplp_primary": (C.c_int, [_P, C.POINTER(C.c_float * 2), C.c_int32]),
+    "evplp_trace_light_paths": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "evplp_gather_vpl": (C.c_int, [_P, C.POINTER(FrameParams)]),
+    "evplp_gather_vsl": (C.c_int, [_P, C.POINTER(FrameParams)]),
+    "evplp_splat_photons": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
+    "evplp_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
+    "evplp_clear_accumulators": (C.c_int, [_P]),
+    "evplp_local_rows": (C.c_int, [_P]),
+    "evplp_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "evplp_bind_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
+    "evplp_download": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
+    "evplp_upload": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
+    "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
+    "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "evplp_save_image": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P]),
+    "evplp_load_pfm": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
+    "evplp_image_mse": (C.c_double, [C.c_int32, _P, _P]),
+    "evplp_image_rel_mse": (C.c_double, [C.c_int32, _P, _P]),
+    "evplp_synth_scene": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32]),
+    "evplp_render_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+class EvplpError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"evplp status {status}: {message}")
+        self.status = status
+
+
+def lib() -> C.CDLL:
+    """Load libevplp_hip.so (built in-tree by `make` / __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
+                              "evplp_amd has no fallback implementation")
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.evplp_abi_version() != ABI_VERSION:
+            raise ImportError("libevplp_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def frame_params(camera_pos, mis_mode=0, pdf_mc=0.0, clamping_value=0.0, photon_radius=0.0, vsl_radius=0.0,
+                 vsl_inv_pi_radius2=0.0, num_light_paths=1, num_vpl_light_paths=1, photons_per_path=1,
+                 do_accumulate=0, rng_seed=0, jitter=(0.0, 0.0)) -> FrameParams:
+    fp = FrameParams()
+    fp.camera_pos = (C.c_float * 3)(*[float(x) for x in camera_pos])
+    fp.mis_mode = MIS_MODES[mis_mode] if isinstance(mis_mode, str) else int(mis_mode)
+    fp.pdf_mc = pdf_mc; fp.clamping_value = clamping_value; fp.photon_radius = photon_radius
+    fp.vsl_radius = vsl_radius; fp.vsl_inv_pi_radius2 = vsl_inv_pi_radius2
+    fp.num_light_paths = num_light_paths; fp.num_vpl_light_paths = num_vpl_light_paths
+    fp.photons_per_path = photons_per_path; fp.do_accumulate = do_accumulate; fp.rng_seed = rng_seed
+    fp.jitter = (C.c_float * 2)(float(jitter[0]), float(jitter[1]))
+    return fp
+
+
+class Context:
+    """One GPU's share of a frame (thin RAII wrapper over evplp_context)."""
+
+    def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
+                 device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
+                 bvh_builder: int = BVH_LBVH, deterministic: bool = False):
+        self._lib = lib()
+        cfg = Config()
+        cfg.abi_version = ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y
+        cfg.strip_rank = strip_rank; cfg.strip_count = strip_count; cfg.strip_rows = strip_rows
+        cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths
+        cfg.photons_per_path = photons_per_path; cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self._lib.evplp_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise EvplpError(rc, self._lib.evplp_last_error(None).decode())
+        self._h = h
+        self.W, self.H = res_x, res_y
+        self.local_rows = self._lib.evplp_local_rows(h)
+        self.num_records = num_light_paths * photons_per_path
+
+    # -- plumbing
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise EvplpError(rc, self._lib.evplp_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.evplp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene
+    def add_texture(self, rgba: np.ndarray) -> int:
+        rgba = _f32(rgba)
+        h, w = rgba.shape[:2]
+        return self._check(self._lib.evplp_add_texture(self._h, w, h, _ptr(rgba)))
+
+    def add_material(self, kd, ks, ns, tex_kd=-1, tex_ks=-1, tex_ns=-1) -> int:
+        m = Material()
+        m.kd = (C.c_float * 3)(*[float(x) for x in kd]); m.ks = (C.c_float * 3)(*[float(x) for x in ks]); m.ns = float(ns)
+        m.tex_kd, m.tex_ks, m.tex_ns = tex_kd, tex_ks, tex_ns
+        return self._check(self._lib.evplp_add_material(self._h, C.byref(m)))
+
+    def add_mesh(self, vertices, indices, material: int, texcoords=None) -> int:
+        v = _f32(vertices).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        t = None if texcoords is None else _f32(texcoords).reshape(-1, 2)
+        return self._check(self._lib.evplp_add_mesh(self._h, _ptr(v), _ptr(t), v.shape[0], _ptr(i), i.shape[0], material))
+
+    def set_arealight(self, mesh: int, intensity: Sequence[float]):
+        arr = (C.c_float * 4)(*[float(x) for x in intensity])
+        self._check(self._lib.evplp_set_arealight(self._h, mesh, C.byref(arr)))
+
+    def set_camera(self, origin, lookat, up, fovy: float, aspect: float):
+        cam = Camera()
+        cam.origin = (C.c_float * 3)(*[float(x) for x in origin]); cam.lookat = (C.c_float * 3)(*[float(x) for x in lookat])
+        cam.up = (C.c_float * 3)(*[float(x) for x in up]); cam.fovy = float(fovy); cam.aspect = float(aspect)
+        self._check(self._lib.evplp_set_camera(self._h, C.byref(cam)))
+
+    def build_accel(self):
+        self._check(self._lib.evplp_build_accel(self._h))
+
+    def scene_metrics(self):
+        r, t, l = C.c_float(), C.c_float(), C.c_float()
+        self._check(self._lib.evplp_scene_metrics(self._h, C.byref(r), C.byref(t), C.byref(l)))
+        return r.value, t.value, l.value
+
+    def accel_info(self):
+        n, l, d, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+        self._check(self._lib.evplp_accel_info(self._h, C.byref(n), C.byref(l), C.byref(d), C.byref(ms)))
+        return {"nodes": n.value, "leaves": l.value, "depth": d.value, "build_ms": ms.value}
+
+    # -- passes
+    def set_stream(self, stream_ptr: int):
+        self._check(self._lib.evplp_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self._lib.evplp_synchronize(self._h))
+
+    def primary(self, jitter=(0.0, 0.0), clear_light=False):
+        j = (C.c_float * 2)(float(jitter[0]), float(jitter[1]))
+        self._check(self._lib.evplp_primary(self._h, C.byref(j), int(clear_light)))
+
+    def trace_light_paths(self, rng_seed: int, path_begin: int = 0, path_count: Optional[int] = None):
+        if path_count is None:
+            path_count = self.cfg.num_light_paths - path_begin
+        self._check(self._lib.evplp_trace_light_paths(self._h, rng_seed, path_begin, path_count))
+
+    def gather_vpl(self, fp: FrameParams):
+        self._check(self._lib.evplp_gather_vpl(self._h, C.byref(fp)))
+
+    def gather_vsl(self, fp: FrameParams):
+        self._check(self._lib.evplp_gather_vsl(self._h, C.byref(fp)))
+
+    def splat_photons(self, fp: FrameParams, clear=False):
+        self._check(self._lib.evplp_splat_photons(self._h, C.byref(fp), int(clear)))
+
+    def resolve(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False) -> np.ndarray:
+        out = np.empty((self.local_rows, self.W, 3), dtype=np.float32)
+        self._check(self._lib.evplp_resolve(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma), _ptr(out)))
+        return out
+
+    def clear_accumulators(self):
+        self._check(self._lib.evplp_clear_accumulators(self._h))
+
+    # -- buffers
+    def buffer_info(self, which: int):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.evplp_buffer_info(self._h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bind_buffer(self, which: int, device_ptr: int, nbytes: int):
+        self._check(self._lib.evplp_bind_buffer(self._h, which, C.c_void_p(device_ptr), nbytes))
+
+    def download(self, which: int) -> np.ndarray:
+        _, n = self.buffer_info(which)
+        if which == BUF_RECORDS:
+            out = np.empty(n // 96, dtype=RECORD_DTYPE)
+        else:
+            out = np.empty((self.local_rows, self.W, 4), dtype=np.float32)
+        self._check(self._lib.evplp_download(self._h, which, _ptr(out), n))
+        return out
+
+    def upload(self, which: int, data: np.ndarray):
+        data = np.ascontiguousarray(data)
+        self._check(self._lib.evplp_upload(self._h, which, _ptr(data), data.nbytes))
+
+    def pass_stats(self, which: int) -> dict:
+        s = PassStats()
+        self._check(self._lib.evplp_pass_stats_get(self._h, which, C.byref(s)))
+        return {"ms": s.ms, "pairs": s.pairs, "rays": s.rays, "usable": s.usable, "dominant_kernel_ms": s.dominant_kernel_ms,
+                "nodes": s.reserved[0] | (s.reserved[1] << 32)}
+
+    # -- strips
+    def global_rows(self) -> np.ndarray:
+        """Global image row of every local row (>= H for padding rows)."""
+        l = np.arange(self.local_rows)
+        sr, sc, rk = self.cfg.strip_rows if self.cfg.strip_count > 1 else self.local_rows, self.cfg.strip_count, self.cfg.strip_rank
+        blk = l // sr
+        return (blk * sc + rk) * sr + (l - blk * sr)
+
+
+def progressive_step(n: int, alpha: float, clamp_start: float, n_vpl: int, n_light: int, radius: float, clamp: float,
+                     pdf_mc: float, force_vsl=False, vsl_radius=0.0, vsl_inv_pi_r2=0.0):
+    r, c, p, vr, vi = C.c_float(radius), C.c_float(clamp), C.c_float(pdf_mc), C.c_float(vsl_radius), C.c_float(vsl_inv_pi_r2)
+    lib().evplp_progressive_step(n, alpha, clamp_start, n_vpl, n_light, C.byref(r), C.byref(c), C.byref(p), int(force_vsl), C.byref(vr), C.byref(vi))
+    return r.value, c.value, p.value, vr.value, vi.value
+
+
+def save_image(path: str, rgb_top_down: np.ndarray):
+    a = _f32(rgb_top_down)
+    h, w = a.shape[:2]
+    rc = lib().evplp_save_image(path.encode(), w, h, _ptr(a))
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_save_image({path})")
+
+
+def load_pfm(path: str) -> np.ndarray:
+    w, h = C.c_int32(), C.c_int32()
+    rc = lib().evplp_load_pfm(path.encode(), C.byref(w), C.byref(h), None, 0)
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_load_pfm({path})")
+    out = np.empty((h.value, w.value, 3), dtype=np.float32)
+    rc = lib().evplp_load_pfm(path.encode(), C.byref(w), C.byref(h), _ptr(out), out.size)
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_load_pfm({path})")
+    return out
+
+
+def synth_scene(out_dir: str, name: str = "conference_synth", target_triangles: int = 331000, seed: int = 1234,
+                res_x: int = 1024, res_y: int = 1024) -> str:
+    rc = lib().evplp_synth_scene(out_dir.encode(), name.encode(), target_triangles, seed, res_x, res_y)
+    if rc < 0:
+        raise EvplpError(rc, "evplp_synth_scene failed")
+    return os.path.join(out_dir, name + ".json")
+
+
+def render_json(json_path: str, overrides: Optional[str] = None, device: int = 0):
+    err = C.create_string_buffer(1024)
+    rc = lib().evplp_render_json(json_path.encode(), overrides.encode() if overrides else None, device, err, 1024)
+    if rc != OK:
+        raise EvplpError(rc, err.value.decode())

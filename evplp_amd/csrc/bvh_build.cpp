@@ -1,0 +1,261 @@
+// Host builders for the flattened BVH consumed by the HIP traversal kernels.
+// Replaces OptiX's closed-source "Trbvh" acceleration (rt/rtcomphoton/rtcomphoton.h:705-707) and the
+// meshBound program (rt/triangleintersect.cu:62-81).  Two builders, one node format:
+//   LBVH : 63-bit Morton codes of triangle centroids, sorted, hierarchy split at the highest
+//          differing code bit (the Karras radix-tree topology, built top-down on the host).
+//   SAH  : top-down binned surface-area heuristic (16 bins).
+// Static scenes are built once per run like the reference's accel, so the host is acceptable.
+#include "evplp_types.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace evplp {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } }
+    void grow(const Box &b) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const float *p) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct TempNode { Box box; int32_t left = -1, right = -1; int32_t first = 0, count = 0; };
+
+struct Builder {
+    const float *verts;
+    std::vector<int32_t> ids;        // valid original triangle ids, permuted during the build
+    std::vector<Box> tbox;           // per original triangle (unpadded)
+    std::vector<float> centroid;     // 3 per original triangle
+    std::vector<uint64_t> morton;    // per position in ids (LBVH)
+    std::vector<TempNode> nodes;
+    int depth = 0;
+
+    int32_t make_leaf(int32_t first, int32_t count) {
+        TempNode n; n.first = first; n.count = count; n.box.reset();
+        for (int32_t i = 0; i < count; i++) n.box.grow(tbox[ids[first + i]]);
+        nodes.push_back(n);
+        return (int32_t)nodes.size() - 1;
+    }
+    int32_t finish_inner(int32_t id) {
+        TempNode &n = nodes[id];
+        n.box = nodes[n.left].box; n.box.grow(nodes[n.right].box);
+        return id;
+    }
+
+    // ---- LBVH -------------------------------------------------------------------------
+    static uint64_t expand21(uint64_t v) {
+        v &= 0x1fffffull;
+        v = (v | v << 32) & 0x1f00000000ffffull;
+        v = (v | v << 16) & 0x1f0000ff0000ffull;
+        v = (v | v << 8) & 0x100f00f00f00f00full;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+        v = (v | v << 2) & 0x1249249249249249ull;
+        return v;
+    }
+    int32_t lbvh_rec(int32_t first, int32_t last /*inclusive*/, int d) {
+        depth = std::max(depth, d);
+        int32_t count = last - first + 1;
+        if (count <= kMaxLeafTris) return make_leaf(first, count);
+        uint64_t a = morton[first], b = morton[last];
+        int32_t split;
+        if (a == b) split = (first + last) >> 1;
+        else {
+            int prefix = __builtin_clzll(a ^ b);
+            // last index whose code shares more than `prefix` leading bits with the first code
+            int32_t lo = first, hi = last;
+            while (lo + 1 < hi) {
+                int32_t mid = (lo + hi) >> 1;
+                uint64_t x = a ^ morton[mid];
+                int p = x ? __builtin_clzll(x) : 64;
+                if (p > prefix) lo = mid; else hi = mid;
+            }
+            split = lo;
+        }
+        int32_t id = (int32_t)nodes.size(); nodes.emplace_back();
+        int32_t l = lbvh_rec(first, split, d + 1);
+        int32_t r = lbvh_rec(split + 1, last, d + 1);
+        nodes[id].left = l; nodes[id].right = r;
+        return finish_inner(id);
+    }
+    int32_t build_lbvh() {
+        Box cb; cb.reset();
+        for (int32_t id : ids) cb.grow(&centroid[3 * (size_t)id]);
+        float ext[3]; for (int k = 0; k < 3; k++) ext[k] = std::max(cb.hi[k] - cb.lo[k], 1e-30f);
+        std::vector<std::pair<uint64_t, int32_t>> keyed(ids.size());
+        for (size_t i = 0; i < ids.size(); i++) {
+            const float *c = &centroid[3 * (size_t)ids[i]];
+            uint64_t q[3];
+            for (int k = 0; k < 3; k++) {
+                double t = ((double)c[k] - cb.lo[k]) / ext[k];
+                t = std::min(std::max(t, 0.0), 1.0);
+                q[k] = (uint64_t)std::min(t * 2097152.0, 2097151.0);
+            }
+            keyed[i] = { (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]), ids[i] };
+        }
+        std::sort(keyed.begin(), keyed.end());
+        morton.resize(ids.size());
+        for (size_t i = 0; i < ids.size(); i++) { morton[i] = keyed[i].first; ids[i] = keyed[i].second; }
+        return lbvh_rec(0, (int32_t)ids.size() - 1, 0);
+    }
+
+    // ---- binned SAH ---------------------------------------------------------------------
+    int32_t sah_rec(int32_t first, int32_t count, int d) {
+        depth = std::max(depth, d);
+        if (count <= kMaxLeafTris && count <= 2) return make_leaf(first, count);
+        Box cb; cb.reset(); Box bb; bb.reset();
+        for (int32_t i = 0; i < count; i++) { cb.grow(&centroid[3 * (size_t)ids[first + i]]); bb.grow(tbox[ids[first + i]]); }
+        constexpr int NB = 16;
+        float best_cost = 3.0e38f; int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float lo = cb.lo[axis], ext = cb.hi[axis] - lo;
+            if (!(ext > 0.f)) continue;
+            Box bins[NB]; int cnt[NB];
+            for (int b = 0; b < NB; b++) { bins[b].reset(); cnt[b] = 0; }
+            float scale = NB / ext;
+            for (int32_t i = 0; i < count; i++) {
+                int32_t id = ids[first + i];
+                int b = std::min(NB - 1, (int)((centroid[3 * (size_t)id + axis] - lo) * scale));
+                bins[b].grow(tbox[id]); cnt[b]++;
+            }
+            float ra[NB]; int rc[NB]; Box acc; acc.reset(); int c = 0;
+            for (int b = NB - 1; b > 0; b--) { acc.grow(bins[b]); c += cnt[b]; ra[b] = acc.area(); rc[b] = c; }
+            acc.reset(); c = 0;
+            for (int b = 0; b < NB - 1; b++) {
+                acc.grow(bins[b]); c += cnt[b];
+                if (c == 0 || rc[b + 1] == 0) continue;
+                float cost = acc.area() * (float)c + ra[b + 1] * (float)rc[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        // leaf if cheaper (cost model: traversal 1.0, triangle 1.0) and it fits
+        if (count <= kMaxLeafTris) {
+            float leaf_cost = (float)count * bb.area();
+            if (best_axis < 0 || best_cost + 1.0f * bb.area() >= leaf_cost) return make_leaf(first, count);
+        }
+        int32_t mid;
+        if (best_axis >= 0) {
+            float lo = cb.lo[best_axis], scale = NB / (cb.hi[best_axis] - lo);
+            auto it = std::partition(ids.begin() + first, ids.begin() + first + count, [&](int32_t id) {
+                int b = std::min(NB - 1, (int)((centroid[3 * (size_t)id + best_axis] - lo) * scale));
+                return b <= best_bin;
+            });
+            mid = (int32_t)(it - ids.begin());
+        } else mid = first;
+        if (mid == first || mid == first + count) {
+            // all centroids coincide (or partition failed): median split on index order
+            mid = first + count / 2;
+        }
+        int32_t id = (int32_t)nodes.size(); nodes.emplace_back();
+        int32_t l = sah_rec(first, mid - first, d + 1);
+        int32_t r = sah_rec(mid, first + count - mid, d + 1);
+        nodes[id].left = l; nodes[id].right = r;
+        return finish_inner(id);
+    }
+};
+
+inline void precompute_tri(const float *v, TriPre *t) {
+    // same operation order as the oracle's tri_test: e0 = p1-p0, e1 = p0-p2, n = cross(e1, e0)
+    for (int k = 0; k < 3; k++) { t->p0[k] = v[k]; t->e0[k] = v[3 + k] - v[k]; t->e1[k] = v[k] - v[6 + k]; }
+    t->n[0] = t->e1[1] * t->e0[2] - t->e1[2] * t->e0[1];
+    t->n[1] = t->e1[2] * t->e0[0] - t->e1[0] * t->e0[2];
+    t->n[2] = t->e1[0] * t->e0[1] - t->e1[1] * t->e0[0];
+}
+
+} // namespace
+
+int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
+    auto t0 = std::chrono::steady_clock::now();
+    Builder B; B.verts = verts;
+    B.tbox.resize((size_t)std::max(ntri, 1)); B.centroid.resize(3 * (size_t)std::max(ntri, 1));
+    Box scene; scene.reset();
+    for (int32_t i = 0; i < ntri; i++) {
+        const float *v = verts + 9 * (size_t)i;
+        // rt/triangleintersect.cu:62-81 meshBound: area = |cross(v1-v0, v2-v0)| must be > 0 and finite
+        float a[3] = { v[3] - v[0], v[4] - v[1], v[5] - v[2] }, b[3] = { v[6] - v[0], v[7] - v[1], v[8] - v[2] };
+        float c[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+        float area = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        Box &tb = B.tbox[i]; tb.reset(); tb.grow(v); tb.grow(v + 3); tb.grow(v + 6);
+        for (int k = 0; k < 3; k++) B.centroid[3 * (size_t)i + k] = 0.5f * (tb.lo[k] + tb.hi[k]);
+        if (area > 0.0f && !std::isinf(area)) { B.ids.push_back(i); scene.grow(tb); }
+    }
+    int32_t nvalid = (int32_t)B.ids.size();
+    B.nodes.reserve((size_t)2 * std::max(nvalid, 1) + 2);
+    int32_t root = -1;
+    if (nvalid > 0) root = (builder == EVPLP_BVH_SAH) ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
+
+    // conservative padding: the device slab test is inexact, the triangle test is exact; a padded
+    // box guarantees no triangle the exact test accepts is ever culled.
+    float diag = 0.f;
+    if (nvalid > 0) { float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2]; diag = std::sqrt(dx * dx + dy * dy + dz * dz); }
+    const float pad = 2e-5f * diag + 1e-30f;
+
+    // flatten: inner nodes in DFS pre-order; each inner node carries both child boxes
+    std::vector<BvhNode> flat; std::vector<int32_t> order; order.reserve((size_t)nvalid);
+    int32_t nleaves = 0;
+    auto set_box = [&](float *lo, float *hi, const Box &b) { for (int k = 0; k < 3; k++) { lo[k] = b.lo[k] - pad; hi[k] = b.hi[k] + pad; } };
+    auto set_empty = [&](float *lo, float *hi) { for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } };
+    struct Item { int32_t temp; int32_t parent; int which; };
+    std::vector<Item> stack;
+    auto emit_leaf = [&](const TempNode &n) -> int32_t {
+        int32_t first = (int32_t)order.size();
+        for (int32_t i = 0; i < n.count; i++) order.push_back(B.ids[n.first + i]);
+        nleaves++;
+        return ~((first << 2) | (n.count - 1));
+    };
+    if (root >= 0) {
+        if (B.nodes[root].left < 0) {
+            // a single leaf: wrap it into a root with an absent second child
+            BvhNode r; std::memset(&r, 0, sizeof(r));
+            set_box(r.lo0, r.hi0, B.nodes[root].box); set_empty(r.lo1, r.hi1);
+            r.c0 = emit_leaf(B.nodes[root]); r.c1 = kNoChild;
+            flat.push_back(r);
+        } else {
+            stack.push_back({ root, -1, 0 });
+            while (!stack.empty()) {
+                Item it = stack.back(); stack.pop_back();
+                const TempNode &n = B.nodes[it.temp];
+                int32_t ref;
+                if (n.left < 0) ref = emit_leaf(n);
+                else {
+                    ref = (int32_t)flat.size();
+                    BvhNode f; std::memset(&f, 0, sizeof(f));
+                    set_box(f.lo0, f.hi0, B.nodes[n.left].box); set_box(f.lo1, f.hi1, B.nodes[n.right].box);
+                    flat.push_back(f);
+                    // push right first so the left subtree is emitted next (pre-order, leaves contiguous)
+                    stack.push_back({ n.right, ref, 1 }); stack.push_back({ n.left, ref, 0 });
+                }
+                if (it.parent >= 0) { if (it.which == 0) flat[it.parent].c0 = ref; else flat[it.parent].c1 = ref; }
+            }
+        }
+    } else {
+        BvhNode r; std::memset(&r, 0, sizeof(r));
+        set_empty(r.lo0, r.hi0); set_empty(r.lo1, r.hi1); r.c0 = r.c1 = kNoChild;
+        flat.push_back(r);
+    }
+    out->nnodes = (int32_t)flat.size();
+    out->nodes = (BvhNode *)std::malloc(sizeof(BvhNode) * flat.size());
+    std::memcpy(out->nodes, flat.data(), sizeof(BvhNode) * flat.size());
+    out->ntris = (int32_t)order.size();
+    out->tris = (TriPre *)std::malloc(sizeof(TriPre) * std::max<size_t>(order.size(), 1));
+    out->tri_index = (int32_t *)std::malloc(sizeof(int32_t) * std::max<size_t>(order.size(), 1));
+    for (size_t i = 0; i < order.size(); i++) { precompute_tri(verts + 9 * (size_t)order[i], &out->tris[i]); out->tri_index[i] = order[i]; }
+    out->nleaves = nleaves; out->depth = B.depth + 1;
+    out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+void free_bvh(BvhBuild *b) {
+    std::free(b->nodes); std::free(b->tris); std::free(b->tri_index);
+    *b = BvhBuild();
+}
+
+} // namespace evplp

@@ -1,0 +1,503 @@
+// C-ABI implementation (include/evplp.h): context, scene upload, pass launchers, statistics.
+// There is deliberately no CPU execution path here: every pass is a HIP kernel launch.
+#include "context.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+using namespace evplp;
+
+static thread_local char g_create_error[512] = "";
+
+void evplp_context::set_error(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(error, sizeof(error), fmt, ap);
+    va_end(ap);
+}
+
+#define CTX_CHECK(ctx) do { if (!(ctx)) return EVPLP_ERR_INVALID; } while (0)
+#define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return EVPLP_ERR_HIP; } } while (0)
+
+static size_t buffer_bytes(const evplp_context *c, int which) {
+    const size_t px = (size_t)c->st.W * c->st.local_rows;
+    if (which == EVPLP_BUF_RECORDS) return sizeof(evplp_record) * (size_t)c->cfg.num_light_paths * c->cfg.photons_per_path;
+    return px * sizeof(float4);
+}
+
+extern "C" int evplp_abi_version(void) { return EVPLP_ABI_VERSION; }
+
+extern "C" const char *evplp_last_error(const evplp_context *ctx) { return ctx ? ctx->error : g_create_error; }
+
+extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
+    if (!cfg || !out) { snprintf(g_create_error, sizeof(g_create_error), "evplp_create: null argument"); return EVPLP_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->abi_version != EVPLP_ABI_VERSION) { snprintf(g_create_error, sizeof(g_create_error), "ABI version mismatch: caller %d, library %d", cfg->abi_version, EVPLP_ABI_VERSION); return EVPLP_ERR_INVALID; }
+    if (cfg->res_x <= 0 || cfg->res_y <= 0 || cfg->photons_per_path == 0 || cfg->num_light_paths == 0) {
+        snprintf(g_create_error, sizeof(g_create_error), "evplp_create: resolution, num_light_paths and photons_per_path must be positive"); return EVPLP_ERR_INVALID;
+    }
+    if (cfg->num_vpl_light_paths > cfg->num_light_paths) {
+        snprintf(g_create_error, sizeof(g_create_error), "evplp_create: num_vpl_light_paths > num_light_paths (VPLs are the first paths of the same set, lighttracing.cu:368)"); return EVPLP_ERR_INVALID;
+    }
+    int strip_count = cfg->strip_count > 0 ? cfg->strip_count : 1;
+    int strip_rows = strip_count == 1 ? ((cfg->res_y + 7) / 8) * 8 : cfg->strip_rows;
+    if (strip_rows <= 0 || (strip_rows % 8) != 0 || cfg->strip_rank < 0 || cfg->strip_rank >= strip_count) {
+        snprintf(g_create_error, sizeof(g_create_error), "evplp_create: strip_rows must be a positive multiple of 8 and 0 <= strip_rank < strip_count"); return EVPLP_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_create_error, sizeof(g_create_error), "no HIP device available (%s); libevplp_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return EVPLP_ERR_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { snprintf(g_create_error, sizeof(g_create_error), "device %d out of range (%d devices)", cfg->device, ndev); return EVPLP_ERR_INVALID; }
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { snprintf(g_create_error, sizeof(g_create_error), "hipSetDevice: %s", hipGetErrorString(e)); return EVPLP_ERR_NO_DEVICE; }
+
+    evplp_context *c = new evplp_context();
+    c->cfg = *cfg; c->cfg.strip_count = strip_count; c->cfg.strip_rows = strip_rows;
+    c->st.W = cfg->res_x; c->st.H = cfg->res_y;
+    c->st.strip_rank = cfg->strip_rank; c->st.strip_count = strip_count; c->st.strip_rows = strip_rows;
+    int nblocks = (cfg->res_y + strip_rows - 1) / strip_rows;
+    int owned = (nblocks + strip_count - 1) / strip_count;  // padded: equal on every rank (all-gather chunks)
+    c->st.local_rows = owned * strip_rows;
+    // rows of this strip that fall inside the image
+    c->rows_in_image = 0;
+    for (int l = 0; l < c->st.local_rows; l++) if (c->st.global_row(l) < c->st.H) c->rows_in_image++;
+
+    auto fail = [&](const char *what, hipError_t err) {
+        snprintf(g_create_error, sizeof(g_create_error), "%s: %s", what, hipGetErrorString(err));
+        evplp_destroy(c); return err == hipErrorOutOfMemory ? EVPLP_ERR_OOM : EVPLP_ERR_HIP;
+    };
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    c->stream = c->own_stream;
+    for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
+        if ((e = hipEventCreate(&c->ev_begin[i])) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipEventCreate(&c->ev_end[i])) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipEventCreate(&c->ev_dom_begin[i])) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipEventCreate(&c->ev_dom_end[i])) != hipSuccess) return fail("hipEventCreate", e);
+    }
+    for (int b = 0; b < EVPLP_BUF_COUNT; b++) {
+        size_t bytes = buffer_bytes(c, b);
+        if ((e = hipMalloc(&c->buf[b], bytes)) != hipSuccess) return fail("hipMalloc(buffer)", e);
+        if ((e = hipMemset(c->buf[b], 0, bytes)) != hipSuccess) return fail("hipMemset", e);
+        c->buf_owned[b] = true;
+    }
+    const uint32_t nvpl_slots = std::max<uint32_t>(cfg->num_vpl_light_paths * cfg->photons_per_path, 1u);
+    if ((e = hipMalloc((void **)&c->d_vpls, sizeof(evplp_record) * nvpl_slots)) != hipSuccess) return fail("hipMalloc(vpls)", e);
+    if ((e = hipMalloc((void **)&c->d_vpl_src, sizeof(uint32_t) * nvpl_slots)) != hipSuccess) return fail("hipMalloc(vpl_src)", e);
+    if ((e = hipMalloc((void **)&c->d_scalars, 64 * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc(scalars)", e);
+    if ((e = hipMemset(c->d_scalars, 0, 64 * sizeof(uint32_t))) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMalloc((void **)&c->d_counters, sizeof(PassCounters) * EVPLP_PASS_COUNT)) != hipSuccess) return fail("hipMalloc(counters)", e);
+    if ((e = hipMemset(c->d_counters, 0, sizeof(PassCounters) * EVPLP_PASS_COUNT)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMalloc((void **)&c->d_rgb, sizeof(float) * 3 * (size_t)c->st.W * c->st.local_rows)) != hipSuccess) return fail("hipMalloc(rgb)", e);
+    // splat workspace
+    c->tiles_x = (c->st.W + 7) / 8; c->tiles_y = c->st.local_rows / 8;
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    const size_t nrec = (size_t)cfg->num_light_paths * cfg->photons_per_path;
+    c->bin_capacity = (uint32_t)std::min<size_t>(std::max<size_t>(nrec * 24, 1u << 20), 0xfffffff0u);
+    if ((e = hipMalloc((void **)&c->d_tile_count, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_count)", e);
+    if ((e = hipMalloc((void **)&c->d_tile_offset, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_offset)", e);
+    if ((e = hipMalloc((void **)&c->d_tile_cursor, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_cursor)", e);
+    if ((e = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * (size_t)c->bin_capacity)) != hipSuccess) return fail("hipMalloc(bin_items)", e);
+    if (cfg->deterministic && (e = hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * (size_t)c->bin_capacity)) != hipSuccess) return fail("hipMalloc(bin_items_tmp)", e);
+    if ((e = hipMalloc((void **)&c->d_compact, sizeof(float4) * kCompactF4 * nrec)) != hipSuccess) return fail("hipMalloc(compact)", e);
+    if ((e = hipMalloc((void **)&c->d_rect, sizeof(uint2) * nrec)) != hipSuccess) return fail("hipMalloc(rect)", e);
+    *out = c;
+    return EVPLP_OK;
+}
+
+static void free_scene_device(evplp_context *c) {
+    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.tris); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
+    hipFree((void *)c->sc.materials); hipFree((void *)c->sc.textures); hipFree((void *)c->sc.tex_pool); hipFree((void *)c->sc.light_cdf);
+    std::memset(&c->sc, 0, sizeof(c->sc));
+}
+
+extern "C" void evplp_destroy(evplp_context *c) {
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
+    free_scene_device(c);
+    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb);
+    hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
+    hipFree(c->d_compact); hipFree(c->d_rect);
+    for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
+        if (c->ev_begin[i]) hipEventDestroy(c->ev_begin[i]);
+        if (c->ev_end[i]) hipEventDestroy(c->ev_end[i]);
+        if (c->ev_dom_begin[i]) hipEventDestroy(c->ev_dom_begin[i]);
+        if (c->ev_dom_end[i]) hipEventDestroy(c->ev_dom_end[i]);
+    }
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int evplp_set_stream(evplp_context *c, void *s) {
+    CTX_CHECK(c);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return EVPLP_OK;
+}
+extern "C" int evplp_synchronize(evplp_context *c) {
+    CTX_CHECK(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EVPLP_OK;
+}
+
+// ------------------------------------------------------------------------------ scene upload
+extern "C" int evplp_add_texture(evplp_context *c, int32_t w, int32_t h, const float *rgba) {
+    CTX_CHECK(c);
+    if (w <= 0 || h <= 0 || !rgba) { c->set_error("evplp_add_texture: bad arguments"); return EVPLP_ERR_INVALID; }
+    HostTexture t; t.w = w; t.h = h; t.rgba.assign(rgba, rgba + (size_t)w * h * 4);
+    c->textures.push_back(std::move(t));
+    return (int)c->textures.size() - 1;
+}
+extern "C" int evplp_add_material(evplp_context *c, const evplp_material *m) {
+    CTX_CHECK(c);
+    if (!m) { c->set_error("evplp_add_material: null"); return EVPLP_ERR_INVALID; }
+    int nt = (int)c->textures.size();
+    if (m->tex_kd >= nt || m->tex_ks >= nt || m->tex_ns >= nt) { c->set_error("evplp_add_material: texture id out of range"); return EVPLP_ERR_INVALID; }
+    Material d; std::memset(&d, 0, sizeof(d));
+    std::memcpy(d.kd, m->kd, 12); std::memcpy(d.ks, m->ks, 12); d.ns = m->ns;
+    d.tex_kd = m->tex_kd < 0 ? -1 : m->tex_kd; d.tex_ks = m->tex_ks < 0 ? -1 : m->tex_ks; d.tex_ns = m->tex_ns < 0 ? -1 : m->tex_ns;
+    c->materials.push_back(d);
+    return (int)c->materials.size() - 1;
+}
+extern "C" int evplp_add_mesh(evplp_context *c, const float *vertices, const float *texcoords, int32_t nverts,
+                              const int32_t *indices, int32_t ntris, int32_t material) {
+    CTX_CHECK(c);
+    if (!vertices || !indices || nverts <= 0 || ntris < 0) { c->set_error("evplp_add_mesh: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (material < 0 || material >= (int)c->materials.size()) { c->set_error("evplp_add_mesh: material %d out of range", material); return EVPLP_ERR_INVALID; }
+    for (int64_t i = 0; i < (int64_t)ntris * 3; i++) if (indices[i] < 0 || indices[i] >= nverts) { c->set_error("evplp_add_mesh: vertex index out of range"); return EVPLP_ERR_INVALID; }
+    HostMesh m; m.material = material;
+    m.verts.assign(vertices, vertices + (size_t)nverts * 3);
+    if (texcoords) m.uvs.assign(texcoords, texcoords + (size_t)nverts * 2); else m.uvs.assign((size_t)nverts * 2, 0.0f);  // rtcommon.h:701-705
+    m.idx.assign(indices, indices + (size_t)ntris * 3);
+    c->meshes.push_back(std::move(m));
+    c->accel_built = false;
+    return (int)c->meshes.size() - 1;
+}
+extern "C" int evplp_set_arealight(evplp_context *c, int32_t mesh, const float intensity[4]) {
+    CTX_CHECK(c);
+    if (mesh < 0 || mesh >= (int)c->meshes.size() || !intensity) { c->set_error("evplp_set_arealight: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (c->light_mesh >= 0) { c->set_error("only one area light is supported (rt/rtcommon.h:770-774)"); return EVPLP_ERR_INVALID; }
+    // rtcommon.h:780-790: xyz scaled by pi, black emitter material carrying mLightIntensity
+    Material d; std::memset(&d, 0, sizeof(d));
+    d.tex_kd = d.tex_ks = d.tex_ns = -1;
+    const float pi = 3.14159265358979323846f;
+    for (int k = 0; k < 3; k++) { c->light_unscaled[k] = intensity[k]; c->light_scaled[k] = intensity[k] * pi; }
+    c->light_unscaled[3] = c->light_scaled[3] = intensity[3];
+    std::memcpy(d.light, c->light_scaled, 16);
+    c->materials.push_back(d);
+    c->meshes[mesh].material = (int)c->materials.size() - 1;
+    c->light_mesh = mesh;
+    c->accel_built = false;
+    return EVPLP_OK;
+}
+extern "C" int evplp_set_camera(evplp_context *c, const evplp_camera *cam) {
+    CTX_CHECK(c);
+    if (!cam) { c->set_error("evplp_set_camera: null"); return EVPLP_ERR_INVALID; }
+    // glm::lookAt (RH) basis + glm::perspective parameters (rt/rtcommon.h:586-591)
+    auto norm = [](float *v) { float inv = 1.0f / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] *= inv; v[1] *= inv; v[2] *= inv; };
+    float f[3] = { cam->lookat[0] - cam->origin[0], cam->lookat[1] - cam->origin[1], cam->lookat[2] - cam->origin[2] };
+    norm(f);
+    float s[3] = { f[1] * cam->up[2] - f[2] * cam->up[1], f[2] * cam->up[0] - f[0] * cam->up[2], f[0] * cam->up[1] - f[1] * cam->up[0] };
+    norm(s);
+    float u[3] = { s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0] };
+    std::memset(&c->cam, 0, sizeof(c->cam));
+    std::memcpy(c->cam.eye, cam->origin, 12); std::memcpy(c->cam.s, s, 12); std::memcpy(c->cam.u, u, 12); std::memcpy(c->cam.f, f, 12);
+    c->cam.tan_half = std::tan(cam->fovy / 2.0f); c->cam.aspect = cam->aspect;
+    c->camera_set = true;
+    return EVPLP_OK;
+}
+
+template <class T> static int upload_array(evplp_context *c, const T *host, size_t n, const T **dev) {
+    void *p = nullptr;
+    size_t bytes = sizeof(T) * std::max<size_t>(n, 1);
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    if (n) HIP_TRY(c, hipMemcpy(p, host, sizeof(T) * n, hipMemcpyHostToDevice));
+    *dev = (const T *)p;
+    return EVPLP_OK;
+}
+
+extern "C" int evplp_build_accel(evplp_context *c) {
+    CTX_CHECK(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (c->meshes.empty()) { c->set_error("evplp_build_accel: no meshes"); return EVPLP_ERR_INVALID; }
+    if (c->light_mesh < 0) { c->set_error("evplp_build_accel: no area light set"); return EVPLP_ERR_INVALID; }
+    free_scene_device(c);
+    // flatten to a triangle soup in mesh order
+    std::vector<float> verts; std::vector<TriAttr> attrs;
+    int32_t light_first = 0, light_count = 0;
+    for (size_t mi = 0; mi < c->meshes.size(); mi++) {
+        const HostMesh &m = c->meshes[mi];
+        if ((int)mi == c->light_mesh) { light_first = (int32_t)attrs.size(); light_count = (int32_t)(m.idx.size() / 3); }
+        for (size_t t = 0; t < m.idx.size() / 3; t++) {
+            TriAttr a; std::memset(&a, 0, sizeof(a));
+            for (int k = 0; k < 3; k++) {
+                int32_t vi = m.idx[3 * t + k];
+                for (int j = 0; j < 3; j++) a.v[3 * k + j] = m.verts[3 * (size_t)vi + j];
+                a.uv[2 * k] = m.uvs[2 * (size_t)vi]; a.uv[2 * k + 1] = m.uvs[2 * (size_t)vi + 1];
+            }
+            a.material = m.material;
+            attrs.push_back(a);
+            verts.insert(verts.end(), a.v, a.v + 9);
+        }
+    }
+    if (light_count <= 0) { c->set_error("evplp_build_accel: the area-light mesh has no triangles"); return EVPLP_ERR_INVALID; }
+    BvhBuild bb;
+    build_bvh(verts.data(), (int32_t)attrs.size(), c->cfg.bvh_builder, &bb);
+    c->accel_nodes = bb.nnodes; c->accel_leaves = bb.nleaves; c->accel_depth = bb.depth; c->accel_build_ms = bb.build_ms;
+    if (bb.depth > kMaxDepth - 2) { free_bvh(&bb); c->set_error("BVH depth %d exceeds the traversal stack (%d)", bb.depth, kMaxDepth); return EVPLP_ERR_INVALID; }
+    // area-light CDF, rt/rtcommon.h:501-531 (running float sum, then normalised); Triangle::ComputeArea
+    auto tri_area = [](const float *v) {
+        float a[3] = { v[3] - v[0], v[4] - v[1], v[5] - v[2] }, b[3] = { v[6] - v[0], v[7] - v[1], v[8] - v[2] };
+        float cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+        return std::sqrt(cx * cx + cy * cy + cz * cz) / 2.0f;
+    };
+    std::vector<float> cdf((size_t)light_count);
+    float sum = 0.f;
+    for (int32_t i = 0; i < light_count; i++) { sum += tri_area(attrs[(size_t)light_first + i].v); cdf[i] = sum; }
+    for (int32_t i = 0; i < light_count; i++) cdf[i] /= sum;
+    // scene metrics (rtcommon.h:759-768, 805-814): per-mesh float sums, bbox over all vertices
+    float total = 0.f; float lo[3] = { 3.4028235e38f, 3.4028235e38f, 3.4028235e38f }, hi[3] = { -3.4028235e38f, -3.4028235e38f, -3.4028235e38f };
+    size_t tcur = 0;
+    for (const HostMesh &m : c->meshes) {
+        float ms = 0.f;
+        for (size_t t = 0; t < m.idx.size() / 3; t++) ms += tri_area(attrs[tcur++].v);
+        total += ms;
+        for (size_t v = 0; v < m.verts.size() / 3; v++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], m.verts[3 * v + k]); hi[k] = std::max(hi[k], m.verts[3 * v + k]); }
+    }
+    float dg[3] = { std::max(hi[0] - lo[0], 0.f), std::max(hi[1] - lo[1], 0.f), std::max(hi[2] - lo[2], 0.f) };
+    c->bounding_radius = std::sqrt(dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2]) / 2.0f;
+    c->total_area = total; c->light_area = sum;
+
+    // textures -> one float4 pool
+    std::vector<TexDesc> tdesc; std::vector<float4> pool;
+    for (const HostTexture &t : c->textures) {
+        TexDesc d; d.w = t.w; d.h = t.h; d.offset = (uint32_t)pool.size(); d.pad = 0;
+        for (size_t i = 0; i < (size_t)t.w * t.h; i++) pool.push_back(make_float4(t.rgba[4 * i], t.rgba[4 * i + 1], t.rgba[4 * i + 2], t.rgba[4 * i + 3]));
+        tdesc.push_back(d);
+    }
+    int rc;
+    if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
+    if ((rc = upload_array(c, bb.tris, (size_t)bb.ntris, &c->sc.tris))) { free_bvh(&bb); return rc; }
+    if ((rc = upload_array(c, bb.tri_index, (size_t)bb.ntris, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
+    c->sc.ntris = bb.ntris;
+    free_bvh(&bb);
+    if ((rc = upload_array(c, attrs.data(), attrs.size(), &c->sc.attrs))) return rc;
+    if ((rc = upload_array(c, c->materials.data(), c->materials.size(), &c->sc.materials))) return rc;
+    if ((rc = upload_array(c, tdesc.data(), tdesc.size(), &c->sc.textures))) return rc;
+    if ((rc = upload_array(c, pool.data(), pool.size(), &c->sc.tex_pool))) return rc;
+    if ((rc = upload_array(c, cdf.data(), cdf.size(), &c->sc.light_cdf))) return rc;
+    c->sc.light_first = light_first; c->sc.light_count = light_count; c->sc.light_area = sum;
+    std::memcpy(c->sc.light_intensity, c->light_scaled, 16); std::memcpy(c->sc.light_unscaled, c->light_unscaled, 16);
+    c->accel_built = true;
+    return EVPLP_OK;
+}
+
+extern "C" int evplp_scene_metrics(evplp_context *c, float *r, float *total, float *light) {
+    CTX_CHECK(c);
+    if (!c->accel_built) { c->set_error("evplp_scene_metrics: call evplp_build_accel first"); return EVPLP_ERR_INVALID; }
+    if (r) *r = c->bounding_radius; if (total) *total = c->total_area; if (light) *light = c->light_area;
+    return EVPLP_OK;
+}
+extern "C" int evplp_accel_info(evplp_context *c, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms) {
+    CTX_CHECK(c);
+    if (nodes) *nodes = c->accel_nodes; if (leaves) *leaves = c->accel_leaves; if (depth) *depth = c->accel_depth; if (build_ms) *build_ms = c->accel_build_ms;
+    return EVPLP_OK;
+}
+
+// ---------------------------------------------------------------------------------- passes
+static int pass_ready(evplp_context *c, const char *name, bool need_camera) {
+    if (!c->accel_built) { c->set_error("%s: scene not built (evplp_build_accel)", name); return EVPLP_ERR_INVALID; }
+    if (need_camera && !c->camera_set) { c->set_error("%s: camera not set", name); return EVPLP_ERR_INVALID; }
+    hipError_t e = hipSetDevice(c->cfg.device);
+    if (e != hipSuccess) { c->set_error("hipSetDevice: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
+    return EVPLP_OK;
+}
+static int pass_begin(evplp_context *c, int pass) {
+    HIP_TRY(c, hipMemsetAsync(&c->d_counters[pass], 0, sizeof(PassCounters), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_begin[pass], c->stream));
+    c->pass_ran[pass] = true; c->pass_has_dom[pass] = false;
+    return EVPLP_OK;
+}
+static int pass_end(evplp_context *c, int pass) {
+    HIP_TRY(c, hipEventRecord(c->ev_end[pass], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return EVPLP_OK;
+}
+
+extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t clear_light) {
+    CTX_CHECK(c);
+    int rc = pass_ready(c, "evplp_primary", true); if (rc) return rc;
+    PrimaryArgs a; std::memset(&a, 0, sizeof(a));
+    a.sc = c->sc; a.st = c->st; a.cam = c->cam;
+    a.jitter[0] = jitter ? jitter[0] : 0.f; a.jitter[1] = jitter ? jitter[1] : 0.f; a.clear_light = clear_light;
+    a.g_pos = (float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
+    a.g_dif = (float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
+    a.g_light = (float4 *)c->buf[EVPLP_BUF_LIGHT];
+    if ((rc = pass_begin(c, EVPLP_PASS_PRIMARY))) return rc;
+    launch_primary(a, c->stream);
+    c->stats_host[EVPLP_PASS_PRIMARY].rays = 2ull * (uint64_t)c->st.W * c->rows_in_image;
+    return pass_end(c, EVPLP_PASS_PRIMARY);
+}
+
+extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint32_t path_begin, uint32_t path_count) {
+    CTX_CHECK(c);
+    int rc = pass_ready(c, "evplp_trace_light_paths", false); if (rc) return rc;
+    if ((uint64_t)path_begin + path_count > c->cfg.num_light_paths) { c->set_error("evplp_trace_light_paths: path range exceeds num_light_paths"); return EVPLP_ERR_INVALID; }
+    LightTraceArgs a; std::memset(&a, 0, sizeof(a));
+    a.sc = c->sc; a.rng_seed = rng_seed; a.path_begin = path_begin; a.path_count = path_count; a.photons_per_path = c->cfg.photons_per_path;
+    a.records = (evplp_record *)c->buf[EVPLP_BUF_RECORDS];
+    if ((rc = pass_begin(c, EVPLP_PASS_LIGHT_TRACE))) return rc;
+    launch_light_trace(a, c->stream);
+    return pass_end(c, EVPLP_PASS_LIGHT_TRACE);
+}
+
+static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, GatherArgs &a, int pass) {
+    std::memset(&a, 0, sizeof(a));
+    a.sc = c->sc; a.st = c->st; a.fp = *fp;
+    a.g_pos = (const float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (const float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
+    a.g_dif = (const float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (const float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
+    a.vpls = c->d_vpls; a.vpl_src_index = c->d_vpl_src; a.nvpl = &c->d_scalars[0];
+    a.out = (float4 *)c->buf[EVPLP_BUF_VPL_ACCUM];
+    a.counters = &c->d_counters[pass];
+    return EVPLP_OK;
+}
+static int check_fp(evplp_context *c, const evplp_frame_params *fp, const char *name) {
+    if (!fp) { c->set_error("%s: null frame params", name); return EVPLP_ERR_INVALID; }
+    if (fp->photons_per_path != c->cfg.photons_per_path || fp->num_light_paths != c->cfg.num_light_paths || fp->num_vpl_light_paths > c->cfg.num_vpl_light_paths) {
+        c->set_error("%s: frame params disagree with the configuration (paths / photons per path)", name); return EVPLP_ERR_INVALID;
+    }
+    if (fp->mis_mode > 5u) { c->set_error("%s: mis_mode %u out of range", name, fp->mis_mode); return EVPLP_ERR_INVALID; }
+    return EVPLP_OK;
+}
+static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) {
+    const int pass = vsl ? EVPLP_PASS_GATHER_VSL : EVPLP_PASS_GATHER_VPL;
+    const char *name = vsl ? "evplp_gather_vsl" : "evplp_gather_vpl";
+    int rc = pass_ready(c, name, false); if (rc) return rc;
+    if ((rc = check_fp(c, fp, name))) return rc;
+    if (fp->num_vpl_light_paths == 0) { c->set_error("%s: num_vpl_light_paths is 0 (the reference disables the pass, rtcomphoton.h:200-203)", name); return EVPLP_ERR_INVALID; }
+    GatherArgs a; fill_gather_args(c, fp, a, pass);
+    if ((rc = pass_begin(c, pass))) return rc;
+    const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
+    launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
+    if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl(a, c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
+    c->pass_has_dom[pass] = true;
+    return pass_end(c, pass);
+}
+extern "C" int evplp_gather_vpl(evplp_context *c, const evplp_frame_params *fp) { CTX_CHECK(c); return run_gather(c, fp, false); }
+extern "C" int evplp_gather_vsl(evplp_context *c, const evplp_frame_params *fp) { CTX_CHECK(c); return run_gather(c, fp, true); }
+
+extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *fp, int32_t clear) {
+    CTX_CHECK(c);
+    int rc = pass_ready(c, "evplp_splat_photons", true); if (rc) return rc;
+    if ((rc = check_fp(c, fp, "evplp_splat_photons"))) return rc;
+    if (!(fp->photon_radius > 0.0f)) { c->set_error("evplp_splat_photons: photon_radius must be > 0"); return EVPLP_ERR_INVALID; }
+    SplatArgs a; std::memset(&a, 0, sizeof(a));
+    a.st = c->st; a.cam = c->cam; a.fp = *fp;
+    a.g_pos = (const float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (const float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
+    a.g_dif = (const float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (const float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
+    a.records = (const evplp_record *)c->buf[EVPLP_BUF_RECORDS];
+    a.num_records = c->cfg.num_light_paths * c->cfg.photons_per_path;   // instances = numLightPaths * P (:832)
+    a.out = (float4 *)c->buf[EVPLP_BUF_PHOTON_ACCUM];
+    a.tile_count = c->d_tile_count; a.tile_offset = c->d_tile_offset; a.tile_cursor = c->d_tile_cursor;
+    a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_capacity = c->bin_capacity;
+    a.compact = c->d_compact; a.rect = c->d_rect; a.overflow = &c->d_scalars[8];
+    a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic;
+    a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
+    if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
+    if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
+    HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
+    launch_splat(a, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
+    return pass_end(c, EVPLP_PASS_SPLAT);
+}
+
+extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
+    CTX_CHECK(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (!out_rgb) { c->set_error("evplp_resolve: null output"); return EVPLP_ERR_INVALID; }
+    int rc;
+    if ((rc = pass_begin(c, EVPLP_PASS_RESOLVE))) return rc;
+    launch_resolve(c->st, (const float4 *)c->buf[EVPLP_BUF_VPL_ACCUM], (const float4 *)c->buf[EVPLP_BUF_PHOTON_ACCUM],
+                   (const float4 *)c->buf[EVPLP_BUF_LIGHT], vs, ps, ls, mask_emitter, gamma, c->d_rgb, c->stream);
+    if ((rc = pass_end(c, EVPLP_PASS_RESOLVE))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_rgb, sizeof(float) * 3 * (size_t)c->st.W * c->st.local_rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EVPLP_OK;
+}
+
+extern "C" int evplp_clear_accumulators(evplp_context *c) {
+    CTX_CHECK(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_VPL_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_VPL_ACCUM), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_LIGHT], 0, buffer_bytes(c, EVPLP_BUF_LIGHT), c->stream));
+    return EVPLP_OK;
+}
+
+// ------------------------------------------------------------------------ buffers / stats
+extern "C" int evplp_local_rows(const evplp_context *c) { return c ? c->st.local_rows : EVPLP_ERR_INVALID; }
+
+extern "C" int evplp_buffer_info(evplp_context *c, int32_t which, void **ptr, size_t *bytes) {
+    CTX_CHECK(c);
+    if (which < 0 || which >= EVPLP_BUF_COUNT) { c->set_error("evplp_buffer_info: bad buffer id %d", which); return EVPLP_ERR_INVALID; }
+    if (ptr) *ptr = c->buf[which]; if (bytes) *bytes = buffer_bytes(c, which);
+    return EVPLP_OK;
+}
+extern "C" int evplp_bind_buffer(evplp_context *c, int32_t which, void *ptr, size_t bytes) {
+    CTX_CHECK(c);
+    if (which < 0 || which >= EVPLP_BUF_COUNT || !ptr) { c->set_error("evplp_bind_buffer: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (bytes < buffer_bytes(c, which)) { c->set_error("evplp_bind_buffer: %zu bytes given, %zu needed", bytes, buffer_bytes(c, which)); return EVPLP_ERR_INVALID; }
+    if (((uintptr_t)ptr & 15u) != 0) { c->set_error("evplp_bind_buffer: pointer must be 16-byte aligned"); return EVPLP_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->buf_owned[which]) hipFree(c->buf[which]);
+    c->buf[which] = ptr; c->buf_owned[which] = false;
+    return EVPLP_OK;
+}
+extern "C" int evplp_download(evplp_context *c, int32_t which, void *dst, size_t bytes) {
+    CTX_CHECK(c);
+    if (which < 0 || which >= EVPLP_BUF_COUNT || !dst || bytes > buffer_bytes(c, which)) { c->set_error("evplp_download: bad arguments"); return EVPLP_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(dst, c->buf[which], bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EVPLP_OK;
+}
+extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, size_t bytes) {
+    CTX_CHECK(c);
+    if (which < 0 || which >= EVPLP_BUF_COUNT || !src || bytes > buffer_bytes(c, which)) { c->set_error("evplp_upload: bad arguments"); return EVPLP_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipMemcpyAsync(c->buf[which], src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EVPLP_OK;
+}
+
+extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_stats *out) {
+    CTX_CHECK(c);
+    if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out) { c->set_error("evplp_pass_stats_get: bad arguments"); return EVPLP_ERR_INVALID; }
+    std::memset(out, 0, sizeof(*out));
+    if (!c->pass_ran[pass]) return EVPLP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_end[pass]));
+    HIP_TRY(c, hipEventElapsedTime(&out->ms, c->ev_begin[pass], c->ev_end[pass]));
+    if (c->pass_has_dom[pass]) HIP_TRY(c, hipEventElapsedTime(&out->dominant_kernel_ms, c->ev_dom_begin[pass], c->ev_dom_end[pass]));
+    else out->dominant_kernel_ms = out->ms;
+    PassCounters pc; uint32_t scal[16];
+    HIP_TRY(c, hipMemcpy(&pc, &c->d_counters[pass], sizeof(pc), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(scal, c->d_scalars, sizeof(scal), hipMemcpyDeviceToHost));
+    const uint64_t px = (uint64_t)c->st.W * c->rows_in_image;
+    if (pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL) {
+        out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = pc.rays; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
+        out->reserved[1] = (uint32_t)(pc.nodes >> 32);
+    } else if (pass == EVPLP_PASS_SPLAT) {
+        out->pairs = pc.pairs; out->rays = 0; out->usable = 0; out->reserved[0] = scal[8];
+        if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }
+    } else if (pass == EVPLP_PASS_PRIMARY) out->rays = c->stats_host[pass].rays;
+    return EVPLP_OK;
+}

@@ -1,0 +1,50 @@
+// evplp_context: owns all device memory of one GPU's share of the frame.
+#pragma once
+#include "evplp_types.h"
+#include "kernels.h"
+
+#include <vector>
+
+namespace evplp {
+struct HostMesh { std::vector<float> verts, uvs; std::vector<int32_t> idx; int32_t material = 0; };
+struct HostTexture { int32_t w = 0, h = 0; std::vector<float> rgba; };
+struct HostStats { uint64_t rays = 0; };
+}
+
+struct evplp_context {
+    evplp_config cfg{};
+    evplp::StripDev st{};
+    int32_t rows_in_image = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev_begin[EVPLP_PASS_COUNT] = {}, ev_end[EVPLP_PASS_COUNT] = {};
+    hipEvent_t ev_dom_begin[EVPLP_PASS_COUNT] = {}, ev_dom_end[EVPLP_PASS_COUNT] = {};
+    bool pass_ran[EVPLP_PASS_COUNT] = {}, pass_has_dom[EVPLP_PASS_COUNT] = {};
+    evplp::HostStats stats_host[EVPLP_PASS_COUNT];
+
+    void *buf[EVPLP_BUF_COUNT] = {};
+    bool buf_owned[EVPLP_BUF_COUNT] = {};
+
+    // host-side scene staging (the RtScene contract, rt/rtcommon.h:816-819)
+    std::vector<evplp::HostMesh> meshes;
+    std::vector<evplp::Material> materials;
+    std::vector<evplp::HostTexture> textures;
+    int32_t light_mesh = -1;
+    float light_unscaled[4] = {}, light_scaled[4] = {};
+    evplp::CamBasis cam{};
+    bool camera_set = false, accel_built = false;
+    float bounding_radius = 0.f, total_area = 0.f, light_area = 0.f;
+    int32_t accel_nodes = 0, accel_leaves = 0, accel_depth = 0; float accel_build_ms = 0.f;
+
+    evplp::SceneDev sc{};
+    evplp_record *d_vpls = nullptr; uint32_t *d_vpl_src = nullptr;
+    uint32_t *d_scalars = nullptr;           // [0] usable VPL count, [8] splat overflow
+    evplp::PassCounters *d_counters = nullptr;
+    float *d_rgb = nullptr;
+    // splat workspace
+    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0;
+    uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
+    float4 *d_compact = nullptr; uint2 *d_rect = nullptr;
+
+    char error[512] = "";
+    void set_error(const char *fmt, ...);
+};

@@ -1,0 +1,98 @@
+// Internal data layout of libevplp_hip.so (host + device).  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "../../include/evplp.h"
+
+namespace evplp {
+
+// Flattened binary BVH node, 64 B = one s_load_dwordx16 / one cache line.  A node stores the
+// boxes of BOTH children so a wave decides the descent from one fetch.
+// child >= 0: inner node index; child < 0: leaf, id = ~child, first = id >> 2, count = (id & 3) + 1.
+// An absent child has an inverted box (lo = +big, hi = -big) and child = kNoChild.
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+constexpr int32_t kNoChild = INT32_MIN;
+constexpr int kMaxLeafTris = 4;
+constexpr int kMaxDepth = 64;
+
+// Pre-computed operands of optix::intersect_triangle_branchless: p0, e0 = p1-p0, e1 = p0-p2,
+// n = cross(e1, e0).  48 B = 3 x float4.
+struct TriPre {
+    float p0[3], e0[3], e1[3], n[3];
+};
+static_assert(sizeof(TriPre) == 48, "TriPre must be 48 bytes");
+
+// Shading attributes per ORIGINAL triangle.
+struct TriAttr {
+    float v[9];      // p0,p1,p2 as uploaded (G-buffer position / normal use the originals)
+    float uv[6];
+    int32_t material;
+};
+static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
+
+struct Material {   // 64 B
+    float kd[3]; float ns;
+    float ks[3]; int32_t tex_kd;
+    float light[4];           // mLightIntensity (I*pi, w); zeros for non-emitters
+    int32_t tex_ks, tex_ns, pad0, pad1;
+};
+static_assert(sizeof(Material) == 64, "Material must be 64 bytes");
+
+struct TexDesc { int32_t w, h; uint32_t offset; uint32_t pad; };  // offset in float4 units into the pool
+
+// Camera basis (glm::lookAt RH + glm::perspective, rt/rtcommon.h:586-591)
+struct CamBasis {
+    float eye[3]; float tan_half;
+    float s[3];   float aspect;
+    float u[3];   float pad0;
+    float f[3];   float pad1;
+};
+
+// Everything a traversal kernel needs, passed by value as a kernel argument (all pointers
+// wave-uniform => scalar loads).
+struct SceneDev {
+    const BvhNode *nodes;
+    const TriPre *tris;          // BVH (leaf) order
+    const int32_t *tri_index;    // BVH order -> original triangle
+    const TriAttr *attrs;        // original order
+    const Material *materials;
+    const TexDesc *textures;
+    const float4 *tex_pool;
+    const float *light_cdf;      // normalised area CDF of the light mesh
+    int32_t ntris;               // triangles in the BVH (degenerate ones dropped)
+    int32_t light_first, light_count; // ORIGINAL triangle index range of the light mesh
+    float light_area;
+    float light_intensity[4];    // (I*pi, w)
+    float light_unscaled[4];     // (I, w)
+};
+
+// Strip geometry shared by all per-pixel kernels.
+struct StripDev {
+    int32_t W, H;
+    int32_t strip_rank, strip_count, strip_rows;
+    int32_t local_rows;
+    __host__ __device__ inline int32_t global_row(int32_t local) const {
+        int32_t blk = local / strip_rows;
+        return (blk * strip_count + strip_rank) * strip_rows + (local - blk * strip_rows);
+    }
+};
+
+// Host-side acceleration structure build result
+struct BvhBuild {
+    BvhNode *nodes = nullptr; int32_t nnodes = 0;
+    TriPre *tris = nullptr;  int32_t *tri_index = nullptr; int32_t ntris = 0;
+    int32_t nleaves = 0, depth = 0;
+    float build_ms = 0.f;
+};
+// verts: 9 floats per original triangle.  Degenerate triangles (rt/triangleintersect.cu:62-81
+// meshBound invalidates them) are dropped.  Returns 0 on success.
+int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out);
+void free_bvh(BvhBuild *b);
+
+} // namespace evplp

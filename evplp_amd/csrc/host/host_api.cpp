@@ -1,0 +1,57 @@
+// Host-side pieces of the reference interface that need no GPU: progressive schedule, image
+// output surface, error metrics.
+#include "../evplp_types.h"
+#include "images.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// rt/rtcomphoton/rtcomphoton.h:1033-1063 (runs after numIterations++; Float = float, reflectcuts.h:56)
+extern "C" void evplp_progressive_step(int32_t n, float alpha, float clamp_start, uint32_t n_vpl, uint32_t n_light,
+                                       float *radius, float *clamp, float *pdf_mc, int32_t force_vsl,
+                                       float *vsl_radius, float *vsl_inv_pi_r2) {
+    const float inv_pi = 0.318309886183790671537767526745028724068919291480912897495f;
+    float ratio = ((float)n + alpha) / (float)(n + 1);                                   // :1037
+    *radius *= std::sqrt(ratio);                                                         // :1038
+    *clamp = clamp_start * std::pow((float)n, alpha);                                    // :1039
+    *pdf_mc = (float)n_vpl / (float)n_light * inv_pi / (*radius * *radius);              // :1040
+    if (force_vsl && vsl_radius && vsl_inv_pi_r2) {
+        *vsl_radius *= std::sqrt(ratio);                                                 // :1049
+        if (*vsl_radius <= 0.008f) *vsl_radius = std::max(*vsl_radius, 0.008f);          // :1050-1054
+        *vsl_inv_pi_r2 = inv_pi / (*vsl_radius * *vsl_radius);                           // :1056
+    }
+}
+
+extern "C" int evplp_save_image(const char *path, int32_t w, int32_t h, const float *rgb) {
+    if (!path || !rgb || w <= 0 || h <= 0) return EVPLP_ERR_INVALID;
+    return evplp::save_image(path, w, h, rgb);
+}
+extern "C" int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb, size_t cap) {
+    if (!path || !w || !h) return EVPLP_ERR_INVALID;
+    return evplp::load_pfm(path, w, h, rgb, cap);
+}
+// common/floatimage/floatimage.cpp:64-84 (Float accumulator)
+extern "C" double evplp_image_mse(int32_t npix, const float *a, const float *ref) {
+    float result = 0;
+    for (int32_t i = 0; i < npix; i++) {
+        float dx = a[3 * i] - ref[3 * i], dy = a[3 * i + 1] - ref[3 * i + 1], dz = a[3 * i + 2] - ref[3 * i + 2];
+        result += dx * dx + dy * dy + dz * dz;
+    }
+    return result / (float)npix;
+}
+// floatimage.cpp:86-112
+extern "C" double evplp_image_rel_mse(int32_t npix, const float *a, const float *ref) {
+    float result = 0;
+    for (int32_t i = 0; i < npix; i++) {
+        float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+        float dx = a[3 * i] - rx, dy = a[3 * i + 1] - ry, dz = a[3 * i + 2] - rz;
+        float num = dx * dx + dy * dy + dz * dz;
+        float den = rx * rx + ry * ry + rz * rz + 0.001f;
+        result += num / den;
+    }
+    return result / (float)npix;
+}

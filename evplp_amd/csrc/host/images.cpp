@@ -1,0 +1,107 @@
+#include "images.hpp"
+#include "../../../include/evplp.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace evplp {
+
+// floatimage.cpp:178-199: "PF\n<w> <h>\n-1\n", then the rows of the (top-down) image written
+// last row first, RGB fp32 little-endian.
+int save_pfm(const char *path, int32_t w, int32_t h, const float *rgb) {
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return EVPLP_ERR_IO;
+    std::fprintf(f, "PF\n%d %d\n-1\n", w, h);
+    for (int32_t i = 0; i < h; i++) {
+        if (std::fwrite(rgb + (size_t)w * (h - i - 1) * 3, sizeof(float), (size_t)w * 3, f) != (size_t)w * 3) { std::fclose(f); return EVPLP_ERR_IO; }
+    }
+    std::fclose(f);
+    return EVPLP_OK;
+}
+
+// floatimage.cpp:133-176 LoadPFM (colour, little-endian only)
+int load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb, size_t cap) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return EVPLP_ERR_IO;
+    char magic[3] = { 0, 0, 0 }; int ww = 0, hh = 0; float scale = 0.f;
+    if (std::fscanf(f, "%2s %d %d %f", magic, &ww, &hh, &scale) != 4 || std::strcmp(magic, "PF") != 0 || ww <= 0 || hh <= 0) { std::fclose(f); return EVPLP_ERR_PARSE; }
+    std::fgetc(f);  // single whitespace after the scale
+    *w = ww; *h = hh;
+    if (!rgb) { std::fclose(f); return EVPLP_OK; }
+    if (cap < (size_t)ww * hh * 3) { std::fclose(f); return EVPLP_ERR_INVALID; }
+    for (int32_t i = 0; i < hh; i++) {
+        if (std::fread(rgb + (size_t)ww * (hh - i - 1) * 3, sizeof(float), (size_t)ww * 3, f) != (size_t)ww * 3) { std::fclose(f); return EVPLP_ERR_IO; }
+    }
+    std::fclose(f);
+    return EVPLP_OK;
+}
+
+namespace {
+uint32_t crc_table[256]; bool crc_ready = false;
+uint32_t crc32(const uint8_t *p, size_t n, uint32_t c = 0) {
+    if (!crc_ready) { for (uint32_t i = 0; i < 256; i++) { uint32_t k = i; for (int j = 0; j < 8; j++) k = (k & 1) ? 0xEDB88320u ^ (k >> 1) : k >> 1; crc_table[i] = k; } crc_ready = true; }
+    c = ~c;
+    for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    return ~c;
+}
+void put32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+void chunk(std::vector<uint8_t> &out, const char *type, const std::vector<uint8_t> &data) {
+    put32(out, (uint32_t)data.size());
+    std::vector<uint8_t> td(type, type + 4); td.insert(td.end(), data.begin(), data.end());
+    out.insert(out.end(), td.begin(), td.end());
+    put32(out, crc32(td.data(), td.size()));
+}
+}
+
+// floatimage.cpp:241-258: p = pow(c, 1/2.2) (fp32), min(p*255.99, 255.0) in double, truncated to a
+// byte; 8-bit RGB PNG.  The container is written with stored (uncompressed) deflate blocks: the
+// decoded pixels are identical to stb_image_write's output, the compressed bytes are not.
+int save_png(const char *path, int32_t w, int32_t h, const float *rgb) {
+    std::vector<uint8_t> raw; raw.reserve((size_t)h * (w * 3 + 1));
+    for (int32_t y = 0; y < h; y++) {
+        raw.push_back(0);  // filter: none
+        for (int32_t x = 0; x < w * 3; x++) {
+            float p = std::pow(rgb[(size_t)y * w * 3 + x], (float)(1 / 2.2));
+            double q = (double)p * 255.99; if (q > 255.0) q = 255.0;
+            p = (float)q;
+            raw.push_back((uint8_t)(int)p);
+        }
+    }
+    std::vector<uint8_t> z; z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < raw.size(); i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    size_t pos = 0;
+    do {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        pos += n;
+    } while (pos < raw.size());
+    put32(z, (b << 16) | a);
+    std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    std::vector<uint8_t> ihdr; put32(ihdr, (uint32_t)w); put32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr); chunk(out, "IDAT", z); chunk(out, "IEND", {});
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return EVPLP_ERR_IO;
+    bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    std::fclose(f);
+    return ok ? EVPLP_OK : EVPLP_ERR_IO;
+}
+
+// floatimage.cpp:260-273 Save: dispatch on the extension (hdr is not part of this round)
+int save_image(const char *path, int32_t w, int32_t h, const float *rgb) {
+    std::string p(path);
+    size_t i = p.find_last_of('.');
+    if (i == std::string::npos || i + 1 >= p.size()) return EVPLP_ERR_INVALID;
+    std::string ext = p.substr(i + 1);
+    if (ext == "pfm") return save_pfm(path, w, h, rgb);
+    if (ext == "png") return save_png(path, w, h, rgb);
+    return EVPLP_ERR_INVALID;  // "unsupported file format"
+}
+
+} // namespace evplp

@@ -1,0 +1,268 @@
+#include "scene_io.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace evplp {
+
+std::string dirname_of(const std::string &path) {
+    size_t i = path.find_last_of("/\\");
+    return i == std::string::npos ? std::string(".") : path.substr(0, i);
+}
+std::string join_path(const std::string &dir, const std::string &rel) {
+    if (!rel.empty() && (rel[0] == '/' || (rel.size() > 1 && rel[1] == ':'))) return rel;  // absolute (main.cpp:52)
+    return dir + "/" + rel;
+}
+std::string read_text_file(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+
+namespace {
+
+struct MtlEntry {
+    float kd[3] = { 0.6f, 0.6f, 0.6f }, ks[3] = { 0, 0, 0 }; float ns = 0.f;   // Assimp DefaultMaterial: grey 0.6
+    std::string map_kd, map_ks, map_ns;
+};
+
+// PFM / binary PPM textures (JPG/PNG decoding is a "next" item).  Stored RGBA32F with
+// alpha 0, gamma 1.0 (no sRGB decode), flipped vertically like stbi_set_flip_vertically_on_load(1)
+// (rtcommon.h:32,44,139-194).
+TextureData load_texture(const std::string &path) {
+    TextureData t; t.path = path;
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open texture " + path);
+    char magic[3] = { 0, 0, 0 };
+    if (std::fscanf(f, "%2s", magic) != 1) { std::fclose(f); throw std::runtime_error("bad texture header " + path); }
+    if (!std::strcmp(magic, "PF")) {
+        int w, h; float scale;
+        if (std::fscanf(f, "%d %d %f", &w, &h, &scale) != 3) { std::fclose(f); throw std::runtime_error("bad PFM header " + path); }
+        std::fgetc(f);
+        std::vector<float> rgb((size_t)w * h * 3);
+        if (std::fread(rgb.data(), sizeof(float), rgb.size(), f) != rgb.size()) { std::fclose(f); throw std::runtime_error("short PFM " + path); }
+        t.w = w; t.h = h; t.rgba.assign((size_t)w * h * 4, 0.f);
+        // PFM rows are bottom-to-top already == flipped image rows in GL texture order
+        for (size_t i = 0; i < (size_t)w * h; i++) for (int k = 0; k < 3; k++) t.rgba[4 * i + k] = rgb[3 * i + k];
+    } else if (!std::strcmp(magic, "P6")) {
+        int w, h, maxv;
+        if (std::fscanf(f, "%d %d %d", &w, &h, &maxv) != 3 || maxv != 255) { std::fclose(f); throw std::runtime_error("bad PPM header " + path); }
+        std::fgetc(f);
+        std::vector<unsigned char> rgb((size_t)w * h * 3);
+        if (std::fread(rgb.data(), 1, rgb.size(), f) != rgb.size()) { std::fclose(f); throw std::runtime_error("short PPM " + path); }
+        t.w = w; t.h = h; t.rgba.assign((size_t)w * h * 4, 0.f);
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int k = 0; k < 3; k++)
+            t.rgba[4 * ((size_t)(h - 1 - y) * w + x) + k] = (float)rgb[3 * ((size_t)y * w + x) + k] / 255.0f;   // u8/255, gamma 1.0
+    } else { std::fclose(f); throw std::runtime_error("unsupported texture format (only PFM / binary PPM this round): " + path); }
+    std::fclose(f);
+    return t;
+}
+
+int texture_id(HostScene &scene, const std::string &path) {
+    for (size_t i = 0; i < scene.textures.size(); i++) if (scene.textures[i].path == path) return (int)i;   // gTexturesMap rtcommon.h:33-51
+    scene.textures.push_back(load_texture(path));
+    return (int)scene.textures.size() - 1;
+}
+
+void parse_mtl(const std::string &path, std::map<std::string, MtlEntry> &out, std::vector<std::string> &order) {
+    std::ifstream f(path);
+    if (!f) return;   // Assimp tolerates a missing MTL: everything gets the default material
+    std::string line, cur;
+    while (std::getline(f, line)) {
+        std::istringstream ss(line); std::string tok; ss >> tok;
+        if (tok == "newmtl") { ss >> cur; out[cur] = MtlEntry(); order.push_back(cur); }
+        else if (cur.empty()) continue;
+        else if (tok == "Kd") ss >> out[cur].kd[0] >> out[cur].kd[1] >> out[cur].kd[2];
+        else if (tok == "Ks") ss >> out[cur].ks[0] >> out[cur].ks[1] >> out[cur].ks[2];
+        else if (tok == "Ns") ss >> out[cur].ns;
+        else if (tok == "map_Kd") ss >> out[cur].map_kd;
+        else if (tok == "map_Ks") ss >> out[cur].map_ks;
+        else if (tok == "map_Ns") ss >> out[cur].map_ns;
+    }
+}
+
+struct ObjResult { std::vector<MeshData> meshes; std::vector<evplp_material> materials; };
+
+// Wavefront OBJ -> one mesh per material (Assimp: one aiMesh per material group; Triangulate +
+// JoinIdenticalVertices, rtcommon.h:650-653).  Vertex normals are not loaded: no device program of
+// the reference reads them.
+ObjResult read_obj(HostScene &scene, const std::string &obj_path, bool want_materials) {
+    std::ifstream f(obj_path);
+    if (!f) throw std::runtime_error("Impossible to load the scene: " + obj_path);   // rtcommon.h:658-661
+    const std::string dir = dirname_of(obj_path);
+    std::vector<float> pos, tex;
+    std::map<std::string, MtlEntry> mtl; std::vector<std::string> mtl_order;
+    // material slot 0 = DefaultMaterial (rtcommon.h:745)
+    std::vector<std::string> mat_names = { "" };
+    std::vector<MeshData> meshes(1);
+    std::vector<std::map<std::pair<int, int>, int32_t>> dedup(1);
+    int cur = 0;
+    std::string line;
+    std::vector<std::pair<int, int>> face;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        const char *s = line.c_str();
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            float x, y, z; if (std::sscanf(s + 2, "%f %f %f", &x, &y, &z) == 3) { pos.push_back(x); pos.push_back(y); pos.push_back(z); }
+        } else if (s[0] == 'v' && s[1] == 't') {
+            float u = 0, v = 0; std::sscanf(s + 3, "%f %f", &u, &v); tex.push_back(u); tex.push_back(v);
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            face.clear();
+            const char *p = s + 2;
+            while (*p) {
+                while (*p == ' ' || *p == '\t' || *p == '\r') p++;
+                if (!*p) break;
+                char *end; long vi = std::strtol(p, &end, 10); long ti = 0;
+                if (end == p) break;
+                p = end;
+                if (*p == '/') { p++; if (*p != '/') { ti = std::strtol(p, &end, 10); p = end; } if (*p == '/') { p++; std::strtol(p, &end, 10); p = end; } }
+                int nv = (int)(pos.size() / 3), nt = (int)(tex.size() / 2);
+                int v = vi < 0 ? nv + (int)vi : (int)vi - 1;
+                int t = ti == 0 ? -1 : (ti < 0 ? nt + (int)ti : (int)ti - 1);
+                if (v < 0 || v >= nv) throw std::runtime_error("OBJ face references a missing vertex: " + obj_path);
+                face.emplace_back(v, t);
+            }
+            MeshData &m = meshes[cur];
+            auto &dd = dedup[cur];
+            auto index_of = [&](const std::pair<int, int> &k) {
+                auto it = dd.find(k);
+                if (it != dd.end()) return it->second;
+                int32_t id = (int32_t)(m.verts.size() / 3);
+                m.verts.insert(m.verts.end(), pos.begin() + 3 * k.first, pos.begin() + 3 * k.first + 3);
+                if (k.second >= 0 && (size_t)(2 * k.second + 1) < tex.size()) { m.uvs.push_back(tex[2 * k.second]); m.uvs.push_back(tex[2 * k.second + 1]); }
+                else { m.uvs.push_back(0.f); m.uvs.push_back(0.f); }   // rtcommon.h:701-705
+                dd[k] = id; return id;
+            };
+            for (size_t k = 1; k + 1 < face.size(); k++) {   // fan triangulation
+                m.idx.push_back(index_of(face[0])); m.idx.push_back(index_of(face[k])); m.idx.push_back(index_of(face[k + 1]));
+            }
+        } else if (!line.compare(0, 6, "usemtl")) {
+            std::istringstream ss(line.substr(6)); std::string name; ss >> name;
+            int found = -1;
+            for (size_t i = 0; i < mat_names.size(); i++) if (mat_names[i] == name) found = (int)i;
+            if (found < 0) { mat_names.push_back(name); meshes.emplace_back(); dedup.emplace_back(); found = (int)mat_names.size() - 1; }
+            cur = found;
+        } else if (!line.compare(0, 6, "mtllib")) {
+            std::istringstream ss(line.substr(6)); std::string name; ss >> name;
+            parse_mtl(join_path(dir, name), mtl, mtl_order);
+        }
+    }
+    ObjResult r;
+    for (size_t i = 0; i < meshes.size(); i++) {
+        if (meshes[i].idx.empty()) continue;
+        MeshData m = std::move(meshes[i]);
+        if (want_materials) {
+            MtlEntry e; auto it = mtl.find(mat_names[i]); if (it != mtl.end()) e = it->second;
+            evplp_material em; std::memset(&em, 0, sizeof(em));
+            std::memcpy(em.kd, e.kd, 12); std::memcpy(em.ks, e.ks, 12);
+            // A constant Ns reaches the renderer unchanged: Assimp's OBJ importer scales it by 4 and the
+            // reference divides the constant by 4 again (rtcommon.h:55-64).
+            em.ns = e.ns;
+            em.tex_kd = e.map_kd.empty() ? -1 : texture_id(scene, join_path(dir, e.map_kd));
+            em.tex_ks = e.map_ks.empty() ? -1 : texture_id(scene, join_path(dir, e.map_ks));
+            em.tex_ns = e.map_ns.empty() ? -1 : texture_id(scene, join_path(dir, e.map_ns));
+            m.material = (int32_t)r.materials.size();
+            r.materials.push_back(em);
+        }
+        r.meshes.push_back(std::move(m));
+    }
+    if (r.meshes.empty()) throw std::runtime_error("OBJ has no faces: " + obj_path);
+    return r;
+}
+
+} // namespace
+
+void add_obj(HostScene &scene, const std::string &obj_path) {
+    ObjResult r = read_obj(scene, obj_path, true);
+    const int32_t mat_offset = (int32_t)scene.materials.size();   // rtcommon.h:663
+    for (auto &m : r.materials) scene.materials.push_back(m);
+    for (auto &m : r.meshes) { m.material += mat_offset; scene.meshes.push_back(std::move(m)); }
+}
+
+void add_arealight(HostScene &scene, const std::string &obj_path, const float intensity[4]) {
+    if (scene.light_mesh >= 0) throw std::runtime_error("only one area light is supported (rtcommon.h:770-774)");
+    ObjResult r = read_obj(scene, obj_path, false);
+    if (r.meshes.size() != 1) throw std::runtime_error("the area-light OBJ must contain exactly one mesh (rtcommon.h:794-795): " + obj_path);
+    // overrideMaterial: the mesh gets a placeholder; evplp_set_arealight installs the emitter material
+    evplp_material black; std::memset(&black, 0, sizeof(black)); black.tex_kd = black.tex_ks = black.tex_ns = -1;
+    r.meshes[0].material = (int32_t)scene.materials.size();
+    scene.materials.push_back(black);
+    scene.meshes.push_back(std::move(r.meshes[0]));
+    scene.light_mesh = (int32_t)scene.meshes.size() - 1;
+    std::memcpy(scene.light_intensity, intensity, 16);
+}
+
+static void vec3_from(const Json &j, float out[3], const char *what) {
+    if (!j.is_array() || j.size() != 3) throw JsonError(std::string(what) + ": expected an array of 3 numbers");
+    for (int k = 0; k < 3; k++) out[k] = j.at((size_t)k).as_float(what);
+}
+
+evplp_camera camera_from_json(const Json &j, float aspect) {
+    evplp_camera c; std::memset(&c, 0, sizeof(c));
+    const float deg = 0.01745329251994329576923690768489f;   // glm::radians
+    if (j.has("fovy")) c.fovy = j.at("fovy").as_float("fovy") * deg;                                           // rtcommon.h:551-555
+    else if (j.has("fovx")) c.fovy = 2.0f * std::atan2(std::tan(j.at("fovx").as_float("fovx") * deg * 0.5f), aspect);   // :556-560
+    else throw JsonError("camera: forgot fov (fovx or fovy)");                                                  // :563
+    vec3_from(j.at("origin"), c.origin, "camera.origin");
+    vec3_from(j.at("direction"), c.lookat, "camera.direction");   // a look-AT point (:567, :588)
+    vec3_from(j.at("up"), c.up, "camera.up");
+    c.aspect = aspect;
+    return c;
+}
+
+HostScene load_scene(const Json &root, const std::string &json_path) {
+    HostScene s;
+    const std::string dir = dirname_of(json_path);
+    s.res_x = (int32_t)root.at("resX").as_int("resX"); s.res_y = (int32_t)root.at("resY").as_int("resY");
+    const Json &list = root.at("scene");                                     // main.cpp:46-58
+    if (!list.is_array()) throw JsonError("scene: expected an array of OBJ paths");
+    for (size_t i = 0; i < list.size(); i++) add_obj(s, join_path(dir, list.at(i).as_string("scene[]")));
+    const Json &al = root.at("arealight");                                   // main.cpp:60-67
+    const Json &I = al.at("intensity");
+    if (!I.is_array() || I.size() != 4) throw JsonError("arealight.intensity: expected 4 numbers");
+    float inten[4]; for (int k = 0; k < 4; k++) inten[k] = I.at((size_t)k).as_float("arealight.intensity");
+    add_arealight(s, join_path(dir, al.at("obj").as_string("arealight.obj")), inten);
+    float aspect = (float)s.res_x / (float)s.res_y;                          // main.cpp:70
+    if (root.has("camera")) { s.camera = camera_from_json(root.at("camera"), aspect); s.has_camera = true; }
+    else if (root.has("stablecamera")) { s.camera = camera_from_json(root.at("stablecamera"), aspect); s.has_camera = true; }
+    else throw JsonError("missing required key \"camera\" (or \"stablecamera\")");
+    return s;
+}
+
+int upload_scene(evplp_context *ctx, const HostScene &scene) {
+    int rc;
+    std::vector<int> tex_ids;
+    for (const TextureData &t : scene.textures) {
+        rc = evplp_add_texture(ctx, t.w, t.h, t.rgba.data());
+        if (rc < 0) return rc;
+        tex_ids.push_back(rc);
+    }
+    std::vector<int> mat_ids;
+    for (evplp_material m : scene.materials) {
+        if (m.tex_kd >= 0) m.tex_kd = tex_ids[m.tex_kd];
+        if (m.tex_ks >= 0) m.tex_ks = tex_ids[m.tex_ks];
+        if (m.tex_ns >= 0) m.tex_ns = tex_ids[m.tex_ns];
+        rc = evplp_add_material(ctx, &m);
+        if (rc < 0) return rc;
+        mat_ids.push_back(rc);
+    }
+    int light = -1;
+    for (size_t i = 0; i < scene.meshes.size(); i++) {
+        const MeshData &m = scene.meshes[i];
+        rc = evplp_add_mesh(ctx, m.verts.data(), m.uvs.data(), (int32_t)(m.verts.size() / 3), m.idx.data(), (int32_t)(m.idx.size() / 3), mat_ids[m.material]);
+        if (rc < 0) return rc;
+        if ((int)i == scene.light_mesh) light = rc;
+    }
+    if (light < 0) return EVPLP_ERR_INVALID;
+    if ((rc = evplp_set_arealight(ctx, light, scene.light_intensity)) < 0) return rc;
+    if ((rc = evplp_set_camera(ctx, &scene.camera)) < 0) return rc;
+    return evplp_build_accel(ctx);
+}
+
+} // namespace evplp

@@ -1,0 +1,262 @@
+// The host side of the reference's technique plugin, restated above the C ABI:
+//   main()                      reflectcuts/main.cpp:87-121      -> evplp_render_json
+//   RtTechnique::render         rt/rttechnique.h:6-9             -> ComPhotonTechnique::render
+//   RtComPhoton::render / run   rt/rtcomphoton/rtcomphoton.h:107-223, 883-1133
+// Same JSON keys, defaults, errors and outputs (three images + stat file); no window, no GL:
+// the frame loop of common/realtime.h reduces to the iteration cap and the wall-clock limit.
+#include "../../../include/evplp.h"
+#include "images.hpp"
+#include "json.hpp"
+#include "scene_io.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace evplp {
+
+namespace {
+const std::map<std::string, int> kFrameModes = { { "accumulate", 1 }, { "cleareveryframe", 2 } };   // rtcomphoton.h:1194-1197
+const std::map<std::string, int> kMisModes = { { "one", 0 }, { "balance", 1 }, { "max", 2 }, { "power2", 3 },
+                                               { "geometryClamp", 4 }, { "geometryBrdfClamp", 5 } }; // :1199-1206
+constexpr float kInvPi = 0.318309886183790671537767526745028724068919291480912897495f;
+
+struct Ctx {   // RAII for the C handle
+    evplp_context *h = nullptr;
+    ~Ctx() { if (h) evplp_destroy(h); }
+};
+void check(evplp_context *h, int rc, const char *what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + evplp_last_error(h));
+}
+// FloatImage::FlipY (floatimage.cpp:114-128) of a bottom-up RGB image + row de-interleave
+std::vector<float> flip_y(const std::vector<float> &rgb, int w, int h) {
+    std::vector<float> out((size_t)w * h * 3);
+    for (int row = 0; row < h; row++) std::memcpy(&out[(size_t)row * w * 3], &rgb[(size_t)(h - 1 - row) * w * 3], sizeof(float) * 3 * w);
+    return out;
+}
+} // namespace
+
+class ComPhotonTechnique {
+public:
+    // rtcomphoton.h:107-223
+    void render(const HostScene &scene, int res_x, int res_y, const Json &json, const std::string &out_dir, int device) {
+        num_light_paths = (int)json.at("numLightPaths").as_int("numLightPaths");
+        num_vpl_light_paths = (int)json.at("numVplLightPaths").as_int("numVplLightPaths");
+        num_max_bounce = (int)json.at("numMaxBounces").as_int("numMaxBounces");
+        photons_per_path = num_max_bounce + 1;
+        radius_percentage = json.at("radiusPercentage").as_float("radiusPercentage");
+        write_every_frame = json.has("writeEveryFrame") ? json.at("writeEveryFrame").as_bool("writeEveryFrame") : false;
+        num_max_iteration = (int)json.at("numMaxIteration").as_int("numMaxIteration");
+        time_limit_ms = json.at("timeLimitMs").as_float("timeLimitMs");
+        {
+            const std::string &fm = json.at("frameMode").as_string("frameMode");
+            auto it = kFrameModes.find(fm);
+            if (it == kFrameModes.end()) throw JsonError("frameMode: unknown value \"" + fm + "\"");
+            frame_mode = it->second;
+        }
+        if (!json.has("misMode")) mis_mode = 1;   // Balance (:128-131)
+        else {
+            const std::string &mm = json.at("misMode").as_string("misMode");
+            auto it = kMisModes.find(mm);
+            if (it == kMisModes.end()) throw JsonError("misMode: unknown value \"" + mm + "\"");
+            mis_mode = it->second;
+        }
+        if (json.has("clampingStart"))            // :137-142
+            throw JsonError("clampingStart option is not use anymore; remove it from your JSON file");
+        if (json.has("targetRenderingTime")) target_rendering_time = json.at("targetRenderingTime").as_float("targetRenderingTime");
+        rng_offset = (uint32_t)json.at("rngOffset").as_int("rngOffset");
+        combined_filename = join_path(out_dir, json.at("combinedFilename").as_string("combinedFilename"));
+        weighted_photon_filename = join_path(out_dir, json.at("weightedPhotonFilename").as_string("weightedPhotonFilename"));
+        weighted_vpl_filename = join_path(out_dir, json.at("weightedVplFilename").as_string("weightedVplFilename"));
+        stat_filename = join_path(out_dir, json.at("statFilename").as_string("statFilename"));
+        use_jitter = json.at("useJitter").as_bool("useJitter");
+        use_stat = json.at("useStat").as_bool("useStat");
+        if (json.has("DoProgressive")) do_progressive = json.at("DoProgressive").as_bool("DoProgressive");
+        if (json.has("AlphaProgressive")) alpha_progressive = json.at("AlphaProgressive").as_float("AlphaProgressive");
+        if (json.has("run")) {                    // :188-197
+            const Json &r = json.at("run");
+            if (r.has("deferredShading")) do_deferred = r.at("deferredShading").as_bool("run.deferredShading");
+            if (r.has("lightTracing")) do_light_tracing = r.at("lightTracing").as_bool("run.lightTracing");
+            if (r.has("vplSplat")) do_vpl_splat = r.at("vplSplat").as_bool("run.vplSplat");
+            if (r.has("photonSplat")) do_photon_splat = r.at("photonSplat").as_bool("run.photonSplat");
+            if (r.has("lightRender")) do_light_render = r.at("lightRender").as_bool("run.lightRender");
+            if (r.has("finalize")) do_finalize = r.at("finalize").as_bool("run.finalize");
+        }
+        if (num_vpl_light_paths == 0) { std::printf("WARN: 0 VPL light paths. Disable mDoVplSplat\n"); do_vpl_splat = false; }   // :200-203
+        if (json.has("forceVsl")) force_vsl = json.at("forceVsl").as_bool("forceVsl");
+        if (json.has("bvhBuilder")) bvh_builder = json.at("bvhBuilder").as_string("bvhBuilder") == "sah" ? EVPLP_BVH_SAH : EVPLP_BVH_LBVH;   // build-only key
+
+        // ---- setup(): context + scene upload (replaces GL/OptiX setup :646-708)
+        evplp_config cfg; std::memset(&cfg, 0, sizeof(cfg));
+        cfg.abi_version = EVPLP_ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y;
+        cfg.strip_rank = 0; cfg.strip_count = 1; cfg.strip_rows = 8;
+        cfg.num_light_paths = (uint32_t)num_light_paths; cfg.num_vpl_light_paths = (uint32_t)num_vpl_light_paths;
+        cfg.photons_per_path = (uint32_t)photons_per_path; cfg.bvh_builder = bvh_builder;
+        Ctx ctx;
+        int rc = evplp_create(&cfg, &ctx.h);
+        if (rc < 0) throw std::runtime_error(std::string("evplp_create: ") + evplp_last_error(nullptr));
+        check(ctx.h, upload_scene(ctx.h, scene), "scene upload");
+        float bsr = 0.f, total_area = 0.f, light_area = 0.f;
+        check(ctx.h, evplp_scene_metrics(ctx.h, &bsr, &total_area, &light_area), "scene metrics");
+
+        photon_radius = bsr * radius_percentage;                                                                 // :118-119
+        pdf_mc = (float)num_vpl_light_paths / (float)num_light_paths * kInvPi / (photon_radius * photon_radius); // :120
+        if (!json.has("clampingCoeff")) {                                                                        // :148-161
+            std::printf("Total area computation: %g\n", total_area);
+            clamping_value = clamping_start = 1.f / total_area;
+        } else clamping_value = clamping_start = json.at("clampingCoeff").as_float("clampingCoeff");
+        if (force_vsl) {                                                                                         // :205-218
+            float pct = json.at("vslRadiusPercentage").as_float("vslRadiusPercentage");
+            vsl_radius = bsr * pct;
+            if (vsl_radius <= 0.008f) { vsl_radius = std::max(vsl_radius, 0.008f); std::printf("warning : vslRadius is too small. clamped vslRadius\n"); }
+            vsl_inv_pi_radius2 = kInvPi / (vsl_radius * vsl_radius);
+        }
+        run(ctx.h, scene, res_x, res_y);
+    }
+
+private:
+    evplp_frame_params params(const HostScene &scene, uint32_t seed, const float jitter[2]) const {
+        evplp_frame_params fp; std::memset(&fp, 0, sizeof(fp));
+        std::memcpy(fp.camera_pos, scene.camera.origin, 12);
+        fp.mis_mode = (uint32_t)mis_mode; fp.pdf_mc = pdf_mc; fp.clamping_value = clamping_value; fp.photon_radius = photon_radius;
+        fp.vsl_radius = vsl_radius; fp.vsl_inv_pi_radius2 = vsl_inv_pi_radius2;
+        fp.num_light_paths = (uint32_t)num_light_paths; fp.num_vpl_light_paths = (uint32_t)num_vpl_light_paths;
+        fp.photons_per_path = (uint32_t)photons_per_path;
+        fp.do_accumulate = frame_mode == 2 ? 0u : 1u;   // :923-930
+        fp.rng_seed = seed; fp.jitter[0] = jitter[0]; fp.jitter[1] = jitter[1];
+        return fp;
+    }
+
+    // rtcomphoton.h:883-1133
+    void run(evplp_context *h, const HostScene &scene, int W, int H) {
+        // IndependentSampler(mRngOffset) -> std::mt19937 (common/rng.h:9-44); the float mapping of
+        // std::uniform_real_distribution is implementation-defined, so a fixed one is used:
+        // u = (x >> 8) * 2^-24, x first then y.
+        std::mt19937 jitter_rng(rng_offset);
+        auto next_float = [&]() { return (float)(jitter_rng() >> 8) * (1.0f / 16777216.0f); };
+        check(h, evplp_clear_accumulators(h), "clear");
+        int num_iterations = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        auto elapsed_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        float prev_timing = 0.f;
+        std::vector<float> rgb((size_t)W * evplp_local_rows(h) * 3);
+        for (;;) {
+            if (num_iterations == num_max_iteration) break;                                   // :938-941
+            float jitter[2] = { 0.f, 0.f };
+            if (use_jitter) {                                                                 // :946-952
+                float ux = next_float(), uy = next_float();
+                jitter[0] = (2.0f * ux - 1.0f) * (1.0f / (float)W); jitter[1] = (2.0f * uy - 1.0f) * (1.0f / (float)H);
+            }
+            evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
+            if (do_deferred) check(h, evplp_primary(h, jitter, (do_light_render && frame_mode == 2) ? 1 : 0), "primary");   // :954-960, 985-995
+            if (do_light_tracing) check(h, evplp_trace_light_paths(h, (uint32_t)num_iterations + rng_offset, 0, (uint32_t)num_light_paths), "light tracing");  // :962-966
+            if (do_vpl_splat) check(h, force_vsl ? evplp_gather_vsl(h, &fp) : evplp_gather_vpl(h, &fp), "gather");  // :968-972
+            // radius 0 (radiusPercentage 0 of the VPL-only configs): the proxy spheres are degenerate, nothing is drawn
+            if (do_photon_splat && photon_radius > 0.0f) check(h, evplp_splat_photons(h, &fp, frame_mode == 2 ? 1 : 0), "photon splat");    // :974-983
+            // [finalize] renders to the window in the reference (:997-1004); headless: nothing to present
+            num_iterations++;
+            if (num_iterations % 20 == 0) {                                                   // :1008-1031
+                check(h, evplp_synchronize(h), "sync");
+                float cur = elapsed_ms();
+                std::printf("numIter: %d | raduis: %g | clamping: %g | timing: %g\n", num_iterations, photon_radius, clamping_value, cur - prev_timing);
+                if (target_rendering_time != -1.f) {
+                    float frame_time = (cur - prev_timing) / 20.f, factor = target_rendering_time / frame_time;
+                    if (factor != 1.f) std::printf("change number of samples: %g | currFrame time: %g\n", factor, frame_time);
+                }
+                prev_timing = cur;
+            }
+            if (do_progressive)                                                               // :1033-1063
+                evplp_progressive_step(num_iterations, alpha_progressive, clamping_start, (uint32_t)num_vpl_light_paths, (uint32_t)num_light_paths,
+                                       &photon_radius, &clamping_value, &pdf_mc, force_vsl ? 1 : 0, &vsl_radius, &vsl_inv_pi_radius2);
+            if (write_every_frame) dump_frame(h, W, H, num_iterations, rgb);                  // :1079-1102
+            if (time_limit_ms < 1e8f) check(h, evplp_synchronize(h), "sync");                 // a wall-clock limit needs finished frames
+            if (elapsed_ms() >= time_limit_ms) break;                                         // :1065
+        }
+        check(h, evplp_synchronize(h), "sync");
+        float time = elapsed_ms();
+        if (use_stat) {                                                                       // :1109-1119
+            Json st = Json::object();
+            st.set("time", Json::number(time)); st.set("numIterations", Json::number(num_iterations));
+            // build-only additions: per-pass device times of the last iteration
+            const char *names[EVPLP_PASS_COUNT] = { "primaryMs", "lightTraceMs", "gatherVplMs", "gatherVslMs", "splatMs", "resolveMs" };
+            for (int p = 0; p < EVPLP_PASS_COUNT; p++) { evplp_pass_stats ps; if (evplp_pass_stats_get(h, p, &ps) == EVPLP_OK && ps.ms > 0) st.set(names[p], Json::number(ps.ms)); }
+            std::ofstream of(stat_filename);
+            if (!of) throw std::runtime_error("cannot write " + stat_filename);
+            of << st.dump() << "\n";
+        }
+        float param = frame_mode == 2 ? 1.0f : 1.0f / (float)std::max(num_iterations, 1);     // :1122
+        // :1124-1132: three composites, un-masked sums, FlipY, Save
+        auto compose = [&](float vs, float ps, float ls) {
+            check(h, evplp_resolve(h, vs, ps, ls, 0, 0, rgb.data()), "resolve");
+            std::vector<float> img(rgb.begin(), rgb.begin() + (size_t)W * H * 3);
+            return flip_y(img, W, H);
+        };
+        std::vector<float> combined = compose(param, param, 1.0f);
+        std::vector<float> vpl = compose(param, 0.0f, 1.0f);
+        std::vector<float> pm = compose(0.0f, param, 0.0f);
+        if (save_image(combined_filename.c_str(), W, H, combined.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + combined_filename);
+        if (save_image(weighted_vpl_filename.c_str(), W, H, vpl.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + weighted_vpl_filename);
+        if (save_image(weighted_photon_filename.c_str(), W, H, pm.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + weighted_photon_filename);
+    }
+
+    void dump_frame(evplp_context *h, int W, int H, int iter, std::vector<float> &rgb) {
+        float param = frame_mode == 2 ? 1.0f : 1.0f / (float)iter;                            // :1088
+        check(h, evplp_resolve(h, param, param, 1.0f, 0, 0, rgb.data()), "resolve");
+        std::vector<float> img(rgb.begin(), rgb.begin() + (size_t)W * H * 3);
+        std::vector<float> top = flip_y(img, W, H);
+        size_t i = weighted_photon_filename.find_last_of('.');                                // :1097-1101
+        std::string path = weighted_photon_filename.substr(0, i) + "_" + std::to_string(iter) + weighted_photon_filename.substr(i);
+        if (save_image(path.c_str(), W, H, top.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + path);
+    }
+
+    int num_light_paths = 0, num_vpl_light_paths = 0, num_max_bounce = 0, photons_per_path = 0;
+    float radius_percentage = 0.f, photon_radius = 0.f, pdf_mc = 0.f;
+    uint32_t rng_offset = 0; int num_max_iteration = 0; int frame_mode = 1; int mis_mode = 1;
+    float time_limit_ms = 0.f, clamping_value = 0.f, clamping_start = 0.f;
+    bool use_jitter = false, use_stat = false;
+    bool do_deferred = true, do_light_tracing = true, do_vpl_splat = true, do_photon_splat = true, do_light_render = true, do_finalize = true;
+    bool do_progressive = false, write_every_frame = false; float alpha_progressive = 0.7f;
+    float target_rendering_time = -1.f;
+    std::string combined_filename, weighted_photon_filename, weighted_vpl_filename, stat_filename;
+    bool force_vsl = false; float vsl_radius = 0.f, vsl_inv_pi_radius2 = 0.f;
+    int bvh_builder = EVPLP_BVH_LBVH;
+};
+
+} // namespace evplp
+
+extern "C" int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap) {
+    using namespace evplp;
+    auto fail = [&](int code, const std::string &msg) { if (err && err_cap) { std::snprintf(err, err_cap, "%s", msg.c_str()); } return code; };
+    if (!json_path) return fail(EVPLP_ERR_INVALID, "null json path");
+    try {
+        std::string text;
+        try { text = read_text_file(json_path); } catch (const std::exception &e) { return fail(EVPLP_ERR_IO, e.what()); }
+        Json root = Json::parse(text);                                                  // main.cpp:99-102
+        HostScene scene;
+        try { scene = load_scene(root, json_path); }                                    // main.cpp:104
+        catch (const JsonError &e) { return fail(EVPLP_ERR_PARSE, e.what()); }
+        catch (const std::exception &e) { return fail(EVPLP_ERR_IO, e.what()); }
+        bool ran = false;
+        if (root.has("pt") && !root.at("pt").is_null())                                 // main.cpp:105-109
+            return fail(EVPLP_ERR_INVALID, "the \"pt\" technique (OptiX path tracer, rt/rtpt/rtpt2.h) is outside the hot path of this build");
+        if (root.has("photonfam") && !root.at("photonfam").is_null()) {                 // main.cpp:111-115
+            Json block = root.at("photonfam");
+            if (json_overrides && *json_overrides) block.merge(Json::parse(json_overrides));
+            ComPhotonTechnique t;
+            t.render(scene, scene.res_x, scene.res_y, block, dirname_of(json_path), device);
+            ran = true;
+        }
+        if (root.has("lvcphotonfam") && !root.at("lvcphotonfam").is_null() && !ran)     // main.cpp:117-121
+            return fail(EVPLP_ERR_INVALID, "the \"lvcphotonfam\" variant (rt/rtcomphoton/rtlvccomphoton.h) is not built");
+        if (!ran) return fail(EVPLP_ERR_PARSE, "no technique block (\"photonfam\") in the scene JSON");
+    } catch (const JsonError &e) { return fail(EVPLP_ERR_PARSE, e.what()); }
+    catch (const std::exception &e) { return fail(EVPLP_ERR_HIP, e.what()); }
+    return EVPLP_OK;
+}

@@ -1,0 +1,71 @@
+// Kernel argument blocks and host-side launchers (defined in the .hip files).
+#pragma once
+#include "evplp_types.h"
+
+namespace evplp {
+
+struct PrimaryArgs {
+    SceneDev sc; StripDev st; CamBasis cam;
+    float jitter[2]; int32_t clear_light; int32_t pad;
+    float4 *g_pos, *g_nrm, *g_dif, *g_phg, *g_light;
+};
+
+struct LightTraceArgs {
+    SceneDev sc;
+    uint32_t rng_seed, path_begin, path_count, photons_per_path;
+    evplp_record *records;
+};
+
+// Device-side counters of one pass (zeroed by the host before the launch)
+struct PassCounters {
+    unsigned long long rays;          // shadow / closest-hit rays actually traced
+    unsigned long long nodes;         // BVH nodes visited (wave-level visits for the gather)
+    unsigned long long pairs;         // splat: (photon, pixel) pairs inside the kernel radius
+    unsigned long long aux;
+};
+
+struct GatherArgs {
+    SceneDev sc; StripDev st;
+    const float4 *g_pos, *g_nrm, *g_dif, *g_phg;
+    const evplp_record *vpls;         // compacted usable VPL records
+    const uint32_t *vpl_src_index;    // VSL only: original record index of each compacted VPL (RNG substream)
+    const uint32_t *nvpl;             // device scalar written by compact_vpl_kernel
+    evplp_frame_params fp;
+    float4 *out;
+    PassCounters *counters;
+};
+
+struct SplatArgs {
+    StripDev st; CamBasis cam;
+    evplp_frame_params fp;
+    const float4 *g_pos, *g_nrm, *g_dif, *g_phg;
+    const evplp_record *records; uint32_t num_records;
+    float4 *out;
+    // binning workspace
+    uint32_t *tile_count;     // [ntiles + 1]
+    uint32_t *tile_offset;    // [ntiles + 1] exclusive scan
+    uint32_t *tile_cursor;    // [ntiles]
+    uint32_t *bin_items;      // [bin_capacity] compact photon ids
+    uint32_t bin_capacity;
+    uint32_t *bin_items_tmp;  // [bin_capacity] (deterministic mode: unsorted fill target)
+    float4 *compact;          // [num_records * kCompactF4] per-photon pre-shaded data
+    uint2 *rect;              // [num_records] packed tile rectangle (x0 | x1<<16, y0 | y1<<16), x0 > x1 = none
+    uint32_t *overflow;       // device flag: bins did not fit
+    int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
+    PassCounters *counters;
+};
+constexpr int kSplatTile = 8;        // pixels per tile edge (one wave per tile)
+constexpr int kCompactF4 = 4;        // float4 per compact photon
+
+void launch_primary(const PrimaryArgs &a, hipStream_t s);
+void launch_light_trace(const LightTraceArgs &a, hipStream_t s);
+void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
+                        uint32_t *count_out, hipStream_t s);
+void launch_gather_vpl(const GatherArgs &a, hipStream_t s);
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
+void launch_splat(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
+void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
+                    float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
+void launch_fill_zero(void *p, size_t bytes, hipStream_t s);
+
+} // namespace evplp

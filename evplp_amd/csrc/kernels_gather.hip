@@ -1,0 +1,301 @@
+// The gather: per-pixel sum over all usable virtual lights with shadow-ray visibility.
+//   gather_vpl_kernel <- splatColor + vplSplat   (rt/lighttracing.cu:348-379, 275-346)
+//   gather_vsl_kernel <- splatSplotch + vslSplat (rt/lighttracing.cu:689-722, 596-686, 395-594)
+//
+// Mapping.  One wavefront owns an 8x8 pixel tile (lane = pixel); a workgroup is 2x2 such tiles.
+// The compacted VPL list streams through LDS in chunks staged cooperatively by the workgroup;
+// every lane reads the SAME record (LDS broadcast).  For one VPL the 64 shadow segments of a wave
+// share their origin (the VPL) and end on neighbouring surface points, so the wave walks the BVH
+// as a packet: one node stack per wavefront in LDS, node/triangle fetches are scalar loads, the
+// descent is decided by ballots over the lanes that are still undecided, and lanes whose
+// un-normalised cosine product is <= 0 (lighttracing.cu:288) never enter the walk.
+#include "device_common.hpp"
+#include "kernels.h"
+
+namespace evplp {
+
+constexpr int kGatherChunk = 128;                 // VPL records per LDS stage (12 KB)
+constexpr int kRecF4 = sizeof(evplp_record) / 16; // 6 float4 per record
+
+struct Pixel {
+    V3 p1, n1, rd, rs; float e; V3 wi10;
+};
+
+struct Vpl {
+    V3 pos, n, flux, fdir, rd, rs; float psel, e;
+};
+EV_DEV Vpl load_vpl(const float4 *r) {
+    Vpl v; float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5];
+    v.pos = v3(a); v.n = v3(b); v.psel = b.w; v.flux = v3(c); v.fdir = v3(d); v.rd = v3(e); v.rs = v3(f); v.e = f.w;
+    return v;
+}
+
+// vplSplat after the visibility test (rt/lighttracing.cu:296-345)
+EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v, V3 v12, float c1c2) {
+    float dist2 = dot(v12, v12);
+    float dist = sqrtf(dist2);
+    V3 wi12 = v12 / dist;
+    V3 brdf2 = v.rd * EV_INV_PI + v.rs * phong_eval_f(-wi12, v.fdir, v.n, v.e);
+    V3 brdf1 = px.rd * EV_INV_PI + px.rs * phong_eval_f(px.wi10, wi12, px.n1, px.e);
+    float g21 = c1c2 / (dist2 * dist2);
+    const uint32_t mode = fp.mis_mode;
+    if (mode == 0u) return v.flux * brdf1 * brdf2 * g21;
+    if (mode <= 3u) {
+        float pdf_de = lambert_pdf_a(v.n, px.n1, -v12) * v.psel;
+        pdf_de += phong_pdf_a(v.n, px.n1, -v12, v.fdir, v.rs, v.e) * (1.0f - v.psel);
+        float w;
+        if (mode == 1u) w = fp.pdf_mc / (fp.pdf_mc + pdf_de);
+        else if (mode == 2u) w = fp.pdf_mc > pdf_de ? 1.0f : 0.0f;
+        else { float a2 = fp.pdf_mc * fp.pdf_mc, b2 = pdf_de * pdf_de; w = a2 / (a2 + b2); }
+        return (v.flux * w) * brdf1 * brdf2 * g21;
+    }
+    if (mode == 4u) return (v.flux * fminf(g21, fp.clamping_value)) * brdf1 * brdf2;
+    V3 x = (brdf1 * g21) * brdf2;
+    x = v3(fminf(x.x, fp.clamping_value), fminf(x.y, fp.clamping_value), fminf(x.z, fp.clamping_value));
+    return v.flux * x;
+}
+
+EV_DEV void stage_chunk(float4 *dst, const evplp_record *src, uint32_t begin, uint32_t n_total, int tid) {
+    uint32_t n = min((uint32_t)kGatherChunk, n_total - begin);
+    const float4 *s = reinterpret_cast<const float4 *>(src + begin);
+    for (uint32_t i = tid; i < n * kRecF4; i += 256) dst[i] = s[i];
+}
+
+// XCD-aware tile order: consecutive block ids land on different XCDs (round-robin dispatch), so
+// give each XCD a contiguous band of tiles and keep neighbouring tiles on one L2.
+EV_DEV int xcd_swizzle(int b, int nb) {
+    int per = nb >> 3;
+    if (per == 0 || b >= per * 8) return b;
+    return (b & 7) * per + (b >> 3);
+}
+
+__global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
+    __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
+    __shared__ int32_t lds_stack[4][kMaxDepth];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = a.st.W;
+    const int tiles_x = (W + 15) >> 4;
+    const int nb = gridDim.x;
+    const int tile = xcd_swizzle(blockIdx.x, nb);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_image = x < W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
+    const size_t p = (size_t)min(ly, a.st.local_rows - 1) * W + min(x, W - 1);
+
+    Pixel px;
+    float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
+    px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
+    px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);  // lighttracing.cu:363
+    const bool valid = in_image && gp.w != 0.0f;        // stencil test, lighttracing.cu:354
+
+    const uint32_t nvpl = *a.nvpl;
+    V3 result = v3(0.f, 0.f, 0.f);
+    uint32_t rays = 0, nodes = 0;
+    int32_t *stack = lds_stack[wave];
+
+    int buf = 0;
+    if (nvpl > 0) stage_chunk(lds_vpl[0], a.vpls, 0, nvpl, tid);
+    __syncthreads();
+    for (uint32_t begin = 0; begin < nvpl; begin += kGatherChunk) {
+        uint32_t next = begin + kGatherChunk;
+        if (next < nvpl) stage_chunk(lds_vpl[buf ^ 1], a.vpls, next, nvpl, tid);
+        const uint32_t n = min((uint32_t)kGatherChunk, nvpl - begin);
+        const float4 *chunk = lds_vpl[buf];
+        for (uint32_t i = 0; i < n; i++) {
+            Vpl v = load_vpl(chunk + i * kRecF4);
+            V3 v12 = v.pos - px.p1;                                         // :282
+            float c1 = fmaxf(dot(px.n1, v12), 0.0f);
+            float c2 = fmaxf(-dot(v.n, v12), 0.0f);
+            float c1c2 = c1 * c2;
+            bool active = valid && !(c1c2 <= 0.0f);                         // :288
+            if (__ballot(active) == 0ull) continue;
+            rays += active ? 1u : 0u;
+            // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
+            bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, stack, nodes);
+            if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (in_image && valid) {
+        // outputBuffer = result / numVplLightPaths + doAccumulate * outputBuffer   :378
+        float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
+        float4 old = a.out[p];
+        a.out[p] = make_float4(result.x / inv + acc * old.x, result.y / inv + acc * old.y, result.z / inv + acc * old.z, 0.0f + acc * old.w);
+    }
+    // statistics: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if (lane == 0) { atomicAdd(&a.counters->rays, (unsigned long long)rays); atomicAdd(&a.counters->nodes, (unsigned long long)nodes); }
+}
+
+// ------------------------------------------------------------------------------------ VSL
+EV_DEV V3 square_to_solid_angle(float sx, float sy, float half_angle_max) {  // lighttracing.cu:382-390
+    float phi = 2.0f * EV_PI * sx;
+    float z = 1.0f - sy * (1.0f - cosf(half_angle_max));
+    float l = sqrtf(1.0f - z * z);
+    return v3(cosf(phi) * l, sinf(phi) * l, z);
+}
+struct VslCtx {
+    float half_cone, cos_half_cone, solid_angle, inv_solid_angle, inv_pi_r2; V3 nd12;
+};
+// shared MIS denominator block (:433-443, 508-518, 581-591) with the reference quirk of SURVEY A.6
+EV_DEV void vsl_pdfs(const Pixel &px, const Vpl &v, V3 wi12, float psel, float &pdf1, float &pdf2) {
+    pdf1 = lambert_pdf_w(px.n1, wi12) * psel + phong_pdf_w(px.n1, wi12, px.wi10, px.rs, px.e) * (1.0f - psel);
+    pdf2 = lambert_pdf_w(v.n, -wi12) * psel + phong_pdf_w(v.n, -wi12, v.fdir, v.rs, v.e);
+}
+EV_DEV V3 vsl_sample_cone(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :395-446
+    const V3 zero = v3(0.f, 0.f, 0.f);
+    float ml = max_color(px.rd), mp = max_color(px.rs);
+    if (ml + mp <= 0.000001f) return zero;
+    float psel = ml / (mp + ml);
+    (void)rng_uniform(rng);
+    float ua = rng_uniform(rng);
+    float ub = rng_uniform(rng);
+    V3 wi12 = normalize(square_to_solid_angle(ua, ub, c.half_cone));
+    Onb o = onb_make(c.nd12);
+    wi12 = normalize(onb_inverse(o, wi12));
+    float c1c2 = fmaxf(dot(px.n1, wi12), 0.0f) * fmaxf(-dot(v.n, wi12), 0.0f);
+    if (c1c2 <= 0.000000001f) return zero;
+    V3 brdf2 = v.rd * EV_INV_PI + v.rs * phong_eval_f(-wi12, v.fdir, v.n, v.e);
+    V3 brdf1 = px.rd * EV_INV_PI + px.rs * phong_eval_f(px.wi10, wi12, px.n1, px.e);
+    float pdf1, pdf2; vsl_pdfs(px, v, wi12, psel, pdf1, pdf2);
+    w = c.inv_solid_angle / (pdf1 + pdf2 + c.inv_solid_angle);
+    return (((v.flux * c.inv_pi_r2) * c1c2) * brdf1 * brdf2) * c.solid_angle;
+}
+EV_DEV V3 vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :448-521
+    const V3 zero = v3(0.f, 0.f, 0.f);
+    float ml = max_color(px.rd), mp = max_color(px.rs);
+    if (ml + mp <= 0.000001f) return zero;
+    float psel = ml / (mp + ml);
+    float choose = fminf(rng_uniform(rng), 0.999999f);
+    V3 wi12, brdf1; float pdfw;
+    if (choose < psel) brdf1 = lambert_sample(wi12, pdfw, px.n1, px.rd, rng) / psel;
+    else brdf1 = phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) / (1.0f - psel);
+    if (dot(wi12, c.nd12) <= c.cos_half_cone) return zero;
+    float cos1 = fmaxf(dot(px.n1, wi12), 0.0f);
+    if (cos1 <= 0.000000001f) return zero;
+    float cos2 = fmaxf(-dot(v.n, wi12), 0.0f);
+    V3 brdf2 = v.rd * EV_INV_PI + v.rs * phong_eval_f(-wi12, v.fdir, v.n, v.e);
+    (void)rng_uniform(rng);  // :506
+    float pdf1, pdf2; vsl_pdfs(px, v, wi12, psel, pdf1, pdf2);
+    w = pdf1 / (pdf1 + pdf2 + c.inv_solid_angle);
+    return ((v.flux * c.inv_pi_r2) * cos2) * brdf1 * brdf2;
+}
+EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :523-594
+    const V3 zero = v3(0.f, 0.f, 0.f);
+    V3 wi21, brdf2; float pdfw;
+    {
+        float ml = max_color(v.rd), mp = max_color(v.rs);
+        if (ml + mp <= 0.000001f) return zero;
+        float psel = ml / (mp + ml);
+        float choose = fminf(rng_uniform(rng), 0.999999f);
+        if (choose < psel) brdf2 = lambert_sample(wi21, pdfw, v.n, v.rd, rng) / psel;
+        else brdf2 = phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) / (1.0f - psel);
+    }
+    if (-dot(wi21, c.nd12) <= c.cos_half_cone) return zero;
+    V3 brdf1 = px.rd * EV_INV_PI + px.rs * phong_eval_f(px.wi10, -wi21, px.n1, px.e);
+    float cos2 = fmaxf(dot(v.n, wi21), 0.0f);
+    if (cos2 <= 0.00000001f) return zero;
+    float cos1 = fmaxf(-dot(px.n1, wi21), 0.0f);
+    float ml = max_color(px.rd), mp = max_color(px.rs);
+    if (ml + mp <= 0.000001f) return zero;
+    float psel = ml / (mp + ml);
+    (void)rng_uniform(rng);  // :579
+    float pdf1, pdf2; vsl_pdfs(px, v, -wi21, psel, pdf1, pdf2);
+    w = pdf2 / (pdf1 + pdf2 + c.inv_solid_angle);
+    return ((v.flux * c.inv_pi_r2) * cos1) * brdf1 * brdf2;
+}
+
+__global__ __launch_bounds__(256) void gather_vsl_kernel(GatherArgs a) {
+    __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
+    __shared__ int32_t lds_stack[4][kMaxDepth];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = a.st.W;
+    const int tiles_x = (W + 15) >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_image = x < W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
+    const size_t p = (size_t)min(ly, a.st.local_rows - 1) * W + min(x, W - 1);
+    const int gy = a.st.global_row(min(ly, a.st.local_rows - 1));
+
+    Pixel px;
+    float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
+    px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
+    px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);   // :704
+    const bool valid = in_image;                        // no stencil test in splatSplotch (:694-695)
+    const uint32_t pixel_id = (uint32_t)gy * (uint32_t)W + (uint32_t)x;  // launchIndex.y * dim.x + launchIndex.x (:711)
+
+    const uint32_t nvpl = *a.nvpl;
+    V3 result = v3(0.f, 0.f, 0.f);
+    uint32_t rays = 0, nodes = 0;
+    int32_t *stack = lds_stack[wave];
+    int buf = 0;
+    if (nvpl > 0) stage_chunk(lds_vpl[0], a.vpls, 0, nvpl, tid);
+    __syncthreads();
+    for (uint32_t begin = 0; begin < nvpl; begin += kGatherChunk) {
+        uint32_t next = begin + kGatherChunk;
+        if (next < nvpl) stage_chunk(lds_vpl[buf ^ 1], a.vpls, next, nvpl, tid);
+        const uint32_t n = min((uint32_t)kGatherChunk, nvpl - begin);
+        const float4 *chunk = lds_vpl[buf];
+        for (uint32_t i = 0; i < n; i++) {
+            Vpl v = load_vpl(chunk + i * kRecF4);
+            V3 v12 = v.pos - px.p1;                                       // :605
+            float dist2 = dot(v12, v12);
+            float dist = sqrtf(dist2);
+            rays += valid ? 1u : 0u;
+            bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid, stack, nodes);  // :612-614
+            V3 nv12 = v12 / dist;
+            float c1c2 = fmaxf(dot(px.n1, nv12), 0.0f) * fmaxf(-dot(v.n, nv12), 0.0f);
+            bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
+            if (__ballot(lit) == 0ull) continue;
+            if (lit) {
+                VslCtx c;
+                float rdratio = a.fp.vsl_radius / dist;
+                c.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
+                c.cos_half_cone = cosf(c.half_cone);
+                c.solid_angle = EV_PI * 2.0f * (1.0f - c.cos_half_cone);
+                c.inv_solid_angle = 1.0f / c.solid_angle;
+                c.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; c.nd12 = nv12;
+                int num_samples = (int)(c.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
+                // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
+                Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[begin + i]);
+                V3 acc = v3(0.f, 0.f, 0.f);
+                for (int s = 0; s < num_samples; s++) {
+                    float wc = 0.f, w1 = 0.f, w2 = 0.f;
+                    V3 rc = vsl_sample_cone(px, v, c, wc, rng);
+                    V3 r1 = vsl_sample_brdf1(px, v, c, w1, rng);
+                    V3 r2 = vsl_sample_brdf2(px, v, c, w2, rng);
+                    acc = acc + rc * wc;
+                    acc = acc + r1 * w1;
+                    acc = acc + r2 * w2;
+                }
+                result = result + acc / (float)num_samples;
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (in_image) {
+        float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
+        float4 old = a.out[p];
+        a.out[p] = make_float4(result.x / inv + acc * old.x, result.y / inv + acc * old.y, result.z / inv + acc * old.z, 0.0f + acc * old.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if (lane == 0) { atomicAdd(&a.counters->rays, (unsigned long long)rays); atomicAdd(&a.counters->nodes, (unsigned long long)nodes); }
+}
+
+static dim3 gather_grid(const StripDev &st) {
+    int tiles_x = (st.W + 15) / 16, tiles_y = (st.local_rows + 15) / 16;
+    return dim3(tiles_x * tiles_y);
+}
+void launch_gather_vpl(const GatherArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a.st), dim3(256), 0, s, a);
+}
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a.st), dim3(256), 0, s, a);
+}
+
+} // namespace evplp

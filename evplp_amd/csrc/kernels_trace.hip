@@ -1,0 +1,186 @@
+// Feeder kernels: primary visibility (G-buffer) and light sub-path tracing.
+//   primary_kernel      <- shaders/deferred.{vert,geom,frag} + light.{vert,frag} drawn by
+//                          runDeferredProgram / runLightProgram (rt/rtcomphoton/rtcomphoton.h:710-754, 839-855)
+//   light_trace_kernel  <- tracePhotons + rtMaterialClosestHit (rt/lighttracing.cu:192-250, 113-182)
+// Both trace incoherent rays: one ray per lane, closest hit, per-lane stack in LDS laid out
+// [entry][lane] so that a push/pop of the whole wave is one conflict-free ds access.
+#include "device_common.hpp"
+#include "kernels.h"
+
+namespace evplp {
+
+constexpr int kLaneStack = kMaxDepth;  // entries per lane
+
+__global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
+    __shared__ int32_t lds_stack[kLaneStack * 64];
+    const int lane = threadIdx.x;
+    const int tiles_x = (a.st.W + 7) >> 3;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    if (x >= a.st.W || ly >= a.st.local_rows) return;
+    const int y = a.st.global_row(ly);
+    if (y >= a.st.H) return;
+    const size_t p = (size_t)ly * a.st.W + x;
+
+    V3 eye = v3(a.cam.eye), S = v3(a.cam.s), U = v3(a.cam.u), F = v3(a.cam.f);
+    float cx = ((float)x + 0.5f) / (float)a.st.W * 2.0f - 1.0f;
+    float cy = ((float)y + 0.5f) / (float)a.st.H * 2.0f - 1.0f;
+    // jittered matrix for the scene, original matrix for the light mesh (rtcomphoton.h:720-727)
+    float jx = (cx - a.jitter[0]) * a.cam.aspect * a.cam.tan_half, jy = (cy - a.jitter[1]) * a.cam.tan_half;
+    float ox = cx * a.cam.aspect * a.cam.tan_half, oy = cy * a.cam.tan_half;
+    V3 dj = S * jx + U * jy + F;
+    V3 d0 = S * ox + U * oy + F;
+
+    int32_t *stack = lds_stack + lane;
+    float t = 0.f, b = 0.f, g = 0.f, tl = 0.f, bl = 0.f, gl = 0.f;
+    // view depth == t because the camera-space z of the direction is -1: near/far = [0.1, 100] (rtcommon.h:586)
+    int32_t tri = closest_lane<64>(a.sc, eye, dj, 0.1f, 100.0f, 1, t, b, g, stack);
+    int32_t ltri = a.sc.light_count > 0 ? closest_lane<64>(a.sc, eye, d0, 0.1f, 100.0f, 2, tl, bl, gl, stack) : -1;
+    bool use_light = ltri >= 0 && (tri < 0 || tl <= t);  // depth LEQUAL, light mesh drawn last
+    if (use_light) { tri = ltri; b = bl; g = gl; }
+
+    float4 pos = make_float4(0.f, 0.f, 0.f, 1.f);  // clear colour (0,0,0,1) rtcomphoton.h:885
+    float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f), dif = nrm, phg = nrm;
+    if (tri >= 0) {
+        const TriAttr &ta = a.sc.attrs[tri];
+        V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
+        V3 P = p1 * b + p2 * g + p0 * (1.0f - b - g);
+        V3 N = normalize(cross(p1 - p0, p2 - p0));  // deferred.geom:16-18 flat winding normal
+        V3 kd, ks; float ns;
+        material_at(a.sc, ta, b, g, kd, ks, ns);
+        pos = make_float4(P.x, P.y, P.z, 1.0f);
+        nrm = make_float4(N.x, N.y, N.z, 0.f);
+        dif = make_float4(kd.x, kd.y, kd.z, 0.f);
+        phg = make_float4(ks.x, ks.y, ks.z, ns);
+    }
+    a.g_pos[p] = pos; a.g_nrm[p] = nrm; a.g_dif[p] = dif; a.g_phg[p] = phg;
+    if (use_light) a.g_light[p] = make_float4(a.sc.light_unscaled[0], a.sc.light_unscaled[1], a.sc.light_unscaled[2], 0.f);
+    else if (a.clear_light) a.g_light[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// lighttracing.cu:93-96
+EV_DEV float russian_prob_lt(V3 f) { return fminf(fmaxf(f.x, fmaxf(f.y, f.z)), 0.98f); }
+
+EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float psel, V3 flux, V3 fdir, V3 rd, V3 rs, float e) {
+    float4 *q = reinterpret_cast<float4 *>(r);
+    q[0] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(flags));
+    q[1] = make_float4(n.x, n.y, n.z, psel);
+    q[2] = make_float4(flux.x, flux.y, flux.z, 0.f);
+    q[3] = make_float4(fdir.x, fdir.y, fdir.z, 0.f);
+    q[4] = make_float4(rd.x, rd.y, rd.z, 0.f);
+    q[5] = make_float4(rs.x, rs.y, rs.z, e);
+}
+
+__global__ __launch_bounds__(64) void light_trace_kernel(LightTraceArgs a) {
+    __shared__ int32_t lds_stack[kLaneStack * 64];
+    const int lane = threadIdx.x;
+    const uint32_t local = blockIdx.x * 64u + lane;
+    if (local >= a.path_count) return;
+    const uint32_t id = a.path_begin + local;
+    const uint32_t P = a.photons_per_path;
+    evplp_record *rec = a.records + (size_t)id * P;
+    int32_t *stack = lds_stack + lane;
+
+    const V3 zero = v3(0.f, 0.f, 0.f);
+    for (uint32_t i = 1; i < P; i++) store_record(&rec[i], zero, 0u, zero, 0.f, zero, zero, zero, zero, 0.f);  // :197-200
+
+    Rng rng; rng_init(rng, id, a.rng_seed, 0u);
+    V3 position, normal; float pdf;
+    V3 flux = light_sample(a.sc, position, normal, pdf, rng);
+    V3 direction; float phong_pdf;
+    V3 att = phong_sample(direction, phong_pdf, normal, normal, v3(1.f, 1.f, 1.f), a.sc.light_intensity[3], rng);
+    // record 0: the on-light vertex is a VPL (:215-225)
+    store_record(&rec[0], position, EVPLP_USABLE_VPL, normal, 0.0f, flux, normal, zero, v3(1.f, 1.f, 1.f), a.sc.light_intensity[3]);
+
+    V3 pflux = flux * att;
+    V3 next_pos = position, next_dir = direction;
+    for (uint32_t i = 1; i < P; i++) {
+        uint32_t flag = (i != P - 1) ? (EVPLP_USABLE_VPL | EVPLP_USABLE_PHOTON) : EVPLP_USABLE_PHOTON;
+        float t, b, g;
+        int32_t tri = closest_lane<64>(a.sc, next_pos, next_dir, 0.0001f, 3.0e38f, 0, t, b, g, stack);
+        if (tri < 0) break;  // no miss program in the reference; a miss ends the path here
+        const TriAttr &ta = a.sc.attrs[tri];
+        V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
+        V3 gn = normalize(cross(p0 - p2, p1 - p0));       // triangleintersect.cu:31
+        V3 wgn = normalize(gn);                           // :115
+        V3 ffn = faceforward(wgn, -next_dir, wgn);        // :116
+        V3 hit_pos = next_pos + next_dir * t;             // :120
+        const Material &m = a.sc.materials[ta.material];
+        if (dot(gn, next_dir) > 0.f || m.light[0] > 0.01f) break;  // :124-128
+        V3 kd, ks; float ns;
+        material_at(a.sc, ta, b, g, kd, ks, ns);
+        float max_l = max_color(kd), max_p = max_color(ks);
+        if (max_l + max_p <= 0.000001f) break;            // :143-147
+        float psel = max_l / (max_p + max_l);
+        float choose = fminf(rng_uniform(rng), 0.999999f);
+        float russian = russian_prob_lt(pflux);           // :164
+        V3 stored_flux = pflux;
+        pflux = pflux / russian;
+        bool done = rng_uniform(rng) >= russian;          // :166
+        V3 dir = zero; float pdfw;
+        if (!done) {
+            if (choose < psel) {
+                V3 w = lambert_sample(dir, pdfw, ffn, kd, rng);
+                pflux = pflux * (w / psel);
+                flag |= EVPLP_LAMBERT_ONLY;
+            } else {
+                V3 w = phong_sample(dir, pdfw, -next_dir, gn, ks, ns, rng);  // un-flipped normal (:176)
+                pflux = pflux * (w / (1.0f - psel));
+                flag |= EVPLP_PHONG_ONLY;
+            }
+        }
+        store_record(&rec[i], hit_pos, flag, ffn, psel, stored_flux, -next_dir, kd, ks, ns);
+        if (done) break;
+        next_pos = hit_pos; next_dir = dir;
+    }
+}
+
+// Stable compaction of the usable VPL records (flags & IsUsableVpl, rt/lighttracing.cu:372) of
+// the first numVplLightPaths paths into a dense list, preserving record order so per-pixel sums
+// run in the reference's loop order.  One workgroup; the list is at most a few 10k records.
+__global__ __launch_bounds__(1024) void compact_vpl_kernel(const evplp_record *records, uint32_t nrec,
+                                                           evplp_record *out, uint32_t *src_index, uint32_t *count_out) {
+    __shared__ uint32_t wave_counts[16];
+    __shared__ uint32_t base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < nrec; start += 1024) {
+        uint32_t i = start + tid;
+        bool usable = i < nrec && (records[i].flags & EVPLP_USABLE_VPL) != 0;
+        unsigned long long m = __ballot(usable);
+        uint32_t prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_counts[wave] = __popcll(m);
+        __syncthreads();
+        uint32_t off = base;
+        for (int w = 0; w < wave; w++) off += wave_counts[w];
+        if (usable) {
+            const float4 *src = reinterpret_cast<const float4 *>(&records[i]);
+            float4 *dst = reinterpret_cast<float4 *>(&out[off + prefix]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) dst[k] = src[k];
+            if (src_index) src_index[off + prefix] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t tot = 0; for (int w = 0; w < 16; w++) tot += wave_counts[w]; base += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) *count_out = base;
+}
+
+void launch_primary(const PrimaryArgs &a, hipStream_t s) {
+    int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
+    hipLaunchKernelGGL(primary_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a);
+}
+void launch_light_trace(const LightTraceArgs &a, hipStream_t s) {
+    if (a.path_count == 0) return;
+    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
+                        uint32_t *count_out, hipStream_t s) {
+    hipLaunchKernelGGL(compact_vpl_kernel, dim3(1), dim3(1024), 0, s, records, nrec, out, src_index, count_out);
+}
+
+} // namespace evplp

@@ -1,0 +1,231 @@
+/*
+ * evplp.h -- C ABI of libevplp_hip.so: the MI355X (gfx950) implementation of evplp's
+ * per-pixel indirect-radiance accumulation path (VPL/VSL gather with shadow rays,
+ * image-space photon splat, and the feeders either side of them).
+ *
+ * This is the boundary a maintainer of jamornsriwasansak/evplp binds instead of OptiX +
+ * OpenGL.  Every entry point names the reference interface it replaces (paths relative to
+ * reflectcuts/; rt/ = realtimetechniques/).  Plain pointers and sizes only; no C++ types,
+ * no exceptions cross the ABI.  Every call returns EVPLP_OK (0) or a negative evplp_status;
+ * evplp_last_error() gives the message.  One caller thread per context; one context per GPU.
+ * There is NO CPU fallback: without a usable HIP device evplp_create fails with
+ * EVPLP_ERR_NO_DEVICE.
+ *
+ * Image convention: row-major, y = 0 at the BOTTOM row (OpenGL / OptiX launch index,
+ * shaders/final.frag:22-23).  With row strips (multi-GPU) a context owns the rows of the
+ * blocks  b = y / strip_rows  with  b % strip_count == strip_rank  and stores them compactly:
+ * local_row = (b / strip_count) * strip_rows + y % strip_rows.
+ */
+#ifndef EVPLP_H
+#define EVPLP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVPLP_ABI_VERSION 1
+
+typedef enum evplp_status {
+    EVPLP_OK = 0,
+    EVPLP_ERR_INVALID = -1,     /* bad argument / call order */
+    EVPLP_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error at creation */
+    EVPLP_ERR_HIP = -3,         /* HIP runtime error (message has the hipError string) */
+    EVPLP_ERR_IO = -4,          /* file could not be read / written */
+    EVPLP_ERR_PARSE = -5,       /* JSON / OBJ syntax or missing required key */
+    EVPLP_ERR_OOM = -6
+} evplp_status;
+
+/* rt/rtcomphoton/rtphotonrecord.h:9-15 PhotonRecordFlag */
+enum {
+    EVPLP_USABLE_VPL = 1, EVPLP_USABLE_PHOTON = 2, EVPLP_LAMBERT_ONLY = 4, EVPLP_PHONG_ONLY = 8
+};
+
+/* rt/rtcomphoton/rtphotonrecord.h:17-25 RtPhotonRecord (GLSL mirror photonsplatinstanced.frag:25-33):
+ * identical 96-byte array-of-structures layout, so record buffers are interchangeable. */
+typedef struct evplp_record {
+    float pos[3];      uint32_t flags;
+    float normal[3];   float p_select_lambert;
+    float flux[3];     float pad1;
+    float flux_dir[3]; float pad2;
+    float rho_d[3];    float pad3;
+    float rho_s[3];    float phong_exp;
+} evplp_record;
+
+/* rt/rtcomphoton/rtcomphoton.h:64-72 EMis */
+typedef enum evplp_mis_mode {
+    EVPLP_MIS_ONE = 0, EVPLP_MIS_BALANCE = 1, EVPLP_MIS_MAX = 2, EVPLP_MIS_POWER2 = 3,
+    EVPLP_MIS_GEOMETRY_CLAMP = 4, EVPLP_MIS_GEOMETRY_BRDF_CLAMP = 5
+} evplp_mis_mode;
+
+typedef enum evplp_bvh_builder {
+    EVPLP_BVH_LBVH = 0,   /* Morton-code LBVH (north-star layout) */
+    EVPLP_BVH_SAH = 1     /* binned-SAH top-down build into the same flattened node format */
+} evplp_bvh_builder;
+
+/* Creation-time configuration: what RtComPhoton::render fixes before setup()
+ * (rtcomphoton.h:107-223) plus the build-only device / strip block. */
+typedef struct evplp_config {
+    int32_t abi_version;         /* EVPLP_ABI_VERSION */
+    int32_t device;              /* HIP device ordinal */
+    int32_t res_x, res_y;        /* main.cpp:108,114 */
+    int32_t strip_rank;          /* row-strip partition; {0,1,H} = whole image */
+    int32_t strip_count;
+    int32_t strip_rows;          /* block height in rows, multiple of 8 */
+    uint32_t num_light_paths;    /* rtcomphoton.h:114 */
+    uint32_t num_vpl_light_paths;/* rtcomphoton.h:115 */
+    uint32_t photons_per_path;   /* numMaxBounces + 1, rtcomphoton.h:116-117 */
+    int32_t bvh_builder;         /* evplp_bvh_builder */
+    int32_t deterministic;       /* 1: photon bins are accumulated in record order (bitwise reproducible) */
+    int32_t reserved[4];
+} evplp_config;
+
+/* rt/rtcommon.h:278-308 RtMaterial: three RGBA32F textures (a constant is a 1x1 texture,
+ * rtcommon.h:80-90) + mLightIntensity.  tex_* = id from evplp_add_texture or -1 for the constant. */
+typedef struct evplp_material {
+    float kd[3]; float ks[3]; float ns;
+    int32_t tex_kd, tex_ks, tex_ns;
+} evplp_material;
+
+/* rt/rtcommon.h:546-598 RtStableCamera ("direction" of the JSON is a look-at point) */
+typedef struct evplp_camera {
+    float origin[3]; float lookat[3]; float up[3];
+    float fovy;     /* radians; fovx is converted by the caller as rtcommon.h:559 */
+    float aspect;
+} evplp_camera;
+
+/* The OptiX variables / GL uniforms RtComPhoton::run() sets per iteration
+ * (rtcomphoton.h:895-930, 819-823, 1043-1061): the de-facto device ABI of the reference. */
+typedef struct evplp_frame_params {
+    float camera_pos[3];         /* cameraPosition / uCameraPosition */
+    uint32_t mis_mode;           /* misMode / uMisMode */
+    float pdf_mc;                /* pdfMc / uPdfMc */
+    float clamping_value;        /* clampingValue / uClampingValue */
+    float photon_radius;         /* radius / uPhotonRadius */
+    float vsl_radius;            /* vslRadius */
+    float vsl_inv_pi_radius2;    /* vslInvPiRadius2 */
+    uint32_t num_light_paths;    /* numLightPaths (1/N = uInvNumLightPaths) */
+    uint32_t num_vpl_light_paths;/* numVplLightPaths */
+    uint32_t photons_per_path;   /* numPhotonsPerLightPath */
+    uint32_t do_accumulate;      /* doAccumulate */
+    uint32_t rng_seed;           /* rngSeed = numIterations + rngOffset (rtcomphoton.h:965) */
+    float jitter[2];             /* NDC translation of the jitter matrix (rtcomphoton.h:949) */
+} evplp_frame_params;
+
+/* Device buffers a caller may read back, bind to external memory, or hand to a collective. */
+typedef enum evplp_buffer {
+    EVPLP_BUF_RECORDS = 0,   /* evplp_record[num_light_paths * photons_per_path]  ("photons", rtcomphoton.h:910) */
+    EVPLP_BUF_GBUF_POSITION, /* float4[local_rows * W]  deferredPositionTexture */
+    EVPLP_BUF_GBUF_NORMAL,   /* float4[...]             deferredNormalTexture */
+    EVPLP_BUF_GBUF_DIFFUSE,  /* float4[...]             deferredDiffuseTexture */
+    EVPLP_BUF_GBUF_PHONG,    /* float4[...]             deferredPhongReflectanceTexture (rgb, exponent) */
+    EVPLP_BUF_LIGHT,         /* float4[...]             mLightTexture */
+    EVPLP_BUF_VPL_ACCUM,     /* float4[...]             outputBuffer (rtcomphoton.h:897) */
+    EVPLP_BUF_PHOTON_ACCUM,  /* float4[...] (rgb used)  mPhotonSplatTexture */
+    EVPLP_BUF_COUNT
+} evplp_buffer;
+
+/* Per-pass statistics of the last call (hipEvent timing on the context stream). */
+typedef struct evplp_pass_stats {
+    float ms;                /* device time of the pass */
+    uint64_t pairs;          /* gather: (pixel, usable record) pairs; splat: (photon, covered pixel) pairs */
+    uint64_t rays;           /* rays traced by the pass */
+    uint64_t usable;         /* usable VPL / photon records consumed */
+    float dominant_kernel_ms;/* device time of the pass's dominant kernel alone */
+    uint32_t reserved[3];
+} evplp_pass_stats;
+
+typedef enum evplp_pass {
+    EVPLP_PASS_PRIMARY = 0, EVPLP_PASS_LIGHT_TRACE, EVPLP_PASS_GATHER_VPL, EVPLP_PASS_GATHER_VSL,
+    EVPLP_PASS_SPLAT, EVPLP_PASS_RESOLVE, EVPLP_PASS_COUNT
+} evplp_pass;
+
+typedef struct evplp_context evplp_context;
+
+/* ---- lifetime.  Replaces RtComPhoton::setup()/destroy() (rtcomphoton.h:646-708, 1135-1138). ---- */
+int evplp_create(const evplp_config *cfg, evplp_context **out);
+void evplp_destroy(evplp_context *ctx);
+const char *evplp_last_error(const evplp_context *ctx); /* ctx may be NULL: error of a failed create */
+int evplp_abi_version(void);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = context's own stream. */
+int evplp_set_stream(evplp_context *ctx, void *hip_stream);
+int evplp_synchronize(evplp_context *ctx);
+
+/* ---- scene upload.  Replaces the createOptix.. / createOpengl.. uploads of RtMesh, RtMaterial and RtTexture
+ * (rt/rtcommon.h:196-245, 357-429) and RtScene::addObject/addAreaLight's results (:644-798).
+ * Host pointers; the library copies.  Call order: textures, materials, meshes, area light,
+ * camera, then evplp_build_accel. ---- */
+int evplp_add_texture(evplp_context *ctx, int32_t w, int32_t h, const float *rgba); /* returns id >= 0 */
+int evplp_add_material(evplp_context *ctx, const evplp_material *m);                /* returns index >= 0 */
+/* RtMesh SoA (rtcommon.h:460-467): vertices float3[nverts], texcoords float2[nverts] (NULL = zeros,
+ * rtcommon.h:701-705), triangle indices int3[ntris], one material.  Returns mesh index >= 0. */
+int evplp_add_mesh(evplp_context *ctx, const float *vertices, const float *texcoords, int32_t nverts,
+                   const int32_t *indices, int32_t ntris, int32_t material);
+/* RtScene::addAreaLight (rtcommon.h:772-798): mesh becomes the single emitter, its material is
+ * replaced by the black emitter material; intensity = JSON [r,g,b,w] (xyz scaled by pi inside). */
+int evplp_set_arealight(evplp_context *ctx, int32_t mesh, const float intensity[4]);
+int evplp_set_camera(evplp_context *ctx, const evplp_camera *cam);
+/* OptiX "Trbvh" acceleration (rtcomphoton.h:705-707) + area-light CDF (rtcommon.h:501-531). */
+int evplp_build_accel(evplp_context *ctx);
+/* RtScene::findBoundingSphereRadius (rtcommon.h:805-814), totalArea (:759-768), light area (:529) */
+int evplp_scene_metrics(evplp_context *ctx, float *bounding_sphere_radius, float *total_area, float *light_area);
+
+/* ---- the per-iteration passes of RtComPhoton::run() (rtcomphoton.h:936-1068) ---- */
+/* [deferredShading] + [lightRender]: runDeferredProgram (:710-754) + runLightProgram (:839-855);
+ * jitter = (2u-1)/res NDC translation (:949); light plane is cleared iff clear_light != 0 (:990-993). */
+int evplp_primary(evplp_context *ctx, const float jitter[2], int32_t clear_light);
+/* [lightTracing]: launch(LightTrace, numLightPaths) (:869-881).  Traces paths
+ * [path_begin, path_begin+path_count) into the record buffer (multi-GPU: each rank a slice). */
+int evplp_trace_light_paths(evplp_context *ctx, uint32_t rng_seed, uint32_t path_begin, uint32_t path_count);
+/* [vplSplat]: launch(VplSplat, W, H) with splatColor (rt/lighttracing.cu:348-379) */
+int evplp_gather_vpl(evplp_context *ctx, const evplp_frame_params *fp);
+/* [vplSplat] with forceVsl: splatSplotch (rt/lighttracing.cu:689-722) */
+int evplp_gather_vsl(evplp_context *ctx, const evplp_frame_params *fp);
+/* [photonSplat]: runPhotonSplat (:789-837); clear != 0 = cleareveryframe (:978-981) */
+int evplp_splat_photons(evplp_context *ctx, const evplp_frame_params *fp, int32_t clear);
+/* [finalize] / dumpImage: runFinalProgram(vplScale, photonScale, lightScale, gamma) (:756-787,
+ * final.frag:19-35).  mask_emitter = on-screen composite (1) or saved-image sum (0, :1121-1132).
+ * out_rgb: HOST pointer, 3 floats per pixel, local_rows * W pixels, y = 0 bottom. */
+int evplp_resolve(evplp_context *ctx, float vpl_scale, float photon_scale, float light_scale,
+                  int32_t mask_emitter, int32_t gamma, float *out_rgb);
+int evplp_clear_accumulators(evplp_context *ctx);
+
+/* ---- buffers / statistics ---- */
+int evplp_local_rows(const evplp_context *ctx);
+int evplp_buffer_info(evplp_context *ctx, int32_t which, void **device_ptr, size_t *bytes);
+/* Use caller-owned device memory (e.g. a torch tensor passed to an RCCL collective). */
+int evplp_bind_buffer(evplp_context *ctx, int32_t which, void *device_ptr, size_t bytes);
+int evplp_download(evplp_context *ctx, int32_t which, void *host_dst, size_t bytes);
+int evplp_upload(evplp_context *ctx, int32_t which, const void *host_src, size_t bytes);
+int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out);
+/* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
+int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
+
+/* ---- host side of the reference interface (no GPU needed for these) ---- */
+/* Progressive schedule, rtcomphoton.h:1033-1063; call after numIterations++ */
+void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clamp_start,
+                            uint32_t n_vpl_paths, uint32_t n_light_paths,
+                            float *photon_radius, float *clamping_value, float *pdf_mc,
+                            int32_t force_vsl, float *vsl_radius, float *vsl_inv_pi_radius2);
+/* FloatImage::Save by extension (common/floatimage/floatimage.cpp:260-273): .pfm / .png.
+ * rgb: top-down rows (after FlipY, rtcomphoton.h:1124-1127), 3 floats per pixel. */
+int evplp_save_image(const char *path, int32_t w, int32_t h, const float *rgb_top_down);
+int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb_top_down, size_t capacity_floats);
+double evplp_image_mse(int32_t npix, const float *img, const float *ref);     /* floatimage.cpp:64-84 */
+double evplp_image_rel_mse(int32_t npix, const float *img, const float *ref); /* floatimage.cpp:86-112 */
+/* Writes a procedural closed "conference-like" room (OBJ + MTL + light OBJ + scene JSON in the
+ * reference's schema) because every mesh of the reference is a Git-LFS stub.
+ * Returns the number of scene triangles written (>= 0) or a negative evplp_status. */
+int evplp_synth_scene(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed,
+                      int32_t res_x, int32_t res_y);
+/* main() + LoadScene + RtComPhoton::render (main.cpp:87-121, rtcomphoton.h:107-223): parse the
+ * scene JSON, load OBJ/MTL, run the `photonfam` technique, write the three images + stat file.
+ * json_overrides: optional JSON object text merged over the `photonfam` block (may be NULL). */
+int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVPLP_H */

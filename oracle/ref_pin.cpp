@@ -1,0 +1,56 @@
+// oracle/_ref/libref_pin.so -- thin extern "C" entry points INTO the reference's own code, used
+// only by tests/test_oracle_pins.py to pin the parts of the oracle that the reference can vouch
+// for in this container:
+//   * FloatImage::Save / FlipY / ComputeMse / ComputeRelMse  (common/floatimage/floatimage.cpp)
+//   * glm::lookAt / glm::perspective / glm::translate exactly as RtStableCamera::computeVpMatrix
+//     and the jitter matrix use them (rt/rtcommon.h:586-591, rt/rtcomphoton/rtcomphoton.h:943-952),
+//     from the GLM 0.9.8 vendored under dependencies/include.
+//   * Aabb::Union / DiagonalLength2 (math/aabb.h) feeding the photon radius (rtcommon.h:805-814).
+// This file contains no reference code; it calls it.
+#include "common/floatimage/floatimage.h"
+#include "math/aabb.h"
+
+#include <glm/gtc/matrix_transform.hpp>
+#include <glm/gtx/transform.hpp>
+
+static FloatImage make_image(int w, int h, const float *rgb) {
+    FloatImage img((size_t)w, (size_t)h);
+    std::memcpy(img.getFloats(), rgb, sizeof(float) * 3 * (size_t)w * h);
+    return img;
+}
+
+extern "C" {
+
+int ref_save(const char *path, int w, int h, const float *rgb_top_down) {
+    try { FloatImage::Save(make_image(w, h, rgb_top_down), path); } catch (...) { return -1; }
+    return 0;
+}
+void ref_flip_y(int w, int h, const float *rgb, float *out) {
+    FloatImage f = FloatImage::FlipY(make_image(w, h, rgb));
+    std::memcpy(out, f.getFloats(), sizeof(float) * 3 * (size_t)w * h);
+}
+double ref_mse(int w, int h, const float *a, const float *ref) { return FloatImage::ComputeMse(make_image(w, h, a), make_image(w, h, ref)); }
+double ref_rel_mse(int w, int h, const float *a, const float *ref) { return FloatImage::ComputeRelMse(make_image(w, h, a), make_image(w, h, ref)); }
+
+// projection * view (rtcommon.h:586-591), optionally pre-multiplied by the jitter translation
+// (rtcomphoton.h:949-951).  out: 16 floats, column-major like GLM.
+void ref_view_projection(const float origin[3], const float lookat[3], const float up[3], float fovy, float aspect,
+                         const float jitter[2], float out[16]) {
+    glm::mat4 view = glm::lookAt(glm::vec3(origin[0], origin[1], origin[2]), glm::vec3(lookat[0], lookat[1], lookat[2]), glm::vec3(up[0], up[1], up[2]));
+    glm::mat4 proj = glm::perspective(fovy, aspect, 0.1f, 100.0f);
+    glm::mat4 m = proj * view;
+    if (jitter) m = glm::translate(glm::vec3(jitter[0], jitter[1], 0)) * m;
+    std::memcpy(out, &m[0][0], sizeof(float) * 16);
+}
+// fovx (degrees) -> fovy exactly as rtcommon.h:556-560
+float ref_fovx_to_fovy(float fovx_degree, float aspect) { return 2.0f * std::atan2(std::tan(glm::radians(fovx_degree) * 0.5f), aspect); }
+
+// RtScene::findBoundingSphereRadius (rtcommon.h:805-814) over a vertex list
+float ref_bounding_sphere_radius(int nverts, const float *verts) {
+    Aabb bbox;
+    for (int i = 0; i < nverts; i++) bbox = Aabb::Union(bbox, Vec3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]));
+    float diameter = std::sqrt(Aabb::DiagonalLength2(bbox));
+    return diameter / 2.0f;
+}
+
+}
