@@ -86,6 +86,8 @@ _SIGNATURES = {
     "evplp_add_mesh": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32]),
     "evplp_set_arealight": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float * 4)]),
     "evplp_set_camera": (C.c_int, [_P, C.POINTER(Camera)]),
+    "evplp_load_scene_json": (C.c_int, [_P, C.c_char_p]),
+    "evplp_get_camera": (C.c_int, [_P, C.POINTER(Camera)]),
     "evplp_build_accel": (C.c_int, [_P]),
     "evplp_scene_metrics": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "evplp_primary": (C.c_int, [_P, C.POINTER(C.c_float * 2), C.c_int32]),
@@ -236,6 +238,16 @@ class Context:
 
     def build_accel(self):
         self._check(self._lib.evplp_build_accel(self._h))
+
+    def load_scene_json(self, json_path: str):
+        rc = self._lib.evplp_load_scene_json(self._h, json_path.encode())
+        if rc < 0:
+            raise EvplpError(rc, f"evplp_load_scene_json({json_path}): " + self._lib.evplp_last_error(self._h).decode())
+
+    def camera(self) -> Camera:
+        cam = Camera()
+        self._check(self._lib.evplp_get_camera(self._h, C.byref(cam)))
+        return cam
 
     def scene_metrics(self):
         r, t, l = C.c_float(), C.c_float(), C.c_float()

@@ -97,7 +97,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     c->tiles_x = (c->st.W + 7) / 8; c->tiles_y = c->st.local_rows / 8;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     const size_t nrec = (size_t)cfg->num_light_paths * cfg->photons_per_path;
-    c->bin_capacity = (uint32_t)std::min<size_t>(std::max<size_t>(nrec * 24, 1u << 20), 0xfffffff0u);
+    c->bin_capacity = (uint32_t)std::min<size_t>(std::max<size_t>(nrec * 8, 1u << 20), 0xfffffff0u);   // grown on demand
     if ((e = hipMalloc((void **)&c->d_tile_count, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_count)", e);
     if ((e = hipMalloc((void **)&c->d_tile_offset, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_offset)", e);
     if ((e = hipMalloc((void **)&c->d_tile_cursor, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_cursor)", e);
@@ -208,7 +208,15 @@ extern "C" int evplp_set_camera(evplp_context *c, const evplp_camera *cam) {
     std::memset(&c->cam, 0, sizeof(c->cam));
     std::memcpy(c->cam.eye, cam->origin, 12); std::memcpy(c->cam.s, s, 12); std::memcpy(c->cam.u, u, 12); std::memcpy(c->cam.f, f, 12);
     c->cam.tan_half = std::tan(cam->fovy / 2.0f); c->cam.aspect = cam->aspect;
+    c->cam_in = *cam;
     c->camera_set = true;
+    return EVPLP_OK;
+}
+
+extern "C" int evplp_get_camera(evplp_context *c, evplp_camera *out) {
+    CTX_CHECK(c);
+    if (!out || !c->camera_set) { c->set_error("evplp_get_camera: camera not set"); return EVPLP_ERR_INVALID; }
+    *out = c->cam_in;
     return EVPLP_OK;
 }
 
@@ -413,7 +421,26 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
     HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
-    launch_splat(a, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    launch_splat_count(a, c->stream);
+    // The number of (photon, tile) bin entries depends on the photon set and the radius; read it back
+    // (4 bytes, one stream sync per splat) and grow the bins when needed instead of dropping photons.
+    uint32_t total = 0;
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->d_tile_offset + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (total > c->bin_capacity) {
+        uint32_t want = (uint32_t)std::min<uint64_t>((uint64_t)total + total / 4 + 1024, 0xfffffff0ull);
+        hipFree(c->d_bin_items); c->d_bin_items = nullptr;
+        if (c->d_bin_items_tmp) { hipFree(c->d_bin_items_tmp); c->d_bin_items_tmp = nullptr; }
+        hipError_t e1 = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * (size_t)want);
+        hipError_t e2 = c->cfg.deterministic ? hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * (size_t)want) : hipSuccess;
+        if (e1 != hipSuccess || e2 != hipSuccess) { c->bin_capacity = 0; c->set_error("photon bins: cannot allocate %u entries", want); return EVPLP_ERR_OOM; }
+        c->bin_capacity = want;
+        a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_capacity = want;
+        HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
+    }
+    c->last_bin_entries = total;
+    launch_splat_tiles(a, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
     return pass_end(c, EVPLP_PASS_SPLAT);
 }
@@ -496,7 +523,7 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
         out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = pc.rays; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
         out->reserved[1] = (uint32_t)(pc.nodes >> 32);
     } else if (pass == EVPLP_PASS_SPLAT) {
-        out->pairs = pc.pairs; out->rays = 0; out->usable = 0; out->reserved[0] = scal[8];
+        out->pairs = pc.pairs; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries;
         if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }
     } else if (pass == EVPLP_PASS_PRIMARY) out->rays = c->stats_host[pass].rays;
     return EVPLP_OK;

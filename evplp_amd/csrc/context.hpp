@@ -30,7 +30,7 @@ struct evplp_context {
     std::vector<evplp::HostTexture> textures;
     int32_t light_mesh = -1;
     float light_unscaled[4] = {}, light_scaled[4] = {};
-    evplp::CamBasis cam{};
+    evplp::CamBasis cam{}; evplp_camera cam_in{};
     bool camera_set = false, accel_built = false;
     float bounding_radius = 0.f, total_area = 0.f, light_area = 0.f;
     int32_t accel_nodes = 0, accel_leaves = 0, accel_depth = 0; float accel_build_ms = 0.f;
@@ -41,7 +41,7 @@ struct evplp_context {
     evplp::PassCounters *d_counters = nullptr;
     float *d_rgb = nullptr;
     // splat workspace
-    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0;
+    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0, last_bin_entries = 0;
     uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
     float4 *d_compact = nullptr; uint2 *d_rect = nullptr;
 

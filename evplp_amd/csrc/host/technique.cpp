@@ -231,6 +231,17 @@ private:
 
 } // namespace evplp
 
+extern "C" int evplp_load_scene_json(evplp_context *ctx, const char *json_path) {
+    using namespace evplp;
+    if (!ctx || !json_path) return EVPLP_ERR_INVALID;
+    try {
+        Json root = Json::parse(read_text_file(json_path));
+        HostScene scene = load_scene(root, json_path);
+        return upload_scene(ctx, scene);
+    } catch (const JsonError &) { return EVPLP_ERR_PARSE; }
+    catch (const std::exception &) { return EVPLP_ERR_IO; }
+}
+
 extern "C" int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap) {
     using namespace evplp;
     auto fail = [&](int code, const std::string &msg) { if (err && err_cap) { std::snprintf(err, err_cap, "%s", msg.c_str()); } return code; };

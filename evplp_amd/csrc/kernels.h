@@ -63,7 +63,8 @@ void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record
                         uint32_t *count_out, hipStream_t s);
 void launch_gather_vpl(const GatherArgs &a, hipStream_t s);
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
-void launch_splat(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
+void launch_splat_count(const SplatArgs &a, hipStream_t s);
+void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s);

@@ -252,12 +252,18 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     if (lane == 0 && pairs) atomicAdd(&a.counters->pairs, (unsigned long long)pairs);
 }
 
-void launch_splat(const SplatArgs &a, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
+// Phase A: compact photons + tile counts + exclusive scan (tile_offset[ntiles] = total bin entries).
+void launch_splat_count(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * (ntiles + 1), s);
     const uint32_t nb = (a.num_records + 255) / 256;
     hipLaunchKernelGGL(splat_prepare_kernel, dim3(nb), dim3(256), 0, s, a);
     hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, s, a.tile_count, a.tile_offset, a.tile_cursor, ntiles, a.bin_capacity, a.overflow);
+}
+// Phase B: fill the bins (capacity already checked by the host) and accumulate the tiles.
+void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
+    const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
+    const uint32_t nb = (a.num_records + 255) / 256;
     if (a.deterministic) {
         hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items_tmp);
         hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_offset, a.bin_items_tmp, a.bin_items, a.bin_capacity);

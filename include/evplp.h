@@ -167,6 +167,10 @@ int evplp_add_mesh(evplp_context *ctx, const float *vertices, const float *texco
  * replaced by the black emitter material; intensity = JSON [r,g,b,w] (xyz scaled by pi inside). */
 int evplp_set_arealight(evplp_context *ctx, int32_t mesh, const float intensity[4]);
 int evplp_set_camera(evplp_context *ctx, const evplp_camera *cam);
+/* LoadScene (main.cpp:42-85) in one call: read the scene JSON (resX/resY, scene[], arealight, camera |
+ * stablecamera), its OBJ/MTL files, upload everything and build the acceleration structure. */
+int evplp_load_scene_json(evplp_context *ctx, const char *json_path);
+int evplp_get_camera(evplp_context *ctx, evplp_camera *out);
 /* OptiX "Trbvh" acceleration (rtcomphoton.h:705-707) + area-light CDF (rtcommon.h:501-531). */
 int evplp_build_accel(evplp_context *ctx);
 /* RtScene::findBoundingSphereRadius (rtcommon.h:805-814), totalArea (:759-768), light area (:529) */
