@@ -245,7 +245,8 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     out->nodes = (BvhNode *)std::malloc(sizeof(BvhNode) * flat.size());
     std::memcpy(out->nodes, flat.data(), sizeof(BvhNode) * flat.size());
     out->ntris = (int32_t)order.size();
-    out->tris = (TriPre *)std::malloc(sizeof(TriPre) * std::max<size_t>(order.size(), 1));
+    // +3 zeroed slots: the leaf fetch of the traversal kernels always reads a block of 4 triangles
+    out->tris = (TriPre *)std::calloc(order.size() + 4, sizeof(TriPre));
     out->tri_index = (int32_t *)std::malloc(sizeof(int32_t) * std::max<size_t>(order.size(), 1));
     for (size_t i = 0; i < order.size(); i++) { precompute_tri(verts + 9 * (size_t)order[i], &out->tris[i]); out->tri_index[i] = order[i]; }
     out->nleaves = nleaves; out->depth = B.depth + 1;

@@ -290,7 +290,7 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     }
     int rc;
     if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
-    if ((rc = upload_array(c, bb.tris, (size_t)bb.ntris, &c->sc.tris))) { free_bvh(&bb); return rc; }
+    if ((rc = upload_array(c, bb.tris, (size_t)bb.ntris + 3, &c->sc.tris))) { free_bvh(&bb); return rc; }   // +3 pad slots (leaf block fetch)
     if ((rc = upload_array(c, bb.tri_index, (size_t)bb.ntris, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
     c->sc.ntris = bb.ntris;
     free_bvh(&bb);

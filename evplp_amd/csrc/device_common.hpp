@@ -251,52 +251,89 @@ EV_DEV float safe_rcp(float d) {
     return __builtin_amdgcn_rcpf(a);
 }
 
+// One wide scalar fetch of a wave-uniform 64-byte block (s_load_dwordx16): the whole BVH node (or a
+// third of a 4-triangle leaf block) arrives with ONE exposed latency instead of one per field.
+typedef int v16i __attribute__((ext_vector_type(16)));
+EV_DEV float f_of(int x) { return __int_as_float(x); }
+
+// exact triangle test on raw dwords d[0..11] = p0, e0, e1, n (same arithmetic as tri_test)
+EV_DEV bool tri_test_raw(float p0x, float p0y, float p0z, float e0x, float e0y, float e0z, float e1x, float e1y, float e1z,
+                         float nx, float ny, float nz, V3 o, V3 d, float tmin, float tmax) {
+#pragma clang fp contract(off)
+    float den = nx * d.x + ny * d.y + nz * d.z;
+    float inv = 1.0f / den;
+    float qx = (p0x - o.x) * inv, qy = (p0y - o.y) * inv, qz = (p0z - o.z) * inv;
+    float ix = d.y * qz - d.z * qy, iy = d.z * qx - d.x * qz, iz = d.x * qy - d.y * qx;
+    float beta = ix * e1x + iy * e1y + iz * e1z;
+    float gamma = ix * e0x + iy * e0y + iz * e0z;
+    float t = nx * qx + ny * qy + nz * qz;
+    return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
+}
+
+// Stack-in-a-VGPR helpers: entry k of the wave's stack is lane k of one register.  A push is a
+// compare + select against the lane id (this clang has no v_writelane builtin), a pop is v_readlane
+// with a scalar lane index; neither touches memory.
+EV_DEV int lane_write(int value, int slot, int old) { return ((int)(threadIdx.x & 63u) == slot) ? value : old; }
+EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot); }
+
 // Any-hit traversal of ONE WAVE whose 64 rays share the origin `o` (a VPL): the node index, the
-// stack (in LDS, one per wavefront) and all node/triangle fetches are wave-uniform (scalar
-// loads); lanes only differ in direction.  `alive` lanes still need an answer; a lane that
-// finds an occluder drops out of the ballots, and the walk ends when no lane is alive or the
-// stack is empty.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit, rt/lighttracing.cu:184-188,290-294.
-// Returns true for lanes whose segment is occluded.
+// stack and all node/triangle fetches are wave-uniform (scalar loads); lanes only differ in
+// direction.  `alive` lanes still need an answer; a lane that finds an occluder drops out of the
+// ballots, and the walk ends when no lane is alive or the stack is empty.
+// The per-wavefront stack lives in the 64 lanes of ONE VGPR (select-by-lane-id push, v_readlane pop,
+// scalar stack pointer: no memory latency on either); entries beyond 64 spill to the wave's LDS stack.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit,
+// rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
 EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive,
                           int32_t *wave_stack, uint32_t &nodes_visited) {
     V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     bool hit = false;
     int sp = 0;
+    int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
     if (__ballot(alive) == 0ull) return false;
     for (;;) {
         if (cur >= 0) {
-            cur = __builtin_amdgcn_readfirstlane(cur);
-            const BvhNode &n = sc.nodes[cur];
+            const v16i *np = reinterpret_cast<const v16i *>(sc.nodes + __builtin_amdgcn_readfirstlane(cur));
+            const v16i n = *np;
             nodes_visited++;
-            bool h0 = alive && slab_hit(n.lo0, n.hi0, inv, noi, tmin, tmax);
-            bool h1 = alive && slab_hit(n.lo1, n.hi1, inv, noi, tmin, tmax);
-            unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-            int32_t c0 = n.c0, c1 = n.c1;
+            const float lo0[3] = { f_of(n[0]), f_of(n[1]), f_of(n[2]) }, hi0[3] = { f_of(n[3]), f_of(n[4]), f_of(n[5]) };
+            const float lo1[3] = { f_of(n[6]), f_of(n[7]), f_of(n[8]) }, hi1[3] = { f_of(n[9]), f_of(n[10]), f_of(n[11]) };
+            const bool h0 = slab_hit(lo0, hi0, inv, noi, tmin, tmax) & alive;
+            const bool h1 = slab_hit(lo1, hi1, inv, noi, tmin, tmax) & alive;
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            const int32_t c0 = n[12], c1 = n[13];
             if (m0 && m1) {
                 // descend into the child wanted by more lanes first
-                bool first0 = __popcll(m0) >= __popcll(m1);
-                int32_t nxt = first0 ? c0 : c1, oth = first0 ? c1 : c0;
-                wave_stack[sp++] = oth;
-                cur = nxt;
+                const bool first0 = __popcll(m0) >= __popcll(m1);
+                const int32_t oth = first0 ? c1 : c0;
+                if (sp < 64) vstack = lane_write(oth, sp, vstack); else wave_stack[sp - 64] = oth;
+                sp++;
+                cur = first0 ? c0 : c1;
                 continue;
             } else if (m0) { cur = c0; continue; }
             else if (m1) { cur = c1; continue; }
         } else if (cur != kNoChild) {
-            int32_t id = __builtin_amdgcn_readfirstlane(~cur);
-            int32_t first = id >> 2, cnt = (id & 3) + 1;
-            for (int32_t k = 0; k < cnt; k++) {
-                const TriPre &tp = sc.tris[first + k];
-                float t, b, g;
-                bool h = tri_test(tp, o, d, tmin, tmax, t, b, g);
-                hit = hit || (alive && h);
-            }
-            alive = alive && !hit;
+            const int32_t id = __builtin_amdgcn_readfirstlane(~cur);
+            const int32_t first = id >> 2, cnt = (id & 3) + 1;
+            // a leaf is a block of up to 4 triangles (192 B); fetch all of it before testing
+            const v16i *tp = reinterpret_cast<const v16i *>(sc.tris + first);
+            const v16i a = tp[0], b = tp[1], c = tp[2];
+            bool h = tri_test_raw(f_of(a[0]), f_of(a[1]), f_of(a[2]), f_of(a[3]), f_of(a[4]), f_of(a[5]), f_of(a[6]), f_of(a[7]), f_of(a[8]),
+                                  f_of(a[9]), f_of(a[10]), f_of(a[11]), o, d, tmin, tmax);
+            if (cnt > 1) h |= tri_test_raw(f_of(a[12]), f_of(a[13]), f_of(a[14]), f_of(a[15]), f_of(b[0]), f_of(b[1]), f_of(b[2]), f_of(b[3]), f_of(b[4]),
+                                           f_of(b[5]), f_of(b[6]), f_of(b[7]), o, d, tmin, tmax);
+            if (cnt > 2) h |= tri_test_raw(f_of(b[8]), f_of(b[9]), f_of(b[10]), f_of(b[11]), f_of(b[12]), f_of(b[13]), f_of(b[14]), f_of(b[15]), f_of(c[0]),
+                                           f_of(c[1]), f_of(c[2]), f_of(c[3]), o, d, tmin, tmax);
+            if (cnt > 3) h |= tri_test_raw(f_of(c[4]), f_of(c[5]), f_of(c[6]), f_of(c[7]), f_of(c[8]), f_of(c[9]), f_of(c[10]), f_of(c[11]), f_of(c[12]),
+                                           f_of(c[13]), f_of(c[14]), f_of(c[15]), o, d, tmin, tmax);
+            hit = hit | (alive & h);
+            alive = alive & !hit;
             if (__ballot(alive) == 0ull) return hit;
         }
         if (sp == 0) return hit;
-        cur = __builtin_amdgcn_readfirstlane(wave_stack[--sp]);
+        sp--;
+        cur = sp < 64 ? lane_read(vstack, sp) : __builtin_amdgcn_readfirstlane(wave_stack[sp - 64]);
     }
 }
 

@@ -2,9 +2,13 @@
 //   gather_vpl_kernel <- splatColor + vplSplat   (rt/lighttracing.cu:348-379, 275-346)
 //   gather_vsl_kernel <- splatSplotch + vslSplat (rt/lighttracing.cu:689-722, 596-686, 395-594)
 //
-// Mapping.  One wavefront owns an 8x8 pixel tile (lane = pixel); a workgroup is 2x2 such tiles.
-// The compacted VPL list streams through LDS in chunks staged cooperatively by the workgroup;
-// every lane reads the SAME record (LDS broadcast).  For one VPL the 64 shadow segments of a wave
+// Mapping.  A workgroup (4 wavefronts) owns ONE 8x8 pixel tile: lane = pixel in every wave, and the
+// compacted VPL list is dealt round-robin to the four waves (VPL i goes to wave i % 4); the four
+// partial sums meet in LDS and are added in wave order (bitwise reproducible).  Small work items
+// (16k+ workgroups at 1024^2) keep all 256 CUs busy to the end of the launch; with one 16x16 tile
+// per workgroup the launch ended on a long tail at ~2.2 of 5 resident waves per SIMD (profiles/
+// r01_bench_ir_pmc_v1.json).  The VPL list streams through LDS in chunks staged cooperatively by
+// the workgroup; every lane reads the SAME record (LDS broadcast).  For one VPL the 64 shadow segments of a wave
 // share their origin (the VPL) and end on neighbouring surface points, so the wave walks the BVH
 // as a packet: one node stack per wavefront in LDS, node/triangle fetches are scalar loads, the
 // descent is decided by ballots over the lanes that are still undecided, and lanes whose
@@ -61,33 +65,63 @@ EV_DEV void stage_chunk(float4 *dst, const evplp_record *src, uint32_t begin, ui
     for (uint32_t i = tid; i < n * kRecF4; i += 256) dst[i] = s[i];
 }
 
-// XCD-aware tile order: consecutive block ids land on different XCDs (round-robin dispatch), so
-// give each XCD a contiguous band of tiles and keep neighbouring tiles on one L2.
-EV_DEV int xcd_swizzle(int b, int nb) {
-    int per = nb >> 3;
-    if (per == 0 || b >= per * 8) return b;
-    return (b & 7) * per + (b >> 3);
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8,
+// speed only, never correctness).  Tiles are grouped into super-tiles of 8x8 tiles (64x64 pixels);
+// the j-th workgroup of an XCD walks super-tile after super-tile, and super-tiles are interleaved
+// over the XCDs, so that (a) neighbouring tiles share one L2 and (b) every XCD gets the same mix of
+// cheap and expensive image regions (a contiguous band per XCD left XCDs idle for half the launch).
+EV_DEV bool map_tile(int b, int nb, int tiles_x, int tiles_y, int &tx, int &ty) {
+    const int sx = (tiles_x + 7) >> 3, sy = (tiles_y + 7) >> 3;   // super-tile grid
+    const int xcd = b & 7, j = b >> 3;
+    const int s = (j >> 6) * 8 + xcd, within = j & 63;
+    if (s >= sx * sy) return false;
+    tx = (s % sx) * 8 + (within & 7);
+    ty = (s / sx) * 8 + (within >> 3);
+    return tx < tiles_x && ty < tiles_y;
+}
+
+constexpr int kWavesPerTile = 4;
+
+struct TileSetup { int x, ly, gy; bool in_image, has_tile; size_t p; };
+EV_DEV TileSetup tile_setup(const StripDev &st, int lane) {
+    const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
+    int tx = 0, ty = 0;
+    const bool has_tile = map_tile(blockIdx.x, gridDim.x, tiles_x, tiles_y, tx, ty);
+    TileSetup t; t.has_tile = has_tile;
+    t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
+    const int cly = min(t.ly, st.local_rows - 1);
+    t.gy = st.global_row(cly);
+    t.in_image = has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
+    t.p = (size_t)cly * st.W + min(t.x, st.W - 1);
+    return t;
+}
+// add the four per-wave partial sums in wave order and apply  out = sum / numVpl + doAccumulate * out
+EV_DEV void reduce_and_store(const GatherArgs &a, float (*red)[64][3], V3 result, int wave, int lane, bool write, size_t p) {
+    red[wave][lane][0] = result.x; red[wave][lane][1] = result.y; red[wave][lane][2] = result.z;
+    __syncthreads();
+    if (wave == 0 && write) {
+        float r[3];
+        for (int k = 0; k < 3; k++) { float s = red[0][lane][k]; for (int w = 1; w < kWavesPerTile; w++) s += red[w][lane][k]; r[k] = s; }
+        float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;   // lighttracing.cu:378
+        float4 old = a.out[p];
+        a.out[p] = make_float4(r[0] / inv + acc * old.x, r[1] / inv + acc * old.y, r[2] / inv + acc * old.z, 0.0f + acc * old.w);
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
     __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
-    __shared__ int32_t lds_stack[4][kMaxDepth];
+    __shared__ int32_t lds_stack[kWavesPerTile][kMaxDepth];
+    __shared__ float lds_red[kWavesPerTile][64][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int W = a.st.W;
-    const int tiles_x = (W + 15) >> 4;
-    const int nb = gridDim.x;
-    const int tile = xcd_swizzle(blockIdx.x, nb);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool in_image = x < W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
-    const size_t p = (size_t)min(ly, a.st.local_rows - 1) * W + min(x, W - 1);
+    const TileSetup t = tile_setup(a.st, lane);
+    if (!t.has_tile) return;   // workgroup-uniform: padding of the super-tile grid
+    const size_t p = t.p;
 
     Pixel px;
     float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
     px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
     px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);  // lighttracing.cu:363
-    const bool valid = in_image && gp.w != 0.0f;        // stencil test, lighttracing.cu:354
+    const bool valid = t.in_image && gp.w != 0.0f;      // stencil test, lighttracing.cu:354
 
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
@@ -102,7 +136,7 @@ __global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
         if (next < nvpl) stage_chunk(lds_vpl[buf ^ 1], a.vpls, next, nvpl, tid);
         const uint32_t n = min((uint32_t)kGatherChunk, nvpl - begin);
         const float4 *chunk = lds_vpl[buf];
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = wave; i < n; i += kWavesPerTile) {
             Vpl v = load_vpl(chunk + i * kRecF4);
             V3 v12 = v.pos - px.p1;                                         // :282
             float c1 = fmaxf(dot(px.n1, v12), 0.0f);
@@ -118,12 +152,7 @@ __global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
         __syncthreads();
         buf ^= 1;
     }
-    if (in_image && valid) {
-        // outputBuffer = result / numVplLightPaths + doAccumulate * outputBuffer   :378
-        float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
-        float4 old = a.out[p];
-        a.out[p] = make_float4(result.x / inv + acc * old.x, result.y / inv + acc * old.y, result.z / inv + acc * old.z, 0.0f + acc * old.w);
-    }
+    reduce_and_store(a, lds_red, result, wave, lane, valid, p);
     // statistics: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0) { atomicAdd(&a.counters->rays, (unsigned long long)rays); atomicAdd(&a.counters->nodes, (unsigned long long)nodes); }
@@ -209,24 +238,21 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float
 
 __global__ __launch_bounds__(256) void gather_vsl_kernel(GatherArgs a) {
     __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
-    __shared__ int32_t lds_stack[4][kMaxDepth];
+    __shared__ int32_t lds_stack[kWavesPerTile][kMaxDepth];
+    __shared__ float lds_red[kWavesPerTile][64][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.st.W;
-    const int tiles_x = (W + 15) >> 4;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool in_image = x < W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
-    const size_t p = (size_t)min(ly, a.st.local_rows - 1) * W + min(x, W - 1);
-    const int gy = a.st.global_row(min(ly, a.st.local_rows - 1));
+    const TileSetup t = tile_setup(a.st, lane);
+    if (!t.has_tile) return;   // workgroup-uniform: padding of the super-tile grid
+    const size_t p = t.p;
+    const bool in_image = t.in_image;
 
     Pixel px;
     float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
     px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
     px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);   // :704
     const bool valid = in_image;                        // no stencil test in splatSplotch (:694-695)
-    const uint32_t pixel_id = (uint32_t)gy * (uint32_t)W + (uint32_t)x;  // launchIndex.y * dim.x + launchIndex.x (:711)
+    const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
 
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(256) void gather_vsl_kernel(GatherArgs a) {
         if (next < nvpl) stage_chunk(lds_vpl[buf ^ 1], a.vpls, next, nvpl, tid);
         const uint32_t n = min((uint32_t)kGatherChunk, nvpl - begin);
         const float4 *chunk = lds_vpl[buf];
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = wave; i < n; i += kWavesPerTile) {
             Vpl v = load_vpl(chunk + i * kRecF4);
             V3 v12 = v.pos - px.p1;                                       // :605
             float dist2 = dot(v12, v12);
@@ -278,18 +304,16 @@ __global__ __launch_bounds__(256) void gather_vsl_kernel(GatherArgs a) {
         __syncthreads();
         buf ^= 1;
     }
-    if (in_image) {
-        float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
-        float4 old = a.out[p];
-        a.out[p] = make_float4(result.x / inv + acc * old.x, result.y / inv + acc * old.y, result.z / inv + acc * old.z, 0.0f + acc * old.w);
-    }
+    reduce_and_store(a, lds_red, result, wave, lane, in_image, p);
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0) { atomicAdd(&a.counters->rays, (unsigned long long)rays); atomicAdd(&a.counters->nodes, (unsigned long long)nodes); }
 }
 
 static dim3 gather_grid(const StripDev &st) {
-    int tiles_x = (st.W + 15) / 16, tiles_y = (st.local_rows + 15) / 16;
-    return dim3(tiles_x * tiles_y);
+    int tiles_x = (st.W + 7) / 8, tiles_y = (st.local_rows + 7) / 8;
+    int sx = (tiles_x + 7) / 8, sy = (tiles_y + 7) / 8;
+    int per_xcd = (sx * sy + 7) / 8;
+    return dim3(per_xcd * 8 * 64);
 }
 void launch_gather_vpl(const GatherArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a.st), dim3(256), 0, s, a);
