@@ -162,12 +162,12 @@ struct Builder {
     }
 };
 
-inline void precompute_tri(const float *v, TriPre *t) {
+inline void precompute_tri(const float *v, TriPair *tp, int half) {
     // same operation order as the oracle's tri_test: e0 = p1-p0, e1 = p0-p2, n = cross(e1, e0)
-    for (int k = 0; k < 3; k++) { t->p0[k] = v[k]; t->e0[k] = v[3 + k] - v[k]; t->e1[k] = v[k] - v[6 + k]; }
-    t->n[0] = t->e1[1] * t->e0[2] - t->e1[2] * t->e0[1];
-    t->n[1] = t->e1[2] * t->e0[0] - t->e1[0] * t->e0[2];
-    t->n[2] = t->e1[0] * t->e0[1] - t->e1[1] * t->e0[0];
+    float e0[3], e1[3];
+    for (int k = 0; k < 3; k++) { e0[k] = v[3 + k] - v[k]; e1[k] = v[k] - v[6 + k]; }
+    float n[3] = { e1[1] * e0[2] - e1[2] * e0[1], e1[2] * e0[0] - e1[0] * e0[2], e1[0] * e0[1] - e1[1] * e0[0] };
+    for (int k = 0; k < 3; k++) { tp->p0[k][half] = v[k]; tp->e0[k][half] = e0[k]; tp->e1[k][half] = e1[k]; tp->n[k][half] = n[k]; }
 }
 
 } // namespace
@@ -199,23 +199,22 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     const float pad = 2e-5f * diag + 1e-30f;
 
     // flatten: inner nodes in DFS pre-order; each inner node carries both child boxes
-    std::vector<BvhNode> flat; std::vector<int32_t> order; order.reserve((size_t)nvalid);
+    std::vector<BvhNode> flat; std::vector<int32_t> order; order.reserve((size_t)nvalid);   // 4 slots per leaf, -1 = empty
     int32_t nleaves = 0;
-    auto set_box = [&](float *lo, float *hi, const Box &b) { for (int k = 0; k < 3; k++) { lo[k] = b.lo[k] - pad; hi[k] = b.hi[k] + pad; } };
-    auto set_empty = [&](float *lo, float *hi) { for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } };
+    auto set_box = [&](BvhNode &f, int child, const Box &b) { for (int k = 0; k < 3; k++) { f.lo[k][child] = b.lo[k] - pad; f.hi[k][child] = b.hi[k] + pad; } };
+    auto set_empty = [&](BvhNode &f, int child) { for (int k = 0; k < 3; k++) { f.lo[k][child] = 3.0e38f; f.hi[k][child] = -3.0e38f; } };
     struct Item { int32_t temp; int32_t parent; int which; };
     std::vector<Item> stack;
     auto emit_leaf = [&](const TempNode &n) -> int32_t {
-        int32_t first = (int32_t)order.size();
-        for (int32_t i = 0; i < n.count; i++) order.push_back(B.ids[n.first + i]);
-        nleaves++;
-        return ~((first << 2) | (n.count - 1));
+        int32_t block = nleaves++;
+        for (int32_t i = 0; i < kMaxLeafTris; i++) order.push_back(i < n.count ? B.ids[n.first + i] : -1);
+        return ~((block << 2) | (n.count - 1));
     };
     if (root >= 0) {
         if (B.nodes[root].left < 0) {
             // a single leaf: wrap it into a root with an absent second child
             BvhNode r; std::memset(&r, 0, sizeof(r));
-            set_box(r.lo0, r.hi0, B.nodes[root].box); set_empty(r.lo1, r.hi1);
+            set_box(r, 0, B.nodes[root].box); set_empty(r, 1);
             r.c0 = emit_leaf(B.nodes[root]); r.c1 = kNoChild;
             flat.push_back(r);
         } else {
@@ -228,7 +227,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
                 else {
                     ref = (int32_t)flat.size();
                     BvhNode f; std::memset(&f, 0, sizeof(f));
-                    set_box(f.lo0, f.hi0, B.nodes[n.left].box); set_box(f.lo1, f.hi1, B.nodes[n.right].box);
+                    set_box(f, 0, B.nodes[n.left].box); set_box(f, 1, B.nodes[n.right].box);
                     flat.push_back(f);
                     // push right first so the left subtree is emitted next (pre-order, leaves contiguous)
                     stack.push_back({ n.right, ref, 1 }); stack.push_back({ n.left, ref, 0 });
@@ -238,24 +237,26 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
         }
     } else {
         BvhNode r; std::memset(&r, 0, sizeof(r));
-        set_empty(r.lo0, r.hi0); set_empty(r.lo1, r.hi1); r.c0 = r.c1 = kNoChild;
+        set_empty(r, 0); set_empty(r, 1); r.c0 = r.c1 = kNoChild;
         flat.push_back(r);
     }
     out->nnodes = (int32_t)flat.size();
     out->nodes = (BvhNode *)std::malloc(sizeof(BvhNode) * flat.size());
     std::memcpy(out->nodes, flat.data(), sizeof(BvhNode) * flat.size());
-    out->ntris = (int32_t)order.size();
-    // +3 zeroed slots: the leaf fetch of the traversal kernels always reads a block of 4 triangles
-    out->tris = (TriPre *)std::calloc(order.size() + 4, sizeof(TriPre));
-    out->tri_index = (int32_t *)std::malloc(sizeof(int32_t) * std::max<size_t>(order.size(), 1));
-    for (size_t i = 0; i < order.size(); i++) { precompute_tri(verts + 9 * (size_t)order[i], &out->tris[i]); out->tri_index[i] = order[i]; }
+    out->ntris = nvalid;
+    out->leaves = (LeafBlock *)std::calloc((size_t)std::max(nleaves, 1), sizeof(LeafBlock));
+    out->tri_index = (int32_t *)std::malloc(sizeof(int32_t) * std::max<size_t>(order.size(), 4));
+    for (size_t i = 0; i < order.size(); i++) {
+        out->tri_index[i] = order[i];
+        if (order[i] >= 0) precompute_tri(verts + 9 * (size_t)order[i], &out->leaves[i >> 2].pair[(i >> 1) & 1], (int)(i & 1));
+    }
     out->nleaves = nleaves; out->depth = B.depth + 1;
     out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 
 void free_bvh(BvhBuild *b) {
-    std::free(b->nodes); std::free(b->tris); std::free(b->tri_index);
+    std::free(b->nodes); std::free(b->leaves); std::free(b->tri_index);
     *b = BvhBuild();
 }
 

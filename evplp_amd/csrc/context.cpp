@@ -110,7 +110,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
 }
 
 static void free_scene_device(evplp_context *c) {
-    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.tris); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
+    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.leaves); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
     hipFree((void *)c->sc.materials); hipFree((void *)c->sc.textures); hipFree((void *)c->sc.tex_pool); hipFree((void *)c->sc.light_cdf);
     std::memset(&c->sc, 0, sizeof(c->sc));
 }
@@ -290,8 +290,8 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     }
     int rc;
     if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
-    if ((rc = upload_array(c, bb.tris, (size_t)bb.ntris + 3, &c->sc.tris))) { free_bvh(&bb); return rc; }   // +3 pad slots (leaf block fetch)
-    if ((rc = upload_array(c, bb.tri_index, (size_t)bb.ntris, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
+    if ((rc = upload_array(c, bb.leaves, (size_t)std::max(bb.nleaves, 1), &c->sc.leaves))) { free_bvh(&bb); return rc; }
+    if ((rc = upload_array(c, bb.tri_index, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
     c->sc.ntris = bb.ntris;
     free_bvh(&bb);
     if ((rc = upload_array(c, attrs.data(), attrs.size(), &c->sc.attrs))) return rc;

@@ -37,17 +37,21 @@ EV_DEV float max_color(V3 c) { return fmaxf(fmaxf(c.x, c.y), c.z); }
 // ---------------------------------------------------------------------------------- EXACT
 // optix::intersect_triangle_branchless (OptiX SDK 4.1.1 optixu_math_namespace.h) as called by
 // meshFineIntersect, rt/triangleintersect.cu:17-41.  Operands pre-computed by build_bvh.
-EV_DEV bool tri_test(const TriPre &tp, V3 o, V3 d, float tmin, float tmax, float &t, float &beta, float &gamma) {
+// The reference is compiled by nvcc with -fmad=true, i.e. with compiler-chosen fused multiply-adds;
+// this build FIXES the placement (below, identical in oracle/evplp_oracle.c tri_test) so that the
+// predicate is bit-identical on CPU and GPU: every dot product is  fma(z, z', fma(y, y', x*x'))  and
+// every cross component is  fma(a, b, -(c*d)).  1/den is an IEEE-correct division.
+typedef float v2f __attribute__((ext_vector_type(2)));
+EV_DEV bool tri_test(const TriPair &tp, int h, V3 o, V3 d, float tmin, float tmax, float &t, float &beta, float &gamma) {
 #pragma clang fp contract(off)
-    // written out in scalars: the contract(off) pragma is lexical and must cover every operation
-    float nx = tp.n[0], ny = tp.n[1], nz = tp.n[2];
-    float den = nx * d.x + ny * d.y + nz * d.z;
+    const float nx = tp.n[0][h], ny = tp.n[1][h], nz = tp.n[2][h];
+    float den = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
     float inv = 1.0f / den;
-    float qx = (tp.p0[0] - o.x) * inv, qy = (tp.p0[1] - o.y) * inv, qz = (tp.p0[2] - o.z) * inv;
-    float ix = d.y * qz - d.z * qy, iy = d.z * qx - d.x * qz, iz = d.x * qy - d.y * qx;
-    beta = ix * tp.e1[0] + iy * tp.e1[1] + iz * tp.e1[2];
-    gamma = ix * tp.e0[0] + iy * tp.e0[1] + iz * tp.e0[2];
-    t = nx * qx + ny * qy + nz * qz;
+    float qx = (tp.p0[0][h] - o.x) * inv, qy = (tp.p0[1][h] - o.y) * inv, qz = (tp.p0[2][h] - o.z) * inv;
+    float ix = __builtin_fmaf(d.y, qz, -(d.z * qy)), iy = __builtin_fmaf(d.z, qx, -(d.x * qz)), iz = __builtin_fmaf(d.x, qy, -(d.y * qx));
+    beta = __builtin_fmaf(iz, tp.e1[2][h], __builtin_fmaf(iy, tp.e1[1][h], ix * tp.e1[0][h]));
+    gamma = __builtin_fmaf(iz, tp.e0[2][h], __builtin_fmaf(iy, tp.e0[1][h], ix * tp.e0[0][h]));
+    t = __builtin_fmaf(nz, qz, __builtin_fmaf(ny, qy, nx * qx));
     return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
 }
 
@@ -252,22 +256,38 @@ EV_DEV float safe_rcp(float d) {
 }
 
 // One wide scalar fetch of a wave-uniform 64-byte block (s_load_dwordx16): the whole BVH node (or a
-// third of a 4-triangle leaf block) arrives with ONE exposed latency instead of one per field.
+// third of a leaf block) arrives with ONE exposed latency instead of one per field.
 typedef int v16i __attribute__((ext_vector_type(16)));
 EV_DEV float f_of(int x) { return __int_as_float(x); }
+EV_DEV v2f pk(int a, int b) { v2f r; r.x = __int_as_float(a); r.y = __int_as_float(b); return r; }
+EV_DEV v2f bc(float a) { v2f r; r.x = a; r.y = a; return r; }
+EV_DEV v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+EV_DEV v2f pk_min(v2f a, v2f b) { return __builtin_elementwise_min(a, b); }
+EV_DEV v2f pk_max(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
 
-// exact triangle test on raw dwords d[0..11] = p0, e0, e1, n (same arithmetic as tri_test)
-EV_DEV bool tri_test_raw(float p0x, float p0y, float p0z, float e0x, float e0y, float e0z, float e1x, float e1y, float e1z,
-                         float nx, float ny, float nz, V3 o, V3 d, float tmin, float tmax) {
+// Exact test of a PAIR of triangles with packed fp32 (half 0 = triangle A, half 1 = B): the same
+// operations in the same order as tri_test, two triangles per instruction.  r[0..23] = the 24 dwords
+// of a TriPair.  Returns the two hit flags.
+struct Hit2 { bool a, b; };
+template <class R> EV_DEV Hit2 tri_pair_test(const R &r, int base, V3 o, V3 d, float tmin, float tmax) {
 #pragma clang fp contract(off)
-    float den = nx * d.x + ny * d.y + nz * d.z;
-    float inv = 1.0f / den;
-    float qx = (p0x - o.x) * inv, qy = (p0y - o.y) * inv, qz = (p0z - o.z) * inv;
-    float ix = d.y * qz - d.z * qy, iy = d.z * qx - d.x * qz, iz = d.x * qy - d.y * qx;
-    float beta = ix * e1x + iy * e1y + iz * e1z;
-    float gamma = ix * e0x + iy * e0y + iz * e0z;
-    float t = nx * qx + ny * qy + nz * qz;
-    return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
+#define EV_P(i) pk(r[base + 2 * (i)], r[base + 2 * (i) + 1])
+    const v2f p0x = EV_P(0), p0y = EV_P(1), p0z = EV_P(2), e0x = EV_P(3), e0y = EV_P(4), e0z = EV_P(5);
+    const v2f e1x = EV_P(6), e1y = EV_P(7), e1z = EV_P(8), nx = EV_P(9), ny = EV_P(10), nz = EV_P(11);
+#undef EV_P
+    const v2f dx = bc(d.x), dy = bc(d.y), dz = bc(d.z);
+    v2f den = pk_fma(nz, dz, pk_fma(ny, dy, nx * dx));
+    v2f inv; inv.x = 1.0f / den.x; inv.y = 1.0f / den.y;
+    v2f qx = (p0x - bc(o.x)) * inv, qy = (p0y - bc(o.y)) * inv, qz = (p0z - bc(o.z)) * inv;
+    v2f ix = pk_fma(dy, qz, -(dz * qy)), iy = pk_fma(dz, qx, -(dx * qz)), iz = pk_fma(dx, qy, -(dy * qx));
+    v2f beta = pk_fma(iz, e1z, pk_fma(iy, e1y, ix * e1x));
+    v2f gamma = pk_fma(iz, e0z, pk_fma(iy, e0y, ix * e0x));
+    v2f t = pk_fma(nz, qz, pk_fma(ny, qy, nx * qx));
+    v2f bg = beta + gamma;
+    Hit2 h;
+    h.a = (t.x < tmax) & (t.x > tmin) & (beta.x >= 0.0f) & (gamma.x >= 0.0f) & (bg.x <= 1.0f);
+    h.b = (t.y < tmax) & (t.y > tmin) & (beta.y >= 0.0f) & (gamma.y >= 0.0f) & (bg.y <= 1.0f);
+    return h;
 }
 
 // Stack-in-a-VGPR helpers: entry k of the wave's stack is lane k of one register.  A push is a
@@ -285,8 +305,10 @@ EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot
 // rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
 EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive,
                           int32_t *wave_stack, uint32_t &nodes_visited) {
-    V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+    const V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
+    const v2f nox = bc(-(o.x * inv.x)), noy = bc(-(o.y * inv.y)), noz = bc(-(o.z * inv.z));
+    const v2f tmin2 = bc(tmin), tmax2 = bc(tmax);
     bool hit = false;
     int sp = 0;
     int vstack = 0;
@@ -294,13 +316,15 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     if (__ballot(alive) == 0ull) return false;
     for (;;) {
         if (cur >= 0) {
-            const v16i *np = reinterpret_cast<const v16i *>(sc.nodes + __builtin_amdgcn_readfirstlane(cur));
-            const v16i n = *np;
+            const v16i n = *reinterpret_cast<const v16i *>(sc.nodes + __builtin_amdgcn_readfirstlane(cur));
             nodes_visited++;
-            const float lo0[3] = { f_of(n[0]), f_of(n[1]), f_of(n[2]) }, hi0[3] = { f_of(n[3]), f_of(n[4]), f_of(n[5]) };
-            const float lo1[3] = { f_of(n[6]), f_of(n[7]), f_of(n[8]) }, hi1[3] = { f_of(n[9]), f_of(n[10]), f_of(n[11]) };
-            const bool h0 = slab_hit(lo0, hi0, inv, noi, tmin, tmax) & alive;
-            const bool h1 = slab_hit(lo1, hi1, inv, noi, tmin, tmax) & alive;
+            // both children at once: half 0 = child 0, half 1 = child 1 (conservative slab test)
+            const v2f t0x = pk_fma(pk(n[0], n[1]), ivx, nox), t1x = pk_fma(pk(n[6], n[7]), ivx, nox);
+            const v2f t0y = pk_fma(pk(n[2], n[3]), ivy, noy), t1y = pk_fma(pk(n[8], n[9]), ivy, noy);
+            const v2f t0z = pk_fma(pk(n[4], n[5]), ivz, noz), t1z = pk_fma(pk(n[10], n[11]), ivz, noz);
+            const v2f tn = pk_max(pk_max(pk_min(t0x, t1x), pk_min(t0y, t1y)), pk_max(pk_min(t0z, t1z), tmin2));
+            const v2f tf = pk_min(pk_min(pk_max(t0x, t1x), pk_max(t0y, t1y)), pk_min(pk_max(t0z, t1z), tmax2));
+            const bool h0 = (tn.x <= tf.x) & alive, h1 = (tn.y <= tf.y) & alive;
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
             const int32_t c0 = n[12], c1 = n[13];
             if (m0 && m1) {
@@ -315,19 +339,28 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             else if (m1) { cur = c1; continue; }
         } else if (cur != kNoChild) {
             const int32_t id = __builtin_amdgcn_readfirstlane(~cur);
-            const int32_t first = id >> 2, cnt = (id & 3) + 1;
-            // a leaf is a block of up to 4 triangles (192 B); fetch all of it before testing
-            const v16i *tp = reinterpret_cast<const v16i *>(sc.tris + first);
-            const v16i a = tp[0], b = tp[1], c = tp[2];
-            bool h = tri_test_raw(f_of(a[0]), f_of(a[1]), f_of(a[2]), f_of(a[3]), f_of(a[4]), f_of(a[5]), f_of(a[6]), f_of(a[7]), f_of(a[8]),
-                                  f_of(a[9]), f_of(a[10]), f_of(a[11]), o, d, tmin, tmax);
-            if (cnt > 1) h |= tri_test_raw(f_of(a[12]), f_of(a[13]), f_of(a[14]), f_of(a[15]), f_of(b[0]), f_of(b[1]), f_of(b[2]), f_of(b[3]), f_of(b[4]),
-                                           f_of(b[5]), f_of(b[6]), f_of(b[7]), o, d, tmin, tmax);
-            if (cnt > 2) h |= tri_test_raw(f_of(b[8]), f_of(b[9]), f_of(b[10]), f_of(b[11]), f_of(b[12]), f_of(b[13]), f_of(b[14]), f_of(b[15]), f_of(c[0]),
-                                           f_of(c[1]), f_of(c[2]), f_of(c[3]), o, d, tmin, tmax);
-            if (cnt > 3) h |= tri_test_raw(f_of(c[4]), f_of(c[5]), f_of(c[6]), f_of(c[7]), f_of(c[8]), f_of(c[9]), f_of(c[10]), f_of(c[11]), f_of(c[12]),
-                                           f_of(c[13]), f_of(c[14]), f_of(c[15]), o, d, tmin, tmax);
-            hit = hit | (alive & h);
+            const int32_t block = id >> 2, cnt = (id & 3) + 1;
+            // a leaf block is two triangle pairs (192 B); fetch all of it before testing
+            const v16i *tp = reinterpret_cast<const v16i *>(sc.leaves + block);
+            const v16i a = tp[0], b = tp[1];
+            int r0[24];
+#pragma unroll
+            for (int k = 0; k < 16; k++) r0[k] = a[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) r0[16 + k] = b[k];
+            Hit2 h = tri_pair_test(r0, 0, o, d, tmin, tmax);
+            bool any = h.a | h.b;    // an empty slot B is all zeros: den = 0 -> never a hit
+            if (cnt > 2) {
+                const v16i c = tp[2];
+                int r1[24];
+#pragma unroll
+                for (int k = 0; k < 8; k++) r1[k] = b[8 + k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) r1[8 + k] = c[k];
+                Hit2 g = tri_pair_test(r1, 0, o, d, tmin, tmax);
+                any = any | g.a | g.b;
+            }
+            hit = hit | (alive & any);
             alive = alive & !hit;
             if (__ballot(alive) == 0ull) return hit;
         }
@@ -353,8 +386,10 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
         if (cur >= 0) {
             const BvhNode &n = sc.nodes[cur];
             bool h0, h1;
-            float n0 = slab_near(n.lo0, n.hi0, inv, noi, tmin, bt, h0);
-            float n1 = slab_near(n.lo1, n.hi1, inv, noi, tmin, bt, h1);
+            const float lo0[3] = { n.lo[0][0], n.lo[1][0], n.lo[2][0] }, hi0[3] = { n.hi[0][0], n.hi[1][0], n.hi[2][0] };
+            const float lo1[3] = { n.lo[0][1], n.lo[1][1], n.lo[2][1] }, hi1[3] = { n.hi[0][1], n.hi[1][1], n.hi[2][1] };
+            float n0 = slab_near(lo0, hi0, inv, noi, tmin, bt, h0);
+            float n1 = slab_near(lo1, hi1, inv, noi, tmin, bt, h1);
             if (h0 && h1) {
                 bool first0 = n0 <= n1;
                 stack[sp * STACK_STRIDE] = first0 ? n.c1 : n.c0; sp++;
@@ -364,13 +399,13 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
             else if (h1) { cur = n.c1; continue; }
         } else if (cur != kNoChild) {
             int32_t id = ~cur;
-            int32_t first = id >> 2, cnt = (id & 3) + 1;
+            int32_t block = id >> 2, cnt = (id & 3) + 1;
             for (int32_t k = 0; k < cnt; k++) {
-                int32_t orig = sc.tri_index[first + k];
+                int32_t orig = sc.tri_index[block * 4 + k];
                 bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
                 if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
                 float t, b, g;
-                if (tri_test(sc.tris[first + k], o, d, tmin, 3.0e38f, t, b, g)) {
+                if (tri_test(sc.leaves[block].pair[k >> 1], k & 1, o, d, tmin, 3.0e38f, t, b, g)) {
                     if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
                 }
             }

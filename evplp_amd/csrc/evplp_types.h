@@ -6,13 +6,15 @@
 
 namespace evplp {
 
-// Flattened binary BVH node, 64 B = one s_load_dwordx16 / one cache line.  A node stores the
-// boxes of BOTH children so a wave decides the descent from one fetch.
-// child >= 0: inner node index; child < 0: leaf, id = ~child, first = id >> 2, count = (id & 3) + 1.
-// An absent child has an inverted box (lo = +big, hi = -big) and child = kNoChild.
+// Flattened binary BVH node, 64 B = one s_load_dwordx16 / one cache line.  A node stores the boxes
+// of BOTH children, interleaved component by component so that the two slab tests run as one
+// stream of packed-fp32 instructions (v_pk_fma_f32 / v_pk_min_f32 / v_pk_max_f32: half 0 = child 0,
+// half 1 = child 1).  child >= 0: inner node index; child < 0: leaf, id = ~child,
+// leaf block = id >> 2, triangle count = (id & 3) + 1.  An absent child has an inverted box
+// (lo = +big, hi = -big) and child = kNoChild.
 struct BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
+    float lo[3][2];   // lo[axis][child]
+    float hi[3][2];   // hi[axis][child]
     int32_t c0, c1;
     int32_t pad[2];
 };
@@ -21,12 +23,16 @@ constexpr int32_t kNoChild = INT32_MIN;
 constexpr int kMaxLeafTris = 4;
 constexpr int kMaxDepth = 64;
 
-// Pre-computed operands of optix::intersect_triangle_branchless: p0, e0 = p1-p0, e1 = p0-p2,
-// n = cross(e1, e0).  48 B = 3 x float4.
-struct TriPre {
-    float p0[3], e0[3], e1[3], n[3];
+// Leaf block, 192 B = three s_load_dwordx16: up to four triangles as TWO PAIRS; every operand of
+// optix::intersect_triangle_branchless (p0, e0 = p1-p0, e1 = p0-p2, n = cross(e1, e0)) is stored as
+// {triangle A, triangle B} so that a pair is tested with packed-fp32 instructions.  Unused slots
+// are zero (den = 0 -> the test is false).
+struct TriPair {
+    float p0[3][2], e0[3][2], e1[3][2], n[3][2];   // [component][A|B]
 };
-static_assert(sizeof(TriPre) == 48, "TriPre must be 48 bytes");
+static_assert(sizeof(TriPair) == 96, "TriPair must be 96 bytes");
+struct LeafBlock { TriPair pair[2]; };
+static_assert(sizeof(LeafBlock) == 192, "LeafBlock must be 192 bytes");
 
 // Shading attributes per ORIGINAL triangle.
 struct TriAttr {
@@ -58,8 +64,8 @@ struct CamBasis {
 // wave-uniform => scalar loads).
 struct SceneDev {
     const BvhNode *nodes;
-    const TriPre *tris;          // BVH (leaf) order
-    const int32_t *tri_index;    // BVH order -> original triangle
+    const LeafBlock *leaves;     // one block per leaf
+    const int32_t *tri_index;    // 4 slots per leaf: original triangle index or -1
     const TriAttr *attrs;        // original order
     const Material *materials;
     const TexDesc *textures;
@@ -86,7 +92,7 @@ struct StripDev {
 // Host-side acceleration structure build result
 struct BvhBuild {
     BvhNode *nodes = nullptr; int32_t nnodes = 0;
-    TriPre *tris = nullptr;  int32_t *tri_index = nullptr; int32_t ntris = 0;
+    LeafBlock *leaves = nullptr;  int32_t *tri_index = nullptr; int32_t ntris = 0;
     int32_t nleaves = 0, depth = 0;
     float build_ms = 0.f;
 };

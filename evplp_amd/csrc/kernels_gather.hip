@@ -18,7 +18,7 @@
 
 namespace evplp {
 
-constexpr int kGatherChunk = 128;                 // VPL records per LDS stage (12 KB)
+constexpr int kGatherChunk = 64;                  // VPL records per LDS stage (6 KB, double-buffered)
 constexpr int kRecF4 = sizeof(evplp_record) / 16; // 6 float4 per record
 
 struct Pixel {
@@ -108,7 +108,7 @@ EV_DEV void reduce_and_store(const GatherArgs &a, float (*red)[64][3], V3 result
     }
 }
 
-__global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
+__global__ __launch_bounds__(256, 8) void gather_vpl_kernel(GatherArgs a) {
     __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
     __shared__ int32_t lds_stack[kWavesPerTile][kMaxDepth];
     __shared__ float lds_red[kWavesPerTile][64][3];
@@ -128,16 +128,18 @@ __global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
     uint32_t rays = 0, nodes = 0;
     int32_t *stack = lds_stack[wave];
 
-    int buf = 0;
-    if (nvpl > 0) stage_chunk(lds_vpl[0], a.vpls, 0, nvpl, tid);
-    __syncthreads();
-    for (uint32_t begin = 0; begin < nvpl; begin += kGatherChunk) {
-        uint32_t next = begin + kGatherChunk;
-        if (next < nvpl) stage_chunk(lds_vpl[buf ^ 1], a.vpls, next, nvpl, tid);
-        const uint32_t n = min((uint32_t)kGatherChunk, nvpl - begin);
-        const float4 *chunk = lds_vpl[buf];
-        for (uint32_t i = wave; i < n; i += kWavesPerTile) {
-            Vpl v = load_vpl(chunk + i * kRecF4);
+    // EXPERIMENT: wave-uniform scalar loads of the VPL record (no LDS staging, no per-chunk barrier)
+    {
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(wave);
+        for (uint32_t i = w0; i < nvpl; i += kWavesPerTile) {
+            const v16i *rp = reinterpret_cast<const v16i *>(a.vpls + i);
+            const v16i ra = rp[0];
+            const int4 rb0 = *reinterpret_cast<const int4 *>(reinterpret_cast<const int *>(a.vpls + i) + 16);
+            const int4 rb1 = *reinterpret_cast<const int4 *>(reinterpret_cast<const int *>(a.vpls + i) + 20);
+            Vpl v;
+            v.pos = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])); v.n = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6])); v.psel = f_of(ra[7]);
+            v.flux = v3(f_of(ra[8]), f_of(ra[9]), f_of(ra[10])); v.fdir = v3(f_of(ra[12]), f_of(ra[13]), f_of(ra[14]));
+            v.rd = v3(f_of(rb0.x), f_of(rb0.y), f_of(rb0.z)); v.rs = v3(f_of(rb1.x), f_of(rb1.y), f_of(rb1.z)); v.e = f_of(rb1.w);
             V3 v12 = v.pos - px.p1;                                         // :282
             float c1 = fmaxf(dot(px.n1, v12), 0.0f);
             float c2 = fmaxf(-dot(v.n, v12), 0.0f);
@@ -149,8 +151,6 @@ __global__ __launch_bounds__(256) void gather_vpl_kernel(GatherArgs a) {
             bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, stack, nodes);
             if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
         }
-        __syncthreads();
-        buf ^= 1;
     }
     reduce_and_store(a, lds_red, result, wave, lane, valid, p);
     // statistics: one atomic per wave

@@ -248,15 +248,20 @@ float evo_scene_bounding_sphere_radius(const evo_scene *s) {
  * from rt/triangleintersect.cu:27.  e0 = p1-p0, e1 = p0-p2, n = cross(e1,e0). */
 static inline int tri_test(v3 p0, v3 p1, v3 p2, v3 o, v3 d, float tmin, float tmax,
                            float *t, float *beta, float *gamma, v3 *nout) {
+    /* The reference is built by nvcc with -fmad=true: its mul+add pairs are fused wherever the compiler
+     * chose to.  This restatement FIXES the fusion placement (shared with the HIP kernels, device_common.hpp
+     * tri_test / tri_pair_test): operand set-up e0, e1, n unfused; every dot product
+     * fma(z, z', fma(y, y', x*x')); every cross component fma(a, b, -(c*d)); IEEE division. */
     v3 e0 = sub(p1, p0);
     v3 e1 = sub(p0, p2);
     v3 n = cross(e1, e0);
-    float inv = 1.0f / dot(n, d);
-    v3 e2 = muls(sub(p0, o), inv);
-    v3 i = cross(d, e2);
-    *beta = dot(i, e1);
-    *gamma = dot(i, e0);
-    *t = dot(n, e2);
+    float den = fmaf(n.z, d.z, fmaf(n.y, d.y, n.x * d.x));
+    float inv = 1.0f / den;
+    v3 q = V3((p0.x - o.x) * inv, (p0.y - o.y) * inv, (p0.z - o.z) * inv);
+    float ix = fmaf(d.y, q.z, -(d.z * q.y)), iy = fmaf(d.z, q.x, -(d.x * q.z)), iz = fmaf(d.x, q.y, -(d.y * q.x));
+    *beta = fmaf(iz, e1.z, fmaf(iy, e1.y, ix * e1.x));
+    *gamma = fmaf(iz, e0.z, fmaf(iy, e0.y, ix * e0.x));
+    *t = fmaf(n.z, q.z, fmaf(n.y, q.y, n.x * q.x));
     if (nout) *nout = n;
     return (*t < tmax) & (*t > tmin) & (*beta >= 0.0f) & (*gamma >= 0.0f) & (*beta + *gamma <= 1.0f);
 }
