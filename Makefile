@@ -4,7 +4,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC = evplp_amd/csrc
 OUT = evplp_amd/lib
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -munsafe-fp-atomics -fno-slp-vectorize
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -munsafe-fp-atomics -fno-slp-vectorize $(EXTRA_HIPFLAGS)
 HOSTFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-unused-value -ffp-contract=off
 
 HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip

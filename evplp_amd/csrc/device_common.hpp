@@ -269,12 +269,9 @@ EV_DEV v2f pk_max(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
 // operations in the same order as tri_test, two triangles per instruction.  r[0..23] = the 24 dwords
 // of a TriPair.  Returns the two hit flags.
 struct Hit2 { bool a, b; };
-template <class R> EV_DEV Hit2 tri_pair_test(const R &r, int base, V3 o, V3 d, float tmin, float tmax) {
+EV_DEV Hit2 tri_pair_test(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, v2f e1x, v2f e1y, v2f e1z, v2f nx, v2f ny, v2f nz,
+                          V3 o, V3 d, float tmin, float tmax) {
 #pragma clang fp contract(off)
-#define EV_P(i) pk(r[base + 2 * (i)], r[base + 2 * (i) + 1])
-    const v2f p0x = EV_P(0), p0y = EV_P(1), p0z = EV_P(2), e0x = EV_P(3), e0y = EV_P(4), e0z = EV_P(5);
-    const v2f e1x = EV_P(6), e1y = EV_P(7), e1z = EV_P(8), nx = EV_P(9), ny = EV_P(10), nz = EV_P(11);
-#undef EV_P
     const v2f dx = bc(d.x), dy = bc(d.y), dz = bc(d.z);
     v2f den = pk_fma(nz, dz, pk_fma(ny, dy, nx * dx));
     v2f inv; inv.x = 1.0f / den.x; inv.y = 1.0f / den.y;
@@ -303,71 +300,72 @@ EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot
 // The per-wavefront stack lives in the 64 lanes of ONE VGPR (select-by-lane-id push, v_readlane pop,
 // scalar stack pointer: no memory latency on either); entries beyond 64 spill to the wave's LDS stack.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit,
 // rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
-EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive,
+EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane,
                           int32_t *wave_stack, uint32_t &nodes_visited) {
+    // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
+    // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d).
     const V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
     const v2f nox = bc(-(o.x * inv.x)), noy = bc(-(o.y * inv.y)), noz = bc(-(o.z * inv.z));
-    const v2f tmin2 = bc(tmin), tmax2 = bc(tmax);
-    bool hit = false;
+    unsigned long long alive = ballot64(alive_lane), hitm = 0ull;
+    if (alive == 0ull) return false;
     int sp = 0;
     int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
-    if (__ballot(alive) == 0ull) return false;
+    const char *node_base = reinterpret_cast<const char *>(sc.nodes);
+    const char *leaf_base = reinterpret_cast<const char *>(sc.leaves);
     for (;;) {
-        if (cur >= 0) {
-            const v16i n = *reinterpret_cast<const v16i *>(sc.nodes + __builtin_amdgcn_readfirstlane(cur));
-            nodes_visited++;
+        while (cur >= 0) {
+            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((size_t)(uint32_t)cur << 6));
             // both children at once: half 0 = child 0, half 1 = child 1 (conservative slab test)
             const v2f t0x = pk_fma(pk(n[0], n[1]), ivx, nox), t1x = pk_fma(pk(n[6], n[7]), ivx, nox);
             const v2f t0y = pk_fma(pk(n[2], n[3]), ivy, noy), t1y = pk_fma(pk(n[8], n[9]), ivy, noy);
             const v2f t0z = pk_fma(pk(n[4], n[5]), ivz, noz), t1z = pk_fma(pk(n[10], n[11]), ivz, noz);
-            const v2f tn = pk_max(pk_max(pk_min(t0x, t1x), pk_min(t0y, t1y)), pk_max(pk_min(t0z, t1z), tmin2));
-            const v2f tf = pk_min(pk_min(pk_max(t0x, t1x), pk_max(t0y, t1y)), pk_min(pk_max(t0z, t1z), tmax2));
-            const bool h0 = (tn.x <= tf.x) & alive, h1 = (tn.y <= tf.y) & alive;
-            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            const float tn0 = fmaxf(fmaxf(fminf(t0x.x, t1x.x), fminf(t0y.x, t1y.x)), fmaxf(fminf(t0z.x, t1z.x), tmin));
+            const float tf0 = fminf(fminf(fmaxf(t0x.x, t1x.x), fmaxf(t0y.x, t1y.x)), fminf(fmaxf(t0z.x, t1z.x), tmax));
+            const float tn1 = fmaxf(fmaxf(fminf(t0x.y, t1x.y), fminf(t0y.y, t1y.y)), fmaxf(fminf(t0z.y, t1z.y), tmin));
+            const float tf1 = fminf(fminf(fmaxf(t0x.y, t1x.y), fmaxf(t0y.y, t1y.y)), fminf(fmaxf(t0z.y, t1z.y), tmax));
+            const unsigned long long m0 = ballot64(tn0 <= tf0) & alive, m1 = ballot64(tn1 <= tf1) & alive;
             const int32_t c0 = n[12], c1 = n[13];
-            if (m0 && m1) {
-                // descend into the child wanted by more lanes first
-                const bool first0 = __popcll(m0) >= __popcll(m1);
+            if ((m0 | m1) == 0ull) { cur = kNoChild; break; }
+            if (m0 != 0ull && m1 != 0ull) {
+                // descend into the child wanted by more lanes first, keep the other one on the stack
+                const bool first0 = __builtin_popcountll(m0) >= __builtin_popcountll(m1);
                 const int32_t oth = first0 ? c1 : c0;
                 if (sp < 64) vstack = lane_write(oth, sp, vstack); else wave_stack[sp - 64] = oth;
                 sp++;
                 cur = first0 ? c0 : c1;
-                continue;
-            } else if (m0) { cur = c0; continue; }
-            else if (m1) { cur = c1; continue; }
-        } else if (cur != kNoChild) {
-            const int32_t id = __builtin_amdgcn_readfirstlane(~cur);
-            const int32_t block = id >> 2, cnt = (id & 3) + 1;
+            } else cur = m0 != 0ull ? c0 : c1;
+        }
+        if (cur != kNoChild) {
+            const uint32_t id = (uint32_t)~cur;
+            const uint32_t cnt = (id & 3u) + 1u;
             // a leaf block is two triangle pairs (192 B); fetch all of it before testing
-            const v16i *tp = reinterpret_cast<const v16i *>(sc.leaves + block);
+            const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (size_t)((id >> 2) * 192u));
             const v16i a = tp[0], b = tp[1];
-            int r0[24];
-#pragma unroll
-            for (int k = 0; k < 16; k++) r0[k] = a[k];
-#pragma unroll
-            for (int k = 0; k < 8; k++) r0[16 + k] = b[k];
-            Hit2 h = tri_pair_test(r0, 0, o, d, tmin, tmax);
+            Hit2 h = tri_pair_test(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
+                                   pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]),
+                                   o, d, tmin, tmax);
             bool any = h.a | h.b;    // an empty slot B is all zeros: den = 0 -> never a hit
-            if (cnt > 2) {
+            if (cnt > 2u) {
                 const v16i c = tp[2];
-                int r1[24];
-#pragma unroll
-                for (int k = 0; k < 8; k++) r1[k] = b[8 + k];
-#pragma unroll
-                for (int k = 0; k < 16; k++) r1[8 + k] = c[k];
-                Hit2 g = tri_pair_test(r1, 0, o, d, tmin, tmax);
+                Hit2 g = tri_pair_test(pk(b[8], b[9]), pk(b[10], b[11]), pk(b[12], b[13]), pk(b[14], b[15]), pk(c[0], c[1]), pk(c[2], c[3]),
+                                       pk(c[4], c[5]), pk(c[6], c[7]), pk(c[8], c[9]), pk(c[10], c[11]), pk(c[12], c[13]), pk(c[14], c[15]),
+                                       o, d, tmin, tmax);
                 any = any | g.a | g.b;
             }
-            hit = hit | (alive & any);
-            alive = alive & !hit;
-            if (__ballot(alive) == 0ull) return hit;
+            hitm |= ballot64(any) & alive;
+            alive &= ~hitm;
+            if (alive == 0ull) break;
         }
-        if (sp == 0) return hit;
+        if (sp == 0) break;
         sp--;
         cur = sp < 64 ? lane_read(vstack, sp) : __builtin_amdgcn_readfirstlane(wave_stack[sp - 64]);
     }
+    (void)nodes_visited;
+    return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
 }
 
 // Per-lane closest-hit traversal with a private stack (incoherent rays: primary visibility and
