@@ -323,10 +323,8 @@ class Context:
     # -- strips
     def global_rows(self) -> np.ndarray:
         """Global image row of every local row (>= H for padding rows)."""
-        l = np.arange(self.local_rows)
-        sr, sc, rk = self.cfg.strip_rows if self.cfg.strip_count > 1 else self.local_rows, self.cfg.strip_count, self.cfg.strip_rank
-        blk = l // sr
-        return (blk * sc + rk) * sr + (l - blk * sr)
+        from . import strips
+        return strips.global_rows(self.H, self.cfg.strip_rank, self.cfg.strip_count, self.cfg.strip_rows)
 
 
 def progressive_step(n: int, alpha: float, clamp_start: float, n_vpl: int, n_light: int, radius: float, clamp: float,

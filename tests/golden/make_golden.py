@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref/libref_pin.so = the reference's
+own floatimage.cpp + its vendored GLM, compiled where they lie by oracle/Makefile).  Run in the
+authoring container (needs /root/reference); the fixtures -- inputs and expected outputs only -- are
+committed so the pins also hold on the GPU box, where the reference does not exist.
+
+Fixtures:
+  output_surface.npz  PFM file bytes, decoded PNG pixels, FlipY, MSE / relMSE of seeded images
+                      (common/floatimage/floatimage.cpp:64-128, 178-199, 241-273)
+  camera.npz          projection*view matrices (with / without the jitter translation) for seeded
+                      cameras incl. the conference camera, fovx->fovy, bounding-sphere radii
+                      (rt/rtcommon.h:548-591, 805-814; rt/rtcomphoton/rtcomphoton.h:943-952)
+"""
+import ctypes as C
+import os
+import struct
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "libref_pin.so")
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def decode_png_rgb8(data: bytes):
+    """Minimal PNG decoder (8-bit RGB, non-interlaced, all five filters)."""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8]); body = data[pos + 8:pos + 8 + n]; pos += 12 + n
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10]); assert depth == 8 and ctype == 2
+        elif typ == b"IDAT":
+            idat += body
+    raw = zlib.decompress(idat)
+    stride = w * 3
+    out = np.zeros((h, stride), np.uint8); prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        f = raw[y * (stride + 1)]; line = np.frombuffer(raw[y * (stride + 1) + 1:(y + 1) * (stride + 1)], np.uint8).astype(np.int32)
+        cur = np.zeros(stride, np.int32)
+        for i in range(stride):
+            a = cur[i - 3] if i >= 3 else 0; b = prev[i]; c = prev[i - 3] if i >= 3 else 0
+            if f == 0: pred = 0
+            elif f == 1: pred = a
+            elif f == 2: pred = b
+            elif f == 3: pred = (a + b) // 2
+            else:
+                p = a + b - c; pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            cur[i] = (line[i] + pred) & 255
+        out[y] = cur; prev = cur
+    return out.reshape(h, w, 3)
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/libref_pin.so missing: run `make -C oracle ref` where /root/reference exists")
+    ref = C.CDLL(REF)
+    ref.ref_save.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    ref.ref_flip_y.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ref.ref_mse.restype = C.c_double; ref.ref_mse.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ref.ref_rel_mse.restype = C.c_double; ref.ref_rel_mse.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ref.ref_view_projection.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    ref.ref_fovx_to_fovy.restype = C.c_float; ref.ref_fovx_to_fovy.argtypes = [C.c_float, C.c_float]
+    ref.ref_bounding_sphere_radius.restype = C.c_float; ref.ref_bounding_sphere_radius.argtypes = [C.c_int, C.c_void_p]
+
+    rng = np.random.RandomState(20261002)
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for name, (w, h) in {"a": (4, 2), "b": (17, 9)}.items():
+        img = (rng.rand(h, w, 3).astype(np.float32) * np.float32(1.6)).astype(np.float32)   # some values > 1 (PNG clamp)
+        img[0, 0] = [0.0, 1.0, 0.5]
+        other = (img + rng.randn(h, w, 3).astype(np.float32) * np.float32(0.05)).astype(np.float32)
+        pfm = os.path.join(tmp, name + ".pfm"); png = os.path.join(tmp, name + ".png")
+        assert ref.ref_save(pfm.encode(), w, h, P(img)) == 0 and ref.ref_save(png.encode(), w, h, P(img)) == 0
+        flipped = np.zeros_like(img); ref.ref_flip_y(w, h, P(img), P(flipped))
+        out[f"{name}_img"] = img; out[f"{name}_other"] = other
+        out[f"{name}_pfm_bytes"] = np.frombuffer(open(pfm, "rb").read(), np.uint8)
+        out[f"{name}_png_pixels"] = decode_png_rgb8(open(png, "rb").read())
+        out[f"{name}_flipy"] = flipped
+        out[f"{name}_mse"] = np.float64(ref.ref_mse(w, h, P(other), P(img)))
+        out[f"{name}_relmse"] = np.float64(ref.ref_rel_mse(w, h, P(other), P(img)))
+    np.savez(os.path.join(HERE, "output_surface.npz"), **out)
+
+    cams = [dict(origin=[15.56, -4.79, 4.37], lookat=[1.15, 2.28, 1.76], up=[0, 0, 1], fovx=70.0, aspect=1280 / 720),   # conference_vpl.json:16-33
+            dict(origin=[15.56, -4.79, 4.37], lookat=[1.15, 2.28, 1.76], up=[0, 0, 1], fovx=70.0, aspect=1.0)]
+    for _ in range(4):
+        o = rng.randn(3) * 5; cams.append(dict(origin=o.tolist(), lookat=(o + rng.randn(3) * 3).tolist(), up=[0, 0, 1], fovx=float(30 + 60 * rng.rand()), aspect=float(0.5 + 1.5 * rng.rand())))
+    cam_out = {"n": np.int32(len(cams))}
+    for i, c in enumerate(cams):
+        o, l, u = (np.asarray(c[k], np.float32) for k in ("origin", "lookat", "up"))
+        fovy = ref.ref_fovx_to_fovy(c["fovx"], c["aspect"])
+        jitter = ((2 * rng.rand(2) - 1) / np.array([1024, 1024])).astype(np.float32)
+        m0 = np.zeros(16, np.float32); m1 = np.zeros(16, np.float32)
+        ref.ref_view_projection(P(o), P(l), P(u), fovy, c["aspect"], None, P(m0))
+        ref.ref_view_projection(P(o), P(l), P(u), fovy, c["aspect"], P(jitter), P(m1))
+        cam_out.update({f"c{i}_origin": o, f"c{i}_lookat": l, f"c{i}_up": u, f"c{i}_fovx": np.float32(c["fovx"]), f"c{i}_aspect": np.float32(c["aspect"]),
+                        f"c{i}_fovy": np.float32(fovy), f"c{i}_jitter": jitter, f"c{i}_mvp": m0.reshape(4, 4), f"c{i}_mvp_jittered": m1.reshape(4, 4)})
+    pts = (rng.randn(500, 3) * [10, 6, 3]).astype(np.float32)
+    cam_out["bsr_points"] = pts
+    cam_out["bsr_radius"] = np.float32(ref.ref_bounding_sphere_radius(pts.shape[0], P(pts)))
+    np.savez(os.path.join(HERE, "camera.npz"), **cam_out)
+    print("wrote", os.listdir(HERE))
+
+
+if __name__ == "__main__":
+    main()

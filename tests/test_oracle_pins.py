@@ -1,0 +1,126 @@
+"""Pins the oracle (and the product's host-side output surface) against golden vectors produced by the
+REFERENCE'S OWN code (tests/golden/make_golden.py: floatimage.cpp + vendored GLM through oracle/_ref).
+No GPU needed.  What is pinned: PFM bytes, PNG pixels, FlipY, MSE/relMSE, the camera model (lookAt /
+perspective / jitter translation / fovx->fovy) and the bounding-sphere radius.  The device arithmetic
+(BRDFs, gather, splat) has no reference-run vectors: "parity unpinned" there."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_golden import decode_png_rgb8  # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "output_surface.npz"))
+CAM = np.load(os.path.join(HERE, "golden", "camera.npz"))
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_pfm_bytes_oracle_and_product(name, oracle, tmp_path, evplp):
+    img = G[f"{name}_img"]; h, w = img.shape[:2]
+    p1 = str(tmp_path / "o.pfm"); p2 = str(tmp_path / "p.pfm")
+    assert oracle.evo_write_pfm(p1.encode(), w, h, oa.ptr(img)) == 0
+    evplp.save_image(p2, img)
+    want = G[f"{name}_pfm_bytes"].tobytes()
+    assert open(p1, "rb").read() == want, "oracle PFM differs from FloatImage::SavePFM"
+    assert open(p2, "rb").read() == want, "libevplp_hip PFM differs from FloatImage::SavePFM"
+    back = evplp.load_pfm(p2)
+    assert np.array_equal(back, img)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_png_pixels_oracle_and_product(name, oracle, tmp_path, evplp):
+    img = G[f"{name}_img"]; h, w = img.shape[:2]
+    want = G[f"{name}_png_pixels"]
+    got = np.zeros(img.size, np.uint8)
+    oracle.evo_png_bytes(img.size, oa.ptr(img), oa.ptr(got))
+    assert np.array_equal(got.reshape(h, w, 3), want), "oracle PNG quantisation differs from FloatImage::SavePNG"
+    p = str(tmp_path / "p.png")
+    evplp.save_image(p, img)
+    assert np.array_equal(decode_png_rgb8(open(p, "rb").read()), want), "libevplp_hip PNG pixels differ from the reference's"
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_error_metrics(name, oracle, evplp):
+    img, other = G[f"{name}_img"], G[f"{name}_other"]
+    n = img.shape[0] * img.shape[1]
+    for fn_o, fn_p, key in ((oracle.evo_mse, evplp.lib().evplp_image_mse, "mse"), (oracle.evo_rel_mse, evplp.lib().evplp_image_rel_mse, "relmse")):
+        want = float(G[f"{name}_{key}"])
+        assert fn_o(n, oa.ptr(other), oa.ptr(img)) == want
+        assert fn_p(n, oa.ptr(other), oa.ptr(img)) == want
+
+
+def test_flip_y_convention():
+    for name in ("a", "b"):
+        assert np.array_equal(G[f"{name}_img"][::-1], G[f"{name}_flipy"])   # FloatImage::FlipY == reversing rows
+
+
+@pytest.mark.parametrize("i", range(int(CAM["n"])))
+def test_camera_model_against_glm(i, oracle):
+    """Oracle primary rays, pushed through the reference's projection*view (and its jitter translation),
+    must land on their own pixel centres: pins lookAt / perspective / fovx->fovy / the jitter sign."""
+    sd = scenes.box_room(seed=2, n_boxes=0, tess=1)
+    # a big inward-facing room around the camera so that every pixel hits something
+    o = CAM[f"c{i}_origin"]
+    sd = scenes.SceneData()
+    m = sd.add_material((0.5, 0.5, 0.5))
+    lo, hi = o - 40.0, o + 40.0
+    sd.add_box(lo, hi, m, outward=False, n=1)
+    lm = sd.add_material((0, 0, 0))
+    sd.light_mesh = sd.add_quad(o + [-1, -1, 39.5], [0, 2, 0], [2, 0, 0], lm)
+    sd.cam_origin, sd.cam_lookat, sd.cam_up = o.tolist(), CAM[f"c{i}_lookat"].tolist(), CAM[f"c{i}_up"].tolist()
+    sd.fovy, sd.aspect = float(CAM[f"c{i}_fovy"]), float(CAM[f"c{i}_aspect"])
+    sd.triangle_soup()
+    osc = oa.Scene(sd)
+    W, H = 24, 16
+    for jit, key in (((0.0, 0.0), "mvp"), (tuple(CAM[f"c{i}_jitter"].tolist()), "mvp_jittered")):
+        pos = osc.primary(W, H, jit)[0]
+        M = CAM[f"c{i}_{key}"].astype(np.float64).T        # column-major GLM -> row-major
+        P = np.concatenate([pos[..., :3].astype(np.float64), np.ones((H, W, 1))], axis=-1) @ M.T
+        ndc = P[..., :2] / P[..., 3:4]
+        px = (ndc[..., 0] * 0.5 + 0.5) * W - 0.5; py = (ndc[..., 1] * 0.5 + 0.5) * H - 0.5
+        xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+        assert np.abs(px - xs).max() < 2e-3 and np.abs(py - ys).max() < 2e-3, (i, key, np.abs(px - xs).max(), np.abs(py - ys).max())
+        depth = P[..., 3]                                   # clip w = view depth: inside [near, far]
+        assert depth.min() > 0.1 and depth.max() < 100.0
+
+
+def test_fovx_to_fovy_and_bounding_sphere(oracle):
+    for i in range(int(CAM["n"])):
+        fovx, aspect = np.float32(CAM[f"c{i}_fovx"]), np.float32(CAM[f"c{i}_aspect"])
+        deg = np.float32(0.01745329251994329576923690768489)
+        fovy = np.float32(2.0) * np.arctan2(np.tan(fovx * deg * np.float32(0.5)), aspect)   # rt/rtcommon.h:559
+        assert abs(float(fovy) - float(CAM[f"c{i}_fovy"])) <= 2e-7
+    pts = CAM["bsr_points"]
+    sd = scenes.SceneData(); m = sd.add_material((0.5,) * 3)
+    idx = np.arange(pts.shape[0] // 3 * 3).reshape(-1, 3)
+    sd.add_mesh(pts[: idx.size], idx, m)
+    sd.light_mesh = sd.add_quad([0, 0, 0], [0, 1e-3, 0], [1e-3, 0, 0], m)   # inside the point cloud's bounds
+    sd.triangle_soup()
+    osc = oa.Scene(sd)
+    full = np.concatenate([pts[: idx.size], sd.meshes[1]["verts"]])
+    lo, hi = full.min(0), full.max(0)
+    want = np.float32(np.sqrt(np.float32(((hi - lo) ** 2).sum(dtype=np.float32)))) / np.float32(2)
+    got = oracle.evo_scene_bounding_sphere_radius(osc.h)
+    assert abs(got - float(want)) <= 1e-6 * float(want)
+    if idx.size == pts.shape[0]:
+        assert abs(got - float(CAM["bsr_radius"])) <= 1e-5 * got
+
+
+def test_reference_build_matches_fixtures_when_present():
+    """Where oracle/_ref exists (authoring container / prebuilt on the GPU box) re-run one reference call
+    live, so stale fixtures cannot hide."""
+    ref_path = os.path.join(oa.ROOT, "oracle", "_ref", "libref_pin.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref not built here")
+    ref = C.CDLL(ref_path)
+    ref.ref_mse.restype = C.c_double
+    ref.ref_mse.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    img, other = G["b_img"], G["b_other"]
+    assert ref.ref_mse(img.shape[1], img.shape[0], oa.ptr(other), oa.ptr(img)) == float(G["b_mse"])

@@ -1,0 +1,182 @@
+"""Self-consistency of the CPU oracle (no GPU): its BVH against brute force, RNG known answers, BRDF
+identities, energy conservation of light tracing, the progressive schedule."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import scenes
+
+
+@pytest.fixture(scope="module")
+def room_scene():
+    room = scenes.box_room(seed=11, n_boxes=6, tess=2, textured=True)
+    return room, oa.Scene(room)
+
+
+def test_record_layout_is_96_bytes():
+    assert oa.RECORD_DTYPE.itemsize == 96                      # rtphotonrecord.h:17-25
+    assert oa.RECORD_DTYPE.fields["flags"][1] == 12 and oa.RECORD_DTYPE.fields["phong_exp"][1] == 92
+
+
+def test_rng_known_answers(oracle):
+    r = oa.Rng()
+    oracle.evo_rng_init(C.byref(r), 0, 0, 0)
+    first = [oracle.evo_rng_u32(C.byref(r)) for _ in range(4)]
+    oracle.evo_rng_init(C.byref(r), 0, 0, 0)
+    assert first == [oracle.evo_rng_u32(C.byref(r)) for _ in range(4)]
+    # pure-python restatement of the generator (splitmix64 + PCG32 XSH-RR)
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+
+    def stream(index, seq, sub, n):
+        s0 = sm((((seq << 32) | index) + sub * 0xD1B54A32D192ED03) & M)
+        inc = sm(s0) | 1
+        state = (s0 + inc) & M
+        out = []
+        for k in range(n + 1):
+            old = state
+            state = (old * 6364136223846793005 + inc) & M
+            xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+            rot = old >> 59
+            out.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        return out[1:]
+    for index, seq, sub in ((0, 0, 0), (7, 3, 0), (123456, 99, 17)):
+        oracle.evo_rng_init(C.byref(r), index, seq, sub)
+        got = [oracle.evo_rng_u32(C.byref(r)) for _ in range(5)]
+        assert got == stream(index, seq, sub, 5)
+    oracle.evo_rng_init(C.byref(r), 1, 2, 3)
+    u = np.array([oracle.evo_rng_uniform(C.byref(r)) for _ in range(20000)])
+    assert u.min() > 0.0 and u.max() <= 1.0 and abs(u.mean() - 0.5) < 0.01      # (0,1] like curand_uniform
+
+
+def test_bvh_matches_brute_force(room_scene, oracle):
+    room, s = room_scene
+    rng = np.random.RandomState(4)
+    for _ in range(3000):
+        o = (rng.rand(3) * [10, 8, 5]).astype(np.float32); e = (rng.rand(3) * [10, 8, 5]).astype(np.float32)
+        d = (e - o).astype(np.float32)
+        assert oracle.evo_occluded(s.h, oa.ptr(o), oa.ptr(d), 1e-4, 1 - 1e-4) == oracle.evo_occluded_brute(s.h, oa.ptr(o), oa.ptr(d), 1e-4, 1 - 1e-4)
+    # closest hit: nearest over all triangles, checked by an independent loop over evo_tri_test
+    verts = s.verts
+    t, b, g = (C.c_float() for _ in range(3))
+    for _ in range(200):
+        o = (np.array([1, 1, 1]) + rng.rand(3) * [8, 6, 3]).astype(np.float32); d = rng.randn(3).astype(np.float32)
+        tri = oracle.evo_closest(s.h, oa.ptr(o), oa.ptr(d), 1e-4, 3e38, 0, C.byref(t), C.byref(b), C.byref(g))
+        best, bt = -1, 3e38
+        tt, bb, gg = (C.c_float() for _ in range(3))
+        for k in range(verts.shape[0]):
+            v = verts[k]
+            if oracle.evo_tri_test(oa.ptr(v[0:3]), oa.ptr(v[3:6]), oa.ptr(v[6:9]), oa.ptr(o), oa.ptr(d), 1e-4, 3e38, C.byref(tt), C.byref(bb), C.byref(gg)):
+                if tt.value < bt:
+                    best, bt = k, tt.value
+        assert tri == best and (tri < 0 or t.value == bt)
+
+
+def test_brdf_identities(oracle):
+    rng = np.random.RandomState(5)
+    for _ in range(200):
+        n = rng.randn(3); n /= np.linalg.norm(n); n = n.astype(np.float32)
+        w = rng.randn(3); w /= np.linalg.norm(w); w = w.astype(np.float32)
+        e = float(rng.rand() * 40)
+        mirror = (2 * n * float(n @ w) - w).astype(np.float32)
+        # PhongEvalF at the mirror direction = (e+2)/(2 pi)   (rtmaterial.cuh:112-118)
+        val = oracle.evo_phong_eval_f(oa.ptr(mirror), oa.ptr(w), oa.ptr(n), e)
+        if float(mirror @ (2 * n * float(n @ w) - w)) > 1e-6:
+            assert abs(val - (e + 2) / (2 * math.pi)) < 1e-3 * (e + 2)
+    # LambertPdfA = GeometryTerm / pi  (rtmaterial.cuh:30-54)
+    n1 = np.array([0, 0, 1], np.float32); n2 = np.array([0, 0, -1], np.float32); v = np.array([0.3, 0.2, 2.0], np.float32)
+    c1, c2, d2 = float(n1 @ v), float(-(n2 @ v)), float(v @ v)
+    assert abs(oracle.evo_lambert_pdf_a(oa.ptr(n1), oa.ptr(n2), oa.ptr(v)) - c1 * c2 / d2 / d2 / math.pi) < 1e-7
+    # thresholds: PhongPdfW is 0 for rho_s.x <= 1e-6 (rtmaterial.cuh:83)
+    z = np.array([0, 0, 0], np.float32)
+    assert oracle.evo_phong_pdf_w(oa.ptr(n1), oa.ptr(v), oa.ptr(v), oa.ptr(z), 10.0) == 0.0
+
+
+def test_light_tracing_structure_and_energy(room_scene):
+    room, s = room_scene
+    N, P = 2000, 4
+    rec = s.trace_light_paths(1, N, P).reshape(N, P)
+    area = s.lib.evo_scene_light_area(s.h)
+    # record 0: on-light VPL with flux = I * pi * A (rtlightsource.cuh:71-79, lighttracing.cu:215-225)
+    assert (rec["flags"][:, 0] == 1).all()
+    want = np.float32(np.array(room.light_intensity[:3], np.float32) * np.float32(math.pi)) * np.float32(area)
+    assert np.allclose(rec["flux"][:, 0], want[None, :], rtol=1e-6)
+    assert np.allclose(rec["pos"][:, 0, 2], 4.9)                           # all samples on the light quads
+    assert (rec["normal"][:, 0, 2] < -0.999).all()
+    # flags: inner vertices VPL|photon (+lobe bit), last slot photon only; flux never grows without bound
+    inner = rec["flags"][:, 1:P - 1]
+    assert set(np.unique(inner & 3).tolist()) <= {0, 3}
+    assert set(np.unique(rec["flags"][:, P - 1] & 3).tolist()) <= {0, 2}
+    used = rec["flags"] != 0
+    assert np.isfinite(rec["flux"][used]).all() and rec["flux"][used].max() < 100 * want.max()
+    # a different seed gives a different set; the same seed the same set
+    assert rec.tobytes() == s.trace_light_paths(1, N, P).tobytes()
+    assert rec.tobytes() != s.trace_light_paths(2, N, P).tobytes()
+
+
+def test_gather_and_path_tracer_agree_in_expectation(room_scene):
+    """Instant radiosity (many VPLs, misMode one) and the NEE path tracer estimate the same image
+    (direct + <= 3 indirect bounces): a coarse statistical cross-check of two restated algorithms."""
+    room, s = room_scene
+    W, H = 24, 16
+    room.aspect = W / H
+    g = s.primary(W, H)
+    fp = dict(camera_pos=room.cam_origin, mis_mode=4, clamping_value=1e9, num_light_paths=400, num_vpl_light_paths=400, photons_per_path=4, do_accumulate=1)
+    acc = np.zeros((H, W, 4), np.float32)
+    for it in range(3):
+        rec = s.trace_light_paths(it, 400, 4)
+        s.gather(oa.frame_params(rng_seed=it, **fp), W, H, g, rec, out=acc)
+    ir = acc[..., :3] / 3
+    pt = np.zeros((H, W, 4), np.float32)
+    n_it = 96
+    for it in range(n_it):
+        s.path_trace(room.cam_origin, it, 3, W, H, g, out=pt)
+    pt = pt[..., :3] / n_it
+    a, b = ir.mean(axis=(0, 1)), pt.mean(axis=(0, 1))
+    assert np.all(np.abs(a - b) < 0.12 * b), (a, b)
+
+
+def test_progressive_schedule_closed_form(oracle, evplp):
+    r0, alpha, cs = 0.05, 0.7, 0.02
+    r, c, p, vr, vi = (C.c_float(x) for x in (r0, cs, 0.0, 0.1, 0.0))
+    pr, pc, pp = r0, cs, 0.0
+    for i in range(1, 101):
+        oracle.evo_progressive_step(i, alpha, cs, 30, 300000, C.byref(r), C.byref(c), C.byref(p), 1, C.byref(vr), C.byref(vi))
+        pr, pc, pp, _, _ = evplp.progressive_step(i, alpha, cs, 30, 300000, pr, pc, pp)
+        assert (r.value, c.value, p.value) == (pr, pc, pp)              # product host code == oracle, bit for bit
+    # Knaus-Zwicker: r_n^2 = r_0^2 * prod (i + alpha) / (i + 1)
+    want = r0 * math.sqrt(np.prod([(i + alpha) / (i + 1) for i in range(1, 101)]))
+    assert abs(r.value - want) < 1e-5 * want
+    assert abs(c.value - cs * 100 ** alpha) < 1e-5 * c.value
+    assert abs(p.value - (30 / 300000) / math.pi / r.value ** 2) < 1e-4 * p.value
+    assert vr.value >= 0.008                                              # floor rtcomphoton.h:1050-1054
+
+
+def test_photon_fragment_modes_are_complements(oracle):
+    """VPL-side weight + photon-side weight = 1 for the MIS modes: checked on the weights the
+    restated shader and vplSplat apply to one fixed geometry."""
+    ph = np.zeros(2, oa.RECORD_DTYPE)
+    ph[0]["pos"] = (0, 0, 2); ph[0]["normal"] = (0, 0, -1); ph[0]["flux"] = (1, 1, 1); ph[0]["flux_dir"] = (0, 0, -1)
+    ph[0]["rho_s"] = (1, 1, 1); ph[0]["flags"] = 1
+    ph[1]["pos"] = (0.2, 0.1, 0); ph[1]["normal"] = (0, 0, 1); ph[1]["flux"] = (0.7, 0.6, 0.5); ph[1]["flux_dir"] = (-0.1, -0.05, 1)
+    ph[1]["rho_d"] = (0.5, 0.5, 0.5); ph[1]["p_select_lambert"] = 1.0; ph[1]["flags"] = 3
+    X = np.array([0.21, 0.11, 0.0], np.float32); N = np.array([0, 0, 1], np.float32)
+    dif = np.array([0.6, 0.6, 0.6], np.float32); phg = np.array([0, 0, 0, 0], np.float32)
+    out0 = np.zeros(3, np.float32); out1 = np.zeros(3, np.float32)
+    base = dict(camera_pos=(0, -3, 1), photon_radius=0.05, num_light_paths=10, num_vpl_light_paths=10, photons_per_path=2)
+    fp0 = oa.frame_params(mis_mode=0, **base)
+    assert oracle.evo_photon_frag(C.byref(fp0), oa.ptr(ph[1:2]), oa.ptr(ph[0:1]), oa.ptr(X), oa.ptr(N), oa.ptr(dif), oa.ptr(phg), oa.ptr(out0)) == 1
+    fp1 = oa.frame_params(mis_mode=1, pdf_mc=0.37, **base)
+    oracle.evo_photon_frag(C.byref(fp1), oa.ptr(ph[1:2]), oa.ptr(ph[0:1]), oa.ptr(X), oa.ptr(N), oa.ptr(dif), oa.ptr(phg), oa.ptr(out1))
+    w_photon = out1 / out0
+    assert np.allclose(w_photon, w_photon[0]) and 0 < w_photon[0] < 1
+    far = np.array([5, 5, 0], np.float32)
+    assert oracle.evo_photon_frag(C.byref(fp0), oa.ptr(ph[1:2]), oa.ptr(ph[0:1]), oa.ptr(far), oa.ptr(N), oa.ptr(dif), oa.ptr(phg), oa.ptr(out0)) == 0   # outside the kernel radius: discard
