@@ -1,0 +1,266 @@
+"""GPU tests above the kernel level: the technique loop driven by the scene JSON (evplp_render_json)
+against the same loop driven over the oracle; full-size (BASELINE config #2) checks through sampled pixels
+and size-independent properties; edge cases (ragged resolutions, tiny scenes, textures)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-30))
+
+
+class MT19937:
+    """std::mt19937 (common/rng.h:9-44 with USE_DETERMINISTIC_RESULT)"""
+
+    def __init__(self, seed):
+        self.mt = [0] * 624; self.idx = 624
+        self.mt[0] = seed & 0xFFFFFFFF
+        for i in range(1, 624):
+            self.mt[i] = (1812433253 * (self.mt[i - 1] ^ (self.mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+
+    def __call__(self):
+        if self.idx >= 624:
+            for i in range(624):
+                y = (self.mt[i] & 0x80000000) | (self.mt[(i + 1) % 624] & 0x7FFFFFFF)
+                self.mt[i] = self.mt[(i + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            self.idx = 0
+        y = self.mt[self.idx]; self.idx += 1
+        y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680; y ^= (y << 15) & 0xEFC60000; y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+
+def oracle_technique(json_path, block):
+    """RtComPhoton::render / run (rtcomphoton.h:107-223, 883-1133) driven over the oracle passes."""
+    sd, root = scenes.load_obj_scene(json_path)
+    osc = oa.Scene(sd)
+    l = oa.load()
+    W, H = root["resX"], root["resY"]
+    nl, nv, P = block["numLightPaths"], block["numVplLightPaths"], block["numMaxBounces"] + 1
+    f32 = np.float32
+    bsr = f32(l.evo_scene_bounding_sphere_radius(osc.h))
+    radius = f32(bsr * f32(block["radiusPercentage"]))
+    inv_pi = f32(0.318309886183790671537767526745028724068919291480912897495)
+    with np.errstate(divide="ignore"):
+        pdf_mc = f32(f32(nv) / f32(nl) * inv_pi / f32(radius * radius))
+    clamp = f32(block["clampingCoeff"]) if "clampingCoeff" in block else f32(1.0) / f32(l.evo_scene_total_area(osc.h))
+    clamp_start = clamp
+    mode = {"one": 0, "balance": 1, "max": 2, "power2": 3, "geometryClamp": 4, "geometryBrdfClamp": 5}[block.get("misMode", "balance")]
+    accumulate = block["frameMode"] == "accumulate"
+    rng = MT19937(block["rngOffset"])
+    vpl = np.zeros((H, W, 4), np.float32); pm = np.zeros((H, W, 4), np.float32); light = np.zeros((H, W, 4), np.float32)
+    import ctypes as C
+    n_it = 0
+    while n_it != block["numMaxIteration"]:
+        jitter = (0.0, 0.0)
+        if block["useJitter"]:
+            ux = f32(rng() >> 8) * f32(1.0 / 16777216.0); uy = f32(rng() >> 8) * f32(1.0 / 16777216.0)
+            jitter = (float((f32(2) * ux - f32(1)) * (f32(1) / f32(W))), float((f32(2) * uy - f32(1)) * (f32(1) / f32(H))))
+        g = osc.primary(W, H, jitter)
+        lit = g[4][..., 0] > 0
+        if not accumulate:
+            light[:] = 0
+        light[lit] = g[4][lit]
+        rec = osc.trace_light_paths(n_it + block["rngOffset"], nl, P)
+        kw = dict(camera_pos=sd.cam_origin, mis_mode=mode, pdf_mc=float(pdf_mc), clamping_value=float(clamp), photon_radius=float(radius),
+                  num_light_paths=nl, num_vpl_light_paths=nv, photons_per_path=P, do_accumulate=int(accumulate), rng_seed=n_it + block["rngOffset"], jitter=jitter)
+        if nv > 0:
+            osc.gather(oa.frame_params(**kw), W, H, g, rec, out=vpl)
+        if radius > 0:
+            if not accumulate:
+                pm[:] = 0
+            oa.splat(oa.frame_params(**kw), W, H, g, rec, out=pm)
+        n_it += 1
+        if block.get("DoProgressive", False):
+            r, c, p, vr, vi = (C.c_float(x) for x in (radius, clamp, pdf_mc, 0.0, 0.0))
+            l.evo_progressive_step(n_it, block.get("AlphaProgressive", 0.7), float(clamp_start), nv, nl, C.byref(r), C.byref(c), C.byref(p), 0, C.byref(vr), C.byref(vi))
+            radius, clamp, pdf_mc = f32(r.value), f32(c.value), f32(p.value)
+    param = 1.0 / n_it if accumulate else 1.0
+    outs = {}
+    for name, (vs, ps, ls) in {"combined": (param, param, 1.0), "vpl": (param, 0.0, 1.0), "pm": (0.0, param, 0.0)}.items():
+        rgb = np.zeros((H, W, 3), np.float32)
+        l.evo_resolve(W, H, oa.ptr(vpl), oa.ptr(pm), oa.ptr(light), vs, ps, ls, 0, 0, oa.ptr(rgb))
+        outs[name] = rgb[::-1]          # FlipY before Save (rtcomphoton.h:1124-1127)
+    return outs
+
+
+@pytest.mark.parametrize("variant", ["progressive_balance", "ir_one_cleareveryframe"])
+def test_render_json_matches_oracle_loop(evplp, tmp_path, variant):
+    jp = evplp.synth_scene(str(tmp_path), "room", 4000, 3, 80, 56)
+    root = json.load(open(jp))
+    block = root["photonfam"]
+    if variant == "progressive_balance":
+        block.update(numLightPaths=96, numVplLightPaths=24, radiusPercentage=0.03, misMode="balance", numMaxIteration=3,
+                     DoProgressive=True, AlphaProgressive=0.7, run={})
+    else:
+        block.update(numLightPaths=48, numVplLightPaths=48, radiusPercentage=0.0, misMode="one", numMaxIteration=2, frameMode="cleareveryframe", rngOffset=5)
+    block.update(combinedFilename=f"{variant}_c.pfm", weightedVplFilename=f"{variant}_v.pfm", weightedPhotonFilename=f"{variant}_p.pfm",
+                 statFilename=f"{variant}_stat.json")
+    root["photonfam"] = block
+    json.dump(root, open(jp, "w"))
+    evplp.render_json(jp)
+    want = oracle_technique(jp, block)
+    stat = json.load(open(tmp_path / f"{variant}_stat.json"))
+    assert stat["numIterations"] == block["numMaxIteration"] and stat["time"] > 0
+    for key, fn in (("combined", "c"), ("vpl", "v"), ("pm", "p")):
+        got = evplp.load_pfm(str(tmp_path / f"{variant}_{fn}.pfm"))
+        assert got.shape == want[key].shape and np.isfinite(got).all()
+        if want[key].max() == 0:
+            assert got.max() == 0
+        else:
+            assert rel_l2(got, want[key]) <= 1e-4, (variant, key, rel_l2(got, want[key]))   # north-star bar: 1e-3
+    assert want["combined"].max() > 0
+    if variant == "progressive_balance":
+        assert want["pm"].max() > 0
+
+
+def test_png_output_and_overrides(evplp, tmp_path):
+    jp = evplp.synth_scene(str(tmp_path), "room", 2000, 3, 40, 24)
+    evplp.render_json(jp, json.dumps(dict(numLightPaths=16, numVplLightPaths=16, numMaxIteration=1, combinedFilename="c.png",
+                                          weightedVplFilename="v.png", weightedPhotonFilename="p.png")))
+    for f in ("c.png", "v.png", "p.png"):
+        data = open(tmp_path / f, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 40 * 24 * 3
+
+
+# ----------------------------------------------------------------------------- full size (BASELINE config #2)
+@pytest.fixture(scope="module")
+def full_scene(evplp, tmp_path_factory):
+    d = tmp_path_factory.mktemp("conf")
+    jp = evplp.synth_scene(str(d), "conference_synth", 331000, 1234, 1024, 1024)
+    return jp
+
+
+def test_full_size_sampled_pixels_and_properties(evplp, full_scene):
+    W = H = 1024; N, P = 1024, 4
+    with evplp.Context(W, H, N, N, P) as c:
+        c.load_scene_json(full_scene)
+        cam = c.camera()
+        c.primary((0.0, 0.0)); c.trace_light_paths(0)
+        kw = dict(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=N, num_vpl_light_paths=N, photons_per_path=P)
+        c.gather_vpl(evplp.frame_params(**kw))
+        a = c.download(evplp.BUF_VPL_ACCUM)
+        st = c.pass_stats(evplp.PASS_GATHER_VPL)
+        rec = c.download(evplp.BUF_RECORDS)
+        gbuf = [c.download(b) for b in (evplp.BUF_GBUF_POSITION, evplp.BUF_GBUF_NORMAL, evplp.BUF_GBUF_DIFFUSE, evplp.BUF_GBUF_PHONG)]
+        # idempotence / determinism: the same launch again gives the same bits
+        c.gather_vpl(evplp.frame_params(**kw))
+        assert a.tobytes() == c.download(evplp.BUF_VPL_ACCUM).tobytes()
+        # linearity: flux x 2 (exact in fp32) -> image x 2, bit for bit
+        rec2 = rec.copy(); rec2["flux"] *= np.float32(2)
+        c.upload(evplp.BUF_RECORDS, rec2)
+        c.gather_vpl(evplp.frame_params(**kw))
+        b = c.download(evplp.BUF_VPL_ACCUM)
+        assert np.array_equal(b[..., :3], a[..., :3] * np.float32(2))
+        # accumulation: out = new + old
+        c.upload(evplp.BUF_RECORDS, rec)
+        c.gather_vpl(evplp.frame_params(do_accumulate=1, **kw))
+        acc = c.download(evplp.BUF_VPL_ACCUM)
+        assert np.allclose(acc[..., :3], a[..., :3] + b[..., :3], rtol=1e-6, atol=0)
+    usable = int((rec["flags"][: N * P] & 1).astype(bool).sum())
+    assert st["usable"] == usable and st["pairs"] == usable * W * H and 0 < st["rays"] <= st["pairs"]
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0.01
+    # sampled pixels against the oracle on the full scene / full VPL set
+    sd, _ = scenes.load_obj_scene(full_scene)
+    osc = oa.Scene(sd)
+    rng = np.random.RandomState(1)
+    ys = rng.randint(0, H, 48)
+    out = np.zeros((H, W, 4), np.float32)
+    okw = dict(kw); okw["mis_mode"] = 0
+    # compare whole rows' worth of 6 random pixels per row through a masked G-buffer: stencil 0 skips the rest
+    gmask = [g.copy() for g in gbuf]
+    keep = np.zeros((H, W), bool)
+    for y in ys:
+        keep[y, rng.randint(0, W, 6)] = True
+    gmask[0][~keep, 3] = 0.0
+    for y in np.unique(ys):
+        osc.gather(oa.frame_params(**okw), W, H, gmask, rec, out=out, rows=(int(y), int(y) + 1))
+    got, ref = a[keep][:, :3], out[keep][:, :3]
+    assert ref.max() > 0
+    err = np.abs(got.astype(np.float64) - ref) / (np.abs(ref) + 1e-3 * ref.max())
+    assert err.max() <= 2e-4, err.max()
+
+
+# ----------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("res", [(50, 37), (8, 8), (129, 65)])
+def test_ragged_resolutions(evplp, res):
+    W, H = res
+    room = scenes.box_room(seed=9, n_boxes=2, tess=1, aspect=W / H, textured=True)
+    osc = oa.Scene(room)
+    N, P = 16, 3
+    r = 0.5
+    kw = dict(camera_pos=room.cam_origin, mis_mode=3, pdf_mc=1 / (math.pi * r * r), photon_radius=r, num_light_paths=N, num_vpl_light_paths=N, photons_per_path=P)
+    with evplp.Context(W, H, N, N, P, deterministic=True) as c:
+        room.upload(c)
+        c.primary((0.0, 0.0), clear_light=True); c.trace_light_paths(2)
+        c.gather_vpl(evplp.frame_params(**kw)); c.splat_photons(evplp.frame_params(**kw), clear=True)
+        vpl = c.download(evplp.BUF_VPL_ACCUM)[:H]; pm = c.download(evplp.BUF_PHOTON_ACCUM)[:H]
+        gdif = c.download(evplp.BUF_GBUF_DIFFUSE)[:H]
+        rec = c.download(evplp.BUF_RECORDS)
+    g = osc.primary(W, H)
+    # texture filtering is shading arithmetic (may be contracted on the GPU): tolerance, not bit equality
+    assert np.allclose(gdif, g[2], rtol=2e-6, atol=1e-7), "textured materials: bilinear-repeat fetch differs"
+    orec = osc.trace_light_paths(2, N, P)
+    assert np.array_equal(rec["flags"], orec["flags"])
+    rv, _ = osc.gather(oa.frame_params(**kw), W, H, g, orec)
+    rp, _ = oa.splat(oa.frame_params(**kw), W, H, g, orec)
+    assert rel_l2(vpl[..., :3], rv[..., :3]) <= 1e-5 and rel_l2(pm[..., :3], rp[..., :3]) <= 1e-5
+
+
+def test_tiny_scene_single_leaf_and_degenerate_triangles(evplp):
+    """A floor quad + a light quad (BVH root is a single leaf) with a zero-area triangle thrown in
+    (meshBound invalidates it, rt/triangleintersect.cu:62-81)."""
+    sd = scenes.SceneData()
+    m = sd.add_material((0.7, 0.6, 0.5)); lm = sd.add_material((0, 0, 0))
+    sd.add_mesh([[-5, -5, 0], [5, -5, 0], [5, 5, 0], [-5, 5, 0], [1, 1, 0]], [[0, 1, 2], [0, 2, 3], [4, 4, 4]], m)
+    sd.light_mesh = sd.add_quad([-0.5, -0.5, 3.0], [0, 1, 0], [1, 0, 0], lm)
+    sd.cam_origin = [0, -6, 2.5]; sd.cam_lookat = [0, 0, 0.5]; sd.fovy = math.radians(50); sd.aspect = 1.5
+    sd.triangle_soup()
+    osc = oa.Scene(sd)
+    W, H, N, P = 48, 32, 8, 2
+    kw = dict(camera_pos=sd.cam_origin, mis_mode=0, num_light_paths=N, num_vpl_light_paths=N, photons_per_path=P)
+    with evplp.Context(W, H, N, N, P) as c:
+        sd.upload(c)
+        info = c.accel_info()
+        assert info["nodes"] == 1 and info["leaves"] == 1
+        c.primary((0, 0), clear_light=True); c.trace_light_paths(0); c.gather_vpl(evplp.frame_params(**kw))
+        vpl = c.download(evplp.BUF_VPL_ACCUM)[:H]; rec = c.download(evplp.BUF_RECORDS); pos = c.download(evplp.BUF_GBUF_POSITION)[:H]
+    g = osc.primary(W, H)
+    orec = osc.trace_light_paths(0, N, P)
+    assert np.array_equal(rec["flags"], orec["flags"])
+    assert np.allclose(pos, g[0], atol=2e-5)
+    rv, _ = osc.gather(oa.frame_params(**kw), W, H, g, orec)
+    assert rv.max() > 0 and rel_l2(vpl[..., :3], rv[..., :3]) <= 1e-5
+
+
+def test_api_misuse_is_reported(evplp):
+    with evplp.Context(16, 16, 4, 4, 2) as c:
+        with pytest.raises(evplp.EvplpError) as e:
+            c.primary()
+        assert "not built" in str(e.value)
+        m = c.add_material((0.5,) * 3, (0,) * 3, 0)
+        with pytest.raises(evplp.EvplpError):
+            c.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 5]], m)            # index out of range
+        with pytest.raises(evplp.EvplpError):
+            c.build_accel()                                                           # no meshes / no light
+        mesh = c.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
+        c.set_arealight(mesh, [1, 1, 1, 0])
+        with pytest.raises(evplp.EvplpError) as e:
+            c.set_arealight(mesh, [1, 1, 1, 0])                                       # only one light (rtcommon.h:770-774)
+        assert "one area light" in str(e.value)
+        c.set_camera([0, -3, 1], [0, 0, 0], [0, 0, 1], 0.8, 1.0); c.build_accel()
+        with pytest.raises(evplp.EvplpError):
+            c.gather_vpl(evplp.frame_params(camera_pos=(0, 0, 0), num_light_paths=4, num_vpl_light_paths=4, photons_per_path=3))   # P mismatch
+        with pytest.raises(evplp.EvplpError):
+            c.splat_photons(evplp.frame_params(camera_pos=(0, 0, 0), num_light_paths=4, num_vpl_light_paths=4, photons_per_path=2, photon_radius=0.0))
+        with pytest.raises(evplp.EvplpError):
+            c.trace_light_paths(0, 2, 10)
