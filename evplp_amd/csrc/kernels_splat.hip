@@ -88,11 +88,13 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
     // (jittered) camera of this iteration: uMVP of runPhotonSplat is the jittered matrix (:982)
     V3 q = ph.pos - v3(a.cam.eye);
     float vx = dot(q, v3(a.cam.s)), vy = dot(q, v3(a.cam.u)), vz = dot(q, v3(a.cam.f));
-    float zlo = vz - r, zhi = vz + r;
+    // visible surface points have view depth in [near, far] = [0.1, 100] (rtcommon.h:586): clip the
+    // sphere's depth range to it -- a photon closer than r to the camera plane then needs no
+    // whole-screen fallback (those few photons used to produce most of the bin entries)
+    const float zlo = fmaxf(vz - r, 0.1f), zhi = fminf(vz + r, 100.0f);
     int x0, x1, y0, y1;
-    if (zhi <= 0.0f) { a.rect[i] = none; return; }
-    if (zlo <= 1e-4f) { x0 = 0; x1 = a.st.W - 1; y0 = 0; y1 = a.st.H - 1; }
-    else {
+    if (zlo > zhi) { a.rect[i] = none; return; }
+    {
         float sx = 1.0f / (a.cam.aspect * a.cam.tan_half), sy = 1.0f / a.cam.tan_half;
         float il = 1.0f / zlo, ih = 1.0f / zhi;
         float nx0 = fminf((vx - r) * il, (vx - r) * ih) * sx + a.fp.jitter[0];
