@@ -332,7 +332,11 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if ((m0 | m1) == 0ull) { cur = kNoChild; break; }
             if (m0 != 0ull && m1 != 0ull) {
                 // descend into the child wanted by more lanes first, keep the other one on the stack
+#ifdef EVPLP_NO_POPCOUNT
+                const bool first0 = true;
+#else
                 const bool first0 = __builtin_popcountll(m0) >= __builtin_popcountll(m1);
+#endif
                 const int32_t oth = first0 ? c1 : c0;
                 if (sp < 64) vstack = lane_write(oth, sp, vstack); else wave_stack[sp - 64] = oth;
                 sp++;

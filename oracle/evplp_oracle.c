@@ -133,43 +133,83 @@ static float tri_area(const float *v) {
     return sqrtf(dot(cr, cr)) / 2.0f;
 }
 
-typedef struct { const float *verts; int axis; } sortctx;
-static const float *g_sort_verts; static int g_sort_axis;
-static int cmp_centroid(const void *pa, const void *pb) {
-    int a = *(const int32_t *)pa, b = *(const int32_t *)pb;
-    const float *va = g_sort_verts + 9 * (size_t)a, *vb = g_sort_verts + 9 * (size_t)b;
-    float ca = va[g_sort_axis] + va[3 + g_sort_axis] + va[6 + g_sort_axis];
-    float cb = vb[g_sort_axis] + vb[3 + g_sort_axis] + vb[6 + g_sort_axis];
-    return (ca > cb) - (ca < cb);
-}
 static void tri_bounds(const float *v, float lo[3], float hi[3]) {
     for (int k = 0; k < 3; k++) {
         lo[k] = minf(minf(v[k], v[3 + k]), v[6 + k]);
         hi[k] = maxf(maxf(v[k], v[3 + k]), v[6 + k]);
     }
 }
+/* private BVH of the oracle: top-down binned SAH (12 bins), leaves of <= 4 triangles.  Any correct
+ * BVH gives the same query results (the triangle test decides); this one only makes the checker and the
+ * CPU baseline reasonably fast. */
 static int32_t build_rec(evo_scene *s, int32_t first, int32_t count) {
     int32_t id = s->nnodes++;
     bnode *n = &s->nodes[id];
+    float clo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, chi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
     for (int k = 0; k < 3; k++) { n->lo[k] = 3.0e38f; n->hi[k] = -3.0e38f; }
     for (int32_t i = 0; i < count; i++) {
         float lo[3], hi[3];
         tri_bounds(s->verts + 9 * (size_t)s->order[first + i], lo, hi);
-        for (int k = 0; k < 3; k++) { n->lo[k] = minf(n->lo[k], lo[k]); n->hi[k] = maxf(n->hi[k], hi[k]); }
+        for (int k = 0; k < 3; k++) {
+            n->lo[k] = minf(n->lo[k], lo[k]); n->hi[k] = maxf(n->hi[k], hi[k]);
+            float c = 0.5f * (lo[k] + hi[k]); clo[k] = minf(clo[k], c); chi[k] = maxf(chi[k], c);
+        }
     }
     for (int k = 0; k < 3; k++) { n->lo[k] -= s->pad; n->hi[k] += s->pad; }
     n->first = first; n->count = count; n->left = n->right = -1;
-    if (count > 4) {
-        int axis = 0; float ext = n->hi[0] - n->lo[0];
-        for (int k = 1; k < 3; k++) if (n->hi[k] - n->lo[k] > ext) { ext = n->hi[k] - n->lo[k]; axis = k; }
-        g_sort_verts = s->verts; g_sort_axis = axis;
-        qsort(s->order + first, (size_t)count, sizeof(int32_t), cmp_centroid);
-        int32_t half = count / 2;
-        int32_t l = build_rec(s, first, half);
-        int32_t r = build_rec(s, first + half, count - half);
-        n = &s->nodes[id];
-        n->left = l; n->right = r; n->count = 0;
+    if (count <= 4) return id;
+    enum { NB = 12 };
+    float best = 3.0e38f; int baxis = -1, bbin = -1;
+    for (int axis = 0; axis < 3; axis++) {
+        float ext = chi[axis] - clo[axis];
+        if (!(ext > 0.f)) continue;
+        float blo[NB][3], bhi[NB][3]; int cnt[NB];
+        for (int b = 0; b < NB; b++) { cnt[b] = 0; for (int k = 0; k < 3; k++) { blo[b][k] = 3.0e38f; bhi[b][k] = -3.0e38f; } }
+        float scale = NB / ext;
+        for (int32_t i = 0; i < count; i++) {
+            float lo[3], hi[3];
+            tri_bounds(s->verts + 9 * (size_t)s->order[first + i], lo, hi);
+            int b = (int)((0.5f * (lo[axis] + hi[axis]) - clo[axis]) * scale); if (b >= NB) b = NB - 1;
+            cnt[b]++;
+            for (int k = 0; k < 3; k++) { blo[b][k] = minf(blo[b][k], lo[k]); bhi[b][k] = maxf(bhi[b][k], hi[k]); }
+        }
+        float ra[NB]; int rc[NB]; float alo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, ahi[3] = { -3.0e38f, -3.0e38f, -3.0e38f }; int c = 0;
+        for (int b = NB - 1; b > 0; b--) {
+            for (int k = 0; k < 3; k++) { alo[k] = minf(alo[k], blo[b][k]); ahi[k] = maxf(ahi[k], bhi[b][k]); }
+            c += cnt[b]; rc[b] = c;
+            float dx = ahi[0] - alo[0], dy = ahi[1] - alo[1], dz = ahi[2] - alo[2];
+            ra[b] = c ? dx * dy + dy * dz + dz * dx : 0.f;
+        }
+        for (int k = 0; k < 3; k++) { alo[k] = 3.0e38f; ahi[k] = -3.0e38f; }
+        c = 0;
+        for (int b = 0; b < NB - 1; b++) {
+            for (int k = 0; k < 3; k++) { alo[k] = minf(alo[k], blo[b][k]); ahi[k] = maxf(ahi[k], bhi[b][k]); }
+            c += cnt[b];
+            if (!c || !rc[b + 1]) continue;
+            float dx = ahi[0] - alo[0], dy = ahi[1] - alo[1], dz = ahi[2] - alo[2];
+            float cost = (dx * dy + dy * dz + dz * dx) * (float)c + ra[b + 1] * (float)rc[b + 1];
+            if (cost < best) { best = cost; baxis = axis; bbin = b; }
+        }
     }
+    int32_t mid = first;
+    if (baxis >= 0) {
+        float scale = NB / (chi[baxis] - clo[baxis]);
+        int32_t i = first, j = first + count - 1;
+        while (i <= j) {
+            float lo[3], hi[3];
+            tri_bounds(s->verts + 9 * (size_t)s->order[i], lo, hi);
+            int b = (int)((0.5f * (lo[baxis] + hi[baxis]) - clo[baxis]) * scale); if (b >= NB) b = NB - 1;
+            if (b <= bbin) i++; else { int32_t t = s->order[i]; s->order[i] = s->order[j]; s->order[j] = t; j--; }
+        }
+        mid = i;
+    }
+    if (mid == first || mid == first + count) {   /* coincident centroids: split by index */
+        mid = first + count / 2;
+    }
+    int32_t l = build_rec(s, first, mid - first);
+    int32_t r = build_rec(s, mid, first + count - mid);
+    n = &s->nodes[id];
+    n->left = l; n->right = r; n->count = 0;
     return id;
 }
 
@@ -339,7 +379,13 @@ int evo_closest(const evo_scene *s, const float o_[3], const float d_[3], float 
                     if (t < bt || (t == bt && best >= 0 && tri < best)) { bt = t; bb = b; bg = g; best = tri; }
                 }
             }
-        } else { stack[sp++] = n->left; stack[sp++] = n->right; }
+        } else {
+            /* near child first (pushed last): split-axis heuristic by box centre along the ray direction */
+            const bnode *L = &s->nodes[n->left], *R = &s->nodes[n->right];
+            float cl = (L->lo[0] + L->hi[0]) * d.x + (L->lo[1] + L->hi[1]) * d.y + (L->lo[2] + L->hi[2]) * d.z;
+            float cr = (R->lo[0] + R->hi[0]) * d.x + (R->lo[1] + R->hi[1]) * d.y + (R->lo[2] + R->hi[2]) * d.z;
+            if (cl <= cr) { stack[sp++] = n->right; stack[sp++] = n->left; } else { stack[sp++] = n->left; stack[sp++] = n->right; }
+        }
     }
     if (best >= 0) { *t_out = bt; *beta_out = bb; *gamma_out = bg; }
     return best;
