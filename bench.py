@@ -91,7 +91,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EVPLP_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (1-GPU smoke of the N>1 path)
+    use_dist = world > 1 or os.environ.get("EVPLP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- inputs: procedural conference stand-in, written once per node
@@ -99,7 +103,7 @@ def main():
     json_path = os.path.join(scene_dir, "conference_synth.json")
     if local_rank == 0:
         ev.synth_scene(scene_dir, "conference_synth", a.tris, 1234, a.res, a.res)
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     W = H = a.res
@@ -112,7 +116,10 @@ def main():
     cam = ctx.camera()
     bsr, total_area, _ = ctx.scene_metrics()
     radius = 0.003 * bsr if a.workload == "evplp" else 0.0
-    stream = torch.cuda.current_stream(dev)
+    # one explicit (non-null) HIP stream carries the kernels AND orders the collectives: torch.distributed
+    # synchronises its RCCL work with the current stream, so kernels must be launched on that stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     # torch owns the buffers that take part in collectives
@@ -121,8 +128,8 @@ def main():
     strip = torch.zeros(ctx.local_rows * W * 4, dtype=torch.float32, device=dev)
     ctx.bind_buffer(ev.BUF_RECORDS, records.data_ptr(), records.numel() * 4)
     ctx.bind_buffer(ev.BUF_VPL_ACCUM, strip.data_ptr(), strip.numel() * 4)
-    full = torch.zeros(world * strip.numel(), dtype=torch.float32, device=dev) if world > 1 else strip
-    split_paths = world > 1 and n_light % world == 0
+    full = torch.zeros(world * strip.numel(), dtype=torch.float32, device=dev) if use_dist else strip
+    split_paths = use_dist and n_light % world == 0
     per_rank = n_light // world if split_paths else n_light
 
     mis = "one" if a.workload == "ir" else "balance"
@@ -145,11 +152,11 @@ def main():
         ctx.gather_vpl(fp)
         if a.workload == "evplp":
             ctx.splat_photons(fp)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(full, strip)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -168,7 +175,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     stats = torch.tensor([dt, float(pairs_local), float(rays_local), float(splat_pairs), sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0]); pairs = float(sm[1]); rays = float(sm[2]); spairs = float(sm[3]); kms = float(mx[4])
@@ -213,7 +220,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(json_path, a.res, a.cpu_iters)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
