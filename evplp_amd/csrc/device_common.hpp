@@ -305,12 +305,15 @@ EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(
 EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane,
                           int32_t *wave_stack, uint32_t &nodes_visited) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
-    // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d).
+    // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
+    // far bound `tfar`: a lane that is inactive or already occluded carries tfar = -1, so its slab tests
+    // fail by themselves and the ballots need no masking with `alive`.
     const V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
     const v2f nox = bc(-(o.x * inv.x)), noy = bc(-(o.y * inv.y)), noz = bc(-(o.z * inv.z));
     unsigned long long alive = ballot64(alive_lane), hitm = 0ull;
     if (alive == 0ull) return false;
+    float tfar = alive_lane ? tmax : -1.0f;
     int sp = 0;
     int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
@@ -318,25 +321,21 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     const char *leaf_base = reinterpret_cast<const char *>(sc.leaves);
     for (;;) {
         while (cur >= 0) {
-            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((size_t)(uint32_t)cur << 6));
+            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
             // both children at once: half 0 = child 0, half 1 = child 1 (conservative slab test)
             const v2f t0x = pk_fma(pk(n[0], n[1]), ivx, nox), t1x = pk_fma(pk(n[6], n[7]), ivx, nox);
             const v2f t0y = pk_fma(pk(n[2], n[3]), ivy, noy), t1y = pk_fma(pk(n[8], n[9]), ivy, noy);
             const v2f t0z = pk_fma(pk(n[4], n[5]), ivz, noz), t1z = pk_fma(pk(n[10], n[11]), ivz, noz);
             const float tn0 = fmaxf(fmaxf(fminf(t0x.x, t1x.x), fminf(t0y.x, t1y.x)), fmaxf(fminf(t0z.x, t1z.x), tmin));
-            const float tf0 = fminf(fminf(fmaxf(t0x.x, t1x.x), fmaxf(t0y.x, t1y.x)), fminf(fmaxf(t0z.x, t1z.x), tmax));
+            const float tf0 = fminf(fminf(fmaxf(t0x.x, t1x.x), fmaxf(t0y.x, t1y.x)), fminf(fmaxf(t0z.x, t1z.x), tfar));
             const float tn1 = fmaxf(fmaxf(fminf(t0x.y, t1x.y), fminf(t0y.y, t1y.y)), fmaxf(fminf(t0z.y, t1z.y), tmin));
-            const float tf1 = fminf(fminf(fmaxf(t0x.y, t1x.y), fmaxf(t0y.y, t1y.y)), fminf(fmaxf(t0z.y, t1z.y), tmax));
-            const unsigned long long m0 = ballot64(tn0 <= tf0) & alive, m1 = ballot64(tn1 <= tf1) & alive;
+            const float tf1 = fminf(fminf(fmaxf(t0x.y, t1x.y), fmaxf(t0y.y, t1y.y)), fminf(fmaxf(t0z.y, t1z.y), tfar));
+            const unsigned long long m0 = ballot64(tn0 <= tf0), m1 = ballot64(tn1 <= tf1);
             const int32_t c0 = n[12], c1 = n[13];
             if ((m0 | m1) == 0ull) { cur = kNoChild; break; }
             if (m0 != 0ull && m1 != 0ull) {
                 // descend into the child wanted by more lanes first, keep the other one on the stack
-#ifdef EVPLP_NO_POPCOUNT
-                const bool first0 = true;
-#else
                 const bool first0 = __builtin_popcountll(m0) >= __builtin_popcountll(m1);
-#endif
                 const int32_t oth = first0 ? c1 : c0;
                 if (sp < 64) vstack = lane_write(oth, sp, vstack); else wave_stack[sp - 64] = oth;
                 sp++;
@@ -347,7 +346,7 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             const uint32_t id = (uint32_t)~cur;
             const uint32_t cnt = (id & 3u) + 1u;
             // a leaf block is two triangle pairs (192 B); fetch all of it before testing
-            const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (size_t)((id >> 2) * 192u));
+            const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
             const v16i a = tp[0], b = tp[1];
             Hit2 h = tri_pair_test(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
                                    pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]),
@@ -360,9 +359,13 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
                                        o, d, tmin, tmax);
                 any = any | g.a | g.b;
             }
-            hitm |= ballot64(any) & alive;
-            alive &= ~hitm;
-            if (alive == 0ull) break;
+            const unsigned long long hm = ballot64(any) & alive;
+            if (hm != 0ull) {
+                hitm |= hm;
+                alive &= ~hm;
+                if (alive == 0ull) break;
+                tfar = any ? -1.0f : tfar;     // newly occluded lanes stop driving the walk
+            }
         }
         if (sp == 0) break;
         sp--;
