@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 using namespace evplp;
 
@@ -93,6 +94,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if ((e = hipMalloc((void **)&c->d_counters, sizeof(PassCounters) * EVPLP_PASS_COUNT)) != hipSuccess) return fail("hipMalloc(counters)", e);
     if ((e = hipMemset(c->d_counters, 0, sizeof(PassCounters) * EVPLP_PASS_COUNT)) != hipSuccess) return fail("hipMemset", e);
     if ((e = hipMalloc((void **)&c->d_rgb, sizeof(float) * 3 * (size_t)c->st.W * c->st.local_rows)) != hipSuccess) return fail("hipMalloc(rgb)", e);
+    if ((e = hipMalloc((void **)&c->d_partial, sizeof(float4) * kVplSplit * (size_t)c->st.W * c->st.local_rows)) != hipSuccess) return fail("hipMalloc(partial)", e);
     // splat workspace
     c->tiles_x = (c->st.W + 7) / 8; c->tiles_y = c->st.local_rows / 8;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
@@ -121,7 +123,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
-    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb);
+    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
     hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
     hipFree(c->d_compact); hipFree(c->d_rect);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -371,6 +373,7 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.g_dif = (const float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (const float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
     a.vpls = c->d_vpls; a.vpl_src_index = c->d_vpl_src; a.nvpl = &c->d_scalars[0];
     a.out = (float4 *)c->buf[EVPLP_BUF_VPL_ACCUM];
+    a.partial = c->d_partial; a.partial_stride = (size_t)c->st.W * c->st.local_rows;
     a.counters = &c->d_counters[pass];
     return EVPLP_OK;
 }
@@ -393,8 +396,7 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
     launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
     HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
-    if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl(a, c->stream);
-    HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
+    if (vsl) launch_gather_vsl(a, c->stream, c->ev_dom_end[pass]); else launch_gather_vpl(a, c->stream, c->ev_dom_end[pass]);
     c->pass_has_dom[pass] = true;
     return pass_end(c, pass);
 }
@@ -522,6 +524,7 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     if (pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL) {
         out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = pc.rays; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
         out->reserved[1] = (uint32_t)(pc.nodes >> 32);
+        if (getenv("EVPLP_PRINT_GATHER_STATS")) fprintf(stderr, "[gather stats] full_occ %llu full_vis %llu mixed+occrays<<32 %llu (mixed %llu, occluded rays(sum of low words) %llu)\n", pc.pairs, pc.aux, pc.nodes, pc.nodes & 0xffffffffull, pc.nodes >> 32);
     } else if (pass == EVPLP_PASS_SPLAT) {
         out->pairs = pc.pairs; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries;
         if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }

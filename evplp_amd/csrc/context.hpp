@@ -40,6 +40,7 @@ struct evplp_context {
     uint32_t *d_scalars = nullptr;           // [0] usable VPL count, [8] splat overflow
     evplp::PassCounters *d_counters = nullptr;
     float *d_rgb = nullptr;
+    float4 *d_partial = nullptr;              // [kVplSplit][local_rows * W] gather partial sums
     // splat workspace
     int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0, last_bin_entries = 0;
     uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;

@@ -32,8 +32,11 @@ struct GatherArgs {
     const uint32_t *nvpl;             // device scalar written by compact_vpl_kernel
     evplp_frame_params fp;
     float4 *out;
+    float4 *partial;                  // [kVplSplit][partial_stride] per-item partial sums
+    size_t partial_stride;            // W * local_rows
     PassCounters *counters;
 };
+constexpr int kVplSplit = 16;         // items per tile: VPL i belongs to item i % kVplSplit (fixed: results must not depend on it)
 
 struct SplatArgs {
     StripDev st; CamBasis cam;
@@ -61,8 +64,8 @@ void launch_primary(const PrimaryArgs &a, hipStream_t s);
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s);
 void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
                         uint32_t *count_out, hipStream_t s);
-void launch_gather_vpl(const GatherArgs &a, hipStream_t s);
-void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
+void launch_gather_vpl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_end);
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_end);
 void launch_splat_count(const SplatArgs &a, hipStream_t s);
 void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,

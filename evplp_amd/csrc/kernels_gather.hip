@@ -2,23 +2,25 @@
 //   gather_vpl_kernel <- splatColor + vplSplat   (rt/lighttracing.cu:348-379, 275-346)
 //   gather_vsl_kernel <- splatSplotch + vslSplat (rt/lighttracing.cu:689-722, 596-686, 395-594)
 //
-// Mapping.  A workgroup (4 wavefronts) owns ONE 8x8 pixel tile: lane = pixel in every wave, and the
-// compacted VPL list is dealt round-robin to the four waves (VPL i goes to wave i % 4); the four
-// partial sums meet in LDS and are added in wave order (bitwise reproducible).  Small work items
-// (16k+ workgroups at 1024^2) keep all 256 CUs busy to the end of the launch; with one 16x16 tile
-// per workgroup the launch ended on a long tail at ~2.2 of 5 resident waves per SIMD (profiles/
-// r01_bench_ir_pmc_v1.json).  The VPL list streams through LDS in chunks staged cooperatively by
-// the workgroup; every lane reads the SAME record (LDS broadcast).  For one VPL the 64 shadow segments of a wave
-// share their origin (the VPL) and end on neighbouring surface points, so the wave walks the BVH
-// as a packet: one node stack per wavefront in LDS, node/triangle fetches are scalar loads, the
-// descent is decided by ballots over the lanes that are still undecided, and lanes whose
-// un-normalised cosine product is <= 0 (lighttracing.cu:288) never enter the walk.
+// Work decomposition.  One work item = one wavefront = (8x8 pixel tile, split s of kVplSplit): lane =
+// pixel, and the item sums the compacted VPLs i with i % kVplSplit == s.  Items write float4 partial
+// sums; gather_reduce_kernel adds the kVplSplit partials of a pixel in split order and applies
+// out = sum / numVplLightPaths + doAccumulate * out (lighttracing.cu:378).  The split is a compile-time
+// constant, so every pixel is summed in the same order on any GPU count (bitwise reproducible), and
+// the launch has 16x more, 16x shorter items than one-tile-per-workgroup: 131k items at 1024^2, still
+// 16k per GPU on an 8-GPU strip partition (2.7 rounds of the 6144 resident waves instead of 1.3).
+//
+// For one VPL the 64 shadow segments of a wave share their origin (the VPL) and end on neighbouring
+// surface points, so the wave walks the BVH as a packet (device_common.hpp::occluded_wave): control
+// state in SGPRs, node/leaf fetches are scalar loads, stack in the lanes of a VGPR, descent decided by
+// ballots, lanes whose un-normalised cosine product is <= 0 (lighttracing.cu:288) never enter.
+// The VPL record is wave-uniform and is fetched with scalar loads through the scalar cache (LDS
+// staging with a barrier per chunk coupled the waves of a workgroup and measured 5% slower).
 #include "device_common.hpp"
 #include "kernels.h"
 
 namespace evplp {
 
-constexpr int kGatherChunk = 64;                  // VPL records per LDS stage (6 KB, double-buffered)
 constexpr int kRecF4 = sizeof(evplp_record) / 16; // 6 float4 per record
 
 struct Pixel {
@@ -59,65 +61,53 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v,
     return v.flux * x;
 }
 
-EV_DEV void stage_chunk(float4 *dst, const evplp_record *src, uint32_t begin, uint32_t n_total, int tid) {
-    uint32_t n = min((uint32_t)kGatherChunk, n_total - begin);
-    const float4 *s = reinterpret_cast<const float4 *>(src + begin);
-    for (uint32_t i = tid; i < n * kRecF4; i += 256) dst[i] = s[i];
-}
-
-// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8,
-// speed only, never correctness).  Tiles are grouped into super-tiles of 8x8 tiles (64x64 pixels);
-// the j-th workgroup of an XCD walks super-tile after super-tile, and super-tiles are interleaved
-// over the XCDs, so that (a) neighbouring tiles share one L2 and (b) every XCD gets the same mix of
-// cheap and expensive image regions (a contiguous band per XCD left XCDs idle for half the launch).
-EV_DEV bool map_tile(int b, int nb, int tiles_x, int tiles_y, int &tx, int &ty) {
-    const int sx = (tiles_x + 7) >> 3, sy = (tiles_y + 7) >> 3;   // super-tile grid
-    const int xcd = b & 7, j = b >> 3;
-    const int s = (j >> 6) * 8 + xcd, within = j & 63;
-    if (s >= sx * sy) return false;
-    tx = (s % sx) * 8 + (within & 7);
-    ty = (s / sx) * 8 + (within >> 3);
-    return tx < tiles_x && ty < tiles_y;
-}
-
-constexpr int kWavesPerTile = 4;
-
-struct TileSetup { int x, ly, gy; bool in_image, has_tile; size_t p; };
-EV_DEV TileSetup tile_setup(const StripDev &st, int lane) {
+// XCD-aware item order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8,
+// speed only, never correctness).  Tiles are grouped into super-tiles of 8x8 tiles (64x64 pixels); an
+// XCD walks a super-tile tile by tile (all kVplSplit items of a tile back to back), and super-tiles
+// are interleaved over the XCDs, so that (a) neighbouring items share one L2 and (b) every XCD gets
+// the same mix of cheap and expensive image regions (a contiguous band per XCD left XCDs idle for
+// half the launch).
+struct Item { int x, ly, gy, split; bool in_image, has_tile; size_t p; };
+EV_DEV Item item_setup(const StripDev &st, int lane) {
     const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    int tx = 0, ty = 0;
-    const bool has_tile = map_tile(blockIdx.x, gridDim.x, tiles_x, tiles_y, tx, ty);
-    TileSetup t; t.has_tile = has_tile;
+    const int sx = (tiles_x + 7) >> 3, sy = (tiles_y + 7) >> 3;   // super-tile grid
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int tile_j = j / kVplSplit;
+    const int stile = (tile_j >> 6) * 8 + xcd, within = tile_j & 63;
+    const int tx = (stile % sx) * 8 + (within & 7), ty = (stile / sx) * 8 + (within >> 3);
+    Item t;
+    t.split = j - tile_j * kVplSplit;
+    t.has_tile = stile < sx * sy && tx < tiles_x && ty < tiles_y;
     t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
     const int cly = min(t.ly, st.local_rows - 1);
     t.gy = st.global_row(cly);
-    t.in_image = has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
+    t.in_image = t.has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
     t.p = (size_t)cly * st.W + min(t.x, st.W - 1);
     return t;
-}
-// add the four per-wave partial sums in wave order and apply  out = sum / numVpl + doAccumulate * out
-EV_DEV void reduce_and_store(const GatherArgs &a, float (*red)[64][3], V3 result, int wave, int lane, bool write, size_t p) {
-    red[wave][lane][0] = result.x; red[wave][lane][1] = result.y; red[wave][lane][2] = result.z;
-    __syncthreads();
-    if (wave == 0 && write) {
-        float r[3];
-        for (int k = 0; k < 3; k++) { float s = red[0][lane][k]; for (int w = 1; w < kWavesPerTile; w++) s += red[w][lane][k]; r[k] = s; }
-        float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;   // lighttracing.cu:378
-        float4 old = a.out[p];
-        a.out[p] = make_float4(r[0] / inv + acc * old.x, r[1] / inv + acc * old.y, r[2] / inv + acc * old.z, 0.0f + acc * old.w);
-    }
 }
 
 #ifndef EVPLP_GATHER_WAVES
 #define EVPLP_GATHER_WAVES 6   // waves per SIMD: 8 spills VGPRs to scratch (209 ms), 6 = 161 ms, 5 = 170 ms (cfg2 frame)
 #endif
-__global__ __launch_bounds__(256, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
-    __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
-    __shared__ int32_t lds_stack[kWavesPerTile][kMaxDepth];
-    __shared__ float lds_red[kWavesPerTile][64][3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TileSetup t = tile_setup(a.st, lane);
-    if (!t.has_tile) return;   // workgroup-uniform: padding of the super-tile grid
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+// wave-uniform scalar fetch of one 96-byte record (s_load_dwordx16 + s_load_dwordx8)
+EV_DEV Vpl fetch_vpl(const evplp_record *r) {
+    const v16i ra = *reinterpret_cast<const v16i *>(r);
+    const v8i rb = *reinterpret_cast<const v8i *>(reinterpret_cast<const int *>(r) + 16);
+    Vpl v;
+    v.pos = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])); v.n = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6])); v.psel = f_of(ra[7]);
+    v.flux = v3(f_of(ra[8]), f_of(ra[9]), f_of(ra[10])); v.fdir = v3(f_of(ra[12]), f_of(ra[13]), f_of(ra[14]));
+    v.rd = v3(f_of(rb[0]), f_of(rb[1]), f_of(rb[2])); v.rs = v3(f_of(rb[4]), f_of(rb[5]), f_of(rb[6])); v.e = f_of(rb[7]);
+    return v;
+}
+
+__global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
+    __shared__ int32_t lds_stack[kMaxDepth];     // spill area of the wave's VGPR-lane stack (depth > 64 only)
+    const int lane = threadIdx.x;
+    const Item t = item_setup(a.st, lane);
+    if (!t.has_tile) return;   // padding of the super-tile grid
     const size_t p = t.p;
 
     Pixel px;
@@ -129,37 +119,51 @@ __global__ __launch_bounds__(256, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gat
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, nodes = 0;
-    int32_t *stack = lds_stack[wave];
-
-    // The VPL record is wave-uniform: it is fetched with scalar loads (s_load_dwordx16 + x8 through the
-    // scalar cache) instead of being staged in LDS -- waves of a workgroup then never wait for each
-    // other until the final reduction (LDS staging with a barrier per chunk measured 5% slower).
-    {
-        typedef int v8i __attribute__((ext_vector_type(8)));
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(wave);
-        for (uint32_t i = w0; i < nvpl; i += kWavesPerTile) {
-            const v16i ra = *reinterpret_cast<const v16i *>(a.vpls + i);
-            const v8i rb = *reinterpret_cast<const v8i *>(reinterpret_cast<const int *>(a.vpls + i) + 16);
-            Vpl v;
-            v.pos = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])); v.n = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6])); v.psel = f_of(ra[7]);
-            v.flux = v3(f_of(ra[8]), f_of(ra[9]), f_of(ra[10])); v.fdir = v3(f_of(ra[12]), f_of(ra[13]), f_of(ra[14]));
-            v.rd = v3(f_of(rb[0]), f_of(rb[1]), f_of(rb[2])); v.rs = v3(f_of(rb[4]), f_of(rb[5]), f_of(rb[6])); v.e = f_of(rb[7]);
-            V3 v12 = v.pos - px.p1;                                         // :282
-            float c1 = fmaxf(dot(px.n1, v12), 0.0f);
-            float c2 = fmaxf(-dot(v.n, v12), 0.0f);
-            float c1c2 = c1 * c2;
-            bool active = valid && !(c1c2 <= 0.0f);                         // :288
-            if (ballot64(active) == 0ull) continue;
-            rays += active ? 1u : 0u;
-            // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
-            bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, stack, nodes);
-            if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
-        }
+#ifdef EVPLP_GATHER_STATS
+    uint32_t st_full_occ = 0, st_full_vis = 0, st_mixed = 0;
+#endif
+    for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
+        const Vpl v = fetch_vpl(a.vpls + i);
+        V3 v12 = v.pos - px.p1;                                         // :282
+        float c1 = fmaxf(dot(px.n1, v12), 0.0f);
+        float c2 = fmaxf(-dot(v.n, v12), 0.0f);
+        float c1c2 = c1 * c2;
+        bool active = valid && !(c1c2 <= 0.0f);                         // :288
+        if (ballot64(active) == 0ull) continue;
+        rays += active ? 1u : 0u;
+        // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
+        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, lds_stack, nodes);
+#ifdef EVPLP_GATHER_STATS
+        { unsigned long long am = ballot64(active), om = ballot64(occ && active);
+          if (om == am) st_full_occ++; else if (om == 0ull) st_full_vis++; else st_mixed++; }
+#endif
+        if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
     }
-    reduce_and_store(a, lds_red, result, wave, lane, valid, p);
+    if (t.in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
     // statistics: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0) { atomicAdd(&a.counters->rays, (unsigned long long)rays); atomicAdd(&a.counters->nodes, (unsigned long long)nodes); }
+    if (lane == 0) {
+        atomicAdd(&a.counters->rays, (unsigned long long)rays);
+#ifdef EVPLP_GATHER_STATS
+        atomicAdd(&a.counters->pairs, (unsigned long long)st_full_occ); atomicAdd(&a.counters->aux, (unsigned long long)st_full_vis);
+        atomicAdd(&a.counters->nodes, (unsigned long long)st_mixed);
+#endif
+    }
+}
+
+// out = (sum of the kVplSplit partials in split order) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378)
+__global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int stencil_test) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)a.st.W * a.st.local_rows;
+    if (i >= n) return;
+    const int ly = (int)(i / a.st.W);
+    if (a.st.global_row(ly) >= a.st.H) return;
+    if (stencil_test && a.g_pos[i].w == 0.0f) return;               // splatColor returns before writing (:354)
+    float4 s = a.partial[i];
+    for (int k = 1; k < kVplSplit; k++) { float4 q = a.partial[(size_t)k * a.partial_stride + i]; s.x += q.x; s.y += q.y; s.z += q.z; }
+    const float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
+    float4 old = a.out[i];
+    a.out[i] = make_float4(s.x / inv + acc * old.x, s.y / inv + acc * old.y, s.z / inv + acc * old.z, 0.0f + acc * old.w);
 }
 
 // ------------------------------------------------------------------------------------ VSL
@@ -240,14 +244,12 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float
     return ((v.flux * c.inv_pi_r2) * cos1) * brdf1 * brdf2;
 }
 
-__global__ __launch_bounds__(256) void gather_vsl_kernel(GatherArgs a) {
-    __shared__ float4 lds_vpl[2][kGatherChunk * kRecF4];
-    __shared__ int32_t lds_stack[kWavesPerTile][kMaxDepth];
-    __shared__ float lds_red[kWavesPerTile][64][3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void gather_vsl_kernel(GatherArgs a) {
+    __shared__ int32_t lds_stack[kMaxDepth];
+    const int lane = threadIdx.x;
     const int W = a.st.W;
-    const TileSetup t = tile_setup(a.st, lane);
-    if (!t.has_tile) return;   // workgroup-uniform: padding of the super-tile grid
+    const Item t = item_setup(a.st, lane);
+    if (!t.has_tile) return;
     const size_t p = t.p;
     const bool in_image = t.in_image;
 
@@ -261,69 +263,65 @@ __global__ __launch_bounds__(256) void gather_vsl_kernel(GatherArgs a) {
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, nodes = 0;
-    int32_t *stack = lds_stack[wave];
-    int buf = 0;
-    if (nvpl > 0) stage_chunk(lds_vpl[0], a.vpls, 0, nvpl, tid);
-    __syncthreads();
-    for (uint32_t begin = 0; begin < nvpl; begin += kGatherChunk) {
-        uint32_t next = begin + kGatherChunk;
-        if (next < nvpl) stage_chunk(lds_vpl[buf ^ 1], a.vpls, next, nvpl, tid);
-        const uint32_t n = min((uint32_t)kGatherChunk, nvpl - begin);
-        const float4 *chunk = lds_vpl[buf];
-        for (uint32_t i = wave; i < n; i += kWavesPerTile) {
-            Vpl v = load_vpl(chunk + i * kRecF4);
-            V3 v12 = v.pos - px.p1;                                       // :605
-            float dist2 = dot(v12, v12);
-            float dist = sqrtf(dist2);
-            rays += valid ? 1u : 0u;
-            bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid, stack, nodes);  // :612-614
-            V3 nv12 = v12 / dist;
-            float c1c2 = fmaxf(dot(px.n1, nv12), 0.0f) * fmaxf(-dot(v.n, nv12), 0.0f);
-            bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
-            if (__ballot(lit) == 0ull) continue;
-            if (lit) {
-                VslCtx c;
-                float rdratio = a.fp.vsl_radius / dist;
-                c.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
-                c.cos_half_cone = cosf(c.half_cone);
-                c.solid_angle = EV_PI * 2.0f * (1.0f - c.cos_half_cone);
-                c.inv_solid_angle = 1.0f / c.solid_angle;
-                c.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; c.nd12 = nv12;
-                int num_samples = (int)(c.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
-                // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
-                Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[begin + i]);
-                V3 acc = v3(0.f, 0.f, 0.f);
-                for (int s = 0; s < num_samples; s++) {
-                    float wc = 0.f, w1 = 0.f, w2 = 0.f;
-                    V3 rc = vsl_sample_cone(px, v, c, wc, rng);
-                    V3 r1 = vsl_sample_brdf1(px, v, c, w1, rng);
-                    V3 r2 = vsl_sample_brdf2(px, v, c, w2, rng);
-                    acc = acc + rc * wc;
-                    acc = acc + r1 * w1;
-                    acc = acc + r2 * w2;
-                }
-                result = result + acc / (float)num_samples;
+    for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
+        const Vpl v = fetch_vpl(a.vpls + i);
+        V3 v12 = v.pos - px.p1;                                       // :605
+        float dist2 = dot(v12, v12);
+        float dist = sqrtf(dist2);
+        rays += valid ? 1u : 0u;
+        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid, lds_stack, nodes);  // :612-614
+        V3 nv12 = v12 / dist;
+        float c1c2 = fmaxf(dot(px.n1, nv12), 0.0f) * fmaxf(-dot(v.n, nv12), 0.0f);
+        bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
+        if (ballot64(lit) == 0ull) continue;
+        if (lit) {
+            VslCtx c;
+            float rdratio = a.fp.vsl_radius / dist;
+            c.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
+            c.cos_half_cone = cosf(c.half_cone);
+            c.solid_angle = EV_PI * 2.0f * (1.0f - c.cos_half_cone);
+            c.inv_solid_angle = 1.0f / c.solid_angle;
+            c.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; c.nd12 = nv12;
+            int num_samples = (int)(c.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
+            // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
+            Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
+            V3 acc = v3(0.f, 0.f, 0.f);
+            for (int s = 0; s < num_samples; s++) {
+                float wc = 0.f, w1 = 0.f, w2 = 0.f;
+                V3 rc = vsl_sample_cone(px, v, c, wc, rng);
+                V3 r1 = vsl_sample_brdf1(px, v, c, w1, rng);
+                V3 r2 = vsl_sample_brdf2(px, v, c, w2, rng);
+                acc = acc + rc * wc;
+                acc = acc + r1 * w1;
+                acc = acc + r2 * w2;
             }
+            result = result + acc / (float)num_samples;
         }
-        __syncthreads();
-        buf ^= 1;
     }
-    reduce_and_store(a, lds_red, result, wave, lane, in_image, p);
+    if (in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0) { atomicAdd(&a.counters->rays, (unsigned long long)rays); atomicAdd(&a.counters->nodes, (unsigned long long)nodes); }
+    if (lane == 0) atomicAdd(&a.counters->rays, (unsigned long long)rays);
 }
 
 static dim3 gather_grid(const StripDev &st) {
     int tiles_x = (st.W + 7) / 8, tiles_y = (st.local_rows + 7) / 8;
     int sx = (tiles_x + 7) / 8, sy = (tiles_y + 7) / 8;
-    int per_xcd = (sx * sy + 7) / 8;
-    return dim3(per_xcd * 8 * 64);
+    int per_xcd = (sx * sy + 7) / 8;                 // super-tiles per XCD (rounded up)
+    return dim3(per_xcd * 64 * kVplSplit * 8);       // x 64 tiles x kVplSplit items x 8 XCDs
 }
-void launch_gather_vpl(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a.st), dim3(256), 0, s, a);
+static void launch_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
+    size_t n = (size_t)a.st.W * a.st.local_rows;
+    hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, stencil_test);
 }
-void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a.st), dim3(256), 0, s, a);
+void launch_gather_vpl(const GatherArgs &a, hipStream_t s, hipEvent_t dom_end) {
+    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a.st), dim3(64), 0, s, a);
+    if (dom_end) hipEventRecord(dom_end, s);
+    launch_reduce(a, 1, s);
+}
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dom_end) {
+    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a.st), dim3(64), 0, s, a);
+    if (dom_end) hipEventRecord(dom_end, s);
+    launch_reduce(a, 0, s);
 }
 
 } // namespace evplp
