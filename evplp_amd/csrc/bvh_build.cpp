@@ -201,8 +201,17 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     // flatten: inner nodes in DFS pre-order; each inner node carries both child boxes
     std::vector<BvhNode> flat; std::vector<int32_t> order; order.reserve((size_t)nvalid);   // 4 slots per leaf, -1 = empty
     int32_t nleaves = 0;
-    auto set_box = [&](BvhNode &f, int child, const Box &b) { for (int k = 0; k < 3; k++) { f.lo[k][child] = b.lo[k] - pad; f.hi[k][child] = b.hi[k] + pad; } };
-    auto set_empty = [&](BvhNode &f, int child) { for (int k = 0; k < 3; k++) { f.lo[k][child] = 3.0e38f; f.hi[k][child] = -3.0e38f; } };
+    // centre / half-size form; the half-size is rounded up so that [ctr - hal, ctr + hal] contains the padded box
+    auto set_box = [&](BvhNode &f, int child, const Box &b) {
+        for (int k = 0; k < 3; k++) {
+            float lo = b.lo[k] - pad, hi = b.hi[k] + pad;
+            float c = 0.5f * (lo + hi);
+            float h = std::max(hi - c, c - lo);
+            h = h + std::abs(h) * 1e-6f + 1e-30f;
+            f.ctr[k][child] = c; f.hal[k][child] = h;
+        }
+    };
+    auto set_empty = [&](BvhNode &f, int child) { for (int k = 0; k < 3; k++) { f.ctr[k][child] = 0.f; f.hal[k][child] = -3.0e38f; } };
     struct Item { int32_t temp; int32_t parent; int which; };
     std::vector<Item> stack;
     auto emit_leaf = [&](const TempNode &n) -> int32_t {

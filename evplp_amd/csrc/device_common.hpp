@@ -310,6 +310,7 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     // fail by themselves and the ballots need no masking with `alive`.
     const V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
+    const v2f avx = bc(fabsf(inv.x)), avy = bc(fabsf(inv.y)), avz = bc(fabsf(inv.z));
     const v2f nox = bc(-(o.x * inv.x)), noy = bc(-(o.y * inv.y)), noz = bc(-(o.z * inv.z));
     unsigned long long alive = ballot64(alive_lane), hitm = 0ull;
     if (alive == 0ull) return false;
@@ -322,14 +323,14 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     for (;;) {
         while (cur >= 0) {
             const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
-            // both children at once: half 0 = child 0, half 1 = child 1 (conservative slab test)
-            const v2f t0x = pk_fma(pk(n[0], n[1]), ivx, nox), t1x = pk_fma(pk(n[6], n[7]), ivx, nox);
-            const v2f t0y = pk_fma(pk(n[2], n[3]), ivy, noy), t1y = pk_fma(pk(n[8], n[9]), ivy, noy);
-            const v2f t0z = pk_fma(pk(n[4], n[5]), ivz, noz), t1z = pk_fma(pk(n[10], n[11]), ivz, noz);
-            const float tn0 = fmaxf(fmaxf(fminf(t0x.x, t1x.x), fminf(t0y.x, t1y.x)), fmaxf(fminf(t0z.x, t1z.x), tmin));
-            const float tf0 = fminf(fminf(fmaxf(t0x.x, t1x.x), fmaxf(t0y.x, t1y.x)), fminf(fmaxf(t0z.x, t1z.x), tfar));
-            const float tn1 = fmaxf(fmaxf(fminf(t0x.y, t1x.y), fminf(t0y.y, t1y.y)), fmaxf(fminf(t0z.y, t1z.y), tmin));
-            const float tf1 = fminf(fminf(fmaxf(t0x.y, t1x.y), fmaxf(t0y.y, t1y.y)), fminf(fmaxf(t0z.y, t1z.y), tfar));
+            // both children at once (half 0 = child 0, half 1 = child 1), conservative slab test in
+            // centre / half-size form: A = ctr/d - o/d, B = hal/|d|, entry = A - B, exit = A + B
+            const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
+            const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
+            const v2f enx = pk_fma(hx, -avx, ax), eny = pk_fma(hy, -avy, ay), enz = pk_fma(hz, -avz, az);
+            const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
+            const float tn0 = fmaxf(fmaxf(enx.x, eny.x), fmaxf(enz.x, tmin)), tf0 = fminf(fminf(exx.x, exy.x), fminf(exz.x, tfar));
+            const float tn1 = fmaxf(fmaxf(enx.y, eny.y), fmaxf(enz.y, tmin)), tf1 = fminf(fminf(exx.y, exy.y), fminf(exz.y, tfar));
             const unsigned long long m0 = ballot64(tn0 <= tf0), m1 = ballot64(tn1 <= tf1);
             const int32_t c0 = n[12], c1 = n[13];
             if ((m0 | m1) == 0ull) { cur = kNoChild; break; }
@@ -391,8 +392,10 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
         if (cur >= 0) {
             const BvhNode &n = sc.nodes[cur];
             bool h0, h1;
-            const float lo0[3] = { n.lo[0][0], n.lo[1][0], n.lo[2][0] }, hi0[3] = { n.hi[0][0], n.hi[1][0], n.hi[2][0] };
-            const float lo1[3] = { n.lo[0][1], n.lo[1][1], n.lo[2][1] }, hi1[3] = { n.hi[0][1], n.hi[1][1], n.hi[2][1] };
+            const float lo0[3] = { n.ctr[0][0] - n.hal[0][0], n.ctr[1][0] - n.hal[1][0], n.ctr[2][0] - n.hal[2][0] };
+            const float hi0[3] = { n.ctr[0][0] + n.hal[0][0], n.ctr[1][0] + n.hal[1][0], n.ctr[2][0] + n.hal[2][0] };
+            const float lo1[3] = { n.ctr[0][1] - n.hal[0][1], n.ctr[1][1] - n.hal[1][1], n.ctr[2][1] - n.hal[2][1] };
+            const float hi1[3] = { n.ctr[0][1] + n.hal[0][1], n.ctr[1][1] + n.hal[1][1], n.ctr[2][1] + n.hal[2][1] };
             float n0 = slab_near(lo0, hi0, inv, noi, tmin, bt, h0);
             float n1 = slab_near(lo1, hi1, inv, noi, tmin, bt, h1);
             if (h0 && h1) {

@@ -8,13 +8,15 @@ namespace evplp {
 
 // Flattened binary BVH node, 64 B = one s_load_dwordx16 / one cache line.  A node stores the boxes
 // of BOTH children, interleaved component by component so that the two slab tests run as one
-// stream of packed-fp32 instructions (v_pk_fma_f32 / v_pk_min_f32 / v_pk_max_f32: half 0 = child 0,
-// half 1 = child 1).  child >= 0: inner node index; child < 0: leaf, id = ~child,
-// leaf block = id >> 2, triangle count = (id & 3) + 1.  An absent child has an inverted box
-// (lo = +big, hi = -big) and child = kNoChild.
+// stream of packed-fp32 instructions (half 0 = child 0, half 1 = child 1).  Boxes are stored as
+// centre + half-size: with A = ctr * (1/d) - o/d and B = hal * |1/d| the slab entry / exit parameters
+// are A - B and A + B, i.e. three v_pk_fma_f32 per axis for BOTH children and no per-lane min/max to
+// sort the near and far plane.  child >= 0: inner node index; child < 0: leaf, id = ~child,
+// leaf block = id >> 2, triangle count = (id & 3) + 1.  An absent child has a negative half-size and
+// child = kNoChild.
 struct BvhNode {
-    float lo[3][2];   // lo[axis][child]
-    float hi[3][2];   // hi[axis][child]
+    float ctr[3][2];  // box centre   [axis][child]
+    float hal[3][2];  // box half-size [axis][child] (>= 0; an absent child has hal = -big: never hit)
     int32_t c0, c1;
     int32_t pad[2];
 };
