@@ -298,7 +298,8 @@ EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot
 // direction.  `alive` lanes still need an answer; a lane that finds an occluder drops out of the
 // ballots, and the walk ends when no lane is alive or the stack is empty.
 // The per-wavefront stack lives in the 64 lanes of ONE VGPR (select-by-lane-id push, v_readlane pop,
-// scalar stack pointer: no memory latency on either); entries beyond 64 spill to the wave's LDS stack.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit,
+// scalar stack pointer: no memory latency on either).  It holds at most one entry per tree level and
+// evplp_build_accel rejects trees deeper than 62 levels, so 64 entries always suffice.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit,
 // rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
 EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -333,15 +334,22 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             const float tn1 = fmaxf(fmaxf(enx.y, eny.y), fmaxf(enz.y, tmin)), tf1 = fminf(fminf(exx.y, exy.y), fminf(exz.y, tfar));
             const unsigned long long m0 = ballot64(tn0 <= tf0), m1 = ballot64(tn1 <= tf1);
             const int32_t c0 = n[12], c1 = n[13];
-            if ((m0 | m1) == 0ull) { cur = kNoChild; break; }
-            if (m0 != 0ull && m1 != 0ull) {
-                // descend into the child wanted by more lanes first, keep the other one on the stack
-                const bool first0 = __builtin_popcountll(m0) >= __builtin_popcountll(m1);
+            // 32-bit scalar compares on purpose: this compiler turns compares of 64-bit masks into lane-mask
+            // booleans (s_cselect_b64 / s_and exec / s_cbranch_vcc, 4-5 instructions per branch)
+            const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
+            if ((a0 | a1) == 0u) { cur = kNoChild; break; }
+            if (a0 == 0u) { cur = c1; continue; }
+            if (a1 == 0u) { cur = c0; continue; }
+            {
+                // both hit: descend into the child wanted by more lanes first, keep the other one on the stack
+                const uint32_t p0 = (uint32_t)(__builtin_popcount((uint32_t)m0) + __builtin_popcount((uint32_t)(m0 >> 32)));
+                const uint32_t p1 = (uint32_t)(__builtin_popcount((uint32_t)m1) + __builtin_popcount((uint32_t)(m1 >> 32)));
+                const bool first0 = p0 >= p1;
                 const int32_t oth = first0 ? c1 : c0;
-                if (sp < 64) vstack = lane_write(oth, sp, vstack); else wave_stack[sp - 64] = oth;
+                vstack = lane_write(oth, sp, vstack);
                 sp++;
                 cur = first0 ? c0 : c1;
-            } else cur = m0 != 0ull ? c0 : c1;
+            }
         }
         if (cur != kNoChild) {
             const uint32_t id = (uint32_t)~cur;
@@ -370,9 +378,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
         }
         if (sp == 0) break;
         sp--;
-        cur = sp < 64 ? lane_read(vstack, sp) : __builtin_amdgcn_readfirstlane(wave_stack[sp - 64]);
+        cur = lane_read(vstack, sp);
     }
-    (void)nodes_visited;
+    (void)nodes_visited; (void)wave_stack;
     return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
 }
 
