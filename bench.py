@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--paths", type=int, default=1024, help="numLightPaths = numVplLightPaths (x4 record slots)")
     ap.add_argument("--tris", type=int, default=331000)
     ap.add_argument("--workload", default="ir", choices=["ir", "evplp"], help="ir = config #2 (headline); evplp = config #3 (+2M photon splat)")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="acceleration-structure builder (same flattened node format)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="path-tracer iterations of the CPU baseline sample (0 = auto, ~15 s)")
     return ap.parse_args()
@@ -111,7 +112,8 @@ def main():
     n_light = a.paths if a.workload == "ir" else 500000
     n_vpl = a.paths
     strip_rows = 16
-    ctx = ev.Context(W, H, n_light, n_vpl, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows)
+    ctx = ev.Context(W, H, n_light, n_vpl, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows,
+                     bvh_builder=ev.BVH_SAH if a.bvh == "sah" else ev.BVH_LBVH)
     ctx.load_scene_json(json_path)
     cam = ctx.camera()
     bsr, total_area, _ = ctx.scene_metrics()
@@ -203,7 +205,7 @@ def main():
                        "resolution": [W, H], "num_light_paths": n_light, "num_vpl_light_paths": n_vpl, "photons_per_path": P,
                        "usable_vpl_records": int(pairs / a.steps / (W * H) + 0.5), "partition": f"{world} x interleaved {strip_rows}-row strips",
                        "path_definition": "gather: (pixel, usable VPL record) pair = 1 shadow ray; splat: (photon, covered pixel) pair",
-                       "mrays_per_s": rays / dt / 1e6},
+                       "mrays_per_s": rays / dt / 1e6, "bvh_builder": a.bvh},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "kernel": "gather_vpl_kernel", "kernel_ms": kms,
                          "note": "fp32 VECTOR-ALU bound (BVH packet traversal + shading, not GEMM-shaped; the f32 MFMA peak equals the "

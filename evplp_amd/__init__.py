@@ -168,7 +168,7 @@ class Context:
 
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
-                 bvh_builder: int = BVH_LBVH, deterministic: bool = False):
+                 bvh_builder: int = BVH_SAH, deterministic: bool = False):
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y

@@ -244,7 +244,10 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float
     return ((v.flux * c.inv_pi_r2) * cos1) * brdf1 * brdf2;
 }
 
-__global__ __launch_bounds__(64) void gather_vsl_kernel(GatherArgs a) {
+#ifndef EVPLP_VSL_WAVES
+#define EVPLP_VSL_WAVES 3
+#endif
+__global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
     __shared__ int32_t lds_stack[kMaxDepth];
     const int lane = threadIdx.x;
     const int W = a.st.W;

@@ -61,8 +61,8 @@ typedef enum evplp_mis_mode {
 } evplp_mis_mode;
 
 typedef enum evplp_bvh_builder {
-    EVPLP_BVH_LBVH = 0,   /* Morton-code LBVH (north-star layout) */
-    EVPLP_BVH_SAH = 1     /* binned-SAH top-down build into the same flattened node format */
+    EVPLP_BVH_LBVH = 0,   /* Morton-code LBVH (Karras topology) */
+    EVPLP_BVH_SAH = 1     /* binned-SAH top-down build into the same flattened node format (default of the host side) */
 } evplp_bvh_builder;
 
 /* Creation-time configuration: what RtComPhoton::render fixes before setup()
