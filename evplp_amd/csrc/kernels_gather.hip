@@ -245,7 +245,7 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float
 }
 
 #ifndef EVPLP_VSL_WAVES
-#define EVPLP_VSL_WAVES 3
+#define EVPLP_VSL_WAVES 6   // 3: 88 ms, 4: 77 ms, 5: 76 ms, 6: 74 ms (512^2, 760 VSLs)
 #endif
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
     __shared__ int32_t lds_stack[kMaxDepth];

@@ -216,7 +216,8 @@ def test_ragged_resolutions(evplp, res):
     assert rel_l2(vpl[..., :3], rv[..., :3]) <= 1e-5 and rel_l2(pm[..., :3], rp[..., :3]) <= 1e-5
 
 
-def test_tiny_scene_single_leaf_and_degenerate_triangles(evplp):
+@pytest.mark.parametrize("builder", [0, 1])
+def test_tiny_scene_single_leaf_and_degenerate_triangles(evplp, builder):
     """A floor quad + a light quad (BVH root is a single leaf) with a zero-area triangle thrown in
     (meshBound invalidates it, rt/triangleintersect.cu:62-81)."""
     sd = scenes.SceneData()
@@ -228,10 +229,10 @@ def test_tiny_scene_single_leaf_and_degenerate_triangles(evplp):
     osc = oa.Scene(sd)
     W, H, N, P = 48, 32, 8, 2
     kw = dict(camera_pos=sd.cam_origin, mis_mode=0, num_light_paths=N, num_vpl_light_paths=N, photons_per_path=P)
-    with evplp.Context(W, H, N, N, P) as c:
+    with evplp.Context(W, H, N, N, P, bvh_builder=builder) as c:
         sd.upload(c)
         info = c.accel_info()
-        assert info["nodes"] == 1 and info["leaves"] == 1
+        assert info["nodes"] == 1 and info["leaves"] == (1 if builder == evplp.BVH_LBVH else 2)   # 4 triangles: one LBVH leaf, two SAH leaves
         c.primary((0, 0), clear_light=True); c.trace_light_paths(0); c.gather_vpl(evplp.frame_params(**kw))
         vpl = c.download(evplp.BUF_VPL_ACCUM)[:H]; rec = c.download(evplp.BUF_RECORDS); pos = c.download(evplp.BUF_GBUF_POSITION)[:H]
     g = osc.primary(W, H)
