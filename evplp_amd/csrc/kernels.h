@@ -36,7 +36,10 @@ struct GatherArgs {
     size_t partial_stride;            // W * local_rows
     PassCounters *counters;
 };
-constexpr int kVplSplit = 16;         // items per tile: VPL i belongs to item i % kVplSplit (fixed: results must not depend on it)
+#ifndef EVPLP_VPL_SPLIT
+#define EVPLP_VPL_SPLIT 64
+#endif
+constexpr int kVplSplit = EVPLP_VPL_SPLIT;   // items per tile: VPL i belongs to item i % kVplSplit (a constant: results must not depend on the GPU count)
 
 struct SplatArgs {
     StripDev st; CamBasis cam;

@@ -61,21 +61,25 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v,
     return v.flux * x;
 }
 
-// XCD-aware item order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8,
-// speed only, never correctness).  Tiles are grouped into super-tiles of 8x8 tiles (64x64 pixels); an
-// XCD walks a super-tile tile by tile (all kVplSplit items of a tile back to back), and super-tiles
-// are interleaved over the XCDs, so that (a) neighbouring items share one L2 and (b) every XCD gets
-// the same mix of cheap and expensive image regions (a contiguous band per XCD left XCDs idle for
-// half the launch).
+// Item order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; speed
+// only, never correctness).  All kVplSplit items of a tile run back to back on one XCD (they share the
+// tile's G-buffer lines and BVH neighbourhood in that L2); consecutive TILES go to different XCDs.
+// Grouping tiles into larger per-XCD super-tiles (kSuper > 1) measured slower: item cost varies by 5x
+// across the image (tiles on furniture silhouettes vs open floor), and balance beats L2 locality here
+// (TCC hit rate stays ~98 % either way).
+#ifndef EVPLP_SUPER_LOG2
+#define EVPLP_SUPER_LOG2 0     // super-tile edge = 2^k tiles; measured per cfg2 frame: k=3 103.9 ms, 2 99.0, 1 94.8, 0 92.0
+#endif
+constexpr int kSuperLog2 = EVPLP_SUPER_LOG2, kSuper = 1 << kSuperLog2, kSuperTiles = kSuper * kSuper;
 struct Item { int x, ly, gy, split; bool in_image, has_tile; size_t p; };
 EV_DEV Item item_setup(const StripDev &st, int lane) {
     const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    const int sx = (tiles_x + 7) >> 3, sy = (tiles_y + 7) >> 3;   // super-tile grid
+    const int sx = (tiles_x + kSuper - 1) >> kSuperLog2, sy = (tiles_y + kSuper - 1) >> kSuperLog2;   // super-tile grid
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int tile_j = j / kVplSplit;
-    const int stile = (tile_j >> 6) * 8 + xcd, within = tile_j & 63;
-    const int tx = (stile % sx) * 8 + (within & 7), ty = (stile / sx) * 8 + (within >> 3);
+    const int stile = (tile_j / kSuperTiles) * 8 + xcd, within = tile_j % kSuperTiles;
+    const int tx = (stile % sx) * kSuper + (within & (kSuper - 1)), ty = (stile / sx) * kSuper + (within >> kSuperLog2);
     Item t;
     t.split = j - tile_j * kVplSplit;
     t.has_tile = stile < sx * sy && tx < tiles_x && ty < tiles_y;
@@ -308,9 +312,9 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
 
 static dim3 gather_grid(const StripDev &st) {
     int tiles_x = (st.W + 7) / 8, tiles_y = (st.local_rows + 7) / 8;
-    int sx = (tiles_x + 7) / 8, sy = (tiles_y + 7) / 8;
-    int per_xcd = (sx * sy + 7) / 8;                 // super-tiles per XCD (rounded up)
-    return dim3(per_xcd * 64 * kVplSplit * 8);       // x 64 tiles x kVplSplit items x 8 XCDs
+    int sx = (tiles_x + kSuper - 1) / kSuper, sy = (tiles_y + kSuper - 1) / kSuper;
+    int per_xcd = (sx * sy + 7) / 8;                          // super-tiles per XCD (rounded up)
+    return dim3(per_xcd * kSuperTiles * kVplSplit * 8);       // x tiles x kVplSplit items x 8 XCDs
 }
 static void launch_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
     size_t n = (size_t)a.st.W * a.st.local_rows;

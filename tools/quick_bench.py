@@ -12,11 +12,14 @@ ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--tris", type=int, default=331000)
 ap.add_argument("--paths", type=int, default=1024)
 ap.add_argument("--vpl-paths", type=int, default=1024)
-ap.add_argument("--builder", type=int, default=0)
+ap.add_argument("--builder", type=int, default=1)
 ap.add_argument("--mode", default="one")
 ap.add_argument("--splat", action="store_true")
 ap.add_argument("--vsl", action="store_true")
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--strip-count", type=int, default=1)
+ap.add_argument("--strip-rank", type=int, default=0)
+ap.add_argument("--strip-rows", type=int, default=16)
 a = ap.parse_args()
 d = "/tmp/evplp_synth"
 t0 = time.time()
@@ -24,7 +27,7 @@ jp = ev.synth_scene(d, "conf", a.tris, 1234, a.res, a.res)
 sd, root = scenes.load_obj_scene(jp)
 print("scene load %.1fs tris %d" % (time.time() - t0, sd.triangle_soup()[2].shape[0]))
 P = 4
-c = ev.Context(a.res, a.res, a.paths, a.vpl_paths, P, bvh_builder=a.builder)
+c = ev.Context(a.res, a.res, a.paths, a.vpl_paths, P, bvh_builder=a.builder, strip_rank=a.strip_rank, strip_count=a.strip_count, strip_rows=a.strip_rows)
 t0 = time.time(); sd.upload(c); print("upload+build %.2fs" % (time.time() - t0), c.accel_info())
 bsr, total, larea = c.scene_metrics()
 radius = 0.003 * bsr
