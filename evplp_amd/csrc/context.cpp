@@ -524,7 +524,7 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     if (pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL) {
         out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = pc.rays; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
         out->reserved[1] = (uint32_t)(pc.nodes >> 32);
-        if (getenv("EVPLP_PRINT_GATHER_STATS")) fprintf(stderr, "[gather stats] full_occ %llu full_vis %llu mixed+occrays<<32 %llu (mixed %llu, occluded rays(sum of low words) %llu)\n", pc.pairs, pc.aux, pc.nodes, pc.nodes & 0xffffffffull, pc.nodes >> 32);
+        if (getenv("EVPLP_PRINT_GATHER_STATS")) fprintf(stderr, "[gather stats] packets over threshold: %llu with %llu nodes; all packets: %llu nodes\n", pc.pairs, pc.aux, pc.nodes);
     } else if (pass == EVPLP_PASS_SPLAT) {
         out->pairs = pc.pairs; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries;
         if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }

@@ -324,6 +324,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     for (;;) {
         while (cur >= 0) {
             const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
+#ifdef EVPLP_GATHER_STATS
+            nodes_visited++;
+#endif
             // both children at once (half 0 = child 0, half 1 = child 1), conservative slab test in
             // centre / half-size form: A = ctr/d - o/d, B = hal/|d|, entry = A - B, exit = A + B
             const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);

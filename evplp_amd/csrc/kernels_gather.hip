@@ -124,7 +124,10 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     V3 result = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, nodes = 0;
 #ifdef EVPLP_GATHER_STATS
-    uint32_t st_full_occ = 0, st_full_vis = 0, st_mixed = 0;
+#ifndef EVPLP_STATS_THRESH
+#define EVPLP_STATS_THRESH 128
+#endif
+    uint32_t st_full_occ = 0, st_full_vis = 0, st_mixed = 0, nodes_prev = 0; unsigned long long st_n256 = 0, st_n96 = 0, st_nlow = 0;
 #endif
     for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
         const Vpl v = fetch_vpl(a.vpls + i);
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
         bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, lds_stack, nodes);
 #ifdef EVPLP_GATHER_STATS
-        { unsigned long long am = ballot64(active), om = ballot64(occ && active);
-          if (om == am) st_full_occ++; else if (om == 0ull) st_full_vis++; else st_mixed++; }
+        { uint32_t nv = nodes - nodes_prev; nodes_prev = nodes;
+          if (nv > EVPLP_STATS_THRESH) { st_full_occ++; st_n256 += nv; } st_nlow += nv; }
 #endif
         if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
     }
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     if (lane == 0) {
         atomicAdd(&a.counters->rays, (unsigned long long)rays);
 #ifdef EVPLP_GATHER_STATS
-        atomicAdd(&a.counters->pairs, (unsigned long long)st_full_occ); atomicAdd(&a.counters->aux, (unsigned long long)st_full_vis);
-        atomicAdd(&a.counters->nodes, (unsigned long long)st_mixed);
+        atomicAdd(&a.counters->pairs, (unsigned long long)st_full_occ); atomicAdd(&a.counters->aux, st_n256);
+        atomicAdd(&a.counters->nodes, st_nlow);
 #endif
     }
 }
