@@ -56,6 +56,18 @@ def oracle_technique(json_path, block):
     clamp_start = clamp
     mode = {"one": 0, "balance": 1, "max": 2, "power2": 3, "geometryClamp": 4, "geometryBrdfClamp": 5}[block.get("misMode", "balance")]
     accumulate = block["frameMode"] == "accumulate"
+    force_vsl = block.get("forceVsl", False)
+    vsl_r = f32(0); vsl_i = f32(0)
+    if force_vsl:                                                   # rtcomphoton.h:205-218
+        vsl_r = f32(bsr * f32(block["vslRadiusPercentage"]))
+        if vsl_r <= f32(0.008):
+            vsl_r = f32(0.008)
+        vsl_i = f32(inv_pi / f32(vsl_r * vsl_r))
+    run = dict(deferredShading=True, lightTracing=True, vplSplat=nv > 0, photonSplat=True)
+    run.update({k: v for k, v in block.get("run", {}).items() if k in run})
+    if nv == 0:
+        run["vplSplat"] = False
+    frames = []
     rng = MT19937(block["rngOffset"])
     vpl = np.zeros((H, W, 4), np.float32); pm = np.zeros((H, W, 4), np.float32); light = np.zeros((H, W, 4), np.float32)
     import ctypes as C
@@ -72,24 +84,32 @@ def oracle_technique(json_path, block):
         light[lit] = g[4][lit]
         rec = osc.trace_light_paths(n_it + block["rngOffset"], nl, P)
         kw = dict(camera_pos=sd.cam_origin, mis_mode=mode, pdf_mc=float(pdf_mc), clamping_value=float(clamp), photon_radius=float(radius),
+                  vsl_radius=float(vsl_r), vsl_inv_pi_radius2=float(vsl_i),
                   num_light_paths=nl, num_vpl_light_paths=nv, photons_per_path=P, do_accumulate=int(accumulate), rng_seed=n_it + block["rngOffset"], jitter=jitter)
-        if nv > 0:
-            osc.gather(oa.frame_params(**kw), W, H, g, rec, out=vpl)
-        if radius > 0:
+        if run["vplSplat"]:
+            osc.gather(oa.frame_params(**kw), W, H, g, rec, out=vpl, vsl=force_vsl)
+        if radius > 0 and run["photonSplat"]:
             if not accumulate:
                 pm[:] = 0
             oa.splat(oa.frame_params(**kw), W, H, g, rec, out=pm)
         n_it += 1
         if block.get("DoProgressive", False):
             r, c, p, vr, vi = (C.c_float(x) for x in (radius, clamp, pdf_mc, 0.0, 0.0))
-            l.evo_progressive_step(n_it, block.get("AlphaProgressive", 0.7), float(clamp_start), nv, nl, C.byref(r), C.byref(c), C.byref(p), 0, C.byref(vr), C.byref(vi))
-            radius, clamp, pdf_mc = f32(r.value), f32(c.value), f32(p.value)
+            r, c, p, vr, vi = (C.c_float(x) for x in (radius, clamp, pdf_mc, vsl_r, vsl_i))
+            l.evo_progressive_step(n_it, block.get("AlphaProgressive", 0.7), float(clamp_start), nv, nl, C.byref(r), C.byref(c), C.byref(p), int(force_vsl), C.byref(vr), C.byref(vi))
+            radius, clamp, pdf_mc, vsl_r, vsl_i = f32(r.value), f32(c.value), f32(p.value), f32(vr.value), f32(vi.value)
+        if block.get("writeEveryFrame", False):                     # rtcomphoton.h:1079-1102
+            pf = 1.0 / n_it if accumulate else 1.0
+            rgb = np.zeros((H, W, 3), np.float32)
+            l.evo_resolve(W, H, oa.ptr(vpl), oa.ptr(pm), oa.ptr(light), pf, pf, 1.0, 0, 0, oa.ptr(rgb))
+            frames.append(rgb[::-1].copy())
     param = 1.0 / n_it if accumulate else 1.0
     outs = {}
     for name, (vs, ps, ls) in {"combined": (param, param, 1.0), "vpl": (param, 0.0, 1.0), "pm": (0.0, param, 0.0)}.items():
         rgb = np.zeros((H, W, 3), np.float32)
         l.evo_resolve(W, H, oa.ptr(vpl), oa.ptr(pm), oa.ptr(light), vs, ps, ls, 0, 0, oa.ptr(rgb))
         outs[name] = rgb[::-1]          # FlipY before Save (rtcomphoton.h:1124-1127)
+    outs["frames"] = frames
     return outs
 
 
@@ -121,6 +141,44 @@ def test_render_json_matches_oracle_loop(evplp, tmp_path, variant):
     assert want["combined"].max() > 0
     if variant == "progressive_balance":
         assert want["pm"].max() > 0
+
+
+def test_render_json_vsl_ppm_and_per_frame_dumps(evplp, tmp_path):
+    """forceVsl (progressive VSL radius), numVplLightPaths = 0 (pure photon mapping: the gather is disabled,
+    rtcomphoton.h:200-203), run{} switches and writeEveryFrame dumps."""
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 4, 64, 40)
+    root = json.load(open(jp))
+    base = dict(root["photonfam"])
+    cases = {
+        "vsl": dict(numLightPaths=32, numVplLightPaths=8, forceVsl=True, vslRadiusPercentage=0.04, radiusPercentage=0.0, numMaxIteration=2,
+                    DoProgressive=True, misMode="one", run={}),
+        "ppm": dict(numLightPaths=400, numVplLightPaths=0, radiusPercentage=0.04, misMode="one", numMaxIteration=3, DoProgressive=True,
+                    writeEveryFrame=True, run={"lightRender": True}),
+        "nosplat": dict(numLightPaths=64, numVplLightPaths=16, radiusPercentage=0.05, misMode="balance", numMaxIteration=1, run={"photonSplat": False}),
+    }
+    for name, upd in cases.items():
+        block = dict(base); block.update(upd)
+        block.update(combinedFilename=f"{name}_c.pfm", weightedVplFilename=f"{name}_v.pfm", weightedPhotonFilename=f"{name}_p.pfm", statFilename=f"{name}_s.json")
+        root["photonfam"] = block
+        json.dump(root, open(jp, "w"))
+        evplp.render_json(jp)
+        want = oracle_technique(jp, block)
+        tol = 2e-3 if name == "vsl" else 1e-4
+        for key, fn in (("combined", "c"), ("vpl", "v"), ("pm", "p")):
+            got = evplp.load_pfm(str(tmp_path / f"{name}_{fn}.pfm"))
+            if want[key].max() == 0:
+                assert got.max() == 0, (name, key)
+            else:
+                assert rel_l2(got, want[key]) <= tol, (name, key, rel_l2(got, want[key]))
+        if name == "ppm":
+            assert want["vpl"].max() == want["combined"].max() or want["pm"].max() > 0
+            for i, fr in enumerate(want["frames"], 1):
+                got = evplp.load_pfm(str(tmp_path / f"ppm_p_{i}.pfm"))
+                assert rel_l2(got, fr) <= 1e-4, i
+        if name == "nosplat":
+            assert want["pm"].max() == 0
+        if name == "vsl":
+            assert want["vpl"].max() > 0
 
 
 def test_png_output_and_overrides(evplp, tmp_path):
