@@ -93,13 +93,74 @@ int save_png(const char *path, int32_t w, int32_t h, const float *rgb) {
     return ok ? EVPLP_OK : EVPLP_ERR_IO;
 }
 
-// floatimage.cpp:260-273 Save: dispatch on the extension (hdr is not part of this round)
+// Radiance RGBE (.hdr), FloatImage::SaveHDR (floatimage.cpp:223-239) -> RGBE_WriteHeader + RGBE_WritePixels_RLE
+// (common/floatimage/rgbe.cpp:73-134, 231-336; Bruce Walter's public rgbe.c format): header
+// "#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y h +X w\n"; per scanline (widths 8..32767) the marker 2,2,w_hi,w_lo and
+// the four channels (r, g, b, e) each run-length encoded with runs of >= 4 equal bytes; other widths are
+// written flat.
+namespace {
+void float_to_rgbe(unsigned char out[4], float r, float g, float b) {
+    float v = r; if (g > v) v = g; if (b > v) v = b;
+    if (v < 1e-32) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    int e; v = (float)(std::frexp(v, &e) * 256.0 / v);
+    out[0] = (unsigned char)(r * v); out[1] = (unsigned char)(g * v); out[2] = (unsigned char)(b * v); out[3] = (unsigned char)(e + 128);
+}
+void rle_channel(std::vector<uint8_t> &out, const unsigned char *data, int n) {
+    const int kMinRun = 4;
+    int cur = 0;
+    while (cur < n) {
+        int beg = cur, run = 0, old_run = 0;
+        while (run < kMinRun && beg < n) {      // next run of at least 4 equal bytes
+            beg += run; old_run = run; run = 1;
+            while (beg + run < n && run < 127 && data[beg] == data[beg + run]) run++;
+        }
+        if (old_run > 1 && old_run == beg - cur) {   // the data before the long run is itself a short run
+            out.push_back((uint8_t)(128 + old_run)); out.push_back(data[cur]);
+            cur = beg;
+        }
+        while (cur < beg) {                          // literal bytes up to the run
+            int cnt = std::min(beg - cur, 128);
+            out.push_back((uint8_t)cnt); out.insert(out.end(), data + cur, data + cur + cnt);
+            cur += cnt;
+        }
+        if (run >= kMinRun) { out.push_back((uint8_t)(128 + run)); out.push_back(data[beg]); cur += run; }
+    }
+}
+}
+int save_hdr(const char *path, int32_t w, int32_t h, const float *rgb) {
+    std::vector<uint8_t> out;
+    char hdr[128];
+    int n = std::snprintf(hdr, sizeof hdr, "#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
+    out.insert(out.end(), hdr, hdr + n);
+    if (w < 8 || w > 0x7fff) {
+        for (size_t i = 0; i < (size_t)w * h; i++) { unsigned char px[4]; float_to_rgbe(px, rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]); out.insert(out.end(), px, px + 4); }
+    } else {
+        std::vector<unsigned char> buf((size_t)4 * w);
+        for (int32_t y = 0; y < h; y++) {
+            out.push_back(2); out.push_back(2); out.push_back((uint8_t)(w >> 8)); out.push_back((uint8_t)(w & 0xff));
+            for (int32_t x = 0; x < w; x++) {
+                unsigned char px[4]; const float *p = rgb + 3 * ((size_t)y * w + x);
+                float_to_rgbe(px, p[0], p[1], p[2]);
+                buf[x] = px[0]; buf[x + w] = px[1]; buf[x + 2 * w] = px[2]; buf[x + 3 * w] = px[3];
+            }
+            for (int c = 0; c < 4; c++) rle_channel(out, buf.data() + (size_t)c * w, w);
+        }
+    }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return EVPLP_ERR_IO;
+    bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    std::fclose(f);
+    return ok ? EVPLP_OK : EVPLP_ERR_IO;
+}
+
+// floatimage.cpp:260-273 Save: dispatch on the extension
 int save_image(const char *path, int32_t w, int32_t h, const float *rgb) {
     std::string p(path);
     size_t i = p.find_last_of('.');
     if (i == std::string::npos || i + 1 >= p.size()) return EVPLP_ERR_INVALID;
     std::string ext = p.substr(i + 1);
     if (ext == "pfm") return save_pfm(path, w, h, rgb);
+    if (ext == "hdr") return save_hdr(path, w, h, rgb);
     if (ext == "png") return save_png(path, w, h, rgb);
     return EVPLP_ERR_INVALID;  // "unsupported file format"
 }

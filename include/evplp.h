@@ -213,7 +213,7 @@ void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clam
                             uint32_t n_vpl_paths, uint32_t n_light_paths,
                             float *photon_radius, float *clamping_value, float *pdf_mc,
                             int32_t force_vsl, float *vsl_radius, float *vsl_inv_pi_radius2);
-/* FloatImage::Save by extension (common/floatimage/floatimage.cpp:260-273): .pfm / .png.
+/* FloatImage::Save by extension (common/floatimage/floatimage.cpp:260-273): .pfm / .hdr / .png.
  * rgb: top-down rows (after FlipY, rtcomphoton.h:1124-1127), 3 floats per pixel. */
 int evplp_save_image(const char *path, int32_t w, int32_t h, const float *rgb_top_down);
 int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb_top_down, size_t capacity_floats);

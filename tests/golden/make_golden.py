@@ -5,8 +5,8 @@ authoring container (needs /root/reference); the fixtures -- inputs and expected
 committed so the pins also hold on the GPU box, where the reference does not exist.
 
 Fixtures:
-  output_surface.npz  PFM file bytes, decoded PNG pixels, FlipY, MSE / relMSE of seeded images
-                      (common/floatimage/floatimage.cpp:64-128, 178-199, 241-273)
+  output_surface.npz  PFM and HDR (RGBE) file bytes, decoded PNG pixels, FlipY, MSE / relMSE of seeded images
+                      (common/floatimage/floatimage.cpp:64-128, 178-199, 223-273; rgbe.cpp)
   camera.npz          projection*view matrices (with / without the jitter translation) for seeded
                       cameras incl. the conference camera, fovx->fovy, bounding-sphere radii
                       (rt/rtcommon.h:548-591, 805-814; rt/rtcomphoton/rtcomphoton.h:943-952)
@@ -74,12 +74,16 @@ def main():
     rng = np.random.RandomState(20261002)
     out = {}
     tmp = tempfile.mkdtemp()
-    for name, (w, h) in {"a": (4, 2), "b": (17, 9)}.items():
+    for name, (w, h) in {"a": (4, 2), "b": (17, 9), "c": (40, 5)}.items():
         img = (rng.rand(h, w, 3).astype(np.float32) * np.float32(1.6)).astype(np.float32)   # some values > 1 (PNG clamp)
         img[0, 0] = [0.0, 1.0, 0.5]
         other = (img + rng.randn(h, w, 3).astype(np.float32) * np.float32(0.05)).astype(np.float32)
-        pfm = os.path.join(tmp, name + ".pfm"); png = os.path.join(tmp, name + ".png")
+        pfm = os.path.join(tmp, name + ".pfm"); png = os.path.join(tmp, name + ".png"); hdr = os.path.join(tmp, name + ".hdr")
         assert ref.ref_save(pfm.encode(), w, h, P(img)) == 0 and ref.ref_save(png.encode(), w, h, P(img)) == 0
+        hdr_img = img.copy(); hdr_img[h // 2, : w // 2] = hdr_img[h // 2, 0]          # a run, to exercise the RLE
+        assert ref.ref_save(hdr.encode(), w, h, P(hdr_img)) == 0
+        out[f"{name}_hdr_img"] = hdr_img
+        out[f"{name}_hdr_bytes"] = np.frombuffer(open(hdr, "rb").read(), np.uint8)
         flipped = np.zeros_like(img); ref.ref_flip_y(w, h, P(img), P(flipped))
         out[f"{name}_img"] = img; out[f"{name}_other"] = other
         out[f"{name}_pfm_bytes"] = np.frombuffer(open(pfm, "rb").read(), np.uint8)

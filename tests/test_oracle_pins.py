@@ -34,6 +34,16 @@ def test_pfm_bytes_oracle_and_product(name, oracle, tmp_path, evplp):
     assert np.array_equal(back, img)
 
 
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_hdr_bytes_product(name, tmp_path, evplp):
+    """Radiance RGBE: flat for widths < 8 (image a), run-length encoded otherwise -- byte-identical to
+    FloatImage::SaveHDR / rgbe.cpp."""
+    img = G[f"{name}_hdr_img"]
+    p = str(tmp_path / "x.hdr")
+    evplp.save_image(p, img)
+    assert open(p, "rb").read() == G[f"{name}_hdr_bytes"].tobytes()
+
+
 @pytest.mark.parametrize("name", ["a", "b"])
 def test_png_pixels_oracle_and_product(name, oracle, tmp_path, evplp):
     img = G[f"{name}_img"]; h, w = img.shape[:2]
