@@ -41,8 +41,18 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v,
     float dist2 = dot(v12, v12);
     float dist = sqrtf(dist2);
     V3 wi12 = v12 / dist;
-    V3 brdf2 = v.rd * EV_INV_PI + v.rs * phong_eval_f(-wi12, v.fdir, v.n, v.e);
-    V3 brdf1 = px.rd * EV_INV_PI + px.rs * phong_eval_f(px.wi10, wi12, px.n1, px.e);
+    // Phong lobes only where they exist: rho_s = 0 makes the term exactly 0 (0 * finite) and e = 0 makes
+    // powf(d, 0) exactly 1, so both shortcuts return the bits the general expression would; they remove the
+    // two powf calls for Lambertian receivers / Lambertian bounce VPLs / the on-light VPL (e = I.w = 0)
+    float ph2 = 0.0f;
+    if (v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f) {              // wave-uniform (the VPL is)
+        if (v.e == 0.0f) { V3 r = reflect(-v.fdir, v.n); ph2 = fmaxf(dot(-wi12, r), 0.0f) <= 0.000001f ? 0.0f : (v.e + 2.0f) * 1.0f * EV_INV_PI * 0.5f; }
+        else ph2 = phong_eval_f(-wi12, v.fdir, v.n, v.e);
+    }
+    float ph1 = 0.0f;
+    if (ballot64(px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f) != 0ull) ph1 = phong_eval_f(px.wi10, wi12, px.n1, px.e);
+    V3 brdf2 = v.rd * EV_INV_PI + v.rs * ph2;
+    V3 brdf1 = px.rd * EV_INV_PI + px.rs * ph1;
     float g21 = c1c2 / (dist2 * dist2);
     const uint32_t mode = fp.mis_mode;
     if (mode == 0u) return v.flux * brdf1 * brdf2 * g21;
