@@ -148,7 +148,8 @@ def main():
         if split_paths:
             ctx.trace_light_paths(it, rank * per_rank, per_rank)
             chunk = records.numel() // world
-            dist.all_gather_into_tensor(records, records[rank * chunk:(rank + 1) * chunk])
+            # out-of-place send buffer (a copy of this rank's slice): no aliasing between input and output
+            dist.all_gather_into_tensor(records, records[rank * chunk:(rank + 1) * chunk].clone())
         else:
             ctx.trace_light_paths(it)
         ctx.gather_vpl(fp)
