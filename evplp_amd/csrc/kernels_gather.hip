@@ -184,19 +184,77 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 }
 
 // ------------------------------------------------------------------------------------ VSL
+// The VSL estimators are ALU-bound (up to 101 sample iterations x 3 estimators per lit pair, each with
+// powf / sinf / cosf).  They use hardware transcendentals (v_log_f32 / v_exp_f32 / v_sin_f32 / v_cos_f32):
+// x^y = exp2(y log2 x), sin(2 pi u) = v_sin(u).  The estimator is Monte-Carlo noise-limited; the result is
+// compared with the oracle (accurate libm) under the VSL tolerance (rel. L2 1e-3, 2 % per pixel).  Light
+// tracing and the VPL gather keep the accurate functions.
+#ifndef EVPLP_VSL_FAST
+#define EVPLP_VSL_FAST 1
+#endif
+namespace vslm {
+#if EVPLP_VSL_FAST
+EV_DEV float fpow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+EV_DEV float sin2pi(float u) { return __builtin_amdgcn_sinf(u); }   // v_sin_f32 takes revolutions
+EV_DEV float cos2pi(float u) { return __builtin_amdgcn_cosf(u); }
+#else
+EV_DEV float fpow(float x, float y) { return powf(x, y); }
+EV_DEV float sin2pi(float u) { return sinf(2.0f * EV_PI * u); }
+EV_DEV float cos2pi(float u) { return cosf(2.0f * EV_PI * u); }
+#endif
+EV_DEV float phong_eval_f(V3 out, V3 in, V3 n, float e) {            // rt/rtmaterial.cuh:112-118
+    V3 r = reflect(-in, n);
+    float d = fmaxf(dot(out, r), 0.0f);
+    if (d <= 0.000001f) return 0.0f;
+    return (e + 2.0f) * fpow(d, e) * EV_INV_PI * 0.5f;
+}
+EV_DEV float phong_pdf_w(V3 n1, V3 v12, V3 in, V3 rho_s, float e) {  // :78-85
+    V3 wi12 = normalize(v12);
+    V3 r = normalize(reflect(-in, n1));
+    float c = fmaxf(dot(wi12, r), 0.f);
+    if (c <= 0.000001f || rho_s.x <= 0.000001f) return 0.0f;
+    return (e + 1.0f) * 0.5f * EV_INV_PI * fpow(c, e);
+}
+EV_DEV V3 lambert_sample(V3 &out, float &pdfw, V3 normal, V3 rho_d, Rng &rng) {   // :56-66
+    float u1 = rng_uniform(rng);
+    float u2 = rng_uniform(rng);
+    float r = sqrtf(u1);
+    V3 p; p.x = r * cos2pi(u2); p.y = r * sin2pi(u2);
+    p.z = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+    Onb o = onb_make(normal);
+    out = onb_inverse(o, p);
+    pdfw = fmaxf(dot(out, normal), 0.f) * EV_INV_PI;
+    return rho_d;
+}
+EV_DEV V3 phong_sample(V3 &out, float &pdfw, V3 in, V3 normal, V3 rho_s, float e, Rng &rng) {   // :120-154
+    V3 r = reflect(-in, normal);
+    float sx = rng_uniform(rng);
+    float sy = rng_uniform(rng);
+    float cos_t = fpow(sx, 1.f / (e + 1.f));
+    float sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));
+    V3 p = v3(sin_t * cos2pi(sy), sin_t * sin2pi(sy), cos_t);
+    Onb o = onb_make(r);
+    out = onb_inverse(o, p);
+    float unsafe_cos = dot(out, normal);
+    float cos_n = fmaxf(unsafe_cos, 0.f);
+    float cos_r = fmaxf(dot(out, r), 0.f);
+    if (unsafe_cos > 0.0f) pdfw = (e + 1.0f) * 0.5f * fpow(cos_r, e) * EV_INV_PI;
+    else pdfw = 0.0f;
+    return rho_s * ((e + 2.0f) / (e + 1.0f) * cos_n);
+}
+} // namespace vslm
 EV_DEV V3 square_to_solid_angle(float sx, float sy, float half_angle_max) {  // lighttracing.cu:382-390
-    float phi = 2.0f * EV_PI * sx;
     float z = 1.0f - sy * (1.0f - cosf(half_angle_max));
-    float l = sqrtf(1.0f - z * z);
-    return v3(cosf(phi) * l, sinf(phi) * l, z);
+    float l = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+    return v3(vslm::cos2pi(sx) * l, vslm::sin2pi(sx) * l, z);
 }
 struct VslCtx {
     float half_cone, cos_half_cone, solid_angle, inv_solid_angle, inv_pi_r2; V3 nd12;
 };
 // shared MIS denominator block (:433-443, 508-518, 581-591) with the reference quirk of SURVEY A.6
 EV_DEV void vsl_pdfs(const Pixel &px, const Vpl &v, V3 wi12, float psel, float &pdf1, float &pdf2) {
-    pdf1 = lambert_pdf_w(px.n1, wi12) * psel + phong_pdf_w(px.n1, wi12, px.wi10, px.rs, px.e) * (1.0f - psel);
-    pdf2 = lambert_pdf_w(v.n, -wi12) * psel + phong_pdf_w(v.n, -wi12, v.fdir, v.rs, v.e);
+    pdf1 = lambert_pdf_w(px.n1, wi12) * psel + vslm::phong_pdf_w(px.n1, wi12, px.wi10, px.rs, px.e) * (1.0f - psel);
+    pdf2 = lambert_pdf_w(v.n, -wi12) * psel + vslm::phong_pdf_w(v.n, -wi12, v.fdir, v.rs, v.e);
 }
 EV_DEV V3 vsl_sample_cone(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :395-446
     const V3 zero = v3(0.f, 0.f, 0.f);
@@ -211,8 +269,8 @@ EV_DEV V3 vsl_sample_cone(const Pixel &px, const Vpl &v, const VslCtx &c, float 
     wi12 = normalize(onb_inverse(o, wi12));
     float c1c2 = fmaxf(dot(px.n1, wi12), 0.0f) * fmaxf(-dot(v.n, wi12), 0.0f);
     if (c1c2 <= 0.000000001f) return zero;
-    V3 brdf2 = v.rd * EV_INV_PI + v.rs * phong_eval_f(-wi12, v.fdir, v.n, v.e);
-    V3 brdf1 = px.rd * EV_INV_PI + px.rs * phong_eval_f(px.wi10, wi12, px.n1, px.e);
+    V3 brdf2 = v.rd * EV_INV_PI + v.rs * vslm::phong_eval_f(-wi12, v.fdir, v.n, v.e);
+    V3 brdf1 = px.rd * EV_INV_PI + px.rs * vslm::phong_eval_f(px.wi10, wi12, px.n1, px.e);
     float pdf1, pdf2; vsl_pdfs(px, v, wi12, psel, pdf1, pdf2);
     w = c.inv_solid_angle / (pdf1 + pdf2 + c.inv_solid_angle);
     return (((v.flux * c.inv_pi_r2) * c1c2) * brdf1 * brdf2) * c.solid_angle;
@@ -224,13 +282,13 @@ EV_DEV V3 vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslCtx &c, float
     float psel = ml / (mp + ml);
     float choose = fminf(rng_uniform(rng), 0.999999f);
     V3 wi12, brdf1; float pdfw;
-    if (choose < psel) brdf1 = lambert_sample(wi12, pdfw, px.n1, px.rd, rng) / psel;
-    else brdf1 = phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) / (1.0f - psel);
+    if (choose < psel) brdf1 = vslm::lambert_sample(wi12, pdfw, px.n1, px.rd, rng) / psel;
+    else brdf1 = vslm::phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) / (1.0f - psel);
     if (dot(wi12, c.nd12) <= c.cos_half_cone) return zero;
     float cos1 = fmaxf(dot(px.n1, wi12), 0.0f);
     if (cos1 <= 0.000000001f) return zero;
     float cos2 = fmaxf(-dot(v.n, wi12), 0.0f);
-    V3 brdf2 = v.rd * EV_INV_PI + v.rs * phong_eval_f(-wi12, v.fdir, v.n, v.e);
+    V3 brdf2 = v.rd * EV_INV_PI + v.rs * vslm::phong_eval_f(-wi12, v.fdir, v.n, v.e);
     (void)rng_uniform(rng);  // :506
     float pdf1, pdf2; vsl_pdfs(px, v, wi12, psel, pdf1, pdf2);
     w = pdf1 / (pdf1 + pdf2 + c.inv_solid_angle);
@@ -244,11 +302,11 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float
         if (ml + mp <= 0.000001f) return zero;
         float psel = ml / (mp + ml);
         float choose = fminf(rng_uniform(rng), 0.999999f);
-        if (choose < psel) brdf2 = lambert_sample(wi21, pdfw, v.n, v.rd, rng) / psel;
-        else brdf2 = phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) / (1.0f - psel);
+        if (choose < psel) brdf2 = vslm::lambert_sample(wi21, pdfw, v.n, v.rd, rng) / psel;
+        else brdf2 = vslm::phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) / (1.0f - psel);
     }
     if (-dot(wi21, c.nd12) <= c.cos_half_cone) return zero;
-    V3 brdf1 = px.rd * EV_INV_PI + px.rs * phong_eval_f(px.wi10, -wi21, px.n1, px.e);
+    V3 brdf1 = px.rd * EV_INV_PI + px.rs * vslm::phong_eval_f(px.wi10, -wi21, px.n1, px.e);
     float cos2 = fmaxf(dot(v.n, wi21), 0.0f);
     if (cos2 <= 0.00000001f) return zero;
     float cos1 = fmaxf(-dot(px.n1, wi21), 0.0f);
