@@ -248,6 +248,44 @@ def test_full_size_sampled_pixels_and_properties(evplp, full_scene):
     assert err.max() <= 2e-4, err.max()
 
 
+def test_full_size_photon_splat_rows(evplp, full_scene):
+    """BASELINE config #3 size: 500 000 light paths x 4 = 2 M record slots splatted at 1024^2 with
+    r = 0.3 % of the bounding-sphere radius, misMode balance; whole rows checked against the oracle, plus
+    linearity (flux x 2 -> image x 2 exactly in deterministic mode) and the pair count."""
+    W = H = 1024; N, NV, P = 500000, 1024, 4
+    with evplp.Context(W, H, N, NV, P, deterministic=True) as c:
+        c.load_scene_json(full_scene)
+        cam = c.camera()
+        bsr, _, _ = c.scene_metrics()
+        r = 0.003 * bsr
+        jitter = (0.0004, -0.0003)
+        kw = dict(camera_pos=list(cam.origin), mis_mode="balance", pdf_mc=(NV / N) / math.pi / (r * r), photon_radius=r,
+                  num_light_paths=N, num_vpl_light_paths=NV, photons_per_path=P, jitter=jitter)
+        c.primary(jitter); c.trace_light_paths(3)
+        c.splat_photons(evplp.frame_params(**kw), clear=True)
+        a = c.download(evplp.BUF_PHOTON_ACCUM)
+        st = c.pass_stats(evplp.PASS_SPLAT)
+        rec = c.download(evplp.BUF_RECORDS)
+        gbuf = [c.download(b) for b in (evplp.BUF_GBUF_POSITION, evplp.BUF_GBUF_NORMAL, evplp.BUF_GBUF_DIFFUSE, evplp.BUF_GBUF_PHONG)]
+        rec2 = rec.copy(); rec2["flux"] *= np.float32(2)
+        c.upload(evplp.BUF_RECORDS, rec2)
+        c.splat_photons(evplp.frame_params(**kw), clear=True)
+        b = c.download(evplp.BUF_PHOTON_ACCUM)
+    assert np.array_equal(b[..., :3], a[..., :3] * np.float32(2)), "splat is not linear in the flux"
+    assert (rec["flags"] & 2).astype(bool).sum() > 1_000_000 and st["pairs"] > 1_000_000
+    rows = [100, 333, 512, 640, 900]
+    out = np.zeros((H, W, 4), np.float32)
+    pairs = 0
+    for y in rows:
+        _, n = oa.splat(oa.frame_params(**{**kw, "mis_mode": 1}), W, H, gbuf, rec, out=out, rows=(y, y + 1))
+        pairs += n
+    got, ref = a[rows][..., :3], out[rows][..., :3]
+    assert pairs > 1000 and ref.max() > 0
+    assert rel_l2(got, ref) <= 1e-5, rel_l2(got, ref)
+    scale = ref.max()
+    assert (np.abs(got - ref) <= 2e-4 * np.maximum(ref, 1e-3 * scale) + 1e-9).all()
+
+
 # ----------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("res", [(50, 37), (8, 8), (129, 65)])
 def test_ragged_resolutions(evplp, res):
