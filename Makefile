@@ -7,7 +7,7 @@ OUT = evplp_amd/lib
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -munsafe-fp-atomics -fno-slp-vectorize $(EXTRA_HIPFLAGS)
 HOSTFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-unused-value -ffp-contract=off
 
-HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip
+HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip $(CSRC)/kernels_pt.hip
 CPP_SRCS = $(CSRC)/context.cpp $(CSRC)/bvh_build.cpp $(wildcard $(CSRC)/host/*.cpp)
 HIP_OBJS = $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 CPP_OBJS = $(patsubst $(CSRC)/%.cpp,build/%.o,$(filter-out $(CSRC)/host/driver_main.cpp,$(CPP_SRCS)))

@@ -29,7 +29,8 @@ MIS_MODES = {"one": 0, "balance": 1, "max": 2, "power2": 3, "geometryClamp": 4, 
 BVH_LBVH, BVH_SAH = 0, 1
 (BUF_RECORDS, BUF_GBUF_POSITION, BUF_GBUF_NORMAL, BUF_GBUF_DIFFUSE, BUF_GBUF_PHONG, BUF_LIGHT,
  BUF_VPL_ACCUM, BUF_PHOTON_ACCUM, BUF_COUNT) = range(9)
-(PASS_PRIMARY, PASS_LIGHT_TRACE, PASS_GATHER_VPL, PASS_GATHER_VSL, PASS_SPLAT, PASS_RESOLVE, PASS_COUNT) = range(7)
+(PASS_PRIMARY, PASS_LIGHT_TRACE, PASS_GATHER_VPL, PASS_GATHER_VSL, PASS_SPLAT, PASS_RESOLVE, PASS_PATH_TRACE,
+ PASS_GATHER_LVC, PASS_COUNT) = range(9)
 
 RECORD_DTYPE = np.dtype([
     ("pos", np.float32, 3), ("flags", np.uint32),
@@ -94,6 +95,8 @@ _SIGNATURES = {
     "evplp_trace_light_paths": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "evplp_gather_vpl": (C.c_int, [_P, C.POINTER(FrameParams)]),
     "evplp_gather_vsl": (C.c_int, [_P, C.POINTER(FrameParams)]),
+    "evplp_gather_lvc": (C.c_int, [_P, C.POINTER(FrameParams)]),
+    "evplp_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_splat_photons": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
     "evplp_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_clear_accumulators": (C.c_int, [_P]),
@@ -280,6 +283,13 @@ class Context:
 
     def gather_vsl(self, fp: FrameParams):
         self._check(self._lib.evplp_gather_vsl(self._h, C.byref(fp)))
+
+    def gather_lvc(self, fp: FrameParams):
+        self._check(self._lib.evplp_gather_lvc(self._h, C.byref(fp)))
+
+    def path_trace(self, camera_pos, rng_seed: int, max_bounces: int, accumulate=True):
+        cp = (C.c_float * 3)(*[float(v) for v in camera_pos])
+        self._check(self._lib.evplp_path_trace(self._h, C.byref(cp), rng_seed, max_bounces, int(accumulate)))
 
     def splat_photons(self, fp: FrameParams, clear=False):
         self._check(self._lib.evplp_splat_photons(self._h, C.byref(fp), int(clear)))

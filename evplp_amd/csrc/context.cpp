@@ -403,6 +403,36 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
 extern "C" int evplp_gather_vpl(evplp_context *c, const evplp_frame_params *fp) { CTX_CHECK(c); return run_gather(c, fp, false); }
 extern "C" int evplp_gather_vsl(evplp_context *c, const evplp_frame_params *fp) { CTX_CHECK(c); return run_gather(c, fp, true); }
 
+// lvclighttracing.cu:348-384: the window covers num_vpl_light_paths paths of ALL num_light_paths * P record slots
+extern "C" int evplp_gather_lvc(evplp_context *c, const evplp_frame_params *fp) {
+    CTX_CHECK(c);
+    const int pass = EVPLP_PASS_GATHER_LVC;
+    int rc = pass_ready(c, "evplp_gather_lvc", false); if (rc) return rc;
+    if ((rc = check_fp(c, fp, "evplp_gather_lvc"))) return rc;
+    if (fp->num_vpl_light_paths == 0) { c->set_error("evplp_gather_lvc: num_vpl_light_paths is 0"); return EVPLP_ERR_INVALID; }
+    GatherArgs a; fill_gather_args(c, fp, a, pass);
+    if ((rc = pass_begin(c, pass))) return rc;
+    launch_gather_lvc(a, (const evplp_record *)c->buf[EVPLP_BUF_RECORDS], c->stream);
+    return pass_end(c, pass);
+}
+
+extern "C" int evplp_path_trace(evplp_context *c, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate) {
+    CTX_CHECK(c);
+    int rc = pass_ready(c, "evplp_path_trace", false); if (rc) return rc;
+    if (!camera_pos) { c->set_error("evplp_path_trace: null camera position"); return EVPLP_ERR_INVALID; }
+    PathTraceArgs a; std::memset(&a, 0, sizeof(a));
+    a.sc = c->sc; a.st = c->st;
+    a.g_pos = (const float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (const float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
+    a.g_dif = (const float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (const float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
+    for (int k = 0; k < 3; k++) a.camera_pos[k] = camera_pos[k];
+    a.rng_seed = rng_seed; a.max_bounces = max_bounces; a.do_accumulate = do_accumulate ? 1u : 0u;
+    a.out = (float4 *)c->buf[EVPLP_BUF_VPL_ACCUM];
+    a.counters = &c->d_counters[EVPLP_PASS_PATH_TRACE];
+    if ((rc = pass_begin(c, EVPLP_PASS_PATH_TRACE))) return rc;
+    launch_path_trace(a, c->stream);
+    return pass_end(c, EVPLP_PASS_PATH_TRACE);
+}
+
 extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *fp, int32_t clear) {
     CTX_CHECK(c);
     int rc = pass_ready(c, "evplp_splat_photons", true); if (rc) return rc;
@@ -524,10 +554,11 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     if (pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL) {
         out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = pc.rays; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
         out->reserved[1] = (uint32_t)(pc.nodes >> 32);
-        if (getenv("EVPLP_PRINT_GATHER_STATS")) fprintf(stderr, "[gather stats] packets over threshold: %llu with %llu nodes; all packets: %llu nodes\n", pc.pairs, pc.aux, pc.nodes);
     } else if (pass == EVPLP_PASS_SPLAT) {
         out->pairs = pc.pairs; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries;
         if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }
-    } else if (pass == EVPLP_PASS_PRIMARY) out->rays = c->stats_host[pass].rays;
+    } else if (pass == EVPLP_PASS_PATH_TRACE) { out->pairs = pc.pairs; out->rays = pc.rays; }
+    else if (pass == EVPLP_PASS_GATHER_LVC) { out->pairs = pc.pairs; out->rays = pc.rays; }
+    else if (pass == EVPLP_PASS_PRIMARY) out->rays = c->stats_host[pass].rays;
     return EVPLP_OK;
 }

@@ -436,4 +436,37 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
     return best;
 }
 
+// Per-lane any-hit walk for incoherent shadow rays (path tracer next-event estimation, light-subpath windows):
+// true iff some triangle has t in (tmin, tmax) -- order independent, so exact against the oracle's evo_occluded.
+template <int STACK_STRIDE>
+EV_DEV bool occluded_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int32_t *stack) {
+    V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode &n = sc.nodes[cur];
+            const float lo0[3] = { n.ctr[0][0] - n.hal[0][0], n.ctr[1][0] - n.hal[1][0], n.ctr[2][0] - n.hal[2][0] };
+            const float hi0[3] = { n.ctr[0][0] + n.hal[0][0], n.ctr[1][0] + n.hal[1][0], n.ctr[2][0] + n.hal[2][0] };
+            const float lo1[3] = { n.ctr[0][1] - n.hal[0][1], n.ctr[1][1] - n.hal[1][1], n.ctr[2][1] - n.hal[2][1] };
+            const float hi1[3] = { n.ctr[0][1] + n.hal[0][1], n.ctr[1][1] + n.hal[1][1], n.ctr[2][1] + n.hal[2][1] };
+            bool h0 = slab_hit(lo0, hi0, inv, noi, tmin, tmax), h1 = slab_hit(lo1, hi1, inv, noi, tmin, tmax);
+            if (h0 && h1) { stack[sp * STACK_STRIDE] = n.c1; sp++; cur = n.c0; continue; }
+            else if (h0) { cur = n.c0; continue; }
+            else if (h1) { cur = n.c1; continue; }
+        } else if (cur != kNoChild) {
+            int32_t id = ~cur;
+            int32_t block = id >> 2, cnt = (id & 3) + 1;
+            for (int32_t k = 0; k < cnt; k++) {
+                float t, b, g;
+                if (tri_test(sc.leaves[block].pair[k >> 1], k & 1, o, d, tmin, tmax, t, b, g)) return true;
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stack[sp * STACK_STRIDE];
+    }
+    return false;
+}
+
 } // namespace evplp

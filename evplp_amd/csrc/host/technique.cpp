@@ -2,6 +2,8 @@
 //   main()                      reflectcuts/main.cpp:87-121      -> evplp_render_json
 //   RtTechnique::render         rt/rttechnique.h:6-9             -> ComPhotonTechnique::render
 //   RtComPhoton::render / run   rt/rtcomphoton/rtcomphoton.h:107-223, 883-1133
+//   RtLvcComPhoton              rt/rtcomphoton/rtlvccomphoton.h  -> ComPhotonTechnique(lvc = true)
+//   RtPt2::render / run         rt/rtpt/rtpt2.h:84-116, 575-719  -> PathTraceTechnique
 // Same JSON keys, defaults, errors and outputs (three images + stat file); no window, no GL:
 // the frame loop of common/realtime.h reduces to the iteration cap and the wall-clock limit.
 #include "../../../include/evplp.h"
@@ -41,10 +43,120 @@ std::vector<float> flip_y(const std::vector<float> &rgb, int w, int h) {
     for (int row = 0; row < h; row++) std::memcpy(&out[(size_t)row * w * 3], &rgb[(size_t)(h - 1 - row) * w * 3], sizeof(float) * 3 * w);
     return out;
 }
+// build-only additions to the stat file: per-pass device times of the last iteration
+void add_pass_times(evplp_context *h, Json &st) {
+    const char *names[EVPLP_PASS_COUNT] = { "primaryMs", "lightTraceMs", "gatherVplMs", "gatherVslMs", "splatMs", "resolveMs", "pathTraceMs", "gatherLvcMs" };
+    for (int p = 0; p < EVPLP_PASS_COUNT; p++) { evplp_pass_stats ps; if (evplp_pass_stats_get(h, p, &ps) == EVPLP_OK && ps.ms > 0) st.set(names[p], Json::number(ps.ms)); }
+}
+// IndependentSampler(mRngOffset) -> std::mt19937 (common/rng.h:9-44); the float mapping of
+// std::uniform_real_distribution is implementation-defined, so a fixed one is used: u = (x >> 8) * 2^-24.
+struct JitterSampler {
+    std::mt19937 rng;
+    explicit JitterSampler(uint32_t seed) : rng(seed) {}
+    float next() { return (float)(rng() >> 8) * (1.0f / 16777216.0f); }
+    // ndc jitter (2 u - 1) / resolution, x first then y (rtcomphoton.h:946-952, rtpt2.h:617-623)
+    void next_jitter(int W, int H, float jitter[2]) {
+        float ux = next(), uy = next();
+        jitter[0] = (2.0f * ux - 1.0f) * (1.0f / (float)W); jitter[1] = (2.0f * uy - 1.0f) * (1.0f / (float)H);
+    }
+};
 } // namespace
+
+// The reference's ground-truth technique: unidirectional path tracing with next-event estimation, one sample per
+// pixel per iteration ("numSamplePerPixel" is read and unused, rtpt2.h:109).
+class PathTraceTechnique {
+public:
+    // rtpt2.h:84-116
+    void render(const HostScene &scene, int res_x, int res_y, const Json &json, const std::string &out_dir, int device) {
+        rng_offset = (uint32_t)json.at("rngOffset").as_int("rngOffset");
+        num_max_iteration = (int)json.at("numMaxIteration").as_int("numMaxIteration");
+        time_limit_ms = json.at("timeLimitMs").as_float("timeLimitMs");
+        {
+            const std::string &fm = json.at("frameMode").as_string("frameMode");
+            auto it = kFrameModes.find(fm);
+            if (it == kFrameModes.end()) throw JsonError("frameMode: unknown value \"" + fm + "\"");
+            frame_mode = it->second;
+        }
+        output_filename = join_path(out_dir, json.at("outputFilename").as_string("outputFilename"));
+        stat_filename = join_path(out_dir, json.at("statFilename").as_string("statFilename"));
+        use_jitter = json.at("useJitter").as_bool("useJitter");
+        use_stat = json.at("useStat").as_bool("useStat");
+        (void)json.at("numSamplePerPixel").as_int("numSamplePerPixel");
+        num_max_bounce = (int)json.at("numMaxBounces").as_int("numMaxBounces");
+        write_every_frame = json.has("writeEveryFrame") ? json.at("writeEveryFrame").as_bool("writeEveryFrame") : false;
+        int bvh_builder = EVPLP_BVH_SAH;
+        if (json.has("bvhBuilder")) bvh_builder = json.at("bvhBuilder").as_string("bvhBuilder") == "sah" ? EVPLP_BVH_SAH : EVPLP_BVH_LBVH;
+
+        evplp_config cfg; std::memset(&cfg, 0, sizeof(cfg));
+        cfg.abi_version = EVPLP_ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y;
+        cfg.strip_rank = 0; cfg.strip_count = 1; cfg.strip_rows = 8;
+        cfg.num_light_paths = 1; cfg.num_vpl_light_paths = 1; cfg.photons_per_path = 1;   // no light sub-paths in this technique
+        cfg.bvh_builder = bvh_builder;
+        Ctx ctx;
+        int rc = evplp_create(&cfg, &ctx.h);
+        if (rc < 0) throw std::runtime_error(std::string("evplp_create: ") + evplp_last_error(nullptr));
+        check(ctx.h, upload_scene(ctx.h, scene), "scene upload");
+        run(ctx.h, scene, res_x, res_y);
+    }
+
+private:
+    // rtpt2.h:575-719
+    void run(evplp_context *h, const HostScene &scene, int W, int H) {
+        JitterSampler sampler(rng_offset);
+        check(h, evplp_clear_accumulators(h), "clear");
+        int num_iterations = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        auto elapsed_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        std::vector<float> rgb((size_t)W * evplp_local_rows(h) * 3);
+        const bool clear_every_frame = frame_mode == 2;
+        for (;;) {
+            if (num_iterations == num_max_iteration) break;                                   // :610-613
+            float jitter[2] = { 0.f, 0.f };
+            if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :618-624
+            check(h, evplp_primary(h, jitter, clear_every_frame ? 1 : 0), "primary");        // :626-629, 633-643
+            check(h, evplp_path_trace(h, scene.camera.origin, (uint32_t)num_iterations + rng_offset, (uint32_t)num_max_bounce,
+                                      clear_every_frame ? 0 : 1), "path trace");             // :631
+            num_iterations++;
+            if (write_every_frame) {                                                          // :669-689
+                size_t i = output_filename.find_last_of('.');
+                save(h, W, H, num_iterations, output_filename.substr(0, i) + "_" + std::to_string(num_iterations) + output_filename.substr(i), rgb);
+            }
+            if (time_limit_ms < 1e8f) check(h, evplp_synchronize(h), "sync");
+            if (elapsed_ms() >= time_limit_ms) break;                                         // :667
+        }
+        check(h, evplp_synchronize(h), "sync");
+        float time = elapsed_ms();
+        if (use_stat) {                                                                       // :694-704
+            Json st = Json::object();
+            st.set("time", Json::number(time)); st.set("numIterations", Json::number(num_iterations));
+            add_pass_times(h, st);
+            std::ofstream of(stat_filename);
+            if (!of) throw std::runtime_error("cannot write " + stat_filename);
+            of << st.dump() << "\n";
+        }
+        save(h, W, H, num_iterations, output_filename, rgb);                                  // :706-719
+    }
+    // clear-every-frame: the composite as shown (masked emitter); accumulate: light image + path-traced image / n
+    void save(evplp_context *h, int W, int H, int n, const std::string &path, std::vector<float> &rgb) {
+        if (frame_mode == 2) check(h, evplp_resolve(h, 1.0f, 0.0f, 1.0f, 1, 0, rgb.data()), "resolve");
+        else check(h, evplp_resolve(h, 1.0f / (float)std::max(n, 1), 0.0f, 1.0f, 0, 0, rgb.data()), "resolve");
+        std::vector<float> img(rgb.begin(), rgb.begin() + (size_t)W * H * 3);
+        std::vector<float> top = flip_y(img, W, H);
+        if (save_image(path.c_str(), W, H, top.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + path);
+    }
+
+    uint32_t rng_offset = 0; int num_max_iteration = 0, num_max_bounce = 0, frame_mode = 1;
+    float time_limit_ms = 0.f;
+    bool use_jitter = false, use_stat = false, write_every_frame = false;
+    std::string output_filename, stat_filename;
+};
 
 class ComPhotonTechnique {
 public:
+    // lvc: the "lvcphotonfam" twin (rtlvccomphoton.h).  It differs from RtComPhoton in the gather program
+    // (per-pixel light-path window, lvclighttracing.cu:348-384), has no forceVsl / writeEveryFrame, and its stat
+    // file carries only "time".
+    explicit ComPhotonTechnique(bool lvc_variant = false) : lvc(lvc_variant) {}
     // rtcomphoton.h:107-223
     void render(const HostScene &scene, int res_x, int res_y, const Json &json, const std::string &out_dir, int device) {
         num_light_paths = (int)json.at("numLightPaths").as_int("numLightPaths");
@@ -52,7 +164,7 @@ public:
         num_max_bounce = (int)json.at("numMaxBounces").as_int("numMaxBounces");
         photons_per_path = num_max_bounce + 1;
         radius_percentage = json.at("radiusPercentage").as_float("radiusPercentage");
-        write_every_frame = json.has("writeEveryFrame") ? json.at("writeEveryFrame").as_bool("writeEveryFrame") : false;
+        write_every_frame = (!lvc && json.has("writeEveryFrame")) ? json.at("writeEveryFrame").as_bool("writeEveryFrame") : false;
         num_max_iteration = (int)json.at("numMaxIteration").as_int("numMaxIteration");
         time_limit_ms = json.at("timeLimitMs").as_float("timeLimitMs");
         {
@@ -90,7 +202,7 @@ public:
             if (r.has("finalize")) do_finalize = r.at("finalize").as_bool("run.finalize");
         }
         if (num_vpl_light_paths == 0) { std::printf("WARN: 0 VPL light paths. Disable mDoVplSplat\n"); do_vpl_splat = false; }   // :200-203
-        if (json.has("forceVsl")) force_vsl = json.at("forceVsl").as_bool("forceVsl");
+        if (!lvc && json.has("forceVsl")) force_vsl = json.at("forceVsl").as_bool("forceVsl");
         if (json.has("bvhBuilder")) bvh_builder = json.at("bvhBuilder").as_string("bvhBuilder") == "sah" ? EVPLP_BVH_SAH : EVPLP_BVH_LBVH;   // build-only key
 
         // ---- setup(): context + scene upload (replaces GL/OptiX setup :646-708)
@@ -136,11 +248,7 @@ private:
 
     // rtcomphoton.h:883-1133
     void run(evplp_context *h, const HostScene &scene, int W, int H) {
-        // IndependentSampler(mRngOffset) -> std::mt19937 (common/rng.h:9-44); the float mapping of
-        // std::uniform_real_distribution is implementation-defined, so a fixed one is used:
-        // u = (x >> 8) * 2^-24, x first then y.
-        std::mt19937 jitter_rng(rng_offset);
-        auto next_float = [&]() { return (float)(jitter_rng() >> 8) * (1.0f / 16777216.0f); };
+        JitterSampler sampler(rng_offset);
         check(h, evplp_clear_accumulators(h), "clear");
         int num_iterations = 0;
         auto t0 = std::chrono::steady_clock::now();
@@ -150,14 +258,11 @@ private:
         for (;;) {
             if (num_iterations == num_max_iteration) break;                                   // :938-941
             float jitter[2] = { 0.f, 0.f };
-            if (use_jitter) {                                                                 // :946-952
-                float ux = next_float(), uy = next_float();
-                jitter[0] = (2.0f * ux - 1.0f) * (1.0f / (float)W); jitter[1] = (2.0f * uy - 1.0f) * (1.0f / (float)H);
-            }
+            if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :946-952
             evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
             if (do_deferred) check(h, evplp_primary(h, jitter, (do_light_render && frame_mode == 2) ? 1 : 0), "primary");   // :954-960, 985-995
             if (do_light_tracing) check(h, evplp_trace_light_paths(h, (uint32_t)num_iterations + rng_offset, 0, (uint32_t)num_light_paths), "light tracing");  // :962-966
-            if (do_vpl_splat) check(h, force_vsl ? evplp_gather_vsl(h, &fp) : evplp_gather_vpl(h, &fp), "gather");  // :968-972
+            if (do_vpl_splat) check(h, lvc ? evplp_gather_lvc(h, &fp) : force_vsl ? evplp_gather_vsl(h, &fp) : evplp_gather_vpl(h, &fp), "gather");  // :968-972
             // radius 0 (radiusPercentage 0 of the VPL-only configs): the proxy spheres are degenerate, nothing is drawn
             if (do_photon_splat && photon_radius > 0.0f) check(h, evplp_splat_photons(h, &fp, frame_mode == 2 ? 1 : 0), "photon splat");    // :974-983
             // [finalize] renders to the window in the reference (:997-1004); headless: nothing to present
@@ -183,10 +288,9 @@ private:
         float time = elapsed_ms();
         if (use_stat) {                                                                       // :1109-1119
             Json st = Json::object();
-            st.set("time", Json::number(time)); st.set("numIterations", Json::number(num_iterations));
-            // build-only additions: per-pass device times of the last iteration
-            const char *names[EVPLP_PASS_COUNT] = { "primaryMs", "lightTraceMs", "gatherVplMs", "gatherVslMs", "splatMs", "resolveMs" };
-            for (int p = 0; p < EVPLP_PASS_COUNT; p++) { evplp_pass_stats ps; if (evplp_pass_stats_get(h, p, &ps) == EVPLP_OK && ps.ms > 0) st.set(names[p], Json::number(ps.ms)); }
+            st.set("time", Json::number(time));
+            if (!lvc) st.set("numIterations", Json::number(num_iterations));              // rtlvccomphoton.h writes the time only
+            add_pass_times(h, st);
             std::ofstream of(stat_filename);
             if (!of) throw std::runtime_error("cannot write " + stat_filename);
             of << st.dump() << "\n";
@@ -226,6 +330,7 @@ private:
     float target_rendering_time = -1.f;
     std::string combined_filename, weighted_photon_filename, weighted_vpl_filename, stat_filename;
     bool force_vsl = false; float vsl_radius = 0.f, vsl_inv_pi_radius2 = 0.f;
+    bool lvc = false;
     int bvh_builder = EVPLP_BVH_SAH;   // measured 9% faster frames than the Morton LBVH on the conference stand-in; "bvhBuilder": "lbvh" selects the LBVH
 };
 
@@ -254,19 +359,29 @@ extern "C" int evplp_render_json(const char *json_path, const char *json_overrid
         try { scene = load_scene(root, json_path); }                                    // main.cpp:104
         catch (const JsonError &e) { return fail(EVPLP_ERR_PARSE, e.what()); }
         catch (const std::exception &e) { return fail(EVPLP_ERR_IO, e.what()); }
+        // every technique block that is present runs, in the reference's order (main.cpp:105-121)
         bool ran = false;
-        if (root.has("pt") && !root.at("pt").is_null())                                 // main.cpp:105-109
-            return fail(EVPLP_ERR_INVALID, "the \"pt\" technique (OptiX path tracer, rt/rtpt/rtpt2.h) is outside the hot path of this build");
-        if (root.has("photonfam") && !root.at("photonfam").is_null()) {                 // main.cpp:111-115
-            Json block = root.at("photonfam");
+        auto block_of = [&](const char *key) {
+            Json block = root.at(key);
             if (json_overrides && *json_overrides) block.merge(Json::parse(json_overrides));
-            ComPhotonTechnique t;
-            t.render(scene, scene.res_x, scene.res_y, block, dirname_of(json_path), device);
+            return block;
+        };
+        if (root.has("pt") && !root.at("pt").is_null()) {                               // main.cpp:105-109
+            PathTraceTechnique t;
+            t.render(scene, scene.res_x, scene.res_y, block_of("pt"), dirname_of(json_path), device);
             ran = true;
         }
-        if (root.has("lvcphotonfam") && !root.at("lvcphotonfam").is_null() && !ran)     // main.cpp:117-121
-            return fail(EVPLP_ERR_INVALID, "the \"lvcphotonfam\" variant (rt/rtcomphoton/rtlvccomphoton.h) is not built");
-        if (!ran) return fail(EVPLP_ERR_PARSE, "no technique block (\"photonfam\") in the scene JSON");
+        if (root.has("photonfam") && !root.at("photonfam").is_null()) {                 // main.cpp:111-115
+            ComPhotonTechnique t;
+            t.render(scene, scene.res_x, scene.res_y, block_of("photonfam"), dirname_of(json_path), device);
+            ran = true;
+        }
+        if (root.has("lvcphotonfam") && !root.at("lvcphotonfam").is_null()) {           // main.cpp:117-121
+            ComPhotonTechnique t(/*lvc_variant=*/true);
+            t.render(scene, scene.res_x, scene.res_y, block_of("lvcphotonfam"), dirname_of(json_path), device);
+            ran = true;
+        }
+        if (!ran) return fail(EVPLP_ERR_PARSE, "no technique block (\"pt\", \"photonfam\", \"lvcphotonfam\") in the scene JSON");
     } catch (const JsonError &e) { return fail(EVPLP_ERR_PARSE, e.what()); }
     catch (const std::exception &e) { return fail(EVPLP_ERR_HIP, e.what()); }
     return EVPLP_OK;

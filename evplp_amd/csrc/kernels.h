@@ -41,6 +41,15 @@ struct GatherArgs {
 #endif
 constexpr int kVplSplit = EVPLP_VPL_SPLIT;   // items per tile: VPL i belongs to item i % kVplSplit (a constant: results must not depend on the GPU count)
 
+struct PathTraceArgs {
+    SceneDev sc; StripDev st;
+    const float4 *g_pos, *g_nrm, *g_dif, *g_phg;
+    float camera_pos[3]; uint32_t rng_seed;
+    uint32_t max_bounces, do_accumulate;
+    float4 *out;
+    PassCounters *counters;
+};
+
 struct SplatArgs {
     StripDev st; CamBasis cam;
     evplp_frame_params fp;
@@ -69,6 +78,8 @@ void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record
                         uint32_t *count_out, hipStream_t s);
 void launch_gather_vpl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_end);
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_end);
+void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
+void launch_path_trace(const PathTraceArgs &a, hipStream_t s);
 void launch_splat_count(const SplatArgs &a, hipStream_t s);
 void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,

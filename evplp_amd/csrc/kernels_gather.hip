@@ -183,6 +183,63 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
     a.out[i] = make_float4(s.x / inv + acc * old.x, s.y / inv + acc * old.y, s.z / inv + acc * old.z, 0.0f + acc * old.w);
 }
 
+// ------------------------------------------------------------------- light-subpath windows
+// "lvcphotonfam" (rt/lvclighttracing.cu:348-384): every pixel gathers the usable records of numVplLightPaths
+// consecutive light paths starting at its own random path.  Neighbouring pixels see different records, so
+// there is no shared origin to build a packet on: one shadow ray per lane, per-lane LDS stack (the authors
+// note the variant is experimental and slower than the plain gather for the same reason).
+__global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evplp_record *records) {
+    __shared__ int32_t lds_stack[kMaxDepth * 64];
+    const int lane = threadIdx.x;
+    const int tiles_x = (a.st.W + 7) >> 3;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    if (x >= a.st.W || ly >= a.st.local_rows) return;
+    const int y = a.st.global_row(ly);
+    if (y >= a.st.H) return;
+    const size_t p = (size_t)ly * a.st.W + x;
+    Pixel px;
+    float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
+    if (gp.w == 0.0f) return;                                            // stencil (:354)
+    px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
+    px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);
+    int32_t *stack = lds_stack + lane;
+
+    Rng rng; rng_init(rng, (uint32_t)y * (uint32_t)a.st.W + (uint32_t)x, a.fp.rng_seed, 0x4c564300u);   // :369-370
+    const uint32_t offset = (uint32_t)(fminf(rng_uniform(rng), 0.999999f) * (float)a.fp.num_light_paths);  // :372
+    V3 result = v3(0.f, 0.f, 0.f);
+    unsigned long long rays = 0, pairs = 0;
+    for (uint32_t i = 0; i < a.fp.num_vpl_light_paths; i++) {
+        const uint32_t path = (i + offset) % a.fp.num_light_paths;
+        for (uint32_t j = 0; j < a.fp.photons_per_path; j++) {
+            const evplp_record *r = records + (size_t)path * a.fp.photons_per_path + j;
+            if ((r->flags & EVPLP_USABLE_VPL) == 0u) continue;
+            pairs++;
+            const Vpl v = load_vpl(reinterpret_cast<const float4 *>(r));
+            V3 v12 = v.pos - px.p1;
+            float c1 = fmaxf(dot(px.n1, v12), 0.0f);
+            float c2 = fmaxf(-dot(v.n, v12), 0.0f);
+            float c1c2 = c1 * c2;
+            if (c1c2 <= 0.0f) continue;
+            rays++;
+            if (occluded_lane<64>(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, stack)) continue;
+            result = result + vpl_shade(a.fp, px, v, v12, c1c2);
+        }
+    }
+    const float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
+    float4 old = a.out[p];
+    a.out[p] = make_float4(result.x / inv + acc * old.x, result.y / inv + acc * old.y, result.z / inv + acc * old.z, 0.0f + acc * old.w);
+    atomicAdd(&a.counters->rays, rays);
+    atomicAdd(&a.counters->pairs, pairs);
+}
+
+void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s) {
+    int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
+    if (tiles_x * tiles_y == 0) return;
+    hipLaunchKernelGGL(gather_lvc_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a, records);
+}
+
 // ------------------------------------------------------------------------------------ VSL
 // The VSL estimators are ALU-bound (up to 101 sample iterations x 3 estimators per lit pair, each with
 // powf / sinf / cosf).  They use hardware transcendentals (v_log_f32 / v_exp_f32 / v_sin_f32 / v_cos_f32):

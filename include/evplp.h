@@ -139,7 +139,7 @@ typedef struct evplp_pass_stats {
 
 typedef enum evplp_pass {
     EVPLP_PASS_PRIMARY = 0, EVPLP_PASS_LIGHT_TRACE, EVPLP_PASS_GATHER_VPL, EVPLP_PASS_GATHER_VSL,
-    EVPLP_PASS_SPLAT, EVPLP_PASS_RESOLVE, EVPLP_PASS_COUNT
+    EVPLP_PASS_SPLAT, EVPLP_PASS_RESOLVE, EVPLP_PASS_PATH_TRACE, EVPLP_PASS_GATHER_LVC, EVPLP_PASS_COUNT
 } evplp_pass;
 
 typedef struct evplp_context evplp_context;
@@ -187,6 +187,16 @@ int evplp_trace_light_paths(evplp_context *ctx, uint32_t rng_seed, uint32_t path
 int evplp_gather_vpl(evplp_context *ctx, const evplp_frame_params *fp);
 /* [vplSplat] with forceVsl: splatSplotch (rt/lighttracing.cu:689-722) */
 int evplp_gather_vsl(evplp_context *ctx, const evplp_frame_params *fp);
+/* The "lvcphotonfam" variant of [vplSplat]: every pixel gathers the usable records of a window of
+ * num_vpl_light_paths consecutive light paths starting at a per-pixel random path (mod num_light_paths):
+ * splatColor of rt/lvclighttracing.cu:348-384, driven by RtLvcComPhoton (rt/rtcomphoton/rtlvccomphoton.h).
+ * Uses fp->rng_seed for the per-pixel offset. */
+int evplp_gather_lvc(evplp_context *ctx, const evplp_frame_params *fp);
+/* The "pt" technique's device pass: launch(PathTrace, W, H) with splatColor/pathTraceSimple
+ * (rt/pathtracing.cu:350-377, 240-348; host runOptixPtProgram rt/rtpt/rtpt2.h:561-573).  One camera path per
+ * visible pixel continued from the G-buffer for at most max_bounces bounces, next-event estimation at every
+ * vertex; radiance is ADDED to EVPLP_BUF_VPL_ACCUM when do_accumulate != 0, else replaces it ("outputBuffer"). */
+int evplp_path_trace(evplp_context *ctx, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
 /* [photonSplat]: runPhotonSplat (:789-837); clear != 0 = cleareveryframe (:978-981) */
 int evplp_splat_photons(evplp_context *ctx, const evplp_frame_params *fp, int32_t clear);
 /* [finalize] / dumpImage: runFinalProgram(vplScale, photonScale, lightScale, gamma) (:756-787,

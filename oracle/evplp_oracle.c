@@ -693,6 +693,52 @@ void evo_vpl_splat_pair(const evo_frame_params *fp, const float wi10[3], const f
     st3(out, r);
 }
 
+/* lvclighttracing.cu:348-384 splatColor of the "lvcphotonfam" variant: a per-pixel random window of
+ * num_vpl_light_paths consecutive light paths (mod num_light_paths) over the uncompacted record buffer */
+void evo_gather_lvc(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                    const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                    const evo_record *records, float *out, uint64_t *pairs_out) {
+    (void)H;
+    uint64_t pairs = 0;
+    v3 cam = ld3(fp->camera_pos);
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : pairs) num_threads(evo_get_threads())
+    for (int32_t y = row_begin; y < row_end; y++) {
+        for (int32_t x = 0; x < W; x++) {
+            size_t p = ((size_t)y * W + x) * 4;
+            v3 p1 = ld3(g_pos + p);
+            if (g_pos[p + 3] == 0.0f) continue;
+            v3 n1 = ld3(g_nrm + p), rd = ld3(g_dif + p), rs = ld3(g_phg + p); float e = g_phg[p + 3];
+            v3 wi01 = normalize(sub(cam, p1));
+            v3 result = V3(0, 0, 0);
+            evo_rng rng; evo_rng_init(&rng, (uint32_t)y * (uint32_t)W + (uint32_t)x, fp->rng_seed, 0x4c564300u); /* :369-370 */
+            uint32_t offset = (uint32_t)(minf(evo_rng_uniform(&rng), 0.999999f) * (float)fp->num_light_paths);   /* :372 */
+            for (uint32_t i = 0; i < fp->num_vpl_light_paths; i++) {
+                uint32_t path = (i + offset) % fp->num_light_paths;
+                for (uint32_t j = 0; j < fp->photons_per_path; j++) {
+                    const evo_record *rec = &records[(size_t)path * fp->photons_per_path + j];
+                    if (!(rec->flags & EVO_USABLE_VPL)) continue;
+                    pairs++;
+                    v3 pv = ld3(rec->pos);
+                    v3 v12 = sub(pv, p1);
+                    float c1 = maxf(dot(n1, v12), 0.0f), c2 = maxf(-dot(ld3(rec->normal), v12), 0.0f);
+                    float c1c2 = c1 * c2;
+                    if (c1c2 <= 0.000f) continue;
+                    float o[3], d[3]; st3(o, pv); st3(d, neg(v12));
+                    if (evo_occluded(s, o, d, 0.0001f, 1.0f - 0.0001f)) continue;
+                    result = add(result, vpl_shade(fp, wi01, p1, n1, rd, rs, e, rec, v12, c1c2));
+                }
+            }
+            float inv = (float)fp->num_vpl_light_paths;
+            float acc = (float)fp->do_accumulate;
+            out[p + 0] = result.x / inv + acc * out[p + 0];
+            out[p + 1] = result.y / inv + acc * out[p + 1];
+            out[p + 2] = result.z / inv + acc * out[p + 2];
+            out[p + 3] = 0.0f + acc * out[p + 3];
+        }
+    }
+    if (pairs_out) *pairs_out = pairs;
+}
+
 /* lighttracing.cu:348-379 splatColor */
 void evo_gather_vpl(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
                     const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,

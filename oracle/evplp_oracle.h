@@ -139,6 +139,11 @@ void evo_trace_light_paths(const evo_scene *s, uint32_t rng_seed, uint32_t path_
 void evo_vpl_splat_pair(const evo_frame_params *fp, const float wi10[3], const float p1[3], const float n1[3],
                         const float rho_d[3], const float rho_s[3], float e,
                         const evo_record *rec, int visible, float out[3]);
+/* lvclighttracing.cu:348-384: splatColor with a per-pixel random light-path window */
+void evo_gather_lvc(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H,
+                    int32_t row_begin, int32_t row_end,
+                    const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                    const evo_record *records, float *out, uint64_t *pairs_out);
 /* lighttracing.cu:348-379 */
 void evo_gather_vpl(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H,
                     int32_t row_begin, int32_t row_end,

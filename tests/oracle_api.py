@@ -86,6 +86,7 @@ def load():
     l.evo_vpl_splat_pair.argtypes = [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, _P]
     l.evo_gather_vpl.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]
     l.evo_gather_vsl.argtypes = l.evo_gather_vpl.argtypes
+    l.evo_gather_lvc.argtypes = l.evo_gather_vpl.argtypes
     l.evo_photon_frag.restype = C.c_int
     l.evo_photon_frag.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P]
     l.evo_splat_photons.argtypes = [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P]
@@ -160,12 +161,12 @@ class Scene:
         self.lib.evo_trace_light_paths(self.h, seed, begin, npaths - begin if count is None else count, P, ptr(records))
         return records
 
-    def gather(self, fp, W, H, gbuf, records, out=None, vsl=False, rows=None):
+    def gather(self, fp, W, H, gbuf, records, out=None, vsl=False, rows=None, lvc=False):
         if out is None:
             out = np.zeros((H, W, 4), dtype=np.float32)
         pairs = C.c_uint64()
         r0, r1 = rows if rows else (0, H)
-        fn = self.lib.evo_gather_vsl if vsl else self.lib.evo_gather_vpl
+        fn = self.lib.evo_gather_lvc if lvc else self.lib.evo_gather_vsl if vsl else self.lib.evo_gather_vpl
         fn(self.h, C.byref(fp), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), ptr(out), C.byref(pairs))
         return out, pairs.value
 

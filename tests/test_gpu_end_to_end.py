@@ -39,8 +39,49 @@ class MT19937:
         return y & 0xFFFFFFFF
 
 
-def oracle_technique(json_path, block):
-    """RtComPhoton::render / run (rtcomphoton.h:107-223, 883-1133) driven over the oracle passes."""
+def jitter_of(rng, W, H):
+    f32 = np.float32
+    ux = f32(rng() >> 8) * f32(1.0 / 16777216.0); uy = f32(rng() >> 8) * f32(1.0 / 16777216.0)
+    return (float((f32(2) * ux - f32(1)) * (f32(1) / f32(W))), float((f32(2) * uy - f32(1)) * (f32(1) / f32(H))))
+
+
+def oracle_pt(json_path, block):
+    """RtPt2::render / run (rt/rtpt/rtpt2.h:84-116, 575-719) driven over the oracle passes."""
+    sd, root = scenes.load_obj_scene(json_path)
+    osc = oa.Scene(sd)
+    l = oa.load()
+    W, H = root["resX"], root["resY"]
+    accumulate = block["frameMode"] == "accumulate"
+    rng = MT19937(block["rngOffset"])
+    pt = np.zeros((H, W, 4), np.float32); light = np.zeros((H, W, 4), np.float32)
+    frames = []
+    n_it = 0
+
+    def composite():
+        rgb = np.zeros((H, W, 3), np.float32)
+        if accumulate:
+            l.evo_resolve(W, H, oa.ptr(pt), None, oa.ptr(light), 1.0 / n_it, 0.0, 1.0, 0, 0, oa.ptr(rgb))
+        else:
+            l.evo_resolve(W, H, oa.ptr(pt), None, oa.ptr(light), 1.0, 0.0, 1.0, 1, 0, oa.ptr(rgb))
+        return rgb[::-1].copy()
+
+    while n_it != block["numMaxIteration"]:
+        jitter = jitter_of(rng, W, H) if block["useJitter"] else (0.0, 0.0)
+        g = osc.primary(W, H, jitter)
+        lit = g[4][..., 0] > 0
+        if not accumulate:
+            light[:] = 0
+        light[lit] = g[4][lit]
+        osc.path_trace(sd.cam_origin, n_it + block["rngOffset"], block["numMaxBounces"], W, H, g, out=pt, accumulate=accumulate)
+        n_it += 1
+        if block.get("writeEveryFrame", False):
+            frames.append(composite())
+    return composite(), frames
+
+
+def oracle_technique(json_path, block, lvc=False):
+    """RtComPhoton::render / run (rtcomphoton.h:107-223, 883-1133) driven over the oracle passes;
+    lvc: RtLvcComPhoton (rtlvccomphoton.h), the same loop with the light-path-window gather."""
     sd, root = scenes.load_obj_scene(json_path)
     osc = oa.Scene(sd)
     l = oa.load()
@@ -56,7 +97,7 @@ def oracle_technique(json_path, block):
     clamp_start = clamp
     mode = {"one": 0, "balance": 1, "max": 2, "power2": 3, "geometryClamp": 4, "geometryBrdfClamp": 5}[block.get("misMode", "balance")]
     accumulate = block["frameMode"] == "accumulate"
-    force_vsl = block.get("forceVsl", False)
+    force_vsl = block.get("forceVsl", False) and not lvc
     vsl_r = f32(0); vsl_i = f32(0)
     if force_vsl:                                                   # rtcomphoton.h:205-218
         vsl_r = f32(bsr * f32(block["vslRadiusPercentage"]))
@@ -75,8 +116,7 @@ def oracle_technique(json_path, block):
     while n_it != block["numMaxIteration"]:
         jitter = (0.0, 0.0)
         if block["useJitter"]:
-            ux = f32(rng() >> 8) * f32(1.0 / 16777216.0); uy = f32(rng() >> 8) * f32(1.0 / 16777216.0)
-            jitter = (float((f32(2) * ux - f32(1)) * (f32(1) / f32(W))), float((f32(2) * uy - f32(1)) * (f32(1) / f32(H))))
+            jitter = jitter_of(rng, W, H)
         g = osc.primary(W, H, jitter)
         lit = g[4][..., 0] > 0
         if not accumulate:
@@ -87,7 +127,7 @@ def oracle_technique(json_path, block):
                   vsl_radius=float(vsl_r), vsl_inv_pi_radius2=float(vsl_i),
                   num_light_paths=nl, num_vpl_light_paths=nv, photons_per_path=P, do_accumulate=int(accumulate), rng_seed=n_it + block["rngOffset"], jitter=jitter)
         if run["vplSplat"]:
-            osc.gather(oa.frame_params(**kw), W, H, g, rec, out=vpl, vsl=force_vsl)
+            osc.gather(oa.frame_params(**kw), W, H, g, rec, out=vpl, vsl=force_vsl, lvc=lvc)
         if radius > 0 and run["photonSplat"]:
             if not accumulate:
                 pm[:] = 0
@@ -141,6 +181,50 @@ def test_render_json_matches_oracle_loop(evplp, tmp_path, variant):
     assert want["combined"].max() > 0
     if variant == "progressive_balance":
         assert want["pm"].max() > 0
+
+
+def test_render_json_pt_and_lvc_blocks(evplp, tmp_path):
+    """main.cpp:105-121: every technique block present in the file runs -- "pt" (RtPt2) and "lvcphotonfam"
+    (RtLvcComPhoton) beside "photonfam"."""
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 5, 72, 48)
+    root = json.load(open(jp))
+    base = dict(root.pop("photonfam"))
+    pt = dict(rngOffset=2, numMaxIteration=3, timeLimitMs=1e9, frameMode="accumulate", outputFilename="pt.pfm", statFilename="pt_stat.json",
+              useJitter=True, useStat=True, numSamplePerPixel=1, numMaxBounces=3, writeEveryFrame=True)
+    lvc = dict(base); lvc.update(numLightPaths=40, numVplLightPaths=10, radiusPercentage=0.04, misMode="balance", numMaxIteration=2, rngOffset=1, run={},
+                                 combinedFilename="lvc_c.pfm", weightedVplFilename="lvc_v.pfm", weightedPhotonFilename="lvc_p.pfm", statFilename="lvc_stat.json")
+    root["pt"] = pt; root["lvcphotonfam"] = lvc
+    json.dump(root, open(jp, "w"))
+    evplp.render_json(jp)
+    # --- pt
+    want, frames = oracle_pt(jp, pt)
+    stat = json.load(open(tmp_path / "pt_stat.json"))
+    assert stat["numIterations"] == 3 and stat["time"] > 0
+    got = evplp.load_pfm(str(tmp_path / "pt.pfm"))
+    assert got.shape == want.shape and np.isfinite(got).all() and want.max() > 0
+    bad = (np.abs(got - want) > 2e-4 * np.maximum(np.abs(want), 1e-3 * want.max())).any(-1)
+    assert bad.mean() <= 8e-3 and rel_l2(got[~bad], want[~bad]) <= 1e-5   # a few pixels per thousand take another path (see test_path_trace)
+    for i, fr in enumerate(frames, 1):
+        g = evplp.load_pfm(str(tmp_path / f"pt_{i}.pfm"))
+        b = (np.abs(g - fr) > 2e-4 * np.maximum(np.abs(fr), 1e-3 * fr.max())).any(-1)
+        assert b.mean() <= 8e-3
+    # cleareveryframe shows the masked composite of the last frame only
+    pt2 = dict(pt); pt2.update(frameMode="cleareveryframe", outputFilename="ptc.pfm", writeEveryFrame=False, numMaxIteration=2)
+    root2 = {k: v for k, v in root.items() if k != "lvcphotonfam"}; root2["pt"] = pt2
+    json.dump(root2, open(jp, "w"))
+    evplp.render_json(jp)
+    want2, _ = oracle_pt(jp, pt2)
+    got2 = evplp.load_pfm(str(tmp_path / "ptc.pfm"))
+    bad2 = (np.abs(got2 - want2) > 2e-4 * np.maximum(np.abs(want2), 1e-3 * want2.max())).any(-1)
+    assert bad2.mean() <= 8e-3
+    # --- lvcphotonfam
+    json.dump(root, open(jp, "w"))
+    wl = oracle_technique(jp, lvc, lvc=True)
+    st = json.load(open(tmp_path / "lvc_stat.json"))
+    assert "numIterations" not in st and st["time"] > 0              # rtlvccomphoton.h writes the time only
+    for key, fn in (("combined", "c"), ("vpl", "v"), ("pm", "p")):
+        g = evplp.load_pfm(str(tmp_path / f"lvc_{fn}.pfm"))
+        assert wl[key].max() > 0 and rel_l2(g, wl[key]) <= 1e-4, (key, rel_l2(g, wl[key]))
 
 
 def test_render_json_vsl_ppm_and_per_frame_dumps(evplp, tmp_path):

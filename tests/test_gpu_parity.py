@@ -142,6 +142,57 @@ def test_gather_vpl_accumulates(ctx, oscene, evplp, inputs):
     assert_image_close(got[..., :3], ref[..., :3], what="accumulate x2 with numVplLightPaths < numLightPaths")
 
 
+def test_gather_lvc_window(ctx, oscene, evplp, inputs):
+    """lvcphotonfam: per-pixel random window of light paths (rt/lvclighttracing.cu:348-384)."""
+    gbuf, records = inputs
+    upload_inputs(ctx, evplp, gbuf, records)
+    kw = dict(camera_pos=oscene.sd.cam_origin, mis_mode=1, pdf_mc=0.35, photon_radius=0.05, num_light_paths=NPATHS,
+              num_vpl_light_paths=NPATHS // 4, photons_per_path=P, do_accumulate=0, rng_seed=9)
+    ctx.clear_accumulators()
+    ctx.gather_lvc(evplp.frame_params(**kw))
+    got = ctx.download(evplp.BUF_VPL_ACCUM)[:H]
+    ref, pairs = oscene.gather(oa.frame_params(**kw), W, H, gbuf, records, lvc=True)
+    st = ctx.pass_stats(evplp.PASS_GATHER_LVC)
+    assert st["pairs"] == pairs > 0
+    assert ref[..., :3].max() > 0
+    assert_image_close(got[..., :3], ref[..., :3], what="gather_lvc")
+    # another seed moves the windows
+    ctx.gather_lvc(evplp.frame_params(**{**kw, "rng_seed": 10}))
+    assert not np.array_equal(ctx.download(evplp.BUF_VPL_ACCUM)[:H], got)
+
+
+def test_path_trace(ctx, oscene, evplp, inputs):
+    """The "pt" technique's device pass against the oracle's restatement of rt/pathtracing.cu.  Paths make
+    discrete choices (lobe, Russian roulette, visibility, the reference's 1e-5 self-intersection epsilon)
+    on values that differ in the last ulps between CPU and GPU libm, so a few pixels per thousand take another
+    path (measured: ~1.5 per thousand per pass); every other pixel agrees to fp32 round-off, and the image
+    energy agrees."""
+    gbuf, _ = inputs
+    upload_inputs(ctx, evplp, gbuf, np.zeros(NPATHS * P, dtype=evplp.RECORD_DTYPE))
+    cam = oscene.sd.cam_origin
+    ctx.clear_accumulators()
+    for seed in (3, 4):
+        ctx.path_trace(cam, seed, 3, accumulate=True)
+    got = ctx.download(evplp.BUF_VPL_ACCUM)[:H]
+    ref, n = oscene.path_trace(cam, 3, 3, W, H, gbuf)
+    ref, n2 = oscene.path_trace(cam, 4, 3, W, H, gbuf, out=ref)
+    st = ctx.pass_stats(evplp.PASS_PATH_TRACE)
+    assert st["pairs"] == n2 == int((gbuf[0][..., 3] != 0).sum()) and st["rays"] >= n2
+    assert ref[..., :3].max() > 0
+    g, r = got[..., :3], ref[..., :3]
+    bad = (np.abs(g - r) > 2e-4 * np.maximum(np.abs(r), 1e-3 * r.max())).any(-1)
+    assert bad.mean() <= 8e-3, f"{int(bad.sum())} of {bad.size} pixels took another path"
+    ok = ~bad
+    assert rel_l2(g[ok], r[ok]) <= 1e-5
+    assert abs(float(g.sum()) / float(r.sum()) - 1.0) <= 5e-3
+    # cleareveryframe: doAccumulate = 0 overwrites
+    ctx.path_trace(cam, 3, 3, accumulate=False)
+    single = ctx.download(evplp.BUF_VPL_ACCUM)[:H]
+    ref1, _ = oscene.path_trace(cam, 3, 3, W, H, gbuf)
+    bad1 = (np.abs(single[..., :3] - ref1[..., :3]) > 2e-4 * np.maximum(np.abs(ref1[..., :3]), 1e-3 * ref1[..., :3].max())).any(-1)
+    assert bad1.mean() <= 4e-3
+
+
 def test_visibility_is_bit_exact(ctx, oscene, evplp, inputs):
     """A 'flux = 1, white, mode one' gather differs between HIP and oracle only through visibility:
     count the pixels whose lit-VPL sets differ by comparing against per-VPL oracle visibility."""

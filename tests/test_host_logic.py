@@ -99,11 +99,16 @@ def test_render_json_error_behaviour(evplp, tmp_path):
     p = tmp_path / "nocam.json"; p.write_text(json.dumps(nocam))
     rc, msg = _render(evplp, str(p))
     assert rc == evplp.ERR_PARSE and "camera" in msg
-    # the pt technique is outside this build
+    # the pt block (RtPt2::render, rtpt2.h:91-111) has its own required keys
     pt = dict(root); pt["pt"] = {"numMaxBounces": 3}; pt.pop("photonfam")
     p = tmp_path / "pt.json"; p.write_text(json.dumps(pt))
     rc, msg = _render(evplp, str(p))
-    assert rc == evplp.ERR_INVALID and "pt" in msg
+    assert rc == evplp.ERR_PARSE and "rngOffset" in msg
+    # no technique block at all
+    none = {k: v for k, v in root.items() if k != "photonfam"}
+    p = tmp_path / "none.json"; p.write_text(json.dumps(none))
+    rc, msg = _render(evplp, str(p))
+    assert rc == evplp.ERR_PARSE and "technique" in msg
     # a valid file reaches context creation: without a GPU that fails loudly, never silently
     import torch
     if not torch.cuda.is_available():
