@@ -16,6 +16,8 @@ ap.add_argument("--builder", type=int, default=1)
 ap.add_argument("--mode", default="one")
 ap.add_argument("--splat", action="store_true")
 ap.add_argument("--vsl", action="store_true")
+ap.add_argument("--pt", action="store_true", help="path tracer: one camera path per pixel per iteration")
+ap.add_argument("--lvc", action="store_true")
 ap.add_argument("--iters", type=int, default=2)
 ap.add_argument("--strip-count", type=int, default=1)
 ap.add_argument("--strip-rank", type=int, default=0)
@@ -34,6 +36,22 @@ radius = 0.003 * bsr
 kw = dict(camera_pos=sd.cam_origin, mis_mode=a.mode, pdf_mc=a.vpl_paths / a.paths / math.pi / radius**2, clamping_value=1.0 / total,
           photon_radius=radius, vsl_radius=0.05 * bsr, vsl_inv_pi_radius2=1 / (math.pi * (0.05 * bsr) ** 2),
           num_light_paths=a.paths, num_vpl_light_paths=a.vpl_paths, photons_per_path=P, do_accumulate=1)
+if a.pt:
+    for it in range(a.iters):
+        c.primary((0, 0)); c.path_trace(sd.cam_origin, it, 3, accumulate=True); c.synchronize()
+        st = c.pass_stats(ev.PASS_PATH_TRACE)
+        print("pt iter %d: %.2f ms, %d paths, %d rays -> %.1f Mpaths/s %.1f Mrays/s" % (it, st["ms"], st["pairs"], st["rays"], st["pairs"] / st["ms"] / 1e3, st["rays"] / st["ms"] / 1e3))
+    img = c.resolve(1.0 / a.iters, 0.0, 1.0)
+    os.makedirs("gpurun_out", exist_ok=True)
+    ev.save_image("gpurun_out/quick_pt.png", img[: a.res][::-1])
+    sys.exit(0)
+if a.lvc:
+    for it in range(a.iters):
+        fp = ev.frame_params(rng_seed=it, **kw)
+        c.primary((0, 0)); c.trace_light_paths(it); c.gather_lvc(fp); c.synchronize()
+        st = c.pass_stats(ev.PASS_GATHER_LVC)
+        print("lvc iter %d: %.2f ms, %.3e pairs, %.3e rays -> %.1f Mpairs/s" % (it, st["ms"], st["pairs"], st["rays"], st["pairs"] / st["ms"] / 1e3))
+    sys.exit(0)
 for it in range(a.iters):
     fp = ev.frame_params(rng_seed=it, **kw)
     t0 = time.time()
