@@ -111,6 +111,7 @@ _SIGNATURES = {
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "evplp_save_image": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P]),
     "evplp_load_pfm": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
+    "evplp_decode_image": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
     "evplp_image_mse": (C.c_double, [C.c_int32, _P, _P]),
     "evplp_image_rel_mse": (C.c_double, [C.c_int32, _P, _P]),
     "evplp_synth_scene": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32]),
@@ -362,6 +363,19 @@ def load_pfm(path: str) -> np.ndarray:
     if rc != OK:
         raise EvplpError(rc, f"evplp_load_pfm({path})")
     return out
+
+
+def decode_image(path: str):
+    """stbi_load(path, .., 3) of the reference (rt/rtcommon.h:144): (pixels uint8 [h, w, 3] top-down, channels in file)."""
+    w, h, ch = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib().evplp_decode_image(path.encode(), C.byref(w), C.byref(h), C.byref(ch), None, C.c_size_t(0))
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_decode_image({path})")
+    out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    rc = lib().evplp_decode_image(path.encode(), C.byref(w), C.byref(h), C.byref(ch), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes))
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_decode_image({path})")
+    return out, ch.value
 
 
 def synth_scene(out_dir: str, name: str = "conference_synth", target_triangles: int = 331000, seed: int = 1234,

@@ -2,6 +2,7 @@
 // output surface, error metrics.
 #include "../evplp_types.h"
 #include "images.hpp"
+#include "decoders.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -29,6 +30,21 @@ extern "C" void evplp_progressive_step(int32_t n, float alpha, float clamp_start
 extern "C" int evplp_save_image(const char *path, int32_t w, int32_t h, const float *rgb) {
     if (!path || !rgb || w <= 0 || h <= 0) return EVPLP_ERR_INVALID;
     return evplp::save_image(path, w, h, rgb);
+}
+extern "C" int evplp_decode_image(const char *path, int32_t *w, int32_t *h, int32_t *channels, uint8_t *rgb, size_t cap) {
+    if (!path || !w || !h) return EVPLP_ERR_INVALID;
+    try {
+        evplp::DecodedImage img = evplp::decode_image_file(path);
+        *w = img.w; *h = img.h; if (channels) *channels = img.channels;
+        if (rgb) {
+            if (cap < img.rgb.size()) return EVPLP_ERR_INVALID;
+            std::memcpy(rgb, img.rgb.data(), img.rgb.size());
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "evplp_decode_image: %s\n", e.what());
+        return std::strstr(e.what(), "cannot open") ? EVPLP_ERR_IO : EVPLP_ERR_PARSE;
+    }
+    return EVPLP_OK;
 }
 extern "C" int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb, size_t cap) {
     if (!path || !w || !h) return EVPLP_ERR_INVALID;

@@ -1,4 +1,5 @@
 #include "scene_io.hpp"
+#include "decoders.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -32,13 +33,26 @@ struct MtlEntry {
     std::string map_kd, map_ks, map_ns;
 };
 
-// PFM / binary PPM textures (JPG/PNG decoding is a "next" item).  Stored RGBA32F with
-// alpha 0, gamma 1.0 (no sRGB decode), flipped vertically like stbi_set_flip_vertically_on_load(1)
-// (rtcommon.h:32,44,139-194).
+// RtTexture(filepath, gamma = 1) (rtcommon.h:139-194): JPEG / PNG decoded to 8-bit RGB (decoders.hpp), texel =
+// byte / 255 (pow(x, 1.0) is the identity), alpha 0, rows flipped vertically as
+// stbi_set_flip_vertically_on_load(1) does (:32).  The reference indexes 4-channel files with the wrong stride
+// (:178-189 reads data[i * 4 + j] from a 3-byte-per-pixel buffer, out of bounds for the last quarter); this build
+// reads them as the RGB they are.  PFM and binary PPM are accepted in addition (build-only, for generated scenes).
 TextureData load_texture(const std::string &path) {
     TextureData t; t.path = path;
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open texture " + path);
+    unsigned char head[8] = { 0 };
+    size_t got = std::fread(head, 1, 8, f);
+    if (is_jpeg(head, got) || is_png(head, got)) {
+        std::fclose(f);
+        DecodedImage img = decode_image_file(path);
+        t.w = img.w; t.h = img.h; t.rgba.assign((size_t)img.w * img.h * 4, 0.f);
+        for (int y = 0; y < img.h; y++) for (int x = 0; x < img.w; x++) for (int k = 0; k < 3; k++)
+            t.rgba[4 * ((size_t)(img.h - 1 - y) * img.w + x) + k] = (float)img.rgb[3 * ((size_t)y * img.w + x) + k] / 255.0f;
+        return t;
+    }
+    std::rewind(f);
     char magic[3] = { 0, 0, 0 };
     if (std::fscanf(f, "%2s", magic) != 1) { std::fclose(f); throw std::runtime_error("bad texture header " + path); }
     if (!std::strcmp(magic, "PF")) {
@@ -59,7 +73,7 @@ TextureData load_texture(const std::string &path) {
         t.w = w; t.h = h; t.rgba.assign((size_t)w * h * 4, 0.f);
         for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int k = 0; k < 3; k++)
             t.rgba[4 * ((size_t)(h - 1 - y) * w + x) + k] = (float)rgb[3 * ((size_t)y * w + x) + k] / 255.0f;   // u8/255, gamma 1.0
-    } else { std::fclose(f); throw std::runtime_error("unsupported texture format (only PFM / binary PPM this round): " + path); }
+    } else { std::fclose(f); throw std::runtime_error("unsupported texture format (JPEG, PNG, PFM or binary PPM expected): " + path); }
     std::fclose(f);
     return t;
 }

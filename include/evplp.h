@@ -227,6 +227,10 @@ void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clam
  * rgb: top-down rows (after FlipY, rtcomphoton.h:1124-1127), 3 floats per pixel. */
 int evplp_save_image(const char *path, int32_t w, int32_t h, const float *rgb_top_down);
 int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb_top_down, size_t capacity_floats);
+/* stbi_load(filepath, &width, &height, &channel, 3) as RtTexture calls it (rt/rtcommon.h:144): JPEG (baseline /
+ * progressive) or PNG by content -> 8-bit RGB, rows top to bottom (no flip), bit-identical to the reference's
+ * vendored decoder.  *channels = components in the file.  rgb may be NULL to query the size. */
+int evplp_decode_image(const char *path, int32_t *w, int32_t *h, int32_t *channels, uint8_t *rgb, size_t capacity_bytes);
 double evplp_image_mse(int32_t npix, const float *img, const float *ref);     /* floatimage.cpp:64-84 */
 double evplp_image_rel_mse(int32_t npix, const float *img, const float *ref); /* floatimage.cpp:86-112 */
 /* Writes a procedural closed "conference-like" room (OBJ + MTL + light OBJ + scene JSON in the

@@ -10,6 +10,10 @@ Fixtures:
   camera.npz          projection*view matrices (with / without the jitter translation) for seeded
                       cameras incl. the conference camera, fovx->fovy, bounding-sphere radii
                       (rt/rtcommon.h:548-591, 805-814; rt/rtcomphoton/rtcomphoton.h:943-952)
+  textures.npz        small JPEG / PNG files (written here with Pillow from seeded images: baseline 4:4:4 / 4:2:2 /
+                      4:2:0 / 4:1:1, grey, progressive, optimised tables, restart intervals, odd sizes; PNG grey / RGB /
+                      RGBA / palette (+tRNS) / 1-2-4-16 bit / Adam7) and the pixels the reference's decoder returns for
+                      them: stbi_load(path, &w, &h, &channel, 3) of the vendored stb_image v2.16 (rt/rtcommon.h:144)
 """
 import ctypes as C
 import os
@@ -59,6 +63,105 @@ def decode_png_rgb8(data: bytes):
     return out.reshape(h, w, 3)
 
 
+def smooth_image(rng, w, h):
+    """Photo-like test image: low-frequency colour field + edges + a little noise (so that chroma upsampling,
+    clamping and every IDCT path matter)."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w, 3))
+    for k in range(3):
+        fx, fy, ph = rng.rand(3) * [0.35, 0.35, 6.28]
+        img[..., k] = 127 + 100 * np.sin(fx * x + ph) * np.cos(fy * y + 0.5 * ph)
+    img[h // 3: h // 3 + max(h // 5, 1), w // 4: w // 4 + max(w // 3, 1)] = [250, 10, 30]      # saturated block: clamping
+    img[:, w // 2] = 0
+    img += rng.randn(h, w, 3) * 6
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def adam7_png(rgb):
+    """Pillow cannot write interlaced PNGs: build an Adam7 RGB8 file by hand (filter type 0/1/2 alternating)."""
+    h, w, _ = rgb.shape
+    xs, ys, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    raw = b""
+    for p in range(7):
+        sub = rgb[ys[p]::dy[p], xs[p]::dx[p]]
+        if sub.size == 0:
+            continue
+        prev = np.zeros(sub.shape[1] * 3, np.int32)
+        for r, row in enumerate(sub):
+            cur = row.reshape(-1).astype(np.int32); f = r % 3
+            if f == 0: enc = cur
+            elif f == 1: enc = cur - np.concatenate([np.zeros(3, np.int32), cur[:-3]])
+            else: enc = cur - prev
+            raw += bytes([f]) + (enc & 255).astype(np.uint8).tobytes(); prev = cur
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+def make_textures(ref):
+    import io
+    from PIL import Image
+    ref.ref_stbi_load.restype = C.c_void_p
+    ref.ref_stbi_load.argtypes = [C.c_char_p] + [C.c_void_p] * 3 + [C.c_int]
+    ref.ref_stbi_free.argtypes = [C.c_void_p]
+    rng = np.random.RandomState(4242)
+    files = {}
+
+    def jpeg(name, img, mode="RGB", **kw):
+        b = io.BytesIO(); Image.fromarray(img, mode).save(b, "JPEG", **kw); files[name + ".jpg"] = b.getvalue()
+
+    def png(name, im, **kw):
+        b = io.BytesIO(); im.save(b, "PNG", **kw); files[name + ".png"] = b.getvalue()
+
+    a = smooth_image(rng, 37, 29); b_ = smooth_image(rng, 64, 48); c = smooth_image(rng, 9, 70); d = smooth_image(rng, 1, 1); e = smooth_image(rng, 50, 3)
+    jpeg("base444_q95", a, quality=95, subsampling=0)
+    jpeg("base422_q85", a, quality=85, subsampling=1)
+    jpeg("base420_q75", a, quality=75, subsampling=2)
+    jpeg("base420_q30_64x48", b_, quality=30, subsampling=2)
+    jpeg("base420_tall", c, quality=90, subsampling=2)
+    jpeg("base420_1x1", d, quality=90, subsampling=2)
+    jpeg("base422_wide", e, quality=90, subsampling=1)
+    jpeg("grey_q80", a[..., 0].copy(), mode="L", quality=80)
+    jpeg("prog420_q80", b_, quality=80, subsampling=2, progressive=True)
+    jpeg("prog444_q92", a, quality=92, subsampling=0, progressive=True)
+    jpeg("prog_grey", c[..., 1].copy(), mode="L", quality=85, progressive=True)
+    jpeg("opt420_q60", b_, quality=60, subsampling=2, optimize=True)
+    jpeg("rst420_q85", b_, quality=85, subsampling=2, restart_marker_blocks=3)
+    jpeg("rst_prog", b_, quality=70, subsampling=2, progressive=True, restart_marker_rows=1)
+    jpeg("q100_444", a, quality=100, subsampling=0)
+    jpeg("base411", b_, quality=85, subsampling="4:1:1")     # h = 4: the replicating upsampler
+    png("rgb8", Image.fromarray(a, "RGB"))
+    png("rgba8", Image.fromarray(np.dstack([a, (a[..., 0] // 2 + 100).astype(np.uint8)]), "RGBA"))
+    png("grey8", Image.fromarray(a[..., 1].copy(), "L"))
+    png("greya8", Image.fromarray(np.dstack([a[..., 1], a[..., 2]]), "LA"))
+    pal = Image.fromarray(b_, "RGB").quantize(colors=61)
+    png("pal8", pal)
+    png("pal8_trns", pal, transparency=5)
+    png("pal4", Image.fromarray(a, "RGB").quantize(colors=13), bits=4)
+    png("pal2", Image.fromarray(a, "RGB").quantize(colors=4), bits=2)
+    png("bilevel", Image.fromarray(a[..., 0] > 127))
+    png("grey16", Image.fromarray((a[..., 0].astype(np.uint16) * 257 + 31).astype(np.uint16)))
+    png("rgb8_trns", Image.fromarray(a, "RGB"), transparency=(250, 10, 30))
+    png("rgb8_opt", Image.fromarray(b_, "RGB"), optimize=True)
+    png("rgb8_stored", Image.fromarray(e, "RGB"), compress_level=0)
+    files["adam7_rgb8.png"] = adam7_png(a)
+    files["adam7_small.png"] = adam7_png(smooth_image(rng, 3, 2))
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for name, data in files.items():
+        path = os.path.join(tmp, name); open(path, "wb").write(data)
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        ptr = ref.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), 0)
+        assert ptr, name
+        px = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_ubyte)), shape=(h.value, w.value, 3)).copy()
+        ref.ref_stbi_free(ptr)
+        key = name.replace(".", "_")
+        out[key + "__file"] = np.frombuffer(data, np.uint8); out[key + "__pixels"] = px; out[key + "__channels"] = np.int32(ch.value)
+    np.savez_compressed(os.path.join(HERE, "textures.npz"), **out)
+    print("textures.npz:", len(files), "files,", sum(len(v) for v in files.values()), "bytes of image files")
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/libref_pin.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -71,6 +174,7 @@ def main():
     ref.ref_fovx_to_fovy.restype = C.c_float; ref.ref_fovx_to_fovy.argtypes = [C.c_float, C.c_float]
     ref.ref_bounding_sphere_radius.restype = C.c_float; ref.ref_bounding_sphere_radius.argtypes = [C.c_int, C.c_void_p]
 
+    make_textures(ref)
     rng = np.random.RandomState(20261002)
     out = {}
     tmp = tempfile.mkdtemp()

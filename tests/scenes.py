@@ -152,8 +152,10 @@ def box_room(seed=1, n_boxes=6, tess=2, glossy=True, textured=False, aspect=1.0)
     return s
 
 
-def load_obj_scene(json_path):
-    """Independent Python reading of a scene JSON + OBJ/MTL (same semantics as csrc/host/scene_io.cpp)."""
+def load_obj_scene(json_path, decode=None):
+    """Independent Python reading of a scene JSON + OBJ/MTL (same semantics as csrc/host/scene_io.cpp).
+    decode(path) -> uint8 (h, w, 3) top-down pixels for map_Kd / map_Ks / map_Ns (RtTexture(filepath, 1.0),
+    rtcommon.h:139-194: byte / 255, flipped vertically)."""
     import json
     root = json.load(open(json_path))
     d = os.path.dirname(json_path)
@@ -175,7 +177,21 @@ def load_obj_scene(json_path):
                 out[cur]["ks"] = [float(x) for x in t[1:4]]
             elif cur and t[0] == "Ns":
                 out[cur]["ns"] = float(t[1])
+            elif cur and t[0] in ("map_Kd", "map_Ks", "map_Ns"):
+                out[cur][t[0]] = os.path.join(os.path.dirname(path), t[1])
         return out
+
+    tex_ids = {}
+
+    def tex_of(m, key):
+        if key not in m:
+            return -1
+        if m[key] not in tex_ids:
+            px = decode(m[key])
+            t = np.zeros(px.shape[:2] + (4,), np.float32)
+            t[..., :3] = px[::-1].astype(np.float32) / np.float32(255.0)
+            tex_ids[m[key]] = len(s.textures); s.textures.append(t)
+        return tex_ids[m[key]]
 
     def read_obj(path, want_materials):
         pos, tex, mtl = [], [], {}
@@ -220,7 +236,7 @@ def load_obj_scene(json_path):
 
     for rel in root["scene"]:
         for g, m in read_obj(os.path.join(d, rel), True):
-            mid = s.add_material(m["kd"], m["ks"], m["ns"])
+            mid = s.add_material(m["kd"], m["ks"], m["ns"], tex_of(m, "map_Kd"), tex_of(m, "map_Ks"), tex_of(m, "map_Ns"))
             s.add_mesh(np.array(g["verts"], np.float32), np.array(g["idx"], np.int32), mid, np.array(g["uvs"], np.float32))
     lg = read_obj(os.path.join(d, root["arealight"]["obj"]), False)
     assert len(lg) == 1

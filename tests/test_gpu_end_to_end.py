@@ -440,6 +440,46 @@ def test_ragged_resolutions(evplp, res):
     assert rel_l2(vpl[..., :3], rv[..., :3]) <= 1e-5 and rel_l2(pm[..., :3], rp[..., :3]) <= 1e-5
 
 
+def test_scene_json_with_jpeg_and_png_textures(evplp, tmp_path):
+    """map_Kd / map_Ks through the C++ loader (RtTexture::LoadRtTexture, rtcommon.h:30-74): JPEG and PNG files
+    decoded by this build (pinned byte-for-byte to the reference's decoder in test_oracle_pins.py), uploaded as
+    bilinear-repeat textures; the G-buffer reflectances must equal the oracle's fetches on the same scene."""
+    tex = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures.npz"))
+    jp = evplp.synth_scene(str(tmp_path), "room", 2500, 8, 88, 60)
+    for key, fn in (("prog420_q80_jpg", "wood.jpg"), ("rgba8_png", "spec.png"), ("base422_q85_jpg", "cloth.jpg")):
+        open(tmp_path / fn, "wb").write(tex[key + "__file"].tobytes())
+    mtl_path = jp.replace(".json", ".mtl")
+    lines = open(mtl_path).read().splitlines()
+    out, n = [], 0
+    for ln in lines:
+        out.append(ln)
+        if ln.startswith("newmtl"):
+            n += 1
+            if n % 3 == 1:
+                out.append("map_Kd wood.jpg")
+            elif n % 3 == 2:
+                out += ["map_Kd cloth.jpg", "map_Ks spec.png"]
+    open(mtl_path, "w").write("\n".join(out) + "\n")
+    sd, root = scenes.load_obj_scene(jp, decode=lambda p: evplp.decode_image(p)[0])
+    assert len(sd.textures) == 3
+    W, H = root["resX"], root["resY"]
+    osc = oa.Scene(sd)
+    with evplp.Context(W, H, 8, 8, 4) as c:
+        c.load_scene_json(jp)
+        c.primary((0.0, 0.0), clear_light=True)
+        got = [c.download(b)[:H] for b in (evplp.BUF_GBUF_NORMAL, evplp.BUF_GBUF_DIFFUSE, evplp.BUF_GBUF_PHONG)]
+    g = osc.primary(W, H)
+    assert np.array_equal(got[0], g[1])
+    # bilinear weights come from (interpolated, tiled uv) x texture size, a number of the order of 10^2..10^3 whose
+    # fp32 ulp is ~6e-5 of a texel: with FMA-contracted interpolation on the GPU a fetch moves by that fraction
+    # of the local texel contrast (up to ~1 on these images).  Mean error stays at round-off.
+    e1, e2 = np.abs(got[1] - g[2]), np.abs(got[2] - g[3])
+    assert e1.max() <= 4e-4 and e1.mean() <= 2e-6, (float(e1.max()), float(e1.mean()))
+    assert e2.max() <= 4e-4 and e2.mean() <= 2e-6, (float(e2.max()), float(e2.mean()))
+    # the textures are really in play: textured surfaces are not constant-coloured
+    assert len(np.unique(np.round(g[2][..., 0], 4))) > 50
+
+
 @pytest.mark.parametrize("builder", [0, 1])
 def test_tiny_scene_single_leaf_and_degenerate_triangles(evplp, builder):
     """A floor quad + a light quad (BVH root is a single leaf) with a zero-area triangle thrown in

@@ -1,7 +1,8 @@
 """Pins the oracle (and the product's host-side output surface) against golden vectors produced by the
 REFERENCE'S OWN code (tests/golden/make_golden.py: floatimage.cpp + vendored GLM through oracle/_ref).
 No GPU needed.  What is pinned: PFM bytes, PNG pixels, FlipY, MSE/relMSE, the camera model (lookAt /
-perspective / jitter translation / fovx->fovy) and the bounding-sphere radius.  The device arithmetic
+perspective / jitter translation / fovx->fovy), the bounding-sphere radius, and the texture decoders (JPEG /
+PNG pixels as the reference's vendored stb_image returns them).  The device arithmetic
 (BRDFs, gather, splat) has no reference-run vectors: "parity unpinned" there."""
 import ctypes as C
 import os
@@ -18,6 +19,8 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 from make_golden import decode_png_rgb8  # noqa: E402
 
 G = np.load(os.path.join(HERE, "golden", "output_surface.npz"))
+TEX = np.load(os.path.join(HERE, "golden", "textures.npz"))
+TEX_NAMES = sorted(k[: -len("__file")] for k in TEX.files if k.endswith("__file"))
 CAM = np.load(os.path.join(HERE, "golden", "camera.npz"))
 
 
@@ -134,3 +137,62 @@ def test_reference_build_matches_fixtures_when_present():
     ref.ref_mse.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     img, other = G["b_img"], G["b_other"]
     assert ref.ref_mse(img.shape[1], img.shape[0], oa.ptr(other), oa.ptr(img)) == float(G["b_mse"])
+
+
+@pytest.mark.parametrize("name", TEX_NAMES)
+def test_texture_decoders_match_the_reference_decoder(name, tmp_path, evplp):
+    """evplp_decode_image == stbi_load(path, &w, &h, &channel, 3) of the stb_image v2.16 the reference links
+    (rt/rtcommon.h:144), byte for byte: baseline / progressive / restart-interval JPEG with every chroma layout,
+    PNG of every colour type and bit depth incl. Adam7."""
+    ext = ".jpg" if name.endswith("_jpg") else ".png"
+    path = str(tmp_path / (name + ext))
+    open(path, "wb").write(TEX[name + "__file"].tobytes())
+    got, channels = evplp.decode_image(path)
+    want = TEX[name + "__pixels"]
+    assert got.shape == want.shape
+    assert channels == int(TEX[name + "__channels"])
+    assert np.array_equal(got, want), f"{int((got != want).sum())} bytes differ, max {int(np.abs(got.astype(int) - want).max())}"
+
+
+def test_texture_decoder_errors(tmp_path, evplp):
+    p = tmp_path / "trunc.jpg"
+    data = TEX["base420_q75_jpg__file"].tobytes()
+    p.write_bytes(data[: len(data) // 8])                       # header only: no EOI
+    with pytest.raises(evplp.EvplpError):
+        evplp.decode_image(str(p))
+    q = tmp_path / "bad.png"
+    png = bytearray(TEX["rgb8_png__file"].tobytes()); png[40] ^= 0xFF   # corrupt the deflate stream
+    q.write_bytes(bytes(png))
+    with pytest.raises(evplp.EvplpError):
+        evplp.decode_image(str(q))
+    with pytest.raises(evplp.EvplpError):
+        evplp.decode_image(str(tmp_path / "missing.png"))
+    r = tmp_path / "not_an_image.jpg"; r.write_bytes(b"hello world, not an image")
+    with pytest.raises(evplp.EvplpError):
+        evplp.decode_image(str(r))
+
+
+def test_texture_decoders_on_the_reference_assets_when_present(evplp):
+    """The living-room textures and the conference mask shipped with the reference (authoring container only):
+    decoded live by the reference's decoder (oracle/_ref) and by this build."""
+    ref_path = os.path.join(oa.ROOT, "oracle", "_ref", "libref_pin.so")
+    assets = "/root/reference/scene"
+    if not os.path.exists(ref_path) or not os.path.isdir(assets):
+        pytest.skip("reference assets / oracle/_ref not present here")
+    import glob
+    ref = C.CDLL(ref_path)
+    if not hasattr(ref, "ref_stbi_load"):
+        pytest.skip("oracle/_ref predates the decoder pin")
+    ref.ref_stbi_load.restype = C.c_void_p
+    ref.ref_stbi_load.argtypes = [C.c_char_p] + [C.c_void_p] * 3 + [C.c_int]
+    ref.ref_stbi_free.argtypes = [C.c_void_p]
+    files = sorted(glob.glob(assets + "/livingroom/textures/*.jpg")) + [assets + "/conference/conference_mask.png"]
+    assert len(files) >= 5
+    for f in files:
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        ptr = ref.ref_stbi_load(f.encode(), C.byref(w), C.byref(h), C.byref(ch), 0)
+        assert ptr, f
+        want = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_ubyte)), shape=(h.value, w.value, 3)).copy()
+        ref.ref_stbi_free(ptr)
+        got, channels = evplp.decode_image(f)
+        assert channels == ch.value and np.array_equal(got, want), f
