@@ -254,31 +254,34 @@ namespace vslm {
 EV_DEV float fpow(float x, float y) { return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 EV_DEV float sin2pi(float u) { return __builtin_amdgcn_sinf(u); }   // v_sin_f32 takes revolutions
 EV_DEV float cos2pi(float u) { return __builtin_amdgcn_cosf(u); }
+// 1-ulp hardware reciprocal / square roots instead of the IEEE-correct expansions (~10 instructions each)
+EV_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+EV_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+EV_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #else
+EV_DEV float rcp(float x) { return 1.0f / x; }
+EV_DEV float rsq(float x) { return 1.0f / sqrtf(x); }
+EV_DEV float fsqrt(float x) { return sqrtf(x); }
 EV_DEV float fpow(float x, float y) { return powf(x, y); }
 EV_DEV float sin2pi(float u) { return sinf(2.0f * EV_PI * u); }
 EV_DEV float cos2pi(float u) { return cosf(2.0f * EV_PI * u); }
 #endif
-EV_DEV float phong_eval_f(V3 out, V3 in, V3 n, float e) {            // rt/rtmaterial.cuh:112-118
-    V3 r = reflect(-in, n);
-    float d = fmaxf(dot(out, r), 0.0f);
-    if (d <= 0.000001f) return 0.0f;
-    return (e + 2.0f) * fpow(d, e) * EV_INV_PI * 0.5f;
-}
-EV_DEV float phong_pdf_w(V3 n1, V3 v12, V3 in, V3 rho_s, float e) {  // :78-85
-    V3 wi12 = normalize(v12);
-    V3 r = normalize(reflect(-in, n1));
-    float c = fmaxf(dot(wi12, r), 0.f);
-    if (c <= 0.000001f || rho_s.x <= 0.000001f) return 0.0f;
-    return (e + 1.0f) * 0.5f * EV_INV_PI * fpow(c, e);
+EV_DEV V3 fnormalize(V3 v) { return v * rsq(dot(v, v)); }
+EV_DEV Onb fonb_make(V3 n) {                                         // optixu Onb
+    Onb o; o.n = n;
+    if (fabsf(n.x) > fabsf(n.z)) o.b = v3(-n.y, n.x, 0.0f);
+    else o.b = v3(0.0f, -n.z, n.y);
+    o.b = fnormalize(o.b);
+    o.t = cross(o.b, o.n);
+    return o;
 }
 EV_DEV V3 lambert_sample(V3 &out, float &pdfw, V3 normal, V3 rho_d, Rng &rng) {   // :56-66
     float u1 = rng_uniform(rng);
     float u2 = rng_uniform(rng);
-    float r = sqrtf(u1);
+    float r = fsqrt(u1);
     V3 p; p.x = r * cos2pi(u2); p.y = r * sin2pi(u2);
-    p.z = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
-    Onb o = onb_make(normal);
+    p.z = fsqrt(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+    Onb o = fonb_make(normal);
     out = onb_inverse(o, p);
     pdfw = fmaxf(dot(out, normal), 0.f) * EV_INV_PI;
     return rho_d;
@@ -287,92 +290,102 @@ EV_DEV V3 phong_sample(V3 &out, float &pdfw, V3 in, V3 normal, V3 rho_s, float e
     V3 r = reflect(-in, normal);
     float sx = rng_uniform(rng);
     float sy = rng_uniform(rng);
-    float cos_t = fpow(sx, 1.f / (e + 1.f));
-    float sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));
+    float cos_t = fpow(sx, rcp(e + 1.f));
+    float sin_t = fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
     V3 p = v3(sin_t * cos2pi(sy), sin_t * sin2pi(sy), cos_t);
-    Onb o = onb_make(r);
+    Onb o = fonb_make(r);
     out = onb_inverse(o, p);
     float unsafe_cos = dot(out, normal);
     float cos_n = fmaxf(unsafe_cos, 0.f);
     float cos_r = fmaxf(dot(out, r), 0.f);
     if (unsafe_cos > 0.0f) pdfw = (e + 1.0f) * 0.5f * fpow(cos_r, e) * EV_INV_PI;
     else pdfw = 0.0f;
-    return rho_s * ((e + 2.0f) / (e + 1.0f) * cos_n);
+    return rho_s * ((e + 2.0f) * rcp(e + 1.0f) * cos_n);
 }
 } // namespace vslm
-EV_DEV V3 square_to_solid_angle(float sx, float sy, float half_angle_max) {  // lighttracing.cu:382-390
-    float z = 1.0f - sy * (1.0f - cosf(half_angle_max));
-    float l = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+EV_DEV V3 square_to_solid_angle(float sx, float sy, float cos_half_angle_max) {  // lighttracing.cu:382-390
+    float z = 1.0f - sy * (1.0f - cos_half_angle_max);
+    float l = vslm::fsqrt(fmaxf(1.0f - z * z, 0.0f));
     return v3(vslm::cos2pi(sx) * l, vslm::sin2pi(sx) * l, z);
 }
 struct VslCtx {
     float half_cone, cos_half_cone, solid_angle, inv_solid_angle, inv_pi_r2; V3 nd12;
 };
-// shared MIS denominator block (:433-443, 508-518, 581-591) with the reference quirk of SURVEY A.6
-EV_DEV void vsl_pdfs(const Pixel &px, const Vpl &v, V3 wi12, float psel, float &pdf1, float &pdf2) {
-    pdf1 = lambert_pdf_w(px.n1, wi12) * psel + vslm::phong_pdf_w(px.n1, wi12, px.wi10, px.rs, px.e) * (1.0f - psel);
-    pdf2 = lambert_pdf_w(v.n, -wi12) * psel + vslm::phong_pdf_w(v.n, -wi12, v.fdir, v.rs, v.e);
+// Per-pixel and per-VSL invariants of the three estimators.  Both Phong lobes are functions of one cosine each:
+//   pixel:  PhongEvalF(wi10, w, n1) and PhongPdfW(n1, w, wi10) both raise  max(w . R1, 0)  to e1,  R1 = reflect(-wi10, n1)
+//           (out . reflect(-in, n) == in . reflect(-out, n));
+//   VSL:    PhongEvalF(-w, fdir, n2) and PhongPdfW(n2, -w, fdir) both raise  max(-w . R2, 0)  to e2,  R2 = reflect(-fdir, n2);
+// so every sampled direction costs one power per lobe instead of two, the reflections are hoisted, and a
+// lobe with rho_s = 0 is skipped altogether (exact: its terms are multiplied by 0 / PhongPdfW returns 0 for
+// rho_s.x <= 1e-6).  The reference normalises already-unit vectors again inside its pdfs; that is dropped
+// here (last-ulp differences, far below the VSL tolerance).
+struct VslPixel { V3 R1; float psel, inv_psel, inv_1mpsel; bool dead, glossy, pdf_glossy; };
+struct VslLight { V3 R2; float psel, inv_psel, inv_1mpsel; bool dead, glossy, pdf_glossy; };
+EV_DEV float lobe_pow(float c, float e) { return c <= 0.000001f ? 0.0f : vslm::fpow(c, e); }
+// brdf1, brdf2 and the shared MIS denominators (:433-443, 508-518, 581-591; reference quirk of SURVEY A.6: pdf2 uses the
+// PIXEL's lobe-selection probability for its Lambert term and no (1 - psel) on its Phong term) for direction w = wi12
+EV_DEV void vsl_terms(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, V3 w, float c1, float c2,
+                      V3 *brdf1, V3 *brdf2, float &pdf1, float &pdf2) {
+    float pw1 = 0.0f, pw2 = 0.0f;
+    if (P.glossy) pw1 = lobe_pow(fmaxf(dot(w, P.R1), 0.0f), px.e);
+    if (L.glossy) pw2 = lobe_pow(fmaxf(-dot(w, L.R2), 0.0f), v.e);
+    if (brdf1) *brdf1 = px.rd * EV_INV_PI + px.rs * ((px.e + 2.0f) * pw1 * EV_INV_PI * 0.5f);
+    if (brdf2) *brdf2 = v.rd * EV_INV_PI + v.rs * ((v.e + 2.0f) * pw2 * EV_INV_PI * 0.5f);
+    float pp1 = P.pdf_glossy ? (px.e + 1.0f) * 0.5f * EV_INV_PI * pw1 : 0.0f;
+    float pp2 = L.pdf_glossy ? (v.e + 1.0f) * 0.5f * EV_INV_PI * pw2 : 0.0f;
+    pdf1 = c1 * P.psel + pp1 * (1.0f - P.psel);
+    pdf2 = c2 * P.psel + pp2;
 }
-EV_DEV V3 vsl_sample_cone(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :395-446
+EV_DEV V3 vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, float &w, Rng &rng) {  // :395-446
     const V3 zero = v3(0.f, 0.f, 0.f);
-    float ml = max_color(px.rd), mp = max_color(px.rs);
-    if (ml + mp <= 0.000001f) return zero;
-    float psel = ml / (mp + ml);
+    if (P.dead) return zero;
     (void)rng_uniform(rng);
     float ua = rng_uniform(rng);
     float ub = rng_uniform(rng);
-    V3 wi12 = normalize(square_to_solid_angle(ua, ub, c.half_cone));
-    Onb o = onb_make(c.nd12);
-    wi12 = normalize(onb_inverse(o, wi12));
-    float c1c2 = fmaxf(dot(px.n1, wi12), 0.0f) * fmaxf(-dot(v.n, wi12), 0.0f);
+    V3 wi12 = vslm::fnormalize(square_to_solid_angle(ua, ub, c.cos_half_cone));
+    Onb o = vslm::fonb_make(c.nd12);
+    wi12 = vslm::fnormalize(onb_inverse(o, wi12));
+    float c1 = fmaxf(dot(px.n1, wi12), 0.0f), c2 = fmaxf(-dot(v.n, wi12), 0.0f);
+    float c1c2 = c1 * c2;
     if (c1c2 <= 0.000000001f) return zero;
-    V3 brdf2 = v.rd * EV_INV_PI + v.rs * vslm::phong_eval_f(-wi12, v.fdir, v.n, v.e);
-    V3 brdf1 = px.rd * EV_INV_PI + px.rs * vslm::phong_eval_f(px.wi10, wi12, px.n1, px.e);
-    float pdf1, pdf2; vsl_pdfs(px, v, wi12, psel, pdf1, pdf2);
-    w = c.inv_solid_angle / (pdf1 + pdf2 + c.inv_solid_angle);
+    V3 brdf1, brdf2; float pdf1, pdf2;
+    vsl_terms(px, v, P, L, wi12, c1, c2, &brdf1, &brdf2, pdf1, pdf2);
+    w = c.inv_solid_angle * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
     return (((v.flux * c.inv_pi_r2) * c1c2) * brdf1 * brdf2) * c.solid_angle;
 }
-EV_DEV V3 vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :448-521
+EV_DEV V3 vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, float &w, Rng &rng) {  // :448-521
     const V3 zero = v3(0.f, 0.f, 0.f);
-    float ml = max_color(px.rd), mp = max_color(px.rs);
-    if (ml + mp <= 0.000001f) return zero;
-    float psel = ml / (mp + ml);
+    if (P.dead) return zero;
     float choose = fminf(rng_uniform(rng), 0.999999f);
     V3 wi12, brdf1; float pdfw;
-    if (choose < psel) brdf1 = vslm::lambert_sample(wi12, pdfw, px.n1, px.rd, rng) / psel;
-    else brdf1 = vslm::phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) / (1.0f - psel);
+    if (choose < P.psel) brdf1 = vslm::lambert_sample(wi12, pdfw, px.n1, px.rd, rng) * P.inv_psel;
+    else brdf1 = vslm::phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) * P.inv_1mpsel;
     if (dot(wi12, c.nd12) <= c.cos_half_cone) return zero;
     float cos1 = fmaxf(dot(px.n1, wi12), 0.0f);
     if (cos1 <= 0.000000001f) return zero;
     float cos2 = fmaxf(-dot(v.n, wi12), 0.0f);
-    V3 brdf2 = v.rd * EV_INV_PI + v.rs * vslm::phong_eval_f(-wi12, v.fdir, v.n, v.e);
     (void)rng_uniform(rng);  // :506
-    float pdf1, pdf2; vsl_pdfs(px, v, wi12, psel, pdf1, pdf2);
-    w = pdf1 / (pdf1 + pdf2 + c.inv_solid_angle);
+    V3 brdf2; float pdf1, pdf2;
+    vsl_terms(px, v, P, L, wi12, cos1, cos2, nullptr, &brdf2, pdf1, pdf2);
+    w = pdf1 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
     return ((v.flux * c.inv_pi_r2) * cos2) * brdf1 * brdf2;
 }
-EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslCtx &c, float &w, Rng &rng) {  // :523-594
+EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, float &w, Rng &rng) {  // :523-594
     const V3 zero = v3(0.f, 0.f, 0.f);
+    if (L.dead) return zero;
     V3 wi21, brdf2; float pdfw;
-    {
-        float ml = max_color(v.rd), mp = max_color(v.rs);
-        if (ml + mp <= 0.000001f) return zero;
-        float psel = ml / (mp + ml);
-        float choose = fminf(rng_uniform(rng), 0.999999f);
-        if (choose < psel) brdf2 = vslm::lambert_sample(wi21, pdfw, v.n, v.rd, rng) / psel;
-        else brdf2 = vslm::phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) / (1.0f - psel);
-    }
+    float choose = fminf(rng_uniform(rng), 0.999999f);
+    if (choose < L.psel) brdf2 = vslm::lambert_sample(wi21, pdfw, v.n, v.rd, rng) * L.inv_psel;
+    else brdf2 = vslm::phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) * L.inv_1mpsel;
     if (-dot(wi21, c.nd12) <= c.cos_half_cone) return zero;
-    V3 brdf1 = px.rd * EV_INV_PI + px.rs * vslm::phong_eval_f(px.wi10, -wi21, px.n1, px.e);
     float cos2 = fmaxf(dot(v.n, wi21), 0.0f);
     if (cos2 <= 0.00000001f) return zero;
     float cos1 = fmaxf(-dot(px.n1, wi21), 0.0f);
-    float ml = max_color(px.rd), mp = max_color(px.rs);
-    if (ml + mp <= 0.000001f) return zero;
-    float psel = ml / (mp + ml);
+    if (P.dead) return zero;
     (void)rng_uniform(rng);  // :579
-    float pdf1, pdf2; vsl_pdfs(px, v, -wi21, psel, pdf1, pdf2);
-    w = pdf2 / (pdf1 + pdf2 + c.inv_solid_angle);
+    V3 brdf1; float pdf1, pdf2;
+    vsl_terms(px, v, P, L, -wi21, cos1, cos2, &brdf1, nullptr, pdf1, pdf2);
+    w = pdf2 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
     return ((v.flux * c.inv_pi_r2) * cos1) * brdf1 * brdf2;
 }
 
@@ -395,6 +408,13 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
     const bool valid = in_image;                        // no stencil test in splatSplotch (:694-695)
     const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
 
+    VslPixel P;
+    {
+        float ml = max_color(px.rd), mp = max_color(px.rs);
+        P.dead = ml + mp <= 0.000001f; P.psel = ml / (mp + ml); P.inv_psel = 1.0f / P.psel; P.inv_1mpsel = 1.0f / (1.0f - P.psel);
+        P.glossy = px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f; P.pdf_glossy = !(px.rs.x <= 0.000001f);
+        P.R1 = reflect(-px.wi10, px.n1);
+    }
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, nodes = 0;
@@ -413,24 +433,31 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
             VslCtx c;
             float rdratio = a.fp.vsl_radius / dist;
             c.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
-            c.cos_half_cone = cosf(c.half_cone);
+            c.cos_half_cone = (rdratio >= 1.0f) ? cosf(EV_PI / 2.0f) : vslm::fsqrt(1.0f - rdratio * rdratio);   // cos(asin x)
             c.solid_angle = EV_PI * 2.0f * (1.0f - c.cos_half_cone);
-            c.inv_solid_angle = 1.0f / c.solid_angle;
+            c.inv_solid_angle = vslm::rcp(c.solid_angle);
             c.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; c.nd12 = nv12;
             int num_samples = (int)(c.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
             // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
             Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
+            VslLight L;
+            {
+                float ml = max_color(v.rd), mp = max_color(v.rs);
+                L.dead = ml + mp <= 0.000001f; L.psel = ml / (mp + ml); L.inv_psel = 1.0f / L.psel; L.inv_1mpsel = 1.0f / (1.0f - L.psel);
+                L.glossy = v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f; L.pdf_glossy = !(v.rs.x <= 0.000001f);
+                L.R2 = reflect(-v.fdir, v.n);
+            }
             V3 acc = v3(0.f, 0.f, 0.f);
             for (int s = 0; s < num_samples; s++) {
                 float wc = 0.f, w1 = 0.f, w2 = 0.f;
-                V3 rc = vsl_sample_cone(px, v, c, wc, rng);
-                V3 r1 = vsl_sample_brdf1(px, v, c, w1, rng);
-                V3 r2 = vsl_sample_brdf2(px, v, c, w2, rng);
+                V3 rc = vsl_sample_cone(px, v, P, L, c, wc, rng);
+                V3 r1 = vsl_sample_brdf1(px, v, P, L, c, w1, rng);
+                V3 r2 = vsl_sample_brdf2(px, v, P, L, c, w2, rng);
                 acc = acc + rc * wc;
                 acc = acc + r1 * w1;
                 acc = acc + r2 * w2;
             }
-            result = result + acc / (float)num_samples;
+            result = result + acc * vslm::rcp((float)num_samples);
         }
     }
     if (in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
