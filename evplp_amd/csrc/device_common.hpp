@@ -303,8 +303,7 @@ EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot
 // rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
 EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane,
-                          int32_t *wave_stack, uint32_t &nodes_visited) {
+EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
     // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
     // far bound `tfar`: a lane that is inactive or already occluded carries tfar = -1, so its slab tests
@@ -324,9 +323,6 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     for (;;) {
         while (cur >= 0) {
             const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
-#ifdef EVPLP_GATHER_STATS
-            nodes_visited++;
-#endif
             // both children at once (half 0 = child 0, half 1 = child 1), conservative slab test in
             // centre / half-size form: A = ctr/d - o/d, B = hal/|d|, entry = A - B, exit = A + B
             const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
@@ -383,7 +379,6 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
         sp--;
         cur = lane_read(vstack, sp);
     }
-    (void)nodes_visited; (void)wave_stack;
     return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
 }
 

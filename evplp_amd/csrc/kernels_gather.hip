@@ -7,8 +7,9 @@
 // sums; gather_reduce_kernel adds the kVplSplit partials of a pixel in split order and applies
 // out = sum / numVplLightPaths + doAccumulate * out (lighttracing.cu:378).  The split is a compile-time
 // constant, so every pixel is summed in the same order on any GPU count (bitwise reproducible), and
-// the launch has 16x more, 16x shorter items than one-tile-per-workgroup: 131k items at 1024^2, still
-// 16k per GPU on an 8-GPU strip partition (2.7 rounds of the 6144 resident waves instead of 1.3).
+// the launch has 64x more, 64x shorter items than one-tile-per-workgroup: 1 M items at 1024^2, still
+// 131k per GPU on an 8-GPU strip partition (item cost varies 5x across the image; short items keep the
+// launch tail small).
 //
 // For one VPL the 64 shadow segments of a wave share their origin (the VPL) and end on neighbouring
 // surface points, so the wave walks the BVH as a packet (device_common.hpp::occluded_wave): control
@@ -118,7 +119,6 @@ EV_DEV Vpl fetch_vpl(const evplp_record *r) {
 }
 
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
-    __shared__ int32_t lds_stack[kMaxDepth];     // spill area of the wave's VGPR-lane stack (depth > 64 only)
     const int lane = threadIdx.x;
     const Item t = item_setup(a.st, lane);
     if (!t.has_tile) return;   // padding of the super-tile grid
@@ -132,13 +132,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
 
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0, nodes = 0;
-#ifdef EVPLP_GATHER_STATS
-#ifndef EVPLP_STATS_THRESH
-#define EVPLP_STATS_THRESH 128
-#endif
-    uint32_t st_full_occ = 0, st_full_vis = 0, st_mixed = 0, nodes_prev = 0; unsigned long long st_n256 = 0, st_n96 = 0, st_nlow = 0;
-#endif
+    uint32_t rays = 0;
     for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
         const Vpl v = fetch_vpl(a.vpls + i);
         V3 v12 = v.pos - px.p1;                                         // :282
@@ -149,23 +143,13 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         if (ballot64(active) == 0ull) continue;
         rays += active ? 1u : 0u;
         // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
-        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, lds_stack, nodes);
-#ifdef EVPLP_GATHER_STATS
-        { uint32_t nv = nodes - nodes_prev; nodes_prev = nodes;
-          if (nv > EVPLP_STATS_THRESH) { st_full_occ++; st_n256 += nv; } st_nlow += nv; }
-#endif
+        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
         if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
     }
     if (t.in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
     // statistics: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0) {
-        atomicAdd(&a.counters->rays, (unsigned long long)rays);
-#ifdef EVPLP_GATHER_STATS
-        atomicAdd(&a.counters->pairs, (unsigned long long)st_full_occ); atomicAdd(&a.counters->aux, st_n256);
-        atomicAdd(&a.counters->nodes, st_nlow);
-#endif
-    }
+    if (lane == 0) atomicAdd(&a.counters->rays, (unsigned long long)rays);
 }
 
 // out = (sum of the kVplSplit partials in split order) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378)
@@ -393,7 +377,6 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, con
 #define EVPLP_VSL_WAVES 6   // 3: 88 ms, 4: 77 ms, 5: 76 ms, 6: 74 ms (512^2, 760 VSLs)
 #endif
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
-    __shared__ int32_t lds_stack[kMaxDepth];
     const int lane = threadIdx.x;
     const int W = a.st.W;
     const Item t = item_setup(a.st, lane);
@@ -417,14 +400,14 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
     }
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0, nodes = 0;
+    uint32_t rays = 0;
     for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
         const Vpl v = fetch_vpl(a.vpls + i);
         V3 v12 = v.pos - px.p1;                                       // :605
         float dist2 = dot(v12, v12);
         float dist = sqrtf(dist2);
         rays += valid ? 1u : 0u;
-        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid, lds_stack, nodes);  // :612-614
+        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid);  // :612-614
         V3 nv12 = v12 / dist;
         float c1c2 = fmaxf(dot(px.n1, nv12), 0.0f) * fmaxf(-dot(v.n, nv12), 0.0f);
         bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
