@@ -368,7 +368,7 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
 
 static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, GatherArgs &a, int pass) {
     std::memset(&a, 0, sizeof(a));
-    a.sc = c->sc; a.st = c->st; a.fp = *fp;
+    a.sc = c->sc; a.st = c->st; a.fp = *fp; a.pdf_mc2 = fp->pdf_mc * fp->pdf_mc;
     a.g_pos = (const float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (const float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
     a.g_dif = (const float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (const float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
     a.vpls = c->d_vpls; a.vpl_src_index = c->d_vpl_src; a.nvpl = &c->d_scalars[0];

@@ -31,6 +31,7 @@ struct GatherArgs {
     const uint32_t *vpl_src_index;    // VSL only: original record index of each compacted VPL (RNG substream)
     const uint32_t *nvpl;             // device scalar written by compact_vpl_kernel
     evplp_frame_params fp;
+    float pdf_mc2; int32_t pad0;      // fp.pdf_mc squared (power2 heuristic)
     float4 *out;
     float4 *partial;                  // [kVplSplit][partial_stride] per-item partial sums
     size_t partial_stride;            // W * local_rows

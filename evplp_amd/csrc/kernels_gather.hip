@@ -38,7 +38,7 @@ EV_DEV Vpl load_vpl(const float4 *r) {
 }
 
 // vplSplat after the visibility test (rt/lighttracing.cu:296-345)
-EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v, V3 v12, float c1c2) {
+EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px, const Vpl &v, V3 v12, float c1c2) {
     float dist2 = dot(v12, v12);
     float dist = sqrtf(dist2);
     V3 wi12 = v12 / dist;
@@ -63,7 +63,7 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v,
         float w;
         if (mode == 1u) w = fp.pdf_mc / (fp.pdf_mc + pdf_de);
         else if (mode == 2u) w = fp.pdf_mc > pdf_de ? 1.0f : 0.0f;
-        else { float a2 = fp.pdf_mc * fp.pdf_mc, b2 = pdf_de * pdf_de; w = a2 / (a2 + b2); }
+        else { float a2 = pdf_mc2, b2 = pdf_de * pdf_de; w = a2 / (a2 + b2); }   // pdfMc^2 squared on the host: a kernel-argument SGPR instead of a hoisted VGPR
         return (v.flux * w) * brdf1 * brdf2 * g21;
     }
     if (mode == 4u) return (v.flux * fminf(g21, fp.clamping_value)) * brdf1 * brdf2;
@@ -82,7 +82,7 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, const Pixel &px, const Vpl &v,
 #define EVPLP_SUPER_LOG2 0     // super-tile edge = 2^k tiles; measured per cfg2 frame: k=3 103.9 ms, 2 99.0, 1 94.8, 0 92.0
 #endif
 constexpr int kSuperLog2 = EVPLP_SUPER_LOG2, kSuper = 1 << kSuperLog2, kSuperTiles = kSuper * kSuper;
-struct Item { int x, ly, gy, split; bool in_image, has_tile; size_t p; };
+struct Item { int x, ly, gy, split; bool in_image, has_tile; uint32_t p; };   // p: pixel index in the strip (W * local_rows < 2^32)
 EV_DEV Item item_setup(const StripDev &st, int lane) {
     const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
     const int sx = (tiles_x + kSuper - 1) >> kSuperLog2, sy = (tiles_y + kSuper - 1) >> kSuperLog2;   // super-tile grid
@@ -98,7 +98,7 @@ EV_DEV Item item_setup(const StripDev &st, int lane) {
     const int cly = min(t.ly, st.local_rows - 1);
     t.gy = st.global_row(cly);
     t.in_image = t.has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
-    t.p = (size_t)cly * st.W + min(t.x, st.W - 1);
+    t.p = (uint32_t)cly * (uint32_t)st.W + (uint32_t)min(t.x, st.W - 1);
     return t;
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     const int lane = threadIdx.x;
     const Item t = item_setup(a.st, lane);
     if (!t.has_tile) return;   // padding of the super-tile grid
-    const size_t p = t.p;
+    const uint32_t p = t.p;
 
     Pixel px;
     float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         rays += active ? 1u : 0u;
         // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
         bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
-        if (active && !occ) result = result + vpl_shade(a.fp, px, v, v12, c1c2);
+        if (active && !occ) result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2);
     }
     if (t.in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
     // statistics: one atomic per wave
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evpl
             if (c1c2 <= 0.0f) continue;
             rays++;
             if (occluded_lane<64>(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, stack)) continue;
-            result = result + vpl_shade(a.fp, px, v, v12, c1c2);
+            result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2);
         }
     }
     const float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
     const int W = a.st.W;
     const Item t = item_setup(a.st, lane);
     if (!t.has_tile) return;
-    const size_t p = t.p;
+    const uint32_t p = t.p;
     const bool in_image = t.in_image;
 
     Pixel px;
