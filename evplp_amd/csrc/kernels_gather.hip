@@ -59,7 +59,7 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
     if (mode == 0u) return v.flux * brdf1 * brdf2 * g21;
     if (mode <= 3u) {
         float pdf_de = lambert_pdf_a(v.n, px.n1, -v12) * v.psel;
-        pdf_de += phong_pdf_a(v.n, px.n1, -v12, v.fdir, v.rs, v.e) * (1.0f - v.psel);
+        if (!(v.rs.x <= 0.000001f)) pdf_de += phong_pdf_a(v.n, px.n1, -v12, v.fdir, v.rs, v.e) * (1.0f - v.psel);   // wave-uniform; PhongPdfA is 0 there (rtmaterial.cuh:92)
         float w;
         if (mode == 1u) w = fp.pdf_mc / (fp.pdf_mc + pdf_de);
         else if (mode == 2u) w = fp.pdf_mc > pdf_de ? 1.0f : 0.0f;
