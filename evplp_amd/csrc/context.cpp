@@ -294,7 +294,7 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
     if ((rc = upload_array(c, bb.leaves, (size_t)std::max(bb.nleaves, 1), &c->sc.leaves))) { free_bvh(&bb); return rc; }
     if ((rc = upload_array(c, bb.tri_index, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
-    c->sc.ntris = bb.ntris;
+    c->sc.ntris = bb.ntris; c->sc.bvh_depth = bb.depth;
     free_bvh(&bb);
     if ((rc = upload_array(c, attrs.data(), attrs.size(), &c->sc.attrs))) return rc;
     if ((rc = upload_array(c, c->materials.data(), c->materials.size(), &c->sc.materials))) return rc;

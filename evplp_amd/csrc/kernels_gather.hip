@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 // there is no shared origin to build a packet on: one shadow ray per lane, per-lane LDS stack (the authors
 // note the variant is experimental and slower than the plain gather for the same reason).
 __global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evplp_record *records) {
-    __shared__ int32_t lds_stack[kMaxDepth * 64];
+    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evpl
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
     if (tiles_x * tiles_y == 0) return;
-    hipLaunchKernelGGL(gather_lvc_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a, records);
+    hipLaunchKernelGGL(gather_lvc_kernel, dim3(tiles_x * tiles_y), dim3(64), lane_stack_bytes(a.sc), s, a, records);
 }
 
 // ------------------------------------------------------------------------------------ VSL

@@ -16,7 +16,7 @@ EV_DEV float russian_prob_pt(V3 t) { return fmaxf(fmaxf(t.x, 0.98f), fmaxf(t.y, 
 EV_DEV float pdf_w2a(V3 n2, V3 v12) { V3 nv = normalize(v12); return fmaxf(-dot(n2, nv), 0.f) / dot(v12, v12); }
 
 __global__ __launch_bounds__(64) void path_trace_kernel(PathTraceArgs a) {
-    __shared__ int32_t lds_stack[kMaxDepth * 64];
+    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
     const int tile = blockIdx.x;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void path_trace_kernel(PathTraceArgs a) {
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
     if (tiles_x * tiles_y == 0) return;
-    hipLaunchKernelGGL(path_trace_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(path_trace_kernel, dim3(tiles_x * tiles_y), dim3(64), lane_stack_bytes(a.sc), s, a);
 }
 
 } // namespace evplp

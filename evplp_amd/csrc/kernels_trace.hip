@@ -9,10 +9,8 @@
 
 namespace evplp {
 
-constexpr int kLaneStack = kMaxDepth;  // entries per lane
-
 __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
-    __shared__ int32_t lds_stack[kLaneStack * 64];
+    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
     const int tile = blockIdx.x;
@@ -74,7 +72,7 @@ EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float ps
 }
 
 __global__ __launch_bounds__(64) void light_trace_kernel(LightTraceArgs a) {
-    __shared__ int32_t lds_stack[kLaneStack * 64];
+    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const uint32_t local = blockIdx.x * 64u + lane;
     if (local >= a.path_count) return;
@@ -172,11 +170,11 @@ __global__ __launch_bounds__(1024) void compact_vpl_kernel(const evplp_record *r
 
 void launch_primary(const PrimaryArgs &a, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
-    hipLaunchKernelGGL(primary_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(primary_kernel, dim3(tiles_x * tiles_y), dim3(64), lane_stack_bytes(a.sc), s, a);
 }
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s) {
     if (a.path_count == 0) return;
-    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), lane_stack_bytes(a.sc), s, a);
 }
 void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
                         uint32_t *count_out, hipStream_t s) {
