@@ -65,7 +65,8 @@ struct SplatArgs {
     uint32_t bin_capacity;
     uint32_t *bin_items_tmp;  // [bin_capacity] (deterministic mode: unsorted fill target)
     float4 *compact;          // [num_records * kCompactF4] per-photon pre-shaded data
-    uint2 *rect;              // [num_records] packed tile rectangle (x0 | x1<<16, y0 | y1<<16), x0 > x1 = none
+    uint4 *stage;             // [bin_capacity] staged bin entries (tile, rank in the tile's bin, photon id, -)
+    uint32_t *entry_cursor;   // device scalar: staged entries so far
     uint32_t *overflow;       // device flag: bins did not fit
     int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
     PassCounters *counters;
@@ -85,7 +86,7 @@ void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_e
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s);
 void launch_splat_count(const SplatArgs &a, hipStream_t s);
-void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
+void launch_splat_tiles(const SplatArgs &a, uint32_t total_entries, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s);

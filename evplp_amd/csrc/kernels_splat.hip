@@ -41,9 +41,9 @@ EV_DEV float g_phong_pdf_w(V3 n1, V3 wi12, V3 inv_, V3 rs, float e) {
     return (e + 1.0f) * 0.5f * EV_INV_PI * powf(d, e);
 }
 
+constexpr int kRecF4 = sizeof(evplp_record) / 16;   // 6 float4 per record
 struct Rec { V3 pos, n, flux, fdir, rd, rs; float psel, e; uint32_t flags; };
-EV_DEV Rec load_rec(const evplp_record *r) {
-    const float4 *q = reinterpret_cast<const float4 *>(r);
+EV_DEV Rec load_rec(const float4 *q) {
     float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
     Rec v; v.pos = v3(a); v.flags = __float_as_uint(a.w); v.n = v3(b); v.psel = b.w; v.flux = v3(c);
     v.fdir = v3(d); v.rd = v3(e); v.rs = v3(f); v.e = f.w;
@@ -51,14 +51,13 @@ EV_DEV Rec load_rec(const evplp_record *r) {
 }
 
 // compact photon: [0] pos.xyz, cpn   [1] w12.xyz, d2   [2] wflux.xyz, alive   [3] brdf2.xyz, n1.w12 (unused)
-__global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.num_records) return;
-    uint2 none = make_uint2(1u, 0u);  // x0 = 1 > x1 = 0
-    if (i == 0) { a.rect[i] = none; return; }
-    Rec ph = load_rec(a.records + i);
-    if (!(ph.flags & EVPLP_USABLE_PHOTON)) { a.rect[i] = none; return; }  // vert:31, geom:20
-    Rec prev = load_rec(a.records + i - 1);                               // frag:163
+// Everything of one photon that does not depend on the pixel (compact record) + its conservative rectangle of 8x8-px
+// tiles, packed (x0 | x1 << 16, y0 | y1 << 16); x0 > x1 = nothing to splat.
+EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_ph, const float4 *s_prev) {
+    const uint2 none = make_uint2(1u, 0u);
+    Rec ph = load_rec(s_ph);
+    if (!(ph.flags & EVPLP_USABLE_PHOTON)) return none;  // vert:31, geom:20
+    Rec prev = load_rec(s_prev);                    // frag:163
 
     const float r = a.fp.photon_radius;
     V3 v12 = prev.pos - ph.pos;                                           // frag:170
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
     // whole-screen fallback (those few photons used to produce most of the bin entries)
     const float zlo = fmaxf(vz - r, 0.1f), zhi = fminf(vz + r, 100.0f);
     int x0, x1, y0, y1;
-    if (zlo > zhi) { a.rect[i] = none; return; }
+    if (zlo > zhi) return none;
     {
         float sx = 1.0f / (a.cam.aspect * a.cam.tan_half), sy = 1.0f / a.cam.tan_half;
         float il = 1.0f / zlo, ih = 1.0f / zhi;
@@ -109,16 +108,58 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
         x0 = max((int)ceilf(fx0), 0); x1 = min((int)floorf(fx1), a.st.W - 1);
         y0 = max((int)ceilf(fy0), 0); y1 = min((int)floorf(fy1), a.st.H - 1);
     }
-    if (x0 > x1 || y0 > y1) { a.rect[i] = none; return; }
+    if (x0 > x1 || y0 > y1) return none;
     int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3;   // GLOBAL tile rows
-    a.rect[i] = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
-    const int tiles_per_block = a.st.strip_rows >> 3;
-    for (int ty = ty0; ty <= ty1; ty++) {
-        int blk = ty / tiles_per_block;
-        if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
-        int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
-        for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tile_count[lty * a.tiles_x + tx], 1u);
+    return make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+}
+
+// The 96-byte AoS records are read ONCE, as a coalesced 16 B/lane stream, into LDS (slot k = record base - 1 + k:
+// every photon also needs its predecessor on the light path, frag:163); a lane then picks its two records from LDS.
+// One lane per record reading its own 6 float4 at a 96-byte stride touched every line six times and every record
+// twice.
+__global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
+    __shared__ float4 s_rec[257 * kRecF4];
+    const uint32_t base = blockIdx.x * 256u;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.records);
+        const uint32_t first = base == 0u ? 0u : base - 1u, last = min(base + 256u, a.num_records);   // records [first, last)
+        const uint32_t n4 = (last - first) * kRecF4, slot0 = (first + 1u - base) * kRecF4;
+        for (uint32_t k = threadIdx.x; k < n4; k += 256u) s_rec[slot0 + k] = src[(size_t)first * kRecF4 + k];
     }
+    __syncthreads();
+    const uint32_t i = base + threadIdx.x;
+    uint2 rc = make_uint2(1u, 0u);
+    if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(threadIdx.x + 1u) * kRecF4], &s_rec[threadIdx.x * kRecF4]);
+    const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
+    // bin entries of this photon on THIS rank's row strips
+    const int tiles_per_block = a.st.strip_rows >> 3;
+    uint32_t k = 0;
+    if (tx0 <= tx1)
+        for (int ty = ty0; ty <= ty1; ty++) if ((ty / tiles_per_block) % a.st.strip_count == a.st.strip_rank) k += (uint32_t)(tx1 - tx0 + 1);
+    // one cursor bump per WAVE reserves the staging slots of its 64 photons (wave-inclusive scan of k); device-scope
+    // atomics execute at the memory side (~20 G/s chip-wide for scattered words), so they are spent only where the
+    // returned value is needed: the per-tile rank below
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = k;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    const uint32_t wave_total = __shfl(incl, 63);
+    uint32_t wave_base = 0;
+    if (wave_total != 0u) {
+        if (lane == 0) wave_base = atomicAdd(a.entry_cursor, wave_total);
+        wave_base = __shfl(wave_base, 0);
+    }
+    uint32_t pos = wave_base + incl - k;
+    if (k != 0u)
+        for (int ty = ty0; ty <= ty1; ty++) {
+            int blk = ty / tiles_per_block;
+            if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
+            int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
+            for (int tx = tx0; tx <= tx1; tx++, pos++) {
+                const uint32_t tile = (uint32_t)(lty * a.tiles_x + tx);
+                const uint32_t rank = atomicAdd(&a.tile_count[tile], 1u);  // position of this photon in the tile's bin
+                if (pos < a.bin_capacity) a.stage[pos] = make_uint4(tile, rank, i, 0u);
+            }
+        }
 }
 
 // single-workgroup exclusive scan over the tile counts (<= a few 100k tiles)
@@ -146,23 +187,12 @@ __global__ __launch_bounds__(1024) void splat_scan_kernel(const uint32_t *count,
     if (tid == 0) { offset[n] = carry; if (carry > capacity) *overflow = carry; }
 }
 
-__global__ __launch_bounds__(256) void splat_fill_kernel(SplatArgs a, uint32_t *items) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.num_records) return;
-    uint2 rc = a.rect[i];
-    int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
-    if (tx0 > tx1) return;
-    const int tiles_per_block = a.st.strip_rows >> 3;
-    for (int ty = ty0; ty <= ty1; ty++) {
-        int blk = ty / tiles_per_block;
-        if (blk % a.st.strip_count != a.st.strip_rank) continue;
-        int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
-        for (int tx = tx0; tx <= tx1; tx++) {
-            int tile = lty * a.tiles_x + tx;
-            uint32_t slot = a.tile_offset[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
-            if (slot < a.bin_capacity) items[slot] = i;
-        }
-    }
+// bin slot = start of the tile's bin + the rank the counting atomic returned: no second round of atomics
+__global__ __launch_bounds__(256) void splat_fill_kernel(SplatArgs a, uint32_t *items, uint32_t total) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= total) return;
+    const uint4 s = a.stage[e];
+    items[a.tile_offset[s.x] + s.y] = s.z;
 }
 
 // deterministic mode: rank sort of every bin (ids are unique) so pixels accumulate in record order
@@ -258,19 +288,22 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
 void launch_splat_count(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * (ntiles + 1), s);
+    hipMemsetAsync(a.entry_cursor, 0, sizeof(uint32_t), s);
     const uint32_t nb = (a.num_records + 255) / 256;
     hipLaunchKernelGGL(splat_prepare_kernel, dim3(nb), dim3(256), 0, s, a);
     hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, s, a.tile_count, a.tile_offset, a.tile_cursor, ntiles, a.bin_capacity, a.overflow);
 }
 // Phase B: fill the bins (capacity already checked by the host) and accumulate the tiles.
-void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
+void launch_splat_tiles(const SplatArgs &a, uint32_t total_entries, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-    const uint32_t nb = (a.num_records + 255) / 256;
-    if (a.deterministic) {
-        hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items_tmp);
-        hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_offset, a.bin_items_tmp, a.bin_items, a.bin_capacity);
-    } else {
-        hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items);
+    const uint32_t nb = (total_entries + 255) / 256;
+    if (nb != 0u) {
+        if (a.deterministic) {
+            hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items_tmp, total_entries);
+            hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_offset, a.bin_items_tmp, a.bin_items, a.bin_capacity);
+        } else {
+            hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items, total_entries);
+        }
     }
     if (dom_begin) hipEventRecord(dom_begin, s);
     hipLaunchKernelGGL(splat_tiles_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
