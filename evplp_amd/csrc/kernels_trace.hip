@@ -2,25 +2,24 @@
 //   primary_kernel      <- shaders/deferred.{vert,geom,frag} + light.{vert,frag} drawn by
 //                          runDeferredProgram / runLightProgram (rt/rtcomphoton/rtcomphoton.h:710-754, 839-855)
 //   light_trace_kernel  <- tracePhotons + rtMaterialClosestHit (rt/lighttracing.cu:192-250, 113-182)
-// Both trace incoherent rays: one ray per lane, closest hit, per-lane stack in LDS laid out
-// [entry][lane] so that a push/pop of the whole wave is one conflict-free ds access.
+// Primary rays of an 8x8 tile share the eye and walk the tree as a packet (closest_wave); light sub-paths are
+// incoherent: one ray per lane, closest hit, per-lane stack in LDS laid out [entry][lane] so that a push/pop of
+// the whole wave is one conflict-free ds access.
 #include "device_common.hpp"
 #include "kernels.h"
 
 namespace evplp {
 
 __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
-    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int x = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
-    if (x >= a.st.W || ly >= a.st.local_rows) return;
-    const int y = a.st.global_row(ly);
-    if (y >= a.st.H) return;
-    const size_t p = (size_t)ly * a.st.W + x;
+    const int y = a.st.global_row(min(ly, a.st.local_rows - 1));
+    const bool in_image = x < a.st.W && ly < a.st.local_rows && y < a.st.H;   // no early return: the walk is wave-collective
+    const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
 
     V3 eye = v3(a.cam.eye), S = v3(a.cam.s), U = v3(a.cam.u), F = v3(a.cam.f);
     float cx = ((float)x + 0.5f) / (float)a.st.W * 2.0f - 1.0f;
@@ -31,11 +30,15 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     V3 dj = S * jx + U * jy + F;
     V3 d0 = S * ox + U * oy + F;
 
-    int32_t *stack = lds_stack + lane;
     float t = 0.f, b = 0.f, g = 0.f, tl = 0.f, bl = 0.f, gl = 0.f;
+    // the 64 primary rays of a tile share the eye: packet walk (closest_wave), no per-lane stack.
     // view depth == t because the camera-space z of the direction is -1: near/far = [0.1, 100] (rtcommon.h:586)
-    int32_t tri = closest_lane<64>(a.sc, eye, dj, 0.1f, 100.0f, 1, t, b, g, stack);
-    int32_t ltri = a.sc.light_count > 0 ? closest_lane<64>(a.sc, eye, d0, 0.1f, 100.0f, 2, tl, bl, gl, stack) : -1;
+    int32_t tri = closest_wave(a.sc, eye, dj, 0.1f, 100.0f, 1, in_image, t, b, g);
+    // the light mesh only matters in front of (or at) the scene hit (depth LEQUAL): bound its walk by that depth --
+    // both directions have camera-space z = -1, so t is the view depth on either ray
+    const float light_far = tri >= 0 ? fminf(t * 1.000001f + 1.0e-30f, 100.0f) : 100.0f;
+    int32_t ltri = a.sc.light_count > 0 ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl) : -1;
+    if (!in_image) return;
     bool use_light = ltri >= 0 && (tri < 0 || tl <= t);  // depth LEQUAL, light mesh drawn last
     if (use_light) { tri = ltri; b = bl; g = gl; }
 
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(1024) void compact_vpl_kernel(const evplp_record *r
 
 void launch_primary(const PrimaryArgs &a, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
-    hipLaunchKernelGGL(primary_kernel, dim3(tiles_x * tiles_y), dim3(64), lane_stack_bytes(a.sc), s, a);
+    hipLaunchKernelGGL(primary_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a);
 }
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s) {
     if (a.path_count == 0) return;
