@@ -1023,7 +1023,8 @@ void evo_splat_photons(const evo_frame_params *fp, int32_t W, int32_t H, int32_t
     float cell = r; int dim[3];
     for (;;) {
         double cells = 1; for (int k = 0; k < 3; k++) { dim[k] = (int)floorf((hi[k] - lo[k]) / cell) + 1; cells *= dim[k]; }
-        if (cells <= 64e6) break; cell *= 2.0f;
+        if (cells <= 64e6) break;
+        cell *= 2.0f;
     }
     size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
     uint32_t *start = (uint32_t *)calloc(ncell + 1, sizeof(uint32_t));
@@ -1052,7 +1053,8 @@ void evo_splat_photons(const evo_frame_params *fp, int32_t W, int32_t H, int32_t
                 int c = (int)floorf((X[k] - lo[k]) / cell);
                 c0[k] = c - reach; c1[k] = c + reach;
                 if (c1[k] < 0 || c0[k] >= dim[k]) skip = 1;
-                if (c0[k] < 0) c0[k] = 0; if (c1[k] >= dim[k]) c1[k] = dim[k] - 1;
+                if (c0[k] < 0) c0[k] = 0;
+                if (c1[k] >= dim[k]) c1[k] = dim[k] - 1;
             }
             if (skip) continue;
             v3 sum = V3(0, 0, 0);
