@@ -260,6 +260,7 @@ def test_row_strips_reassemble_bitwise(room, evplp, oscene, inputs):
     frames = {}
     for count in (1, 2, 4):
         vpl = np.zeros((H, W, 4), np.float32); pm = np.zeros((H, W, 4), np.float32)
+        lvc = np.zeros((H, W, 4), np.float32); pt = np.zeros((H, W, 4), np.float32); vsl = np.zeros((H, W, 4), np.float32)
         for rank in range(count):
             with evplp.Context(W, H, NPATHS, NPATHS, P, strip_rank=rank, strip_count=count, strip_rows=8, deterministic=True) as c:
                 room.upload(c)
@@ -271,11 +272,18 @@ def test_row_strips_reassemble_bitwise(room, evplp, oscene, inputs):
                 ok = rows < H
                 vpl[rows[ok]] = c.download(evplp.BUF_VPL_ACCUM)[ok]
                 pm[rows[ok]] = c.download(evplp.BUF_PHOTON_ACCUM)[ok]
-        frames[count] = (vpl, pm)
+                # the per-pixel RNG streams of the other techniques are keyed by the GLOBAL pixel id
+                c.gather_lvc(evplp.frame_params(**{**kw, "num_vpl_light_paths": NPATHS // 4, "rng_seed": 3}))
+                lvc[rows[ok]] = c.download(evplp.BUF_VPL_ACCUM)[ok]
+                c.gather_vsl(evplp.frame_params(**{**kw, "num_vpl_light_paths": 8, "vsl_radius": 0.4, "vsl_inv_pi_radius2": 1 / (math.pi * 0.16), "rng_seed": 4}))
+                vsl[rows[ok]] = c.download(evplp.BUF_VPL_ACCUM)[ok]
+                c.path_trace(oscene.sd.cam_origin, 6, 3, accumulate=False)
+                pt[rows[ok]] = c.download(evplp.BUF_VPL_ACCUM)[ok]
+        frames[count] = (vpl, pm, lvc, vsl, pt)
     for count in (2, 4):
-        assert frames[count][0].tobytes() == frames[1][0].tobytes(), f"gather differs with {count} strips"
-        assert frames[count][1].tobytes() == frames[1][1].tobytes(), f"splat differs with {count} strips"
-    assert frames[1][0][..., :3].max() > 0 and frames[1][1][..., :3].max() > 0
+        for k, name in enumerate(("gather", "splat", "lvc gather", "vsl gather", "path tracer")):
+            assert frames[count][k].tobytes() == frames[1][k].tobytes(), f"{name} differs with {count} strips"
+    assert all(f[..., :3].max() > 0 for f in frames[1])
 
 
 def test_resolve_composite(ctx, evplp, oracle):
