@@ -59,14 +59,15 @@ struct SplatArgs {
     float4 *out;
     // binning workspace
     uint32_t *tile_count;     // [ntiles + 1]
+    uint32_t *tile_pairs;     // [ntiles] (photon, pixel) pairs accepted in the tile (statistics; summed by the host on demand)
+    float2 *tile_z;           // [ntiles] view-depth range (min, max) of the tile's G-buffer positions
     uint32_t *tile_offset;    // [ntiles + 1] exclusive scan
     uint32_t *tile_cursor;    // [ntiles]
     uint32_t *bin_items;      // [bin_capacity] compact photon ids
     uint32_t bin_capacity;
     uint32_t *bin_items_tmp;  // [bin_capacity] (deterministic mode: unsorted fill target)
     float4 *compact;          // [num_records * kCompactF4] per-photon pre-shaded data
-    uint4 *stage;             // [bin_capacity] staged bin entries (tile, rank in the tile's bin, photon id, -)
-    uint32_t *entry_cursor;   // device scalar: staged entries so far
+    uint4 *rect;              // [num_records] tile rectangle (x0 | x1<<16, y0 | y1<<16; x0 > x1 = none) + 64-bit mask of its tiles that survive the depth cull
     uint32_t *overflow;       // device flag: bins did not fit
     int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
     PassCounters *counters;
@@ -86,7 +87,7 @@ void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_e
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s);
 void launch_splat_count(const SplatArgs &a, hipStream_t s);
-void launch_splat_tiles(const SplatArgs &a, uint32_t total_entries, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
+void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s);

@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 // note the variant is experimental and slower than the plain gather for the same reason).
 __global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evplp_record *records) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
+    __shared__ unsigned long long s_stats[2];
     const int lane = threadIdx.x;
+    if (lane < 2) s_stats[lane] = 0ull;      // single-wave workgroup: in-order LDS, no barrier needed
     const int tiles_x = (a.st.W + 7) >> 3;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int x = tx * 8 + (lane & 7);
@@ -214,8 +216,10 @@ __global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evpl
     const float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
     float4 old = a.out[p];
     a.out[p] = make_float4(result.x / inv + acc * old.x, result.y / inv + acc * old.y, result.z / inv + acc * old.z, 0.0f + acc * old.w);
-    atomicAdd(&a.counters->rays, rays);
-    atomicAdd(&a.counters->pairs, pairs);
+    // statistics: per-wave partial sums through LDS (lanes of masked-out pixels have left), one global atomic each
+    atomicAdd(&s_stats[0], rays); atomicAdd(&s_stats[1], pairs);
+    __threadfence_block();
+    if ((int)__ffsll((long long)__ballot(1)) - 1 == lane) { atomicAdd(&a.counters->rays, s_stats[0]); atomicAdd(&a.counters->pairs, s_stats[1]); }
 }
 
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s) {

@@ -15,21 +15,8 @@ EV_DEV float russian_prob_pt(V3 t) { return fmaxf(fmaxf(t.x, 0.98f), fmaxf(t.y, 
 // pathtracing.cu:93-97
 EV_DEV float pdf_w2a(V3 n2, V3 v12) { V3 nv = normalize(v12); return fmaxf(-dot(n2, nv), 0.f) / dot(v12, v12); }
 
-__global__ __launch_bounds__(64) void path_trace_kernel(PathTraceArgs a) {
-    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
-    const int lane = threadIdx.x;
-    const int tiles_x = (a.st.W + 7) >> 3;
-    const int tile = blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = tx * 8 + (lane & 7);
-    const int ly = ty * 8 + (lane >> 3);
-    if (x >= a.st.W || ly >= a.st.local_rows) return;
-    const int y = a.st.global_row(ly);
-    if (y >= a.st.H) return;
-    const size_t p = (size_t)ly * a.st.W + x;
-    const float4 gp = a.g_pos[p];
-    if (gp.w == 0.0f) return;                                             // stencil (:357)
-    int32_t *stack = lds_stack + lane;
+// one camera path continued from the G-buffer texel p of pixel (x, y); returns the rays it traced
+EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y, size_t p, float4 gp, int32_t *stack) {
 
     const V3 first_pos = v3(gp), first_n = v3(a.g_nrm[p]), rd1 = v3(a.g_dif[p]);
     const float4 ph = a.g_phg[p];
@@ -138,10 +125,27 @@ __global__ __launch_bounds__(64) void path_trace_kernel(PathTraceArgs a) {
     }
     float4 o = a.do_accumulate ? a.out[p] : make_float4(0.f, 0.f, 0.f, 0.f);
     a.out[p] = make_float4(o.x + result.x, o.y + result.y, o.z + result.z, o.w);
-    if (a.counters) {
-        atomicAdd(&a.counters->rays, rays);
-        atomicAdd(&a.counters->pairs, 1ull);
-    }
+    return rays;
+}
+
+__global__ __launch_bounds__(64) void path_trace_kernel(PathTraceArgs a) {
+    extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
+    const int lane = threadIdx.x;
+    const int tiles_x = (a.st.W + 7) >> 3;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const int y = a.st.global_row(min(ly, a.st.local_rows - 1));
+    const bool in_image = x < a.st.W && ly < a.st.local_rows && y < a.st.H;
+    const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
+    const float4 gp = a.g_pos[p];
+    const bool valid = in_image && gp.w != 0.0f;                          // stencil (:357)
+    unsigned long long rays = 0, paths = valid ? 1ull : 0ull;
+    if (valid) rays = path_trace_pixel(a, x, y, p, gp, lds_stack + lane);
+    // statistics: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) { rays += __shfl_xor(rays, off); paths += __shfl_xor(paths, off); }
+    if (lane == 0 && a.counters && paths) { atomicAdd(&a.counters->rays, rays); atomicAdd(&a.counters->pairs, paths); }
 }
 
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s) {

@@ -53,7 +53,7 @@ EV_DEV Rec load_rec(const float4 *q) {
 // compact photon: [0] pos.xyz, cpn   [1] w12.xyz, d2   [2] wflux.xyz, alive   [3] brdf2.xyz, n1.w12 (unused)
 // Everything of one photon that does not depend on the pixel (compact record) + its conservative rectangle of 8x8-px
 // tiles, packed (x0 | x1 << 16, y0 | y1 << 16); x0 > x1 = nothing to splat.
-EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_ph, const float4 *s_prev) {
+EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_ph, const float4 *s_prev, float &view_z) {
     const uint2 none = make_uint2(1u, 0u);
     Rec ph = load_rec(s_ph);
     if (!(ph.flags & EVPLP_USABLE_PHOTON)) return none;  // vert:31, geom:20
@@ -87,6 +87,7 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     // (jittered) camera of this iteration: uMVP of runPhotonSplat is the jittered matrix (:982)
     V3 q = ph.pos - v3(a.cam.eye);
     float vx = dot(q, v3(a.cam.s)), vy = dot(q, v3(a.cam.u)), vz = dot(q, v3(a.cam.f));
+    view_z = vz;
     // visible surface points have view depth in [near, far] = [0.1, 100] (rtcommon.h:586): clip the
     // sphere's depth range to it -- a photon closer than r to the camera plane then needs no
     // whole-screen fallback (those few photons used to produce most of the bin entries)
@@ -113,6 +114,30 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     return make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
 }
 
+// View-depth range of every 8x8-px tile's G-buffer positions (one wave per tile).  A pixel can only receive a
+// photon whose centre is within r of its position, hence within r of its view depth: splat_prepare drops the
+// (photon, tile) entries whose depth intervals cannot meet.  Screen-space bins otherwise collect every photon along
+// the tile's frustum -- floor under the table, wall behind the chairs -- ~6x more than ever pass the radius test.
+// Every in-image pixel counts, background included (its position is the clear colour, which is what the radius test
+// of frag:152-154 sees too).
+__global__ __launch_bounds__(256) void splat_tile_depth_kernel(SplatArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
+    const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
+    const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
+    float zmin = 3.0e38f, zmax = -3.0e38f;
+    if (in_image) {
+        float4 gp = a.g_pos[(size_t)ly * a.st.W + x];
+        float z = dot(v3(gp) - v3(a.cam.eye), v3(a.cam.f));
+        zmin = zmax = z;
+    }
+    for (int off = 32; off > 0; off >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off)); }
+    if (lane == 0) a.tile_z[tile] = make_float2(zmin, zmax);
+}
+
 // The 96-byte AoS records are read ONCE, as a coalesced 16 B/lane stream, into LDS (slot k = record base - 1 + k:
 // every photon also needs its predecessor on the light path, frag:163); a lane then picks its two records from LDS.
 // One lane per record reading its own 6 float4 at a 96-byte stride touched every line six times and every record
@@ -129,35 +154,42 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
     __syncthreads();
     const uint32_t i = base + threadIdx.x;
     uint2 rc = make_uint2(1u, 0u);
-    if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(threadIdx.x + 1u) * kRecF4], &s_rec[threadIdx.x * kRecF4]);
+    float vz = 0.f;
+    if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(threadIdx.x + 1u) * kRecF4], &s_rec[threadIdx.x * kRecF4], vz);
     const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
-    // bin entries of this photon on THIS rank's row strips
+    // depth interval of the photon's sphere, widened by the rounding of the two depth computations (|error| ~ 1e-6 of
+    // the coordinates): a tile whose positions all lie outside it cannot hold a pixel within r of the photon
+    const float zguard = a.fp.photon_radius * 1.0e-3f + 1.0e-4f * fmaxf(fabsf(vz), 1.0f);
+    const float zlo = vz - a.fp.photon_radius - zguard, zhi = vz + a.fp.photon_radius + zguard;
+    // bin entries of this photon on THIS rank's row strips: a 64-bit mask over the (<= 64) tiles of its rectangle,
+    // larger rectangles (huge radii) are not depth-culled
     const int tiles_per_block = a.st.strip_rows >> 3;
+    const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+    const bool small = tx0 <= tx1 && nx * ny <= 64;
+    unsigned long long keep = 0ull;
     uint32_t k = 0;
     if (tx0 <= tx1)
-        for (int ty = ty0; ty <= ty1; ty++) if ((ty / tiles_per_block) % a.st.strip_count == a.st.strip_rank) k += (uint32_t)(tx1 - tx0 + 1);
-    // one cursor bump per WAVE reserves the staging slots of its 64 photons (wave-inclusive scan of k); device-scope
-    // atomics execute at the memory side (~20 G/s chip-wide for scattered words), so they are spent only where the
-    // returned value is needed: the per-tile rank below
-    const int lane = threadIdx.x & 63;
-    uint32_t incl = k;
-    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
-    const uint32_t wave_total = __shfl(incl, 63);
-    uint32_t wave_base = 0;
-    if (wave_total != 0u) {
-        if (lane == 0) wave_base = atomicAdd(a.entry_cursor, wave_total);
-        wave_base = __shfl(wave_base, 0);
-    }
-    uint32_t pos = wave_base + incl - k;
+        for (int ty = ty0; ty <= ty1; ty++) {
+            int blk = ty / tiles_per_block;
+            if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
+            if (!small) { k += (uint32_t)nx; continue; }
+            int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const float2 tz = a.tile_z[lty * a.tiles_x + tx];
+                if (tz.y < zlo || tz.x > zhi) continue;
+                keep |= 1ull << ((ty - ty0) * nx + (tx - tx0));
+                k++;
+            }
+        }
+    if (i < a.num_records) a.rect[i] = make_uint4(rc.x, rc.y, (uint32_t)keep, (uint32_t)(keep >> 32));
     if (k != 0u)
         for (int ty = ty0; ty <= ty1; ty++) {
             int blk = ty / tiles_per_block;
             if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
             int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
-            for (int tx = tx0; tx <= tx1; tx++, pos++) {
-                const uint32_t tile = (uint32_t)(lty * a.tiles_x + tx);
-                const uint32_t rank = atomicAdd(&a.tile_count[tile], 1u);  // position of this photon in the tile's bin
-                if (pos < a.bin_capacity) a.stage[pos] = make_uint4(tile, rank, i, 0u);
+            for (int tx = tx0; tx <= tx1; tx++) {
+                if (small && !((keep >> ((ty - ty0) * nx + (tx - tx0))) & 1ull)) continue;
+                atomicAdd(&a.tile_count[lty * a.tiles_x + tx], 1u);
             }
         }
 }
@@ -187,12 +219,28 @@ __global__ __launch_bounds__(1024) void splat_scan_kernel(const uint32_t *count,
     if (tid == 0) { offset[n] = carry; if (carry > capacity) *overflow = carry; }
 }
 
-// bin slot = start of the tile's bin + the rank the counting atomic returned: no second round of atomics
-__global__ __launch_bounds__(256) void splat_fill_kernel(SplatArgs a, uint32_t *items, uint32_t total) {
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    if (e >= total) return;
-    const uint4 s = a.stage[e];
-    items[a.tile_offset[s.x] + s.y] = s.z;
+// second walk over the photon's surviving tiles: slot = start of the tile's bin + a cursor bump
+__global__ __launch_bounds__(256) void splat_fill_kernel(SplatArgs a, uint32_t *items) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.num_records) return;
+    const uint4 rc = a.rect[i];
+    const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
+    if (tx0 > tx1) return;
+    const unsigned long long keep = (unsigned long long)rc.z | ((unsigned long long)rc.w << 32);
+    const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+    const bool small = nx * ny <= 64;
+    const int tiles_per_block = a.st.strip_rows >> 3;
+    for (int ty = ty0; ty <= ty1; ty++) {
+        int blk = ty / tiles_per_block;
+        if (blk % a.st.strip_count != a.st.strip_rank) continue;
+        int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
+        for (int tx = tx0; tx <= tx1; tx++) {
+            if (small && !((keep >> ((ty - ty0) * nx + (tx - tx0))) & 1ull)) continue;
+            int tile = lty * a.tiles_x + tx;
+            uint32_t slot = a.tile_offset[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
+            if (slot < a.bin_capacity) items[slot] = i;
+        }
+    }
 }
 
 // deterministic mode: rank sort of every bin (ids are unique) so pixels accumulate in record order
@@ -217,7 +265,7 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
     const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
     const uint32_t b = a.tile_offset[tile], e = min(a.tile_offset[tile + 1], a.bin_capacity);
-    if (b >= e) return;
+    if (b >= e) { if (lane == 0) a.tile_pairs[tile] = 0u; return; }
 
     float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
     V3 X = v3(gp), sn = v3(gn), sd = v3(gd), sps = v3(gs); float se = gs.w;
@@ -228,8 +276,10 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     V3 sum = v3(0.f, 0.f, 0.f);
     uint32_t pairs = 0;
     float4 *stage = lds[wave];
+    // no specular lobe anywhere in the tile: PhongEval is rho_s * (...) = exactly 0, skip its powf (wave-uniform)
+    const bool tile_glossy = __ballot(sps.x != 0.0f || sps.y != 0.0f || sps.z != 0.0f) != 0ull;
 
-    for (uint32_t base = b; base < e; base += 64) {
+    for (uint32_t base = b; base < e; base += 64u) {
         uint32_t n = min(64u, e - base);
         if ((uint32_t)lane < n) {
             uint32_t id = a.bin_items[base + lane];
@@ -248,7 +298,8 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
             if (inside) {
                 pairs++;
                 V3 w12 = v3(c1);
-                V3 brdf1 = g_lambert_eval(w10, w12, sn, sd) + g_phong_eval(w10, w12, sn, sps, se);  // frag:181
+                V3 brdf1 = g_lambert_eval(w10, w12, sn, sd);                                       // frag:181
+                if (tile_glossy) brdf1 = brdf1 + g_phong_eval(w10, w12, sn, sps, se);
                 if (c2.w != 0.0f) {                                       // mixPdfW > 0, frag:191
                     V3 col;
                     if (mode <= 3u) col = brdf1 * v3(c2);
@@ -281,29 +332,27 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
         a.out[p] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w);   // additive blend ONE, ONE (:793)
     }
     for (int off = 32; off > 0; off >>= 1) pairs += __shfl_down(pairs, off);
-    if (lane == 0 && pairs) atomicAdd(&a.counters->pairs, (unsigned long long)pairs);
+    if (lane == 0) a.tile_pairs[tile] = pairs;
 }
 
 // Phase A: compact photons + tile counts + exclusive scan (tile_offset[ntiles] = total bin entries).
 void launch_splat_count(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * (ntiles + 1), s);
-    hipMemsetAsync(a.entry_cursor, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(splat_tile_depth_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
     const uint32_t nb = (a.num_records + 255) / 256;
     hipLaunchKernelGGL(splat_prepare_kernel, dim3(nb), dim3(256), 0, s, a);
     hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, s, a.tile_count, a.tile_offset, a.tile_cursor, ntiles, a.bin_capacity, a.overflow);
 }
 // Phase B: fill the bins (capacity already checked by the host) and accumulate the tiles.
-void launch_splat_tiles(const SplatArgs &a, uint32_t total_entries, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
+void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-    const uint32_t nb = (total_entries + 255) / 256;
-    if (nb != 0u) {
-        if (a.deterministic) {
-            hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items_tmp, total_entries);
-            hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_offset, a.bin_items_tmp, a.bin_items, a.bin_capacity);
-        } else {
-            hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items, total_entries);
-        }
+    const uint32_t nb = (a.num_records + 255) / 256;
+    if (a.deterministic) {
+        hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items_tmp);
+        hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_offset, a.bin_items_tmp, a.bin_items, a.bin_capacity);
+    } else {
+        hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items);
     }
     if (dom_begin) hipEventRecord(dom_begin, s);
     hipLaunchKernelGGL(splat_tiles_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
