@@ -450,7 +450,7 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.out = (float4 *)c->buf[EVPLP_BUF_PHOTON_ACCUM];
     a.tile_count = c->d_tile_count; a.tile_z = c->d_tile_z; a.tile_pairs = c->d_tile_pairs; a.tile_offset = c->d_tile_offset; a.tile_cursor = c->d_tile_cursor;
     a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_capacity = c->bin_capacity;
-    a.compact = c->d_compact; a.rect = c->d_rect; a.overflow = &c->d_scalars[8];
+    a.compact = c->d_compact; a.rect = c->d_rect; a.overflow = &c->d_scalars[8]; a.summary = &c->d_scalars[10];
     a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic;
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
@@ -459,10 +459,10 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     launch_splat_count(a, c->stream);
     // The number of (photon, tile) bin entries depends on the photon set and the radius; read it back
     // (4 bytes, one stream sync per splat) and grow the bins when needed instead of dropping photons.
-    uint32_t total = 0;
-    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
-    HIP_TRY(c, hipMemcpyAsync(&total, c->d_tile_offset + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    uint32_t summary[2] = { 0, 0 };
+    HIP_TRY(c, hipMemcpyAsync(summary, &c->d_scalars[10], sizeof(summary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t total = summary[0];
     if (total > c->bin_capacity) {
         uint32_t want = (uint32_t)std::min<uint64_t>((uint64_t)total + total / 4 + 1024, 0xfffffff0ull);
         hipFree(c->d_bin_items); c->d_bin_items = nullptr;
@@ -475,7 +475,14 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
         HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
     }
     c->last_bin_entries = total;
-    launch_splat_tiles(a, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    // Tile kernel variant.  One wave per tile is cheapest while bins are short; when some bins are very full (tiles
+    // that see a floor at grazing angle collect thousands of photons) those waves set the duration of the launch and
+    // four waves per tile win.  Deterministic mode always uses one variant: the fold order is part of the result.
+    // Measured (tiles kernel, ms): fullest bin 1405 entries (config #3): 0.31 with one wave, 0.18 with four; fullest bin 365
+    // (config #4 shape): 0.12 / 0.22.
+    const bool split_tiles = c->cfg.deterministic ? true : summary[1] >= 768u;
+    c->last_bin_max = summary[1];
+    launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
     return pass_end(c, EVPLP_PASS_SPLAT);
 }
@@ -563,7 +570,7 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
         std::vector<uint32_t> tp((size_t)c->tiles_x * c->tiles_y);
         HIP_TRY(c, hipMemcpy(tp.data(), c->d_tile_pairs, tp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint64_t sum = 0; for (uint32_t v : tp) sum += v;
-        out->pairs = sum; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries;
+        out->pairs = sum; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries; out->reserved[1] = c->last_bin_max;
         if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }
     } else if (pass == EVPLP_PASS_PATH_TRACE) { out->pairs = pc.pairs; out->rays = pc.rays; }
     else if (pass == EVPLP_PASS_GATHER_LVC) { out->pairs = pc.pairs; out->rays = pc.rays; }

@@ -42,7 +42,7 @@ struct evplp_context {
     float *d_rgb = nullptr;
     float4 *d_partial = nullptr;              // [kVplSplit][local_rows * W] gather partial sums
     // splat workspace
-    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0, last_bin_entries = 0;
+    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0, last_bin_entries = 0, last_bin_max = 0;
     uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
     float4 *d_compact = nullptr; uint4 *d_rect = nullptr; float2 *d_tile_z = nullptr; uint32_t *d_tile_pairs = nullptr;
 

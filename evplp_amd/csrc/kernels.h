@@ -69,6 +69,7 @@ struct SplatArgs {
     float4 *compact;          // [num_records * kCompactF4] per-photon pre-shaded data
     uint4 *rect;              // [num_records] tile rectangle (x0 | x1<<16, y0 | y1<<16; x0 > x1 = none) + 64-bit mask of its tiles that survive the depth cull
     uint32_t *overflow;       // device flag: bins did not fit
+    uint32_t *summary;        // device: [0] total bin entries, [1] entries of the fullest bin
     int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
     PassCounters *counters;
 };
@@ -87,7 +88,7 @@ void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_e
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s);
 void launch_splat_count(const SplatArgs &a, hipStream_t s);
-void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
+void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s);

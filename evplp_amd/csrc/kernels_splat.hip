@@ -196,15 +196,17 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
 
 // single-workgroup exclusive scan over the tile counts (<= a few 100k tiles)
 __global__ __launch_bounds__(1024) void splat_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor, uint32_t n,
-                                                          uint32_t capacity, uint32_t *overflow) {
+                                                          uint32_t capacity, uint32_t *overflow, uint32_t *summary) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t carry, biggest;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
+    if (tid == 0) { carry = 0; biggest = 0; }
     __syncthreads();
+    uint32_t my_max = 0;
     for (uint32_t start = 0; start < n; start += 1024) {
         uint32_t i = start + tid;
         uint32_t v = i < n ? count[i] : 0u;
+        my_max = max(my_max, v);
         uint32_t incl = v;
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
         if (lane == 63) wsum[wave] = incl;
@@ -216,7 +218,10 @@ __global__ __launch_bounds__(1024) void splat_scan_kernel(const uint32_t *count,
         if (tid == 0) { uint32_t tot = 0; for (int w = 0; w < 16; w++) tot += wsum[w]; carry += tot; }
         __syncthreads();
     }
-    if (tid == 0) { offset[n] = carry; if (carry > capacity) *overflow = carry; }
+    atomicMax(&biggest, my_max);
+    __syncthreads();
+    // summary[0] = total bin entries, summary[1] = fullest bin (the host sizes the bins and picks the tile kernel with them)
+    if (tid == 0) { offset[n] = carry; summary[0] = carry; summary[1] = biggest; if (carry > capacity) *overflow = carry; }
 }
 
 // second walk over the photon's surviving tiles: slot = start of the tile's bin + a cursor bump
@@ -254,20 +259,28 @@ __global__ __launch_bounds__(256) void splat_sort_kernel(const uint32_t *offset,
     }
 }
 
+template <int WAVES>   // waves per tile: 1 (four tiles per workgroup) or 4 (one tile per workgroup, for launches with very full bins)
 __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
+    // One workgroup = one tile; its four waves share the bin (wave w takes the 64-photon batches w, w + 4, ...) and
+    // their per-pixel sums are folded in wave order: the fullest bins (tiles that see a floor at grazing angle) set
+    // the duration of the launch.
     __shared__ float4 lds[4][64 * kCompactF4];
+    __shared__ float4 red[3][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
+    const int part = WAVES == 4 ? wave : 0;                       // this wave's share of the bin
+    const int tile = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (tile >= a.tiles_x * a.tiles_y) return;                    // (WAVES == 1 only: whole waves leave, no barrier below)
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
     const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
     const uint32_t b = a.tile_offset[tile], e = min(a.tile_offset[tile + 1], a.bin_capacity);
-    if (b >= e) { if (lane == 0) a.tile_pairs[tile] = 0u; return; }
+    if (b >= e) { if (lane == 0 && part == 0) a.tile_pairs[tile] = 0u; return; }
 
-    float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
+    // a wave without a batch of its own (most bins hold one or two) only takes part in the fold below
+    const bool has_work = b + 64u * (uint32_t)part < e;
+    float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), gn = gp, gd = gp, gs = gp;
+    if (has_work) { gp = a.g_pos[p]; gn = a.g_nrm[p]; gd = a.g_dif[p]; gs = a.g_phg[p]; }
     V3 X = v3(gp), sn = v3(gn), sd = v3(gd), sps = v3(gs); float se = gs.w;
     V3 w10 = normalize(v3(a.fp.camera_pos) - X);                          // frag:177
     const float r2 = a.fp.photon_radius * a.fp.photon_radius;             // frag:152
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     // no specular lobe anywhere in the tile: PhongEval is rho_s * (...) = exactly 0, skip its powf (wave-uniform)
     const bool tile_glossy = __ballot(sps.x != 0.0f || sps.y != 0.0f || sps.z != 0.0f) != 0ull;
 
-    for (uint32_t base = b; base < e; base += 64u) {
+    for (uint32_t base = b + 64u * (uint32_t)part; base < e; base += 64u * WAVES) {
         uint32_t n = min(64u, e - base);
         if ((uint32_t)lane < n) {
             uint32_t id = a.bin_items[base + lane];
@@ -327,12 +340,19 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (in_image) {
-        float4 o = a.out[p];
-        a.out[p] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w);   // additive blend ONE, ONE (:793)
-    }
     for (int off = 32; off > 0; off >>= 1) pairs += __shfl_down(pairs, off);
-    if (lane == 0) a.tile_pairs[tile] = pairs;
+    if (WAVES == 4) {
+        if (wave != 0) red[wave - 1][lane] = make_float4(sum.x, sum.y, sum.z, lane == 0 ? __uint_as_float(pairs) : 0.f);
+        __syncthreads();
+    }
+    if (part == 0) {
+        if (WAVES == 4) for (int w = 0; w < 3; w++) { float4 q = red[w][lane]; sum = sum + v3(q); if (lane == 0) pairs += __float_as_uint(q.w); }
+        if (in_image) {
+            float4 o = a.out[p];
+            a.out[p] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w);   // additive blend ONE, ONE (:793)
+        }
+        if (lane == 0) a.tile_pairs[tile] = pairs;
+    }
 }
 
 // Phase A: compact photons + tile counts + exclusive scan (tile_offset[ntiles] = total bin entries).
@@ -342,10 +362,10 @@ void launch_splat_count(const SplatArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(splat_tile_depth_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
     const uint32_t nb = (a.num_records + 255) / 256;
     hipLaunchKernelGGL(splat_prepare_kernel, dim3(nb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, s, a.tile_count, a.tile_offset, a.tile_cursor, ntiles, a.bin_capacity, a.overflow);
+    hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, s, a.tile_count, a.tile_offset, a.tile_cursor, ntiles, a.bin_capacity, a.overflow, a.summary);
 }
 // Phase B: fill the bins (capacity already checked by the host) and accumulate the tiles.
-void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
+void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     const uint32_t nb = (a.num_records + 255) / 256;
     if (a.deterministic) {
@@ -355,7 +375,8 @@ void launch_splat_tiles(const SplatArgs &a, hipStream_t s, hipEvent_t dom_begin,
         hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items);
     }
     if (dom_begin) hipEventRecord(dom_begin, s);
-    hipLaunchKernelGGL(splat_tiles_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
+    if (split_tiles) hipLaunchKernelGGL(splat_tiles_kernel<4>, dim3(ntiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(splat_tiles_kernel<1>, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
     if (dom_end) hipEventRecord(dom_end, s);
 }
 

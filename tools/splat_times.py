@@ -14,4 +14,4 @@ for (W, H, N, mode) in ((1024, 1024, 500000, "balance"), (1920, 1080, 300000, "o
         for it in range(3):
             c.splat_photons(ev.frame_params(**kw), clear=True); c.synchronize()
         st = c.pass_stats(ev.PASS_SPLAT)
-        print("%dx%d N=%d %s: splat %.3f ms (tiles %.3f) pairs %.3e bin entries %d light %.3f primary %.3f" % (W, H, N, mode, st["ms"], st["dominant_kernel_ms"], st["pairs"], st["nodes"], c.pass_stats(ev.PASS_LIGHT_TRACE)["ms"], c.pass_stats(ev.PASS_PRIMARY)["ms"]))
+        print("%dx%d N=%d %s: splat %.3f ms (tiles %.3f) pairs %.3e bin entries %d (fullest bin %d) light %.3f primary %.3f" % (W, H, N, mode, st["ms"], st["dominant_kernel_ms"], st["pairs"], st["nodes"] & 0xffffffff, st["nodes"] >> 32, c.pass_stats(ev.PASS_LIGHT_TRACE)["ms"], c.pass_stats(ev.PASS_PRIMARY)["ms"]))
