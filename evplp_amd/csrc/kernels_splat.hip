@@ -167,31 +167,22 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
     const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
     const bool small = tx0 <= tx1 && nx * ny <= 64;
     unsigned long long keep = 0ull;
-    uint32_t k = 0;
     if (tx0 <= tx1)
         for (int ty = ty0; ty <= ty1; ty++) {
             int blk = ty / tiles_per_block;
             if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
-            if (!small) { k += (uint32_t)nx; continue; }
             int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
             for (int tx = tx0; tx <= tx1; tx++) {
-                const float2 tz = a.tile_z[lty * a.tiles_x + tx];
-                if (tz.y < zlo || tz.x > zhi) continue;
-                keep |= 1ull << ((ty - ty0) * nx + (tx - tx0));
-                k++;
+                const int tile = lty * a.tiles_x + tx;
+                if (small) {
+                    const float2 tz = a.tile_z[tile];
+                    if (tz.y < zlo || tz.x > zhi) continue;
+                    keep |= 1ull << ((ty - ty0) * nx + (tx - tx0));
+                }
+                atomicAdd(&a.tile_count[tile], 1u);
             }
         }
     if (i < a.num_records) a.rect[i] = make_uint4(rc.x, rc.y, (uint32_t)keep, (uint32_t)(keep >> 32));
-    if (k != 0u)
-        for (int ty = ty0; ty <= ty1; ty++) {
-            int blk = ty / tiles_per_block;
-            if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
-            int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
-            for (int tx = tx0; tx <= tx1; tx++) {
-                if (small && !((keep >> ((ty - ty0) * nx + (tx - tx0))) & 1ull)) continue;
-                atomicAdd(&a.tile_count[lty * a.tiles_x + tx], 1u);
-            }
-        }
 }
 
 // single-workgroup exclusive scan over the tile counts (<= a few 100k tiles)
