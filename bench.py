@@ -221,11 +221,21 @@ def main():
                                      "tiles_kernel_ms": sum(splat_tiles_ms) / len(splat_tiles_ms), "pairs_per_frame": spairs / a.steps}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(json_path, a.res, a.cpu_iters)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     ctx.close()
+    # The JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio, which is
+    # block-buffered on a pipe and would otherwise surface after it at exit.  Every rank pushes its C buffers
+    # out, all ranks meet, then rank 0 prints.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
