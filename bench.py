@@ -235,6 +235,8 @@ def main():
         dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
     if rank == 0:
+        if world > 1:
+            time.sleep(1.0)       # let the other ranks' processes drain whatever they still print while exiting
         print(json.dumps(out), flush=True)
 
 
