@@ -37,6 +37,19 @@ struct Ctx {   // RAII for the C handle
 void check(evplp_context *h, int rc, const char *what) {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + evplp_last_error(h));
 }
+// Output files named in the technique block.  The shipped scene files carry the authors' Windows paths
+// ("C://result/conference/3_pm.pfm"): off Windows a drive-letter path keeps only its file name and lands next to
+// the scene JSON, so those files run unchanged; every other path is used as the reference would (relative to the
+// working directory there, to the JSON's directory here).
+std::string output_path(const std::string &out_dir, const std::string &name) {
+    if (name.size() > 1 && name[1] == ':' && ((name[0] >= 'A' && name[0] <= 'Z') || (name[0] >= 'a' && name[0] <= 'z'))) {
+        size_t cut = name.find_last_of("/\\");
+        std::string base = cut == std::string::npos ? name.substr(2) : name.substr(cut + 1);
+        std::fprintf(stderr, "note: output \"%s\" has a drive letter; writing %s/%s\n", name.c_str(), out_dir.c_str(), base.c_str());
+        return out_dir + "/" + base;
+    }
+    return join_path(out_dir, name);
+}
 // FloatImage::FlipY (floatimage.cpp:114-128) of a bottom-up RGB image + row de-interleave
 std::vector<float> flip_y(const std::vector<float> &rgb, int w, int h) {
     std::vector<float> out((size_t)w * h * 3);
@@ -77,8 +90,8 @@ public:
             if (it == kFrameModes.end()) throw JsonError("frameMode: unknown value \"" + fm + "\"");
             frame_mode = it->second;
         }
-        output_filename = join_path(out_dir, json.at("outputFilename").as_string("outputFilename"));
-        stat_filename = join_path(out_dir, json.at("statFilename").as_string("statFilename"));
+        output_filename = output_path(out_dir, json.at("outputFilename").as_string("outputFilename"));
+        stat_filename = output_path(out_dir, json.at("statFilename").as_string("statFilename"));
         use_jitter = json.at("useJitter").as_bool("useJitter");
         use_stat = json.at("useStat").as_bool("useStat");
         (void)json.at("numSamplePerPixel").as_int("numSamplePerPixel");
@@ -184,10 +197,10 @@ public:
             throw JsonError("clampingStart option is not use anymore; remove it from your JSON file");
         if (json.has("targetRenderingTime")) target_rendering_time = json.at("targetRenderingTime").as_float("targetRenderingTime");
         rng_offset = (uint32_t)json.at("rngOffset").as_int("rngOffset");
-        combined_filename = join_path(out_dir, json.at("combinedFilename").as_string("combinedFilename"));
-        weighted_photon_filename = join_path(out_dir, json.at("weightedPhotonFilename").as_string("weightedPhotonFilename"));
-        weighted_vpl_filename = join_path(out_dir, json.at("weightedVplFilename").as_string("weightedVplFilename"));
-        stat_filename = join_path(out_dir, json.at("statFilename").as_string("statFilename"));
+        combined_filename = output_path(out_dir, json.at("combinedFilename").as_string("combinedFilename"));
+        weighted_photon_filename = output_path(out_dir, json.at("weightedPhotonFilename").as_string("weightedPhotonFilename"));
+        weighted_vpl_filename = output_path(out_dir, json.at("weightedVplFilename").as_string("weightedVplFilename"));
+        stat_filename = output_path(out_dir, json.at("statFilename").as_string("statFilename"));
         use_jitter = json.at("useJitter").as_bool("useJitter");
         use_stat = json.at("useStat").as_bool("useStat");
         if (json.has("DoProgressive")) do_progressive = json.at("DoProgressive").as_bool("DoProgressive");

@@ -227,6 +227,30 @@ def test_render_json_pt_and_lvc_blocks(evplp, tmp_path):
         assert wl[key].max() > 0 and rel_l2(g, wl[key]) <= 1e-4, (key, rel_l2(g, wl[key]))
 
 
+def test_render_json_blocks_shaped_like_the_shipped_scene_files(evplp, tmp_path):
+    """The reference's scene files use drive-letter output paths, an extra "renderMode" key nobody reads, and
+    numMaxIteration = -1 with a wall-clock limit (e.g. scene/conference/conference_pm_progressive.json): such blocks
+    must run unchanged -- outputs land next to the scene file, the loop ends on the time limit."""
+    jp = evplp.synth_scene(str(tmp_path), "room", 2500, 2, 64, 40)
+    root = json.load(open(jp))
+    root["photonfam"] = {
+        "rngOffset": 0, "numMaxIteration": -1, "timeLimitMs": 120.0, "frameMode": "accumulate", "renderMode": "pm", "misMode": "one",
+        "combinedFilename": "C://result/room/3_pm.pfm", "weightedPhotonFilename": "C://result/none.pfm", "weightedVplFilename": "C://result/none.pfm",
+        "statFilename": "test.json", "useJitter": True, "useStat": True, "numLightPaths": 2000, "numVplLightPaths": 0, "numMaxBounces": 3,
+        "radiusPercentage": 0.02, "DoProgressive": True, "AlphaProgressive": 0.7}
+    root["pt"] = {"rngOffset": 0, "numMaxIteration": -1, "timeLimitMs": 60.0, "frameMode": "accumulate", "outputFilename": "D:\\out\\room_pt.pfm",
+                  "statFilename": "pt_stat.json", "useJitter": True, "useStat": True, "numSamplePerPixel": 1, "numMaxBounces": 3, "DoProgressive": False}
+    json.dump(root, open(jp, "w"))
+    evplp.render_json(jp)
+    st = json.load(open(tmp_path / "test.json")); pst = json.load(open(tmp_path / "pt_stat.json"))
+    assert st["numIterations"] >= 1 and st["time"] >= 120.0 and pst["numIterations"] >= 1 and pst["time"] >= 60.0
+    pm = evplp.load_pfm(str(tmp_path / "3_pm.pfm")); pt = evplp.load_pfm(str(tmp_path / "room_pt.pfm"))
+    assert os.path.exists(tmp_path / "none.pfm")
+    assert np.isfinite(pm).all() and np.isfinite(pt).all() and pm.max() > 0 and pt.max() > 0
+    # two estimators of the same image (pure photon mapping vs path tracing), both only partly converged here
+    assert abs(pm.mean() / pt.mean() - 1.0) < 0.25
+
+
 def test_render_json_vsl_ppm_and_per_frame_dumps(evplp, tmp_path):
     """forceVsl (progressive VSL radius), numVplLightPaths = 0 (pure photon mapping: the gather is disabled,
     rtcomphoton.h:200-203), run{} switches and writeEveryFrame dumps."""

@@ -148,3 +148,28 @@ def test_image_io_roundtrip_and_errors(evplp, tmp_path):
         evplp.save_image(str(tmp_path / "x.bmp"), img)        # "unsupported file format" floatimage.cpp:272
     with pytest.raises(evplp.EvplpError):
         evplp.load_pfm(str(tmp_path / "none.pfm"))
+
+
+def test_shipped_scene_files_carry_every_key_the_techniques_require():
+    """All 30 scene JSONs of the reference (authoring container only) parse, and their technique blocks hold the
+    keys RtComPhoton::render / RtPt2::render read unconditionally (rtcomphoton.h:114-186, rtpt2.h:91-110)."""
+    import glob
+    files = sorted(glob.glob("/root/reference/scene/*/*.json"))
+    if not files:
+        pytest.skip("reference scenes not present here")
+    need = {"photonfam": ["numLightPaths", "numVplLightPaths", "numMaxBounces", "radiusPercentage", "numMaxIteration", "timeLimitMs", "frameMode", "rngOffset",
+                          "combinedFilename", "weightedPhotonFilename", "weightedVplFilename", "statFilename", "useJitter", "useStat"],
+            "pt": ["rngOffset", "numMaxIteration", "timeLimitMs", "frameMode", "outputFilename", "statFilename", "useJitter", "useStat", "numSamplePerPixel", "numMaxBounces"]}
+    seen = 0
+    for f in files:
+        root = json.load(open(f))
+        assert {"resX", "resY", "scene", "arealight"} <= set(root) and ("camera" in root or "stablecamera" in root), f
+        for block, keys in need.items():
+            if block in root:
+                seen += 1
+                missing = [k for k in keys if k not in root[block]]
+                assert not missing, (f, block, missing)
+                assert root[block]["frameMode"] in ("accumulate", "cleareveryframe")
+                if "misMode" in root[block]:
+                    assert root[block]["misMode"] in ("one", "balance", "max", "power2", "geometryClamp", "geometryBrdfClamp")
+    assert seen == len(files) == 30
