@@ -186,7 +186,12 @@ ObjResult read_obj(HostScene &scene, const std::string &obj_path, bool want_mate
         }
         r.meshes.push_back(std::move(m));
     }
-    if (r.meshes.empty()) throw std::runtime_error("OBJ has no faces: " + obj_path);
+    if (r.meshes.empty()) {
+        std::ifstream head(obj_path); std::string first; std::getline(head, first);
+        if (first.compare(0, 22, "version https://git-lf") == 0)
+            throw std::runtime_error("Impossible to load the scene: " + obj_path + " is a Git-LFS pointer, not the mesh (fetch the asset with git lfs pull)");
+        throw std::runtime_error("OBJ has no faces: " + obj_path);
+    }
     return r;
 }
 

@@ -173,3 +173,11 @@ def test_shipped_scene_files_carry_every_key_the_techniques_require():
                 if "misMode" in root[block]:
                     assert root[block]["misMode"] in ("one", "balance", "max", "power2", "geometryClamp", "geometryBrdfClamp")
     assert seen == len(files) == 30
+
+
+def test_lfs_pointer_meshes_are_reported_as_such(evplp):
+    f = "/root/reference/scene/conference/conference_ours.json"
+    if not os.path.exists(f):
+        pytest.skip("reference scenes not present here")
+    rc, msg = _render(evplp, f)
+    assert rc == evplp.ERR_IO and "Git-LFS pointer" in msg
