@@ -95,9 +95,12 @@ void parse_mtl(const std::string &path, std::map<std::string, MtlEntry> &out, st
         else if (tok == "Kd") ss >> out[cur].kd[0] >> out[cur].kd[1] >> out[cur].kd[2];
         else if (tok == "Ks") ss >> out[cur].ks[0] >> out[cur].ks[1] >> out[cur].ks[2];
         else if (tok == "Ns") ss >> out[cur].ns;
-        else if (tok == "map_Kd") ss >> out[cur].map_kd;
-        else if (tok == "map_Ks") ss >> out[cur].map_ks;
-        else if (tok == "map_Ns") ss >> out[cur].map_ns;
+        else if (tok == "map_Kd" || tok == "map_Ks" || tok == "map_Ns") {
+            // the file name is the last token (options such as "-s 1 1 1" may precede it); backslashes of Windows exporters
+            std::string name, t; while (ss >> t) name = t;
+            for (char &ch : name) if (ch == '\\') ch = '/';
+            (tok == "map_Kd" ? out[cur].map_kd : tok == "map_Ks" ? out[cur].map_ks : out[cur].map_ns) = name;
+        }
     }
 }
 
