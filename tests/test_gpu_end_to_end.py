@@ -356,6 +356,36 @@ def test_full_size_sampled_pixels_and_properties(evplp, full_scene):
     assert err.max() <= 2e-4, err.max()
 
 
+def test_largest_baseline_shapes_run(evplp, full_scene):
+    """Buffer sizes of the largest BASELINE shapes: 2048^2 (config #5; 4.3 GB of gather partials) and 1920x1080
+    (config #4), every pass once with small path counts; finite, non-empty results and consistent counters."""
+    for (W, H) in ((2048, 2048), (1920, 1080)):
+        N, NV, P = 20000, 16, 4
+        with evplp.Context(W, H, N, NV, P) as c:
+            c.load_scene_json(full_scene)
+            cam = c.camera(); bsr, total, _ = c.scene_metrics(); r = 0.003 * bsr
+            # the scene file was written for a square image: give the context's aspect to the camera
+            c.set_camera(list(cam.origin), list(cam.lookat), list(cam.up), cam.fovy, W / H)
+            kw = dict(camera_pos=list(cam.origin), mis_mode="balance", pdf_mc=(NV / N) / math.pi / (r * r), photon_radius=r, vsl_radius=0.05 * bsr,
+                      vsl_inv_pi_radius2=1.0 / (math.pi * (0.05 * bsr) ** 2), num_light_paths=N, num_vpl_light_paths=NV, photons_per_path=P)
+            c.primary((0.0, 0.0), clear_light=True); c.trace_light_paths(1)
+            c.gather_vpl(evplp.frame_params(**kw))
+            vpl = c.download(evplp.BUF_VPL_ACCUM)[:H]
+            st = c.pass_stats(evplp.PASS_GATHER_VPL)
+            assert st["pairs"] == st["usable"] * W * H and st["usable"] > NV
+            c.gather_vsl(evplp.frame_params(**{**kw, "num_vpl_light_paths": 2}))
+            vsl = c.download(evplp.BUF_VPL_ACCUM)[:H]
+            c.splat_photons(evplp.frame_params(**kw), clear=True)
+            pm = c.download(evplp.BUF_PHOTON_ACCUM)[:H]
+            assert c.pass_stats(evplp.PASS_SPLAT)["pairs"] > 10000
+            c.path_trace(list(cam.origin), 0, 3, accumulate=False)
+            pt = c.download(evplp.BUF_VPL_ACCUM)[:H]
+            img = c.resolve(1.0, 1.0, 1.0)[:H]
+        for name, im in (("vpl", vpl), ("vsl", vsl), ("pm", pm), ("pt", pt), ("resolve", img)):
+            assert np.isfinite(im).all() and im[..., :3].max() > 0, (W, H, name)
+        assert (pt[..., :3].sum(-1) > 0).mean() > 0.9
+
+
 def test_full_size_photon_splat_rows(evplp, full_scene):
     """BASELINE config #3 size: 500 000 light paths x 4 = 2 M record slots splatted at 1024^2 with
     r = 0.3 % of the bounding-sphere radius, misMode balance; whole rows checked against the oracle, plus
