@@ -302,19 +302,27 @@ EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot
 // evplp_build_accel rejects trees deeper than 62 levels, so 64 entries always suffice.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit,
 // rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
 EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// [0, 1] clamp that the backend folds into the clamp modifier of the instruction producing x
+EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
 EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
     // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
     // far bound `tfar`: a lane that is inactive or already occluded carries tfar = -1, so its slab tests
     // fail by themselves and the ballots need no masking with `alive`.
-    const V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    // The slab test runs in the segment's own parameter u = (t - tmin) / (tmax - tmin): entry / exit distances are
+    // clamped to [0, 1] by the clamp modifier of the v_max3 / v_min3 that form them (no separate max with tmin /
+    // min with tmax), and a box is entered iff entry < exit (a box wholly before the start or beyond the end clamps
+    // both to the same end point; a box that holds part of a triangle inside the range is padded, so its interval
+    // is far wider than an ulp).  Lanes without a live ray are masked out of the ballots by `alive`.
+    const V3 inv0 = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const float ku = 1.0f / (tmax - tmin);
+    const V3 inv = inv0 * ku;
     const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
     const v2f avx = bc(fabsf(inv.x)), avy = bc(fabsf(inv.y)), avz = bc(fabsf(inv.z));
-    const v2f nox = bc(-(o.x * inv.x)), noy = bc(-(o.y * inv.y)), noz = bc(-(o.z * inv.z));
+    const v2f nox = bc((-(o.x * inv0.x) - tmin) * ku), noy = bc((-(o.y * inv0.y) - tmin) * ku), noz = bc((-(o.z * inv0.z) - tmin) * ku);
     unsigned long long alive = ballot64(alive_lane), hitm = 0ull;
     if (alive == 0ull) return false;
-    float tfar = alive_lane ? tmax : -1.0f;
     int sp = 0;
     int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
@@ -329,9 +337,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
             const v2f enx = pk_fma(hx, -avx, ax), eny = pk_fma(hy, -avy, ay), enz = pk_fma(hz, -avz, az);
             const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
-            const float tn0 = fmaxf(fmaxf(enx.x, eny.x), fmaxf(enz.x, tmin)), tf0 = fminf(fminf(exx.x, exy.x), fminf(exz.x, tfar));
-            const float tn1 = fmaxf(fmaxf(enx.y, eny.y), fmaxf(enz.y, tmin)), tf1 = fminf(fminf(exx.y, exy.y), fminf(exz.y, tfar));
-            const unsigned long long m0 = ballot64(tn0 <= tf0), m1 = ballot64(tn1 <= tf1);
+            const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
+            const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
+            const unsigned long long m0 = ballot64(tn0 < tf0) & alive, m1 = ballot64(tn1 < tf1) & alive;
             const int32_t c0 = n[12], c1 = n[13];
             // 32-bit scalar compares on purpose: this compiler turns compares of 64-bit masks into lane-mask
             // booleans (s_cselect_b64 / s_and exec / s_cbranch_vcc, 4-5 instructions per branch)
@@ -371,8 +379,7 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if (hm != 0ull) {
                 hitm |= hm;
                 alive &= ~hm;
-                if (alive == 0ull) break;
-                tfar = any ? -1.0f : tfar;     // newly occluded lanes stop driving the walk
+                if (alive == 0ull) break;      // (newly occluded lanes leave `alive`: they stop driving the walk)
             }
         }
         if (sp == 0) break;
