@@ -59,12 +59,17 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
     const uint32_t mode = fp.mis_mode;
     if (mode == 0u) return v.flux * brdf1 * brdf2 * g21;
     if (mode <= 3u) {
-        float pdf_de = lambert_pdf_a(v.n, px.n1, -v12) * v.psel;
-        if (!(v.rs.x <= 0.000001f)) pdf_de += phong_pdf_a(v.n, px.n1, -v12, v.fdir, v.rs, v.e) * (1.0f - v.psel);   // wave-uniform; PhongPdfA is 0 there (rtmaterial.cuh:92)
+        // pdf of having sampled this segment from the VPL side (:318-323), from terms that are already here:
+        //   LambertPdfA(n2, n1, -v12) = cos1 cos2 / d^4 / pi = g21 / pi                      (rtmaterial.cuh:46-54)
+        //   PhongPdfA(n2, n1, -v12, fdir) = (e + 1) / (2 pi) c^e * max(n1 . w12, 0) / d^2    (:87-102), and c is the
+        //   cosine of the VPL's own Phong lobe: c^e = ph2 * 2 pi / (e + 2); zero for rho_s.x <= 1e-6 (:92), wave-uniform
+        float pdf_de = g21 * EV_INV_PI * v.psel;
+        if (!(v.rs.x <= 0.000001f))
+            pdf_de += ph2 * ((v.e + 1.0f) * __builtin_amdgcn_rcpf(v.e + 2.0f)) * fmaxf(dot(px.n1, wi12), 0.0f) * __builtin_amdgcn_rcpf(dist2) * (1.0f - v.psel);
         float w;
-        if (mode == 1u) w = fp.pdf_mc / (fp.pdf_mc + pdf_de);
+        if (mode == 1u) w = fp.pdf_mc * __builtin_amdgcn_rcpf(fp.pdf_mc + pdf_de);
         else if (mode == 2u) w = fp.pdf_mc > pdf_de ? 1.0f : 0.0f;
-        else { float a2 = pdf_mc2, b2 = pdf_de * pdf_de; w = a2 / (a2 + b2); }   // pdfMc^2 squared on the host: a kernel-argument SGPR instead of a hoisted VGPR
+        else { float a2 = pdf_mc2, b2 = pdf_de * pdf_de; w = a2 * __builtin_amdgcn_rcpf(a2 + b2); }   // pdfMc^2 squared on the host: a kernel-argument SGPR
         return (v.flux * w) * brdf1 * brdf2 * g21;
     }
     if (mode == 4u) return (v.flux * fminf(g21, fp.clamping_value)) * brdf1 * brdf2;
