@@ -314,13 +314,16 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     // clamped to [0, 1] by the clamp modifier of the v_max3 / v_min3 that form them (no separate max with tmin /
     // min with tmax), and a box is entered iff entry < exit (a box wholly before the start or beyond the end clamps
     // both to the same end point; a box that holds part of a triangle inside the range is padded, so its interval
-    // is far wider than an ulp).  Lanes without a live ray are masked out of the ballots by `alive`.
+    // is far wider than an ulp).  A lane without a live ray carries +inf as its origin term: every entry and exit
+    // distance is +inf, both clamp to 1, and the lane never enters a box -- the ballots need no masking.
     const V3 inv0 = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const float ku = 1.0f / (tmax - tmin);
     const V3 inv = inv0 * ku;
     const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
     const v2f avx = bc(fabsf(inv.x)), avy = bc(fabsf(inv.y)), avz = bc(fabsf(inv.z));
-    const v2f nox = bc((-(o.x * inv0.x) - tmin) * ku), noy = bc((-(o.y * inv0.y) - tmin) * ku), noz = bc((-(o.z * inv0.z) - tmin) * ku);
+    const float dead = __builtin_inff();
+    v2f nox = bc(alive_lane ? (-(o.x * inv0.x) - tmin) * ku : dead), noy = bc(alive_lane ? (-(o.y * inv0.y) - tmin) * ku : dead),
+        noz = bc(alive_lane ? (-(o.z * inv0.z) - tmin) * ku : dead);
     unsigned long long alive = ballot64(alive_lane), hitm = 0ull;
     if (alive == 0ull) return false;
     int sp = 0;
@@ -339,7 +342,7 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
             const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
             const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
-            const unsigned long long m0 = ballot64(tn0 < tf0) & alive, m1 = ballot64(tn1 < tf1) & alive;
+            const unsigned long long m0 = ballot64(tn0 < tf0), m1 = ballot64(tn1 < tf1);
             const int32_t c0 = n[12], c1 = n[13];
             // 32-bit scalar compares on purpose: this compiler turns compares of 64-bit masks into lane-mask
             // booleans (s_cselect_b64 / s_and exec / s_cbranch_vcc, 4-5 instructions per branch)
@@ -379,7 +382,8 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if (hm != 0ull) {
                 hitm |= hm;
                 alive &= ~hm;
-                if (alive == 0ull) break;      // (newly occluded lanes leave `alive`: they stop driving the walk)
+                if (alive == 0ull) break;
+                if (any) { nox = bc(dead); noy = bc(dead); noz = bc(dead); }   // newly occluded lanes stop driving the walk
             }
         }
         if (sp == 0) break;
