@@ -352,8 +352,7 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if (a1 == 0u) { cur = c0; continue; }
             {
                 // both hit: descend into the child wanted by more lanes first, keep the other one on the stack
-                const uint32_t p0 = (uint32_t)(__builtin_popcount((uint32_t)m0) + __builtin_popcount((uint32_t)(m0 >> 32)));
-                const uint32_t p1 = (uint32_t)(__builtin_popcount((uint32_t)m1) + __builtin_popcount((uint32_t)(m1 >> 32)));
+                const uint32_t p0 = (uint32_t)__builtin_popcountll(m0), p1 = (uint32_t)__builtin_popcountll(m1);
                 const bool first0 = p0 >= p1;
                 const int32_t oth = first0 ? c1 : c0;
                 vstack = lane_write(oth, sp, vstack);
