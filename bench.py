@@ -111,7 +111,7 @@ def main():
     P = 4                                   # numMaxBounces 3 -> 4 record slots per path
     n_light = a.paths if a.workload == "ir" else 500000
     n_vpl = a.paths
-    strip_rows = 16
+    strip_rows = 8      # finest interleave (tiles are 8 rows): slowest / mean rank time 10.9 / 10.4 ms at 8 ranks vs 11.8 / 10.4 with 16-row strips
     ctx = ev.Context(W, H, n_light, n_vpl, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows,
                      bvh_builder=ev.BVH_SAH if a.bvh == "sah" else ev.BVH_LBVH)
     ctx.load_scene_json(json_path)

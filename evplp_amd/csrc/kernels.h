@@ -38,7 +38,7 @@ struct GatherArgs {
     PassCounters *counters;
 };
 #ifndef EVPLP_VPL_SPLIT
-#define EVPLP_VPL_SPLIT 64
+#define EVPLP_VPL_SPLIT 128
 #endif
 constexpr int kVplSplit = EVPLP_VPL_SPLIT;   // items per tile: VPL i belongs to item i % kVplSplit (a constant: results must not depend on the GPU count)
 

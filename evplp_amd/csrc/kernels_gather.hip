@@ -7,8 +7,8 @@
 // sums; gather_reduce_kernel adds the kVplSplit partials of a pixel in split order and applies
 // out = sum / numVplLightPaths + doAccumulate * out (lighttracing.cu:378).  The split is a compile-time
 // constant, so every pixel is summed in the same order on any GPU count (bitwise reproducible), and
-// the launch has 64x more, 64x shorter items than one-tile-per-workgroup: 1 M items at 1024^2, still
-// 131k per GPU on an 8-GPU strip partition (item cost varies 5x across the image; short items keep the
+// the launch has 128x more, 128x shorter items than one-tile-per-workgroup: 2 M items at 1024^2, still
+// 262k per GPU on an 8-GPU strip partition (item cost varies 5x across the image; short items keep the
 // launch tail small).
 //
 // For one VPL the 64 shadow segments of a wave share their origin (the VPL) and end on neighbouring
