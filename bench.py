@@ -131,7 +131,9 @@ def main():
     ctx.bind_buffer(ev.BUF_RECORDS, records.data_ptr(), records.numel() * 4)
     ctx.bind_buffer(ev.BUF_VPL_ACCUM, strip.data_ptr(), strip.numel() * 4)
     full = torch.zeros(world * strip.numel(), dtype=torch.float32, device=dev) if use_dist else strip
-    split_paths = use_dist and n_light % world == 0
+    # a light-tracing launch is latency-bound (0.26 ms for 1024 paths, 0.25 ms for 128): small path counts are traced
+    # redundantly by every rank (identical records, no exchange); large ones are split and all-gathered
+    split_paths = use_dist and n_light % world == 0 and (n_light >= 16384 or os.environ.get("EVPLP_BENCH_FORCE_DIST") == "1")
     per_rank = n_light // world if split_paths else n_light
 
     mis = "one" if a.workload == "ir" else "balance"
