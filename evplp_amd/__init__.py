@@ -111,6 +111,8 @@ _SIGNATURES = {
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "evplp_save_image": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P]),
     "evplp_load_pfm": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
+    "evplp_load_image": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
+    "evplp_image_error_heat": (C.c_int, [C.c_int32, _P, _P, C.c_float, C.c_int32, _P]),
     "evplp_decode_image": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
     "evplp_image_mse": (C.c_double, [C.c_int32, _P, _P]),
     "evplp_image_rel_mse": (C.c_double, [C.c_int32, _P, _P]),
@@ -362,6 +364,28 @@ def load_pfm(path: str) -> np.ndarray:
     rc = lib().evplp_load_pfm(path.encode(), C.byref(w), C.byref(h), _ptr(out), out.size)
     if rc != OK:
         raise EvplpError(rc, f"evplp_load_pfm({path})")
+    return out
+
+
+def load_image(path: str) -> np.ndarray:
+    """FloatImage::LoadPFM / LoadHDR by extension: float32 [h, w, 3], rows top to bottom."""
+    w, h = C.c_int32(), C.c_int32()
+    rc = lib().evplp_load_image(path.encode(), C.byref(w), C.byref(h), None, 0)
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_load_image({path})")
+    out = np.empty((h.value, w.value, 3), dtype=np.float32)
+    rc = lib().evplp_load_image(path.encode(), C.byref(w), C.byref(h), _ptr(out), out.size)
+    if rc != OK:
+        raise EvplpError(rc, f"evplp_load_image({path})")
+    return out
+
+
+def error_heat(img: np.ndarray, ref: np.ndarray, max_error: float, relative: bool = False) -> np.ndarray:
+    a, b = _f32(img), _f32(ref)
+    out = np.empty_like(a)
+    rc = lib().evplp_image_error_heat(a.shape[0] * a.shape[1], _ptr(a), _ptr(b), max_error, int(relative), _ptr(out))
+    if rc != OK:
+        raise EvplpError(rc, "evplp_image_error_heat")
     return out
 
 

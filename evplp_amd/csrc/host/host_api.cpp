@@ -5,6 +5,7 @@
 #include "decoders.hpp"
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -46,9 +47,48 @@ extern "C" int evplp_decode_image(const char *path, int32_t *w, int32_t *h, int3
     }
     return EVPLP_OK;
 }
+extern "C" int evplp_load_image(const char *path, int32_t *w, int32_t *h, float *rgb, size_t cap) {
+    if (!path || !w || !h) return EVPLP_ERR_INVALID;
+    std::string p(path);
+    size_t i = p.find_last_of('.');
+    std::string ext = i == std::string::npos ? "" : p.substr(i + 1);
+    for (char &c : ext) c = (char)std::tolower((unsigned char)c);
+    if (ext == "hdr") return evplp::load_hdr(path, w, h, rgb, cap);
+    return evplp::load_pfm(path, w, h, rgb, cap);
+}
 extern "C" int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb, size_t cap) {
     if (!path || !w || !h) return EVPLP_ERR_INVALID;
     return evplp::load_pfm(path, w, h, rgb, cap);
+}
+// math/color.h:18-46, 83-88: Heat(t) = Hsl2Rgb(((1 - t) * 240) / 360, 1, 0.5), with the reference's Hsl2Rgb as written
+// (its l < 0.5 branch multiplies by the hue instead of the saturation; Heat always takes the other branch)
+namespace {
+float hue2rgb(float v1, float v2, float h) {
+    if (h < 0.0f) h += 1.0f;
+    if (h > 1.0f) h -= 1.0f;
+    if ((6.0f * h) < 1.0f) return v1 + (v2 - v1) * 6.0f * h;
+    if ((2.0f * h) < 1.0f) return v2;
+    if ((3.0f * h) < 2.0f) return v1 + (v2 - v1) * ((2.0f / 3.0f) - h) * 6.0f;
+    return v1;
+}
+void heat(float t, float *rgb) {
+    const float h = ((1.0f - t) * 240.0f) / 360.0f, s = 1.0f, l = 0.5f;
+    const float v2 = (l < 0.5f) ? (l * (1.0f + h)) : ((s + l) - (s * l));
+    const float v1 = 2.0f * l - v2;
+    rgb[0] = hue2rgb(v1, v2, h + (1.0f / 3.0f)); rgb[1] = hue2rgb(v1, v2, h); rgb[2] = hue2rgb(v1, v2, h - (1.0f / 3.0f));
+}
+} // namespace
+// FloatImage::ComputeSquareErrorHeatImage / ComputeRelSquareErrorHeatImage (common/floatimage/floatimage.cpp:21-62)
+extern "C" int evplp_image_error_heat(int32_t npix, const float *img, const float *ref, float max_error, int32_t relative, float *out_rgb) {
+    if (npix < 0 || !img || !ref || !out_rgb) return EVPLP_ERR_INVALID;
+    for (int32_t i = 0; i < npix; i++) {
+        float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+        float dx = img[3 * i] - rx, dy = img[3 * i + 1] - ry, dz = img[3 * i + 2] - rz;
+        float e = dx * dx + dy * dy + dz * dz;                       // glm::distance2 / dot(diff, diff)
+        if (relative) e = e / (rx * rx + ry * ry + rz * rz + 0.001f);
+        heat(std::min(e / max_error, 1.0f), out_rgb + 3 * (size_t)i);
+    }
+    return EVPLP_OK;
 }
 // common/floatimage/floatimage.cpp:64-84 (Float accumulator)
 extern "C" double evplp_image_mse(int32_t npix, const float *a, const float *ref) {

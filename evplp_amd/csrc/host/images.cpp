@@ -153,6 +153,55 @@ int save_hdr(const char *path, int32_t w, int32_t h, const float *rgb) {
     return ok ? EVPLP_OK : EVPLP_ERR_IO;
 }
 
+// FloatImage::LoadHDR (floatimage.cpp:201-221) = RGBE_ReadHeader + RGBE_ReadPixels_RLE (rgbe.cpp): Radiance picture,
+// "-Y h +X w", flat or new-style run-length-encoded scanlines; rgb = mantissa * 2^(e - 136), (0,0,0) for e = 0.
+int load_hdr(const char *path, int32_t *w, int32_t *h, float *rgb, size_t cap) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return EVPLP_ERR_IO;
+    char line[256]; int ww = 0, hh = 0; bool have_size = false;
+    if (!std::fgets(line, sizeof line, f) || std::strncmp(line, "#?", 2) != 0) { std::fclose(f); return EVPLP_ERR_PARSE; }
+    while (std::fgets(line, sizeof line, f)) if (std::sscanf(line, "-Y %d +X %d", &hh, &ww) == 2) { have_size = true; break; }
+    if (!have_size || ww <= 0 || hh <= 0) { std::fclose(f); return EVPLP_ERR_PARSE; }
+    *w = ww; *h = hh;
+    if (!rgb) { std::fclose(f); return EVPLP_OK; }
+    if (cap < (size_t)ww * hh * 3) { std::fclose(f); return EVPLP_ERR_INVALID; }
+    auto to_float = [](const unsigned char *px, float *out) {
+        if (px[3]) { float s = std::ldexp(1.0f, (int)px[3] - (128 + 8)); out[0] = px[0] * s; out[1] = px[1] * s; out[2] = px[2] * s; }
+        else out[0] = out[1] = out[2] = 0.0f;
+    };
+    std::vector<unsigned char> scan((size_t)4 * ww);
+    for (int y = 0; y < hh; y++) {
+        unsigned char px[4];
+        if (std::fread(px, 1, 4, f) != 4) { std::fclose(f); return EVPLP_ERR_IO; }
+        float *row = rgb + (size_t)y * ww * 3;
+        if (ww < 8 || ww > 0x7fff || px[0] != 2 || px[1] != 2 || (px[2] & 0x80)) {
+            // flat scanline (and, as in rgbe.cpp, the rest of the file is flat too)
+            to_float(px, row);
+            size_t rest = (size_t)ww * (hh - y) - 1;
+            for (size_t i = 0; i < rest; i++) { if (std::fread(px, 1, 4, f) != 4) { std::fclose(f); return EVPLP_ERR_IO; } to_float(px, row + 3 * (i + 1)); }
+            std::fclose(f);
+            return EVPLP_OK;
+        }
+        if ((((int)px[2]) << 8 | px[3]) != ww) { std::fclose(f); return EVPLP_ERR_PARSE; }
+        for (int c = 0; c < 4; c++) {
+            unsigned char *dst = scan.data() + (size_t)c * ww; int x = 0;
+            while (x < ww) {
+                unsigned char b[2];
+                if (std::fread(b, 1, 2, f) != 2) { std::fclose(f); return EVPLP_ERR_IO; }
+                if (b[0] > 128) { int n = b[0] - 128; if (n == 0 || n > ww - x) { std::fclose(f); return EVPLP_ERR_PARSE; } while (n--) dst[x++] = b[1]; }
+                else {
+                    int n = b[0]; if (n == 0 || n > ww - x) { std::fclose(f); return EVPLP_ERR_PARSE; }
+                    dst[x++] = b[1];
+                    if (--n > 0) { if (std::fread(dst + x, 1, (size_t)n, f) != (size_t)n) { std::fclose(f); return EVPLP_ERR_IO; } x += n; }
+                }
+            }
+        }
+        for (int x = 0; x < ww; x++) { unsigned char q[4] = { scan[x], scan[x + ww], scan[x + 2 * ww], scan[x + 3 * ww] }; to_float(q, row + 3 * x); }
+    }
+    std::fclose(f);
+    return EVPLP_OK;
+}
+
 // floatimage.cpp:260-273 Save: dispatch on the extension
 int save_image(const char *path, int32_t w, int32_t h, const float *rgb) {
     std::string p(path);

@@ -11,4 +11,5 @@ int save_pfm(const char *path, int32_t w, int32_t h, const float *rgb);
 int save_png(const char *path, int32_t w, int32_t h, const float *rgb);
 int save_hdr(const char *path, int32_t w, int32_t h, const float *rgb);
 int load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb, size_t capacity_floats);
+int load_hdr(const char *path, int32_t *w, int32_t *h, float *rgb, size_t capacity_floats);
 }

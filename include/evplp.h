@@ -227,11 +227,16 @@ void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clam
  * rgb: top-down rows (after FlipY, rtcomphoton.h:1124-1127), 3 floats per pixel. */
 int evplp_save_image(const char *path, int32_t w, int32_t h, const float *rgb_top_down);
 int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *rgb_top_down, size_t capacity_floats);
+/* FloatImage::LoadPFM / LoadHDR by extension (floatimage.cpp:146-176, 201-221); rgb may be NULL to query the size */
+int evplp_load_image(const char *path, int32_t *w, int32_t *h, float *rgb_top_down, size_t capacity_floats);
 /* stbi_load(filepath, &width, &height, &channel, 3) as RtTexture calls it (rt/rtcommon.h:144): JPEG (baseline /
  * progressive) or PNG by content -> 8-bit RGB, rows top to bottom (no flip), bit-identical to the reference's
  * vendored decoder.  *channels = components in the file.  rgb may be NULL to query the size. */
 int evplp_decode_image(const char *path, int32_t *w, int32_t *h, int32_t *channels, uint8_t *rgb, size_t capacity_bytes);
 double evplp_image_mse(int32_t npix, const float *img, const float *ref);     /* floatimage.cpp:64-84 */
+/* FloatImage::ComputeSquareErrorHeatImage (relative = 0) / ComputeRelSquareErrorHeatImage (floatimage.cpp:21-62):
+ * per-pixel (relative) squared error / max_error, clamped to 1, through Color::Heat (math/color.h:83-88) */
+int evplp_image_error_heat(int32_t npix, const float *img, const float *ref, float max_error, int32_t relative, float *out_rgb);
 double evplp_image_rel_mse(int32_t npix, const float *img, const float *ref); /* floatimage.cpp:86-112 */
 /* Writes a procedural closed "conference-like" room (OBJ + MTL + light OBJ + scene JSON in the
  * reference's schema) because every mesh of the reference is a Git-LFS stub.

@@ -29,6 +29,18 @@ void ref_flip_y(int w, int h, const float *rgb, float *out) {
     FloatImage f = FloatImage::FlipY(make_image(w, h, rgb));
     std::memcpy(out, f.getFloats(), sizeof(float) * 3 * (size_t)w * h);
 }
+// FloatImage::Compute[Rel]SquareErrorHeatImage (floatimage.cpp:21-62) and FloatImage::Load (PFM / HDR)
+void ref_error_heat(int w, int h, const float *a, const float *ref, float max_error, int relative, float *out) {
+    FloatImage r = relative ? FloatImage::ComputeRelSquareErrorHeatImage(make_image(w, h, a), make_image(w, h, ref), max_error)
+                            : FloatImage::ComputeSquareErrorHeatImage(make_image(w, h, a), make_image(w, h, ref), max_error);
+    std::memcpy(out, r.getFloats(), sizeof(float) * 3 * (size_t)w * h);
+}
+int ref_load_hdr(const char *path, int w, int h, float *out) {
+    FloatImage r = FloatImage::LoadHDR(path);
+    if ((int)r.getSize().x != w || (int)r.getSize().y != h) return -1;
+    std::memcpy(out, r.getFloats(), sizeof(float) * 3 * (size_t)w * h);
+    return 0;
+}
 double ref_mse(int w, int h, const float *a, const float *ref) { return FloatImage::ComputeMse(make_image(w, h, a), make_image(w, h, ref)); }
 double ref_rel_mse(int w, int h, const float *a, const float *ref) { return FloatImage::ComputeRelMse(make_image(w, h, a), make_image(w, h, ref)); }
 

@@ -5,7 +5,8 @@ authoring container (needs /root/reference); the fixtures -- inputs and expected
 committed so the pins also hold on the GPU box, where the reference does not exist.
 
 Fixtures:
-  output_surface.npz  PFM and HDR (RGBE) file bytes, decoded PNG pixels, FlipY, MSE / relMSE of seeded images
+  output_surface.npz  PFM and HDR (RGBE) file bytes, decoded PNG pixels, FlipY, MSE / relMSE, error heat images and
+                      LoadHDR read-back of seeded images
                       (common/floatimage/floatimage.cpp:64-128, 178-199, 223-273; rgbe.cpp)
   camera.npz          projection*view matrices (with / without the jitter translation) for seeded
                       cameras incl. the conference camera, fovx->fovy, bounding-sphere radii
@@ -170,6 +171,8 @@ def main():
     ref.ref_flip_y.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     ref.ref_mse.restype = C.c_double; ref.ref_mse.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     ref.ref_rel_mse.restype = C.c_double; ref.ref_rel_mse.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ref.ref_error_heat.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    ref.ref_load_hdr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
     ref.ref_view_projection.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     ref.ref_fovx_to_fovy.restype = C.c_float; ref.ref_fovx_to_fovy.argtypes = [C.c_float, C.c_float]
     ref.ref_bounding_sphere_radius.restype = C.c_float; ref.ref_bounding_sphere_radius.argtypes = [C.c_int, C.c_void_p]
@@ -193,6 +196,12 @@ def main():
         out[f"{name}_pfm_bytes"] = np.frombuffer(open(pfm, "rb").read(), np.uint8)
         out[f"{name}_png_pixels"] = decode_png_rgb8(open(png, "rb").read())
         out[f"{name}_flipy"] = flipped
+        for rel in (0, 1):                                                              # floatimage.cpp:21-62
+            heat = np.zeros_like(img); ref.ref_error_heat(w, h, P(other), P(img), np.float32(0.004), rel, P(heat))
+            out[f"{name}_heat{rel}"] = heat
+        back = np.zeros_like(img)
+        assert ref.ref_load_hdr(hdr.encode(), w, h, P(back)) == 0                        # FloatImage::LoadHDR of the file written above
+        out[f"{name}_hdr_decoded"] = back
         out[f"{name}_mse"] = np.float64(ref.ref_mse(w, h, P(other), P(img)))
         out[f"{name}_relmse"] = np.float64(ref.ref_rel_mse(w, h, P(other), P(img)))
     np.savez(os.path.join(HERE, "output_surface.npz"), **out)

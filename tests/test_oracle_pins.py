@@ -59,6 +59,24 @@ def test_png_pixels_oracle_and_product(name, oracle, tmp_path, evplp):
     assert np.array_equal(decode_png_rgb8(open(p, "rb").read()), want), "libevplp_hip PNG pixels differ from the reference's"
 
 
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_error_heat_images_and_hdr_readback(name, tmp_path, evplp):
+    """FloatImage::Compute[Rel]SquareErrorHeatImage through Color::Heat (floatimage.cpp:21-62, math/color.h) and
+    FloatImage::LoadHDR (rgbe.cpp RLE reader) -- the product's functions against the reference's own outputs."""
+    img, other = G[f"{name}_img"], G[f"{name}_other"]
+    for rel in (0, 1):
+        got = evplp.error_heat(other, img, 0.004, relative=bool(rel))
+        assert np.allclose(got, G[f"{name}_heat{rel}"], rtol=0, atol=2e-6), (rel, float(np.abs(got - G[f"{name}_heat{rel}"]).max()))
+    p = str(tmp_path / "x.hdr")
+    open(p, "wb").write(G[f"{name}_hdr_bytes"].tobytes())
+    back = evplp.load_image(p)
+    assert np.array_equal(back, G[f"{name}_hdr_decoded"])
+    # PFM through the same entry point
+    q = str(tmp_path / "x.pfm")
+    open(q, "wb").write(G[f"{name}_pfm_bytes"].tobytes()) if f"{name}_pfm_bytes" in G.files else evplp.save_image(q, img)
+    assert np.array_equal(evplp.load_image(q), img)
+
+
 @pytest.mark.parametrize("name", ["a", "b"])
 def test_error_metrics(name, oracle, evplp):
     img, other = G[f"{name}_img"], G[f"{name}_other"]
