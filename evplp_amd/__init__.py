@@ -116,6 +116,7 @@ _SIGNATURES = {
     "evplp_decode_image": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_size_t]),
     "evplp_image_mse": (C.c_double, [C.c_int32, _P, _P]),
     "evplp_image_rel_mse": (C.c_double, [C.c_int32, _P, _P]),
+    "evplp_image_rel_mse_masked": (C.c_double, [C.c_int32, _P, _P, _P]),
     "evplp_synth_scene": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32]),
     "evplp_render_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]),
 }

@@ -60,6 +60,21 @@ extern "C" int evplp_load_pfm(const char *path, int32_t *w, int32_t *h, float *r
     if (!path || !w || !h) return EVPLP_ERR_INVALID;
     return evplp::load_pfm(path, w, h, rgb, cap);
 }
+// relMSE over the pixels a mask keeps (mask_rgb8: 3 bytes per pixel as evplp_decode_image returns them; a pixel is
+// kept when any channel is non-zero).  The reference ships scene/conference/conference_mask.png -- white with black
+// outlines around the emitters, whose edges it does not anti-alias (scene/conference/README.md) -- and leaves the
+// masked metric to external scripts; this is ComputeRelMse (floatimage.cpp:86-112) restricted to the kept pixels.
+extern "C" double evplp_image_rel_mse_masked(int32_t npix, const float *a, const float *ref, const uint8_t *mask_rgb8) {
+    float result = 0; int64_t kept = 0;
+    for (int32_t i = 0; i < npix; i++) {
+        if (mask_rgb8 && !(mask_rgb8[3 * i] | mask_rgb8[3 * i + 1] | mask_rgb8[3 * i + 2])) continue;
+        float rx = ref[3 * i], ry = ref[3 * i + 1], rz = ref[3 * i + 2];
+        float dx = a[3 * i] - rx, dy = a[3 * i + 1] - ry, dz = a[3 * i + 2] - rz;
+        result += (dx * dx + dy * dy + dz * dz) / (rx * rx + ry * ry + rz * rz + 0.001f);
+        kept++;
+    }
+    return kept ? result / (float)kept : 0.0;
+}
 // math/color.h:18-46, 83-88: Heat(t) = Hsl2Rgb(((1 - t) * 240) / 360, 1, 0.5), with the reference's Hsl2Rgb as written
 // (its l < 0.5 branch multiplies by the hue instead of the saturation; Heat always takes the other branch)
 namespace {

@@ -238,6 +238,9 @@ double evplp_image_mse(int32_t npix, const float *img, const float *ref);     /*
  * per-pixel (relative) squared error / max_error, clamped to 1, through Color::Heat (math/color.h:83-88) */
 int evplp_image_error_heat(int32_t npix, const float *img, const float *ref, float max_error, int32_t relative, float *out_rgb);
 double evplp_image_rel_mse(int32_t npix, const float *img, const float *ref); /* floatimage.cpp:86-112 */
+/* the same over the pixels a mask keeps (any non-zero channel; e.g. evplp_decode_image of scene/conference/conference_mask.png,
+ * which blanks the emitters' aliased outlines, scene/conference/README.md); NULL mask = all pixels */
+double evplp_image_rel_mse_masked(int32_t npix, const float *img, const float *ref, const uint8_t *mask_rgb8);
 /* Writes a procedural closed "conference-like" room (OBJ + MTL + light OBJ + scene JSON in the
  * reference's schema) because every mesh of the reference is a Git-LFS stub.
  * Returns the number of scene triangles written (>= 0) or a negative evplp_status. */

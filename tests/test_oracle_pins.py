@@ -77,6 +77,20 @@ def test_error_heat_images_and_hdr_readback(name, tmp_path, evplp):
     assert np.array_equal(evplp.load_image(q), img)
 
 
+def test_masked_rel_mse(evplp):
+    img, other = G["b_img"], G["b_other"]
+    n = img.shape[0] * img.shape[1]
+    l = evplp.lib()
+    full = l.evplp_image_rel_mse_masked(n, oa.ptr(other), oa.ptr(img), None)
+    assert full == l.evplp_image_rel_mse(n, oa.ptr(other), oa.ptr(img)) == float(G["b_relmse"])
+    mask = np.full(img.shape, 255, np.uint8); mask[2:5, 3:9] = 0
+    keep = mask.any(-1)
+    r, d = img[keep].astype(np.float32), (other[keep] - img[keep]).astype(np.float32)
+    want = float(np.float32(((d * d).sum(-1) / ((r * r).sum(-1) + np.float32(0.001))).astype(np.float32).sum(dtype=np.float32)) / np.float32(keep.sum()))
+    got = l.evplp_image_rel_mse_masked(n, oa.ptr(other), oa.ptr(img), mask.ctypes.data_as(C.c_void_p))
+    assert abs(got - want) <= 2e-6 * want and got != full
+
+
 @pytest.mark.parametrize("name", ["a", "b"])
 def test_error_metrics(name, oracle, evplp):
     img, other = G[f"{name}_img"], G[f"{name}_other"]
