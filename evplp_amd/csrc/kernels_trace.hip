@@ -11,6 +11,10 @@
 namespace evplp {
 
 __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
+    // ray set-up and the hit point are written without fused multiply-adds, in the oracle's operation order: together
+    // with the exact closest hit the G-buffer POSITIONS are then bit-identical to the CPU restatement, and so is every
+    // threshold test downstream that reads them (the photon radius test |X_p - X|^2 <= r^2, frag:152-154)
+#pragma clang fp contract(off)
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
     const int tile = blockIdx.x;
@@ -27,8 +31,9 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     // jittered matrix for the scene, original matrix for the light mesh (rtcomphoton.h:720-727)
     float jx = (cx - a.jitter[0]) * a.cam.aspect * a.cam.tan_half, jy = (cy - a.jitter[1]) * a.cam.tan_half;
     float ox = cx * a.cam.aspect * a.cam.tan_half, oy = cy * a.cam.tan_half;
-    V3 dj = S * jx + U * jy + F;
-    V3 d0 = S * ox + U * oy + F;
+    // (component-wise: the V3 operators are compiled with contraction allowed and would fuse after inlining)
+    V3 dj = v3((S.x * jx + U.x * jy) + F.x, (S.y * jx + U.y * jy) + F.y, (S.z * jx + U.z * jy) + F.z);
+    V3 d0 = v3((S.x * ox + U.x * oy) + F.x, (S.y * ox + U.y * oy) + F.y, (S.z * ox + U.z * oy) + F.z);
 
     float t = 0.f, b = 0.f, g = 0.f, tl = 0.f, bl = 0.f, gl = 0.f;
     // the 64 primary rays of a tile share the eye: packet walk (closest_wave), no per-lane stack.
@@ -47,7 +52,8 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     if (tri >= 0) {
         const TriAttr &ta = a.sc.attrs[tri];
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
-        V3 P = p1 * b + p2 * g + p0 * (1.0f - b - g);
+        const float w0 = 1.0f - b - g;
+        V3 P = v3((p1.x * b + p2.x * g) + p0.x * w0, (p1.y * b + p2.y * g) + p0.y * w0, (p1.z * b + p2.z * g) + p0.z * w0);
         V3 N = normalize(cross(p1 - p0, p2 - p0));  // deferred.geom:16-18 flat winding normal
         V3 kd, ks; float ns;
         material_at(a.sc, ta, b, g, kd, ks, ns);
