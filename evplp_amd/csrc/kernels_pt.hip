@@ -128,7 +128,10 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
     return rays;
 }
 
-__global__ __launch_bounds__(64) void path_trace_kernel(PathTraceArgs a) {
+#ifndef EVPLP_PT_WAVES
+#define EVPLP_PT_WAVES 6   // waves per SIMD: 5 = 3.00 ms, 6 = 2.71, 7 = 2.86, 8 = 2.87 per sample per pixel at 1024^2
+#endif
+__global__ __launch_bounds__(64, EVPLP_PT_WAVES) void path_trace_kernel(PathTraceArgs a) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;

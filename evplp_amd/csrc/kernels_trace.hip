@@ -80,7 +80,10 @@ EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float ps
     q[5] = make_float4(rs.x, rs.y, rs.z, e);
 }
 
-__global__ __launch_bounds__(64) void light_trace_kernel(LightTraceArgs a) {
+#ifndef EVPLP_LT_WAVES
+#define EVPLP_LT_WAVES 7
+#endif
+__global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTraceArgs a) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     const int lane = threadIdx.x;
     const uint32_t local = blockIdx.x * 64u + lane;
