@@ -6,14 +6,15 @@
 // The reference rasterises one icosphere proxy per record and lets the ROP blend every fragment
 // (one RMW of HBM per fragment).  Here (ideal kernel of SURVEY A.4: photon i adds to pixel p iff
 // |X_p - P_i|^2 <= r^2):
-//   1. splat_prepare : one lane per record.  Everything of the fragment shader that does not
-//      depend on the pixel (w12, the MIS/clamp weight, 1/(pi r^2 N) scaling) is folded into a
-//      64-byte compact photon; the conservative screen rectangle of the radius-r sphere is
-//      counted into 8x8-pixel tile bins.
-//   2. splat_scan    : exclusive scan of the tile counts.
+//   0. splat_tile_depth : view-depth range of every 8x8-pixel tile of the G-buffer.
+//   1. splat_prepare : one lane per record (records staged through LDS).  Everything of the fragment
+//      shader that does not depend on the pixel (w12, the MIS/clamp weight, 1/(pi r^2 N) scaling) is
+//      folded into a 64-byte compact photon; the conservative screen rectangle of the radius-r sphere
+//      is counted into the 8x8-pixel tile bins whose depth range meets the photon's.
+//   2. splat_scan    : exclusive scan of the tile counts (+ total and fullest bin for the host).
 //   3. splat_fill    : scatter photon ids into their bins.  (deterministic mode: + rank sort so
 //      every pixel accumulates in ascending record order, like the oracle.)
-//   4. splat_tiles   : one wavefront per tile, lane = pixel with its G-buffer texel in registers;
+//   4. splat_tiles   : one wavefront per tile (four when bins are very full), lane = pixel with its G-buffer texel in registers;
 //      the bin streams through LDS 64 photons at a time (each lane fetches one compact photon,
 //      all lanes then read it back as an LDS broadcast); RGB accumulates in registers and is
 //      written once per pixel with coalesced 16-byte stores -- no atomics, no per-fragment RMW.
