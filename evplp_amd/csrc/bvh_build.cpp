@@ -255,9 +255,15 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     out->ntris = nvalid;
     out->leaves = (LeafBlock *)std::calloc((size_t)std::max(nleaves, 1), sizeof(LeafBlock));
     out->tri_index = (int32_t *)std::malloc(sizeof(int32_t) * std::max<size_t>(order.size(), 4));
+    out->tri_flat = (TriFlat *)std::calloc(std::max<size_t>(order.size(), 4), sizeof(TriFlat));
     for (size_t i = 0; i < order.size(); i++) {
         out->tri_index[i] = order[i];
-        if (order[i] >= 0) precompute_tri(verts + 9 * (size_t)order[i], &out->leaves[i >> 2].pair[(i >> 1) & 1], (int)(i & 1));
+        if (order[i] >= 0) {
+            TriPair &tp = out->leaves[i >> 2].pair[(i >> 1) & 1]; const int h = (int)(i & 1);
+            precompute_tri(verts + 9 * (size_t)order[i], &tp, h);
+            TriFlat &tf = out->tri_flat[i];
+            for (int k = 0; k < 3; k++) { tf.p0[k] = tp.p0[k][h]; tf.e0[k] = tp.e0[k][h]; tf.e1[k] = tp.e1[k][h]; tf.n[k] = tp.n[k][h]; }
+        }
     }
     out->nleaves = nleaves; out->depth = B.depth + 1;
     out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -265,7 +271,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
 }
 
 void free_bvh(BvhBuild *b) {
-    std::free(b->nodes); std::free(b->leaves); std::free(b->tri_index);
+    std::free(b->nodes); std::free(b->leaves); std::free(b->tri_flat); std::free(b->tri_index);
     *b = BvhBuild();
 }
 

@@ -115,7 +115,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
 }
 
 static void free_scene_device(evplp_context *c) {
-    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.leaves); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
+    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.leaves); hipFree((void *)c->sc.tri_flat); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
     hipFree((void *)c->sc.materials); hipFree((void *)c->sc.textures); hipFree((void *)c->sc.tex_pool); hipFree((void *)c->sc.light_cdf);
     std::memset(&c->sc, 0, sizeof(c->sc));
 }
@@ -297,6 +297,7 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
     if ((rc = upload_array(c, bb.leaves, (size_t)std::max(bb.nleaves, 1), &c->sc.leaves))) { free_bvh(&bb); return rc; }
     if ((rc = upload_array(c, bb.tri_index, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
+    if ((rc = upload_array(c, bb.tri_flat, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_flat))) { free_bvh(&bb); return rc; }
     c->sc.ntris = bb.ntris; c->sc.bvh_depth = bb.depth;
     free_bvh(&bb);
     if ((rc = upload_array(c, attrs.data(), attrs.size(), &c->sc.attrs))) return rc;

@@ -55,6 +55,22 @@ EV_DEV bool tri_test(const TriPair &tp, int h, V3 o, V3 d, float tmin, float tma
     return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
 }
 
+// tri_test on the one-triangle-per-48-bytes copy (three 16-byte loads); same operations, same order.
+EV_DEV bool tri_test_flat(const TriFlat *tf, V3 o, V3 d, float tmin, float tmax, float &t, float &beta, float &gamma) {
+#pragma clang fp contract(off)
+    const float4 *q4 = reinterpret_cast<const float4 *>(tf);
+    const float4 a = q4[0], b = q4[1], c = q4[2];
+    const float p0x = a.x, p0y = a.y, p0z = a.z, e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w, e1z = c.x, nx = c.y, ny = c.z, nz = c.w;
+    float den = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
+    float inv = 1.0f / den;
+    float qx = (p0x - o.x) * inv, qy = (p0y - o.y) * inv, qz = (p0z - o.z) * inv;
+    float ix = __builtin_fmaf(d.y, qz, -(d.z * qy)), iy = __builtin_fmaf(d.z, qx, -(d.x * qz)), iz = __builtin_fmaf(d.x, qy, -(d.y * qx));
+    beta = __builtin_fmaf(iz, e1z, __builtin_fmaf(iy, e1y, ix * e1x));
+    gamma = __builtin_fmaf(iz, e0z, __builtin_fmaf(iy, e0y, ix * e0x));
+    t = __builtin_fmaf(nz, qz, __builtin_fmaf(ny, qy, nx * qx));
+    return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
+}
+
 // ------------------------------------------------------------------------------------ RNG
 // Build-defined generator shared bit-for-bit with the oracle: PCG32 XSH-RR seeded through
 // splitmix64; one stream per (index, sequence, substream).  Stands in for
@@ -526,7 +542,7 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
                 bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
                 if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
                 float t, b, g;
-                if (tri_test(sc.leaves[block].pair[k >> 1], k & 1, o, d, tmin, 3.0e38f, t, b, g)) {
+                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, 3.0e38f, t, b, g)) {
                     if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
                 }
             }
@@ -562,7 +578,7 @@ EV_DEV bool occluded_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             int32_t block = id >> 2, cnt = (id & 3) + 1;
             for (int32_t k = 0; k < cnt; k++) {
                 float t, b, g;
-                if (tri_test(sc.leaves[block].pair[k >> 1], k & 1, o, d, tmin, tmax, t, b, g)) return true;
+                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, tmax, t, b, g)) return true;
             }
         }
         if (sp == 0) break;

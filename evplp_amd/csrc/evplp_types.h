@@ -35,6 +35,10 @@ struct TriPair {
 static_assert(sizeof(TriPair) == 96, "TriPair must be 96 bytes");
 struct LeafBlock { TriPair pair[2]; };
 static_assert(sizeof(LeafBlock) == 192, "LeafBlock must be 192 bytes");
+// The same operands once more, one triangle per 48 contiguous bytes (slot = 4 * leaf block + k): the per-lane walks
+// fetch a triangle with three 16-byte loads instead of twelve strided words of the pair layout.
+struct TriFlat { float p0[3], e0[3], e1[3], n[3]; };
+static_assert(sizeof(TriFlat) == 48, "TriFlat must be 48 bytes");
 
 // Shading attributes per ORIGINAL triangle.
 struct TriAttr {
@@ -67,6 +71,7 @@ struct CamBasis {
 struct SceneDev {
     const BvhNode *nodes;
     const LeafBlock *leaves;     // one block per leaf
+    const TriFlat *tri_flat;     // 4 slots per leaf (per-lane walks)
     const int32_t *tri_index;    // 4 slots per leaf: original triangle index or -1
     const TriAttr *attrs;        // original order
     const Material *materials;
@@ -96,6 +101,7 @@ struct StripDev {
 struct BvhBuild {
     BvhNode *nodes = nullptr; int32_t nnodes = 0;
     LeafBlock *leaves = nullptr;  int32_t *tri_index = nullptr; int32_t ntris = 0;
+    TriFlat *tri_flat = nullptr;
     int32_t nleaves = 0, depth = 0;
     float build_ms = 0.f;
 };
