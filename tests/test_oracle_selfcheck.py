@@ -180,3 +180,74 @@ def test_photon_fragment_modes_are_complements(oracle):
     assert np.allclose(w_photon, w_photon[0]) and 0 < w_photon[0] < 1
     far = np.array([5, 5, 0], np.float32)
     assert oracle.evo_photon_frag(C.byref(fp0), oa.ptr(ph[1:2]), oa.ptr(ph[0:1]), oa.ptr(far), oa.ptr(N), oa.ptr(dif), oa.ptr(phg), oa.ptr(out0)) == 0   # outside the kernel radius: discard
+
+
+def test_vpl_splat_known_answers(oracle):
+    """vplSplat (rt/lighttracing.cu:275-346) on a geometry whose result can be written down by hand: shading point at
+    the origin facing +z, VPL two units above it facing down, both Lambertian with rho = 0.5, unit flux.
+      v12 = (0,0,2), cos1 = cos2 = 2 (un-normalised, :284-287), d^2 = 4, G = cos1 cos2 / d^4 = 1/4 (:303)
+      brdf1 = brdf2 = 0.5 / pi;  one: flux brdf1 brdf2 G (:309-312);  geometryClamp: G -> min(G, c) (:333-336);
+      geometryBrdfClamp: min(brdf1 G brdf2, c) (:338-344);  MIS modes: pdf_de = LambertPdfA p_sel = G / pi (:318-320),
+      weight = pdfMc/(pdfMc+pdf_de), [pdfMc > pdf_de], pdfMc^2/(pdfMc^2+pdf_de^2) (:321-331)."""
+    rec = np.zeros(1, oa.RECORD_DTYPE)
+    rec[0]["pos"] = (0, 0, 2); rec[0]["normal"] = (0, 0, -1); rec[0]["flux"] = (1, 1, 1); rec[0]["flux_dir"] = (0, 0, 1)
+    rec[0]["rho_d"] = (0.5, 0.5, 0.5); rec[0]["p_select_lambert"] = 1.0; rec[0]["flags"] = 1
+    wi10 = np.array([0, 0.6, 0.8], np.float32); p1 = np.zeros(3, np.float32); n1 = np.array([0, 0, 1], np.float32)
+    rd = np.full(3, 0.5, np.float32); rs = np.zeros(3, np.float32)
+    G = 0.25; f = 0.5 / math.pi; plain = f * f * G
+    pdf_mc = 0.1; pdf_de = G / math.pi
+    want = {0: plain, 1: plain * pdf_mc / (pdf_mc + pdf_de), 2: plain * (1.0 if pdf_mc > pdf_de else 0.0), 3: plain * pdf_mc ** 2 / (pdf_mc ** 2 + pdf_de ** 2),
+            4: f * f * min(G, 0.1), 5: min(plain, 0.004)}
+    for mode, w in want.items():
+        fp = oa.frame_params(camera_pos=(0, 3, 4), mis_mode=mode, pdf_mc=pdf_mc, clamping_value=0.1 if mode == 4 else 0.004,
+                             num_light_paths=1, num_vpl_light_paths=1, photons_per_path=1)
+        out = np.zeros(3, np.float32)
+        oracle.evo_vpl_splat_pair(C.byref(fp), oa.ptr(wi10), oa.ptr(p1), oa.ptr(n1), oa.ptr(rd), oa.ptr(rs), 0.0, oa.ptr(rec), 1, oa.ptr(out))
+        assert np.allclose(out, w, rtol=2e-6, atol=0), (mode, out, w)
+        oracle.evo_vpl_splat_pair(C.byref(fp), oa.ptr(wi10), oa.ptr(p1), oa.ptr(n1), oa.ptr(rd), oa.ptr(rs), 0.0, oa.ptr(rec), 0, oa.ptr(out))
+        assert (out == 0).all()                                  # occluded: no contribution (:296-298)
+    # back-facing VPL: cos2 <= 0 -> culled before the shadow ray (:288)
+    rec[0]["normal"] = (0, 0, 1)
+    fp = oa.frame_params(camera_pos=(0, 3, 4), mis_mode=0, num_light_paths=1, num_vpl_light_paths=1, photons_per_path=1)
+    out = np.ones(3, np.float32)
+    oracle.evo_vpl_splat_pair(C.byref(fp), oa.ptr(wi10), oa.ptr(p1), oa.ptr(n1), oa.ptr(rd), oa.ptr(rs), 0.0, oa.ptr(rec), 1, oa.ptr(out))
+    assert (out == 0).all()
+    # a Phong receiver seen along its mirror direction: brdf1 += rho_s (e + 2) / (2 pi) (rtmaterial.cuh:112-118)
+    rec[0]["normal"] = (0, 0, -1)
+    rs2 = np.full(3, 0.2, np.float32); e = 10.0
+    up = np.array([0, 0, 1], np.float32)
+    oracle.evo_vpl_splat_pair(C.byref(fp), oa.ptr(up), oa.ptr(p1), oa.ptr(n1), oa.ptr(rd), oa.ptr(rs2), e, oa.ptr(rec), 1, oa.ptr(out))
+    assert np.allclose(out, (f + 0.2 * (e + 2) / (2 * math.pi)) * f * G, rtol=2e-6)
+
+
+def test_photon_fragment_known_answers(oracle):
+    """photonsplatinstanced.frag:146-240 on a hand-computable geometry: photon at the origin on a +z surface, its
+    predecessor two units above facing down (Lambertian, p_select = 1), shading point 0.01 away inside r = 0.05.
+      brdf1 = rho_d / pi (frag:42-50);  k = 1 / (pi r^2) / N (frag:196);  w12 = (0,0,1), d^2 = 4
+      mixPdfW = cos / pi * p_sel = 1/pi (frag:65-69,184-187);  mixPdfA = mixPdfW * (n1.w12) / d^2 = 1/(4 pi) (frag:189)
+      one: brdf1 k flux;  balance / max / power2: * heuristic(mixPdfA, pdfMc) (frag:199-213)
+      geometryClamp: * max(G - c, 0) / G with G = 1/4 (frag:214-222);  geometryBrdfClamp: k flux max(brdf1 brdf2 G - c, 0) / (G brdf2)"""
+    ph = np.zeros(1, oa.RECORD_DTYPE); prev = np.zeros(1, oa.RECORD_DTYPE)
+    prev[0]["pos"] = (0, 0, 2); prev[0]["normal"] = (0, 0, -1); prev[0]["flux_dir"] = (0, 0, -1); prev[0]["rho_d"] = (0.5, 0.5, 0.5)
+    prev[0]["p_select_lambert"] = 1.0; prev[0]["flags"] = 1
+    ph[0]["pos"] = (0, 0, 0); ph[0]["normal"] = (0, 0, 1); ph[0]["flux"] = (0.7, 0.6, 0.5); ph[0]["flux_dir"] = (0, 0, 1)
+    ph[0]["rho_d"] = (0.4, 0.4, 0.4); ph[0]["p_select_lambert"] = 1.0; ph[0]["flags"] = 3
+    X = np.array([0.01, 0, 0], np.float32); N = np.array([0, 0, 1], np.float32)
+    dif = np.full(3, 0.6, np.float32); phg = np.zeros(4, np.float32)
+    r, npaths, pdf_mc = 0.05, 10, 0.05
+    flux = np.array([0.7, 0.6, 0.5])
+    brdf1 = 0.6 / math.pi; brdf2 = 0.5 / math.pi; k = 1.0 / (math.pi * r * r) / npaths
+    mix_a = 1.0 / (4.0 * math.pi); G = 0.25
+    base = brdf1 * k * flux
+    want = {0: base, 1: base * mix_a / (mix_a + pdf_mc), 2: base * (1.0 if mix_a > pdf_mc else 0.0), 3: base * mix_a ** 2 / (mix_a ** 2 + pdf_mc ** 2),
+            4: base * max(G - 0.1, 0.0) / G, 5: k * flux * max(brdf1 * brdf2 * G - 0.004, 0.0) / (G * brdf2)}
+    for mode, w in want.items():
+        fp = oa.frame_params(camera_pos=(0, -3, 4), mis_mode=mode, pdf_mc=pdf_mc, clamping_value=0.1 if mode == 4 else 0.004, photon_radius=r,
+                             num_light_paths=npaths, num_vpl_light_paths=npaths, photons_per_path=2)
+        out = np.zeros(3, np.float32)
+        assert oracle.evo_photon_frag(C.byref(fp), oa.ptr(ph), oa.ptr(prev), oa.ptr(X), oa.ptr(N), oa.ptr(dif), oa.ptr(phg), oa.ptr(out)) == 1
+        assert np.allclose(out, w, rtol=3e-6, atol=0), (mode, out, w)
+    # VPL weight + photon weight = 1 for the three MIS heuristics with the same pdfs (the energy-compensation identity)
+    for mode, wp in ((1, mix_a / (mix_a + pdf_mc)), (3, mix_a ** 2 / (mix_a ** 2 + pdf_mc ** 2))):
+        wv = {1: pdf_mc / (pdf_mc + mix_a), 3: pdf_mc ** 2 / (pdf_mc ** 2 + mix_a ** 2)}[mode]
+        assert abs(wp + wv - 1.0) < 1e-12
