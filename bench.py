@@ -215,6 +215,14 @@ def main():
                                  "vector peak, 157.3 TFLOP/s). achieved = 125 algorithmic flop per evaluated pair (SURVEY 8d) x pairs per "
                                  "launch / HIP-event kernel time; traversal flops are overhead and not counted."},
         }
+        # the same launch against the HBM roofline (north star: "fraction of HBM roofline"): the gather is not HBM-bound, so
+        # the fraction is tiny by construction -- algorithmic bytes W*H*(64 + 16 + 16) + n_vpl*96, and the bytes
+        # the PMC counters saw (per-item partial sums, BVH lines missing the per-XCD L2s)
+        n_usable = pairs / a.steps / (W * H)
+        alg_bytes = (W * H * (64 + 16 + 16)) / max(world, 1) + n_usable * 96
+        out["roofline_hbm"] = {"bound": "hbm", "achieved": alg_bytes / (kms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+                               "traffic_frac": (traffic / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None, "kernel": "gather_vpl_kernel"}
         if a.workload == "evplp" and splat_ms:
             nrec_bytes = nrec * 96 + W * H * 64 + W * H * 24          # SURVEY 8(d) algorithmic bytes per frame
             sms = sum(splat_ms) / len(splat_ms)
