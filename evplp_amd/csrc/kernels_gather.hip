@@ -384,7 +384,7 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, con
 }
 
 #ifndef EVPLP_VSL_WAVES
-#define EVPLP_VSL_WAVES 6   // 3: 88 ms, 4: 77 ms, 5: 76 ms, 6: 74 ms (512^2, 760 VSLs)
+#define EVPLP_VSL_WAVES 8   // 5: 56.4 ms, 6: 51.0, 7: 48.0, 8: 46.0 (512^2, 760 VSLs): occupancy beats the spills it costs
 #endif
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
     const int lane = threadIdx.x;
