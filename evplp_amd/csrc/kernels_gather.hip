@@ -109,7 +109,7 @@ EV_DEV Item item_setup(const StripDev &st, int lane) {
 }
 
 #ifndef EVPLP_GATHER_WAVES
-#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups): 5 = 147 ms, 6 = 139.5 ms, 7 = 135.2 ms, 8 = 198 ms (scratch spills) per cfg2 frame
+#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups): 6 = 81.7 ms, 7 = 77.3 ms, 8 = 82.4 ms (spills) per cfg2 launch
 #endif
 typedef int v8i __attribute__((ext_vector_type(8)));
 
