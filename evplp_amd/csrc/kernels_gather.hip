@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 // consecutive light paths starting at its own random path.  Neighbouring pixels see different records, so
 // there is no shared origin to build a packet on: one shadow ray per lane, per-lane LDS stack (the authors
 // note the variant is experimental and slower than the plain gather for the same reason).
-__global__ __launch_bounds__(64) void gather_lvc_kernel(GatherArgs a, const evplp_record *records) {
+#ifndef EVPLP_LVC_WAVES
+#define EVPLP_LVC_WAVES 6   // 5 = 56.7 ms, 6 = 53.5, 7 = 54.4, 8 = 55.9 (1024^2, 64-path windows)
+#endif
+__global__ __launch_bounds__(64, EVPLP_LVC_WAVES) void gather_lvc_kernel(GatherArgs a, const evplp_record *records) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
     __shared__ unsigned long long s_stats[2];
     const int lane = threadIdx.x;
