@@ -9,21 +9,29 @@ HOSTFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-unused-value -ffp-contract=off
 
 HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip $(CSRC)/kernels_pt.hip
 CPP_SRCS = $(CSRC)/context.cpp $(CSRC)/bvh_build.cpp $(wildcard $(CSRC)/host/*.cpp)
-HIP_OBJS = $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
-CPP_OBJS = $(patsubst $(CSRC)/%.cpp,build/%.o,$(filter-out $(CSRC)/host/driver_main.cpp,$(CPP_SRCS)))
+# VARIANT selects a separate object directory and library name (developer builds, e.g. `make stats`)
+VARIANT ?=
+BUILD = build$(if $(VARIANT),/$(VARIANT),)
+LIBSO = $(OUT)/libevplp_hip$(if $(VARIANT),_$(VARIANT),).so
+HIP_OBJS = $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIP_SRCS))
+CPP_OBJS = $(patsubst $(CSRC)/%.cpp,$(BUILD)/%.o,$(filter-out $(CSRC)/host/driver_main.cpp,$(CPP_SRCS)))
 HDRS = $(wildcard $(CSRC)/*.h $(CSRC)/*.hpp $(CSRC)/host/*.hpp include/*.h)
 
 all: $(OUT)/libevplp_hip.so $(OUT)/evplp-render oracle
 
-$(OUT)/libevplp_hip.so: $(HIP_OBJS) $(CPP_OBJS)
+$(LIBSO): $(HIP_OBJS) $(CPP_OBJS)
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-build/%.o: $(CSRC)/%.hip $(HDRS)
+# diagnostic build with traversal counters (nodes / leaf blocks / triangle pairs per walk): tools/traversal_stats.py
+stats:
+	$(MAKE) VARIANT=stats EXTRA_HIPFLAGS=-DEVPLP_TRAVERSAL_STATS=1 $(OUT)/libevplp_hip_stats.so
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-build/%.o: $(CSRC)/%.cpp $(HDRS)
+$(BUILD)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HOSTFLAGS) -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $< -o $@
 
@@ -41,4 +49,4 @@ clean:
 	rm -rf build $(OUT)/*.so $(OUT)/evplp-render
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean isa
+.PHONY: all oracle clean isa stats

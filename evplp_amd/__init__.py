@@ -15,7 +15,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libevplp_hip.so")
+# EVPLP_LIB: developer override (e.g. the -DEVPLP_TRAVERSAL_STATS=1 diagnostic build of tools/traversal_stats.py)
+LIB_PATH = os.environ.get("EVPLP_LIB") or os.path.join(_HERE, "lib", "libevplp_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 ABI_VERSION = 1
@@ -106,6 +107,7 @@ _SIGNATURES = {
     "evplp_download": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_upload": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
+    "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -118,6 +120,7 @@ _SIGNATURES = {
     "evplp_image_rel_mse": (C.c_double, [C.c_int32, _P, _P]),
     "evplp_image_rel_mse_masked": (C.c_double, [C.c_int32, _P, _P, _P]),
     "evplp_synth_scene": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32]),
+    "evplp_synth_scene_ex": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32]),
     "evplp_render_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]),
 }
 
@@ -334,6 +337,11 @@ class Context:
         return {"ms": s.ms, "pairs": s.pairs, "rays": s.rays, "usable": s.usable, "dominant_kernel_ms": s.dominant_kernel_ms,
                 "nodes": s.reserved[0] | (s.reserved[1] << 32)}
 
+    def debug_counters(self, which: int) -> np.ndarray:
+        out = np.zeros(64, dtype=np.uint64)
+        n = self._check(self._lib.evplp_debug_counters(self._h, which, _ptr(out), out.size))
+        return out[:n]
+
     # -- strips
     def global_rows(self) -> np.ndarray:
         """Global image row of every local row (>= H for padding rows)."""
@@ -403,9 +411,14 @@ def decode_image(path: str):
     return out, ch.value
 
 
+SCENE_STYLES = {"easy": 0, "hard": 1}
+
+
 def synth_scene(out_dir: str, name: str = "conference_synth", target_triangles: int = 331000, seed: int = 1234,
-                res_x: int = 1024, res_y: int = 1024) -> str:
-    rc = lib().evplp_synth_scene(out_dir.encode(), name.encode(), target_triangles, seed, res_x, res_y)
+                res_x: int = 1024, res_y: int = 1024, style=0) -> str:
+    """style: 0 / "easy" = tessellated boxes, 1 / "hard" = furnished with curved and thin parts."""
+    style = SCENE_STYLES[style] if isinstance(style, str) else int(style)
+    rc = lib().evplp_synth_scene_ex(out_dir.encode(), name.encode(), target_triangles, seed, res_x, res_y, style)
     if rc < 0:
         raise EvplpError(rc, "evplp_synth_scene failed")
     return os.path.join(out_dir, name + ".json")

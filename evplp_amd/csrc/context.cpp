@@ -548,6 +548,19 @@ extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, si
     return EVPLP_OK;
 }
 
+// raw device counters of a pass (diagnostic builds fill the histogram part; see kernels.h PassCounters)
+extern "C" int evplp_debug_counters(evplp_context *c, int32_t pass, uint64_t *out, int32_t capacity) {
+    CTX_CHECK(c);
+    if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out || capacity <= 0) { c->set_error("evplp_debug_counters: bad arguments"); return EVPLP_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    PassCounters pc;
+    HIP_TRY(c, hipMemcpy(&pc, &c->d_counters[pass], sizeof(pc), hipMemcpyDeviceToHost));
+    const int n = std::min<int>(capacity, (int)(sizeof(pc) / sizeof(uint64_t)));
+    std::memcpy(out, &pc, sizeof(uint64_t) * (size_t)n);
+    return n;
+}
+
 extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_stats *out) {
     CTX_CHECK(c);
     if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out) { c->set_error("evplp_pass_stats_get: bad arguments"); return EVPLP_ERR_INVALID; }

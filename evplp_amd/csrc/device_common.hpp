@@ -321,7 +321,12 @@ EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(
 // [0, 1] clamp that the backend folds into the clamp modifier of the instruction producing x
 EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
-EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane) {
+#ifndef EVPLP_TRAVERSAL_STATS
+#define EVPLP_TRAVERSAL_STATS 0    // 1: count node visits / leaf blocks / triangle pairs per walk (diagnostic build, tools/traversal_stats.py)
+#endif
+struct WalkStats { uint32_t nodes, leaves, pairs; };
+
+EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
     // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
     // far bound `tfar`: a lane that is inactive or already occluded carries tfar = -1, so its slab tests
@@ -350,6 +355,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     for (;;) {
         while (cur >= 0) {
             const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
+#if EVPLP_TRAVERSAL_STATS
+            if (ws) ws->nodes++;
+#endif
             // both children at once (half 0 = child 0, half 1 = child 1), conservative slab test in
             // centre / half-size form: A = ctr/d - o/d, B = hal/|d|, entry = A - B, exit = A + B
             const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
@@ -382,6 +390,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             // a leaf block is two triangle pairs (192 B); fetch all of it before testing
             const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
             const v16i a = tp[0], b = tp[1];
+#if EVPLP_TRAVERSAL_STATS
+            if (ws) { ws->leaves++; ws->pairs += cnt > 2u ? 2u : 1u; }
+#endif
             Hit2 h = tri_pair_test(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
                                    pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]),
                                    o, d, tmin, tmax);

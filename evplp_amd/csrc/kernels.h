@@ -22,6 +22,9 @@ struct PassCounters {
     unsigned long long nodes;         // BVH nodes visited (wave-level visits for the gather)
     unsigned long long pairs;         // splat: (photon, pixel) pairs inside the kernel radius
     unsigned long long aux;
+    // EVPLP_TRAVERSAL_STATS builds only (tools/traversal_stats.py): histogram of leaf blocks tested per (wave, VPL) walk
+    // ([31] = 31 or more), [32] = walks, [33] = triangle pairs tested, [34] = walks that ended with every lane occluded
+    unsigned long long hist[40];
 };
 
 struct GatherArgs {

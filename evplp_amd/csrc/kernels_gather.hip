@@ -149,7 +149,19 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         if (ballot64(active) == 0ull) continue;
         rays += active ? 1u : 0u;
         // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
+#if EVPLP_TRAVERSAL_STATS
+        WalkStats ws = { 0u, 0u, 0u };
+        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
+        if (lane == 0) {
+            atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
+            atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
+            atomicAdd(&a.counters->hist[32], 1ull);
+            atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
+            if (ballot64(active && !occ) == 0ull) atomicAdd(&a.counters->hist[34], 1ull);
+        }
+#else
         bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+#endif
         if (active && !occ) result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2);
     }
     if (t.in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);

@@ -214,6 +214,9 @@ int evplp_bind_buffer(evplp_context *ctx, int32_t which, void *device_ptr, size_
 int evplp_download(evplp_context *ctx, int32_t which, void *host_dst, size_t bytes);
 int evplp_upload(evplp_context *ctx, int32_t which, const void *host_src, size_t bytes);
 int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out);
+/* Raw device-side counters of the last run of `pass` (rays, node visits, pairs, aux, then the traversal histogram that
+ * only -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds fill).  Returns the number of 64-bit words written. */
+int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_t capacity);
 /* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
 int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
 
@@ -246,6 +249,11 @@ double evplp_image_rel_mse_masked(int32_t npix, const float *img, const float *r
  * Returns the number of scene triangles written (>= 0) or a negative evplp_status. */
 int evplp_synth_scene(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed,
                       int32_t res_x, int32_t res_y);
+/* style 0: the room of tessellated boxes above ("easy"); style 1: the same room, light and camera furnished with curved and
+ * thin parts (ellipsoid cushions, cylinder legs, rotated clutter, ~2400 small occluders) -- closer to what the real
+ * conference model (curved chairs, scene/conference/conference_exported.obj, an LFS stub) asks of an any-hit walk. */
+int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed,
+                         int32_t res_x, int32_t res_y, int32_t style);
 /* main() + LoadScene + RtComPhoton::render (main.cpp:87-121, rtcomphoton.h:107-223): parse the
  * scene JSON, load OBJ/MTL, run the `photonfam` technique, write the three images + stat file.
  * json_overrides: optional JSON object text merged over the `photonfam` block (may be NULL). */
