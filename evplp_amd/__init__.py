@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVPLP_LIB") or os.path.join(_HERE, "lib", "libevplp_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # evplp_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_OOM = 0, -1, -2, -3, -4, -5, -6
@@ -48,7 +48,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("res_x", C.c_int32), ("res_y", C.c_int32),
                 ("strip_rank", C.c_int32), ("strip_count", C.c_int32), ("strip_rows", C.c_int32),
                 ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
-                ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("gather_splits_per_wave", C.c_int32),
+                ("gather_no_shaft_lists", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Material(C.Structure):
@@ -71,7 +72,8 @@ class FrameParams(C.Structure):
 
 class PassStats(C.Structure):
     _fields_ = [("ms", C.c_float), ("pairs", C.c_uint64), ("rays", C.c_uint64), ("usable", C.c_uint64),
-                ("dominant_kernel_ms", C.c_float), ("reserved", C.c_uint32 * 3)]
+                ("dominant_kernel_ms", C.c_float), ("reserved", C.c_uint32 * 3), ("shaded", C.c_uint64), ("launches", C.c_uint32),
+                ("pad", C.c_uint32)]
 
 
 # every symbol include/evplp.h declares: (restype, argtypes)
@@ -178,13 +180,15 @@ class Context:
 
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
-                 bvh_builder: int = BVH_SAH, deterministic: bool = False):
+                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0,
+                 shaft_lists: bool = True):
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.strip_rank = strip_rank; cfg.strip_count = strip_count; cfg.strip_rows = strip_rows
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths
         cfg.photons_per_path = photons_per_path; cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
+        cfg.gather_splits_per_wave = gather_splits_per_wave; cfg.gather_no_shaft_lists = 0 if shaft_lists else 1
         self.cfg = cfg
         h = C.c_void_p()
         rc = self._lib.evplp_create(C.byref(cfg), C.byref(h))
@@ -335,10 +339,10 @@ class Context:
         s = PassStats()
         self._check(self._lib.evplp_pass_stats_get(self._h, which, C.byref(s)))
         return {"ms": s.ms, "pairs": s.pairs, "rays": s.rays, "usable": s.usable, "dominant_kernel_ms": s.dominant_kernel_ms,
-                "nodes": s.reserved[0] | (s.reserved[1] << 32)}
+                "nodes": s.reserved[0] | (s.reserved[1] << 32), "shaded": s.shaded, "launches": s.launches}
 
     def debug_counters(self, which: int) -> np.ndarray:
-        out = np.zeros(64, dtype=np.uint64)
+        out = np.zeros(256, dtype=np.uint64)
         n = self._check(self._lib.evplp_debug_counters(self._h, which, _ptr(out), out.size))
         return out[:n]
 

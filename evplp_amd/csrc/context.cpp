@@ -40,6 +40,9 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if (cfg->res_x <= 0 || cfg->res_y <= 0 || cfg->photons_per_path == 0 || cfg->num_light_paths == 0) {
         snprintf(g_create_error, sizeof(g_create_error), "evplp_create: resolution, num_light_paths and photons_per_path must be positive"); return EVPLP_ERR_INVALID;
     }
+    if (cfg->gather_splits_per_wave < 0 || cfg->gather_splits_per_wave > 32 || (cfg->gather_splits_per_wave & (cfg->gather_splits_per_wave - 1)) != 0) {
+        snprintf(g_create_error, sizeof(g_create_error), "evplp_create: gather_splits_per_wave must be 0 (automatic) or a power of two <= 32"); return EVPLP_ERR_INVALID;
+    }
     if (cfg->num_vpl_light_paths > cfg->num_light_paths) {
         snprintf(g_create_error, sizeof(g_create_error), "evplp_create: num_vpl_light_paths > num_light_paths (VPLs are the first paths of the same set, lighttracing.cu:368)"); return EVPLP_ERR_INVALID;
     }
@@ -95,7 +98,6 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if ((e = hipMalloc((void **)&c->d_counters, sizeof(PassCounters) * EVPLP_PASS_COUNT)) != hipSuccess) return fail("hipMalloc(counters)", e);
     if ((e = hipMemset(c->d_counters, 0, sizeof(PassCounters) * EVPLP_PASS_COUNT)) != hipSuccess) return fail("hipMemset", e);
     if ((e = hipMalloc((void **)&c->d_rgb, sizeof(float) * 3 * (size_t)c->st.W * c->st.local_rows)) != hipSuccess) return fail("hipMalloc(rgb)", e);
-    if ((e = hipMalloc((void **)&c->d_partial, sizeof(float4) * kVplSplit * (size_t)c->st.W * c->st.local_rows)) != hipSuccess) return fail("hipMalloc(partial)", e);
     // splat workspace
     c->tiles_x = (c->st.W + 7) / 8; c->tiles_y = c->st.local_rows / 8;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
@@ -127,6 +129,8 @@ extern "C" void evplp_destroy(evplp_context *c) {
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
+    hipFree(c->d_tile_bounds); hipFree(c->d_lists);
+    for (hipEvent_t ev : c->ev_band) hipEventDestroy(ev);
     hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
     hipFree(c->d_compact); hipFree(c->d_rect); hipFree(c->d_tile_z); hipFree(c->d_tile_pairs);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -377,8 +381,62 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.g_dif = (const float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (const float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
     a.vpls = c->d_vpls; a.vpl_src_index = c->d_vpl_src; a.nvpl = &c->d_scalars[0];
     a.out = (float4 *)c->buf[EVPLP_BUF_VPL_ACCUM];
-    a.partial = c->d_partial; a.partial_stride = (size_t)c->st.W * c->st.local_rows;
+    a.partial_stride = (size_t)c->st.W * c->st.local_rows;
     a.counters = &c->d_counters[pass];
+    a.max_vpls = std::max<uint32_t>(c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1u);
+    // tile enumeration: super-tiles of SW x SH tiles, SH = the tile rows a row strip keeps adjacent (8 for a whole image)
+    const int tiles_x = (c->st.W + 7) / 8, tiles_y = (c->st.local_rows + 7) / 8;
+    int sh = 8;
+    if (c->st.strip_count > 1) { sh = 1; while (sh * 2 <= std::min(8, c->st.strip_rows / 8) && (c->st.strip_rows / 8) % (sh * 2) == 0) sh *= 2; }
+    int swl = 0; while ((64 >> swl) > sh) swl++;
+    a.super_w_log2 = swl;
+    a.nsx = (tiles_x + (1 << swl) - 1) >> swl; a.nsy = (tiles_y + sh - 1) / sh;
+    a.band_first_super = 0; a.band_supers = a.nsx * a.nsy;
+    a.splits_per_wave = 1;
+    return EVPLP_OK;
+}
+// gather workspace (lazy): partial sums for `groups` groups, tile bounds, and -- for the VPL gather -- the shaft lists of one band
+static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t groups, bool want_lists, int *bands_out) {
+    const size_t px = (size_t)c->st.W * c->st.local_rows;
+    if (c->partial_groups < groups) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_partial); c->d_partial = nullptr; c->partial_groups = 0;
+        hipError_t e = hipMalloc((void **)&c->d_partial, sizeof(float4) * groups * px);
+        if (e != hipSuccess) { c->set_error("gather: cannot allocate %zu bytes of partial sums: %s", sizeof(float4) * groups * px, hipGetErrorString(e)); return EVPLP_ERR_OOM; }
+        c->partial_groups = groups;
+    }
+    a.partial = c->d_partial;
+    const size_t ntid = (size_t)a.nsx * a.nsy * 64;
+    if (!c->d_tile_bounds) {
+        hipError_t e = hipMalloc((void **)&c->d_tile_bounds, sizeof(TileBound) * ntid);
+        if (e != hipSuccess) { c->set_error("gather: cannot allocate tile bounds: %s", hipGetErrorString(e)); return EVPLP_ERR_OOM; }
+    }
+    a.tile_bounds = c->d_tile_bounds;
+    int bands = 1;
+    if (want_lists) {
+        // one list entry (32 B) per (tile, VPL slot): the image is processed in bands of super-tiles whose lists fit the budget
+        size_t budget = (size_t)1 << 30;
+        if (const char *mb = std::getenv("EVPLP_LIST_MB")) budget = (size_t)std::max(1, atoi(mb)) << 20;
+        const size_t per_super = (size_t)a.max_vpls * 64 * kListWords * sizeof(uint32_t);
+        const int total = a.nsx * a.nsy;
+        int per_band = (int)std::max<size_t>(1, std::min<size_t>((size_t)total, budget / per_super));
+        bands = (total + per_band - 1) / per_band;
+        per_band = (total + bands - 1) / bands;           // even bands
+        const size_t words = (size_t)per_band * per_super / sizeof(uint32_t);
+        if (c->list_words < words) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_lists); c->d_lists = nullptr; c->list_words = 0;
+            hipError_t e = hipMalloc((void **)&c->d_lists, words * sizeof(uint32_t));
+            if (e != hipSuccess) { c->set_error("gather: cannot allocate %zu bytes of shaft lists: %s", words * sizeof(uint32_t), hipGetErrorString(e)); return EVPLP_ERR_OOM; }
+            c->list_words = words;
+        }
+        a.lists = c->d_lists;
+        a.band_supers = per_band;
+    }
+    while (c->ev_band.size() < (size_t)bands * 2) {
+        hipEvent_t ev; HIP_TRY(c, hipEventCreate(&ev)); c->ev_band.push_back(ev);
+    }
+    *bands_out = bands;
     return EVPLP_OK;
 }
 static int check_fp(evplp_context *c, const evplp_frame_params *fp, const char *name) {
@@ -396,11 +454,34 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     if ((rc = check_fp(c, fp, name))) return rc;
     if (fp->num_vpl_light_paths == 0) { c->set_error("%s: num_vpl_light_paths is 0 (the reference disables the pass, rtcomphoton.h:200-203)", name); return EVPLP_ERR_INVALID; }
     GatherArgs a; fill_gather_args(c, fp, a, pass);
+    // work-item size: k consecutive splits per wavefront.  One GPU: 16 (8 partials per pixel, 131 k items at 1024^2); row
+    // strips keep the item count per GPU up with smaller k.  The per-item statistics need (VPLs per split) * k < 65536.
+    int k = 1;
+    if (!vsl) {
+        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : std::max(1, 16 / std::max(1, c->st.strip_count));
+        if (const char *e = std::getenv("EVPLP_GATHER_K")) { int v = atoi(e); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k = v; }
+        while (k > 1 && ((size_t)a.max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
+    }
+    a.splits_per_wave = k;
+    const bool want_lists = !vsl && !c->cfg.gather_no_shaft_lists && std::getenv("EVPLP_NO_SHAFT_LISTS") == nullptr;
+    int bands = 1;
+    if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k), want_lists, &bands))) return rc;
     if ((rc = pass_begin(c, pass))) return rc;
     const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
     launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
-    HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
-    if (vsl) launch_gather_vsl(a, c->stream, c->ev_dom_end[pass]); else launch_gather_vpl(a, c->stream, c->ev_dom_end[pass]);
+    if (want_lists) launch_tile_bounds(a, c->stream);
+    const int total = a.nsx * a.nsy, per_band = a.band_supers;
+    for (int b = 0; b < bands; b++) {
+        a.band_first_super = b * per_band;
+        a.band_supers = std::min(per_band, total - a.band_first_super);
+        if (a.band_supers <= 0) { bands = b; break; }
+        if (want_lists) launch_shaft_walk(a, c->stream);
+        HIP_TRY(c, hipEventRecord(c->ev_band[2 * b], c->stream));
+        if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl_items(a, c->stream);
+        HIP_TRY(c, hipEventRecord(c->ev_band[2 * b + 1], c->stream));
+    }
+    c->gather_launches[pass] = bands;
+    launch_gather_reduce(a, vsl ? 0 : 1, c->stream);
     c->pass_has_dom[pass] = true;
     return pass_end(c, pass);
 }
@@ -569,14 +650,21 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipEventSynchronize(c->ev_end[pass]));
     HIP_TRY(c, hipEventElapsedTime(&out->ms, c->ev_begin[pass], c->ev_end[pass]));
-    if (c->pass_has_dom[pass]) HIP_TRY(c, hipEventElapsedTime(&out->dominant_kernel_ms, c->ev_dom_begin[pass], c->ev_dom_end[pass]));
-    else out->dominant_kernel_ms = out->ms;
+    const bool is_gather = pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL;
+    if (is_gather) {
+        float sum = 0.f;
+        for (int b = 0; b < c->gather_launches[pass]; b++) { float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_band[2 * b], c->ev_band[2 * b + 1])); sum += ms; }
+        out->dominant_kernel_ms = sum; out->launches = (uint32_t)c->gather_launches[pass];
+    } else if (c->pass_has_dom[pass]) { HIP_TRY(c, hipEventElapsedTime(&out->dominant_kernel_ms, c->ev_dom_begin[pass], c->ev_dom_end[pass])); out->launches = 1; }
+    else { out->dominant_kernel_ms = out->ms; out->launches = 1; }
     PassCounters pc; uint32_t scal[16];
     HIP_TRY(c, hipMemcpy(&pc, &c->d_counters[pass], sizeof(pc), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(scal, c->d_scalars, sizeof(scal), hipMemcpyDeviceToHost));
     const uint64_t px = (uint64_t)c->st.W * c->rows_in_image;
     if (pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL) {
-        out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = pc.rays; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
+        unsigned long long rays = 0, shaded = 0;
+        for (int k = 0; k < kCounterShards; k++) { rays += pc.shard_rays[k]; shaded += pc.shard_shaded[k]; }
+        out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = rays; out->shaded = shaded; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
         out->reserved[1] = (uint32_t)(pc.nodes >> 32);
     } else if (pass == EVPLP_PASS_SPLAT) {
         // per-tile pair counts (a single counter word would take one device-scope atomic per tile: measured 0.28 ms of

@@ -23,9 +23,32 @@ struct PassCounters {
     unsigned long long pairs;         // splat: (photon, pixel) pairs inside the kernel radius
     unsigned long long aux;
     // EVPLP_TRAVERSAL_STATS builds only (tools/traversal_stats.py): histogram of leaf blocks tested per (wave, VPL) walk
-    // ([31] = 31 or more), [32] = walks, [33] = triangle pairs tested, [34] = walks that ended with every lane occluded
-    unsigned long long hist[40];
+    // ([31] = 31 or more), [32] = walks, [33] = triangle pairs tested, [34] = walks that ended with every lane occluded,
+    // [35] = (tile, VPL) items served from a shaft list, [36] = leaf blocks tested from lists, [40 + n] = lists of n leaves,
+    // [48] = list entries flagged skip, [49] = flagged overflow
+    unsigned long long hist[64];
+    // gather: shadow rays / unoccluded pairs, summed by gather_reduce_kernel into 64 shards (one device-scope atomic per
+    // workgroup; a single word saturates near 90 atomics per microsecond)
+    unsigned long long shard_rays[64], shard_shaded[64];
 };
+constexpr int kCounterShards = 64;
+
+// Bounds of the lit part of one 8x8-pixel tile of the G-buffer (pixels with a non-zero normal: a zero normal makes the
+// receiver cosine of lighttracing.cu:284 exactly 0, such a pixel never traces a shadow ray), written once per frame.
+struct TileBound {
+    float lo[3]; uint32_t flags;      // AABB of the positions
+    float hi[3]; float pad0;
+    float n[3]; float pad1;           // the common normal when every lit pixel of the tile has the same one (kTileFlat)
+};
+static_assert(sizeof(TileBound) == 48, "TileBound must be 48 bytes");
+constexpr uint32_t kTileLit = 1u, kTileFlat = 2u;
+// Candidate list of one (tile, VPL) shaft, written by shaft_walk_kernel and consumed by gather_vpl_kernel: 32 bytes = one
+// s_load_dwordx8.  word 0 = number of leaf references (0..kListLeaves) | flags, words 1..7 = leaf references (~child id).
+constexpr int kListLeaves = 7;
+constexpr int kListWords = 8;
+constexpr uint32_t kListCountMask = 0xfu;
+constexpr uint32_t kListOverflow = 0x100u;   // more than kListLeaves leaves met the shaft: the gather walks the tree itself
+constexpr uint32_t kListSkip = 0x200u;       // no pixel of the tile can pass the cosine test against this VPL (or the tile has no lit pixel)
 
 struct GatherArgs {
     SceneDev sc; StripDev st;
@@ -36,14 +59,24 @@ struct GatherArgs {
     evplp_frame_params fp;
     float pdf_mc2; int32_t pad0;      // fp.pdf_mc squared (power2 heuristic)
     float4 *out;
-    float4 *partial;                  // [kVplSplit][partial_stride] per-item partial sums
+    float4 *partial;                  // [kVplSplit / splits_per_wave][partial_stride] per-item partial sums
     size_t partial_stride;            // W * local_rows
     PassCounters *counters;
+    // tile enumeration: super-tiles of (1 << super_w_log2) x (64 >> super_w_log2) tiles, tile id = super-tile * 64 + lane
+    TileBound *tile_bounds;           // [nsx * nsy * 64]
+    uint32_t *lists;                  // [max usable VPLs][band_supers * 64][kListWords]; null: no shaft lists (walk per item)
+    int32_t super_w_log2, nsx, nsy;
+    int32_t band_first_super, band_supers;   // the super-tiles this launch covers
+    int32_t splits_per_wave;          // k: a wave sums k consecutive splits (a power of two <= 32) and folds them in tree order
+    uint32_t max_vpls;                // allocated VPL slots (grid bound of shaft_walk_kernel)
+    int32_t pad1;
 };
 #ifndef EVPLP_VPL_SPLIT
 #define EVPLP_VPL_SPLIT 128
 #endif
-constexpr int kVplSplit = EVPLP_VPL_SPLIT;   // items per tile: VPL i belongs to item i % kVplSplit (a constant: results must not depend on the GPU count)
+// VPL i belongs to split i % kVplSplit; a pixel's sum is the balanced binary tree over the kVplSplit per-split sums, each
+// split summed in increasing i.  A constant, and a fixed tree: results must not depend on the GPU count or on splits_per_wave.
+constexpr int kVplSplit = EVPLP_VPL_SPLIT;
 
 struct PathTraceArgs {
     SceneDev sc; StripDev st;
@@ -86,8 +119,12 @@ void launch_primary(const PrimaryArgs &a, hipStream_t s);
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s);
 void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
                         uint32_t *count_out, hipStream_t s);
-void launch_gather_vpl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_end);
-void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dominant_end);
+// VPL gather = tile bounds, then per band of super-tiles: shaft lists (when a.lists) + the gather items, then one reduce
+void launch_tile_bounds(const GatherArgs &a, hipStream_t s);
+void launch_shaft_walk(const GatherArgs &a, hipStream_t s);
+void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s);
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
+void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s);
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s);
 void launch_splat_count(const SplatArgs &a, hipStream_t s);

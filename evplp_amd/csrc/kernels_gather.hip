@@ -78,30 +78,38 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
     return v.flux * x;
 }
 
-// Item order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; speed
-// only, never correctness).  All kVplSplit items of a tile run back to back on one XCD (they share the
-// tile's G-buffer lines and BVH neighbourhood in that L2); consecutive TILES go to different XCDs.
-// Grouping tiles into larger per-XCD super-tiles (kSuper > 1) measured slower: item cost varies by 5x
-// across the image (tiles on furniture silhouettes vs open floor), and balance beats L2 locality here
-// (TCC hit rate stays ~98 % either way).
-#ifndef EVPLP_SUPER_LOG2
-#define EVPLP_SUPER_LOG2 0     // super-tile edge = 2^k tiles; measured per cfg2 frame: k=3 103.9 ms, 2 99.0, 1 94.8, 0 92.0
-#endif
-constexpr int kSuperLog2 = EVPLP_SUPER_LOG2, kSuper = 1 << kSuperLog2, kSuperTiles = kSuper * kSuper;
-struct Item { int x, ly, gy, split; bool in_image, has_tile; uint32_t p; };   // p: pixel index in the strip (W * local_rows < 2^32)
-EV_DEV Item item_setup(const StripDev &st, int lane) {
-    const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    const int sx = (tiles_x + kSuper - 1) >> kSuperLog2, sy = (tiles_y + kSuper - 1) >> kSuperLog2;   // super-tile grid
+// Tile enumeration.  Tiles are grouped into super-tiles of SW x SH tiles (SW * SH = 64, SH = as many tile rows as a row
+// strip keeps adjacent); tile id = super-tile * 64 + (ty % SH) * SW + tx % SW.  One launch covers a band of super-tiles.
+struct TileXY { int tx, ty; bool exists; };
+EV_DEV TileXY tile_of(const GatherArgs &a, uint32_t tid) {
+    const int tiles_x = (a.st.W + 7) >> 3, tiles_y = (a.st.local_rows + 7) >> 3;
+    const int swl = a.super_w_log2, sw = 1 << swl;
+    const int st = (int)(tid >> 6), l = (int)(tid & 63u);
+    const int stx = st % a.nsx, sty = st / a.nsx;
+    TileXY t;
+    t.tx = (stx << swl) + (l & (sw - 1)); t.ty = sty * (64 >> swl) + (l >> swl);
+    t.exists = sty < a.nsy && t.tx < tiles_x && t.ty < tiles_y;
+    return t;
+}
+// Item order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; speed only, never
+// correctness).  All items of a tile run back to back on one XCD (they share the tile's G-buffer lines, its shaft lists
+// and BVH neighbourhood in that L2); consecutive TILES go to different XCDs (item cost varies by 5x across the image --
+// furniture silhouettes vs open floor -- and balance beats L2 locality: per-XCD super-tiles of 2x2 / 4x4 tiles
+// measured 3 % / 13 % slower in round 1).
+struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p, tile_in_band; };   // p: pixel index in the strip (W * local_rows < 2^32)
+EV_DEV Item item_setup(const GatherArgs &a, int lane) {
+    const StripDev &st = a.st;
+    const int groups = kVplSplit / a.splits_per_wave;
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
-    const int tile_j = j / kVplSplit;
-    const int stile = (tile_j / kSuperTiles) * 8 + xcd, within = tile_j % kSuperTiles;
-    const int tx = (stile % sx) * kSuper + (within & (kSuper - 1)), ty = (stile / sx) * kSuper + (within >> kSuperLog2);
+    const int tile_j = j / groups;
     Item t;
-    t.split = j - tile_j * kVplSplit;
-    t.has_tile = stile < sx * sy && tx < tiles_x && ty < tiles_y;
-    t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
-    const int cly = min(t.ly, st.local_rows - 1);
+    t.group = j - tile_j * groups;
+    t.tile_in_band = (uint32_t)(tile_j * 8 + xcd);
+    const TileXY xy = tile_of(a, (uint32_t)a.band_first_super * 64u + t.tile_in_band);
+    t.has_tile = t.tile_in_band < (uint32_t)a.band_supers * 64u && xy.exists;
+    t.x = xy.tx * 8 + (lane & 7); t.ly = xy.ty * 8 + (lane >> 3);
+    const int cly = max(min(t.ly, st.local_rows - 1), 0);
     t.gy = st.global_row(cly);
     t.in_image = t.has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
     t.p = (uint32_t)cly * (uint32_t)st.W + (uint32_t)min(t.x, st.W - 1);
@@ -109,7 +117,7 @@ EV_DEV Item item_setup(const StripDev &st, int lane) {
 }
 
 #ifndef EVPLP_GATHER_WAVES
-#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups): 6 = 81.7 ms, 7 = 77.3 ms, 8 = 82.4 ms (spills) per cfg2 launch
+#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups)
 #endif
 typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -124,9 +132,183 @@ EV_DEV Vpl fetch_vpl(const evplp_record *r) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------- shaft lists
+// Phase 0: bounds of the lit pixels of every tile (one wave per tile id).
+__global__ __launch_bounds__(64) void tile_bounds_kernel(GatherArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t tid = blockIdx.x;
+    const TileXY xy = tile_of(a, tid);
+    const int x = xy.tx * 8 + (lane & 7), ly = xy.ty * 8 + (lane >> 3);
+    const int cly = max(min(ly, a.st.local_rows - 1), 0);
+    const bool in_image = xy.exists && x < a.st.W && ly < a.st.local_rows && a.st.global_row(cly) < a.st.H;
+    const size_t p = (size_t)cly * a.st.W + min(x, a.st.W - 1);
+    float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), gn = gp;
+    if (in_image) { gp = a.g_pos[p]; gn = a.g_nrm[p]; }
+    const bool lit = in_image && gp.w != 0.0f && (gn.x != 0.0f || gn.y != 0.0f || gn.z != 0.0f);
+    const float big = 3.0e38f;
+    float lo[3] = { lit ? gp.x : big, lit ? gp.y : big, lit ? gp.z : big }, hi[3] = { lit ? gp.x : -big, lit ? gp.y : -big, lit ? gp.z : -big };
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+    const unsigned long long lm = ballot64(lit);
+    uint32_t flags = 0u; float n[3] = { 0.f, 0.f, 0.f };
+    if (lm != 0ull) {
+        flags = kTileLit;
+        const int first = (int)__ffsll((long long)lm) - 1;
+        n[0] = __shfl(gn.x, first); n[1] = __shfl(gn.y, first); n[2] = __shfl(gn.z, first);
+        if (ballot64(lit && (gn.x != n[0] || gn.y != n[1] || gn.z != n[2])) == 0ull) flags |= kTileFlat;
+    }
+    if (lane == 0) {
+        TileBound tb;
+        for (int k = 0; k < 3; k++) { tb.lo[k] = lo[k]; tb.hi[k] = hi[k]; tb.n[k] = n[k]; }
+        tb.flags = flags; tb.pad0 = tb.pad1 = 0.f;
+        a.tile_bounds[tid] = tb;
+    }
+}
+
+// Phase 1: one wave = (super-tile, VPL), lane = tile.  Every lane carries the SHAFT of its tile -- the union of the segments
+// from the VPL to every point of the tile's position box, o + t (p - o), p in [lo, hi], t in [tmin, tmax] -- and the wave
+// walks the tree once for all 64 shafts (the packet walk of occluded_wave with lanes = tiles): a node visit costs 18 vector
+// instructions for 64 (tile, VPL) pairs instead of 15 per pair.  Leaves met by a lane's shaft are appended to that lane's
+// list (LDS, [slot][lane]).  A ray of the tile can only hit a triangle whose (padded) leaf box its segment meets, hence a
+// leaf on the list: testing the listed leaves' triangles with the exact predicate gives the same visibility bits as the
+// walk.  Per axis the shaft occupies o + t [dlo, dhi] (dlo = lo - o, dhi = hi - o) and meets the node slab [ctr - hal, ctr + hal]
+// while  t dhi >= ctr - hal - o  and  t dlo <= ctr + hal - o:
+//   dlo > 0          entry (ctr - o - hal) / dhi,  exit (ctr - o + hal) / dlo
+//   dhi < 0          entry (ctr - o + hal) / dlo,  exit (ctr - o - hal) / dhi
+//   dlo <= 0 <= dhi  the tile's extent straddles the origin on this axis: only the entry (ctr - o - hal) / dhi is kept and
+//                    the exit is +inf (conservative; rare -- the VPL coordinate has to fall inside the tile's few cm)
+// i.e.  entry = ctr rE + cE - hal |rE|,  exit = ctr rX + cX + hal |rX|  with per-lane constants: the two-child packed
+// slab test of occluded_wave with separate reciprocals for entry and exit.
+#ifndef EVPLP_SHAFT_WAVES
+#define EVPLP_SHAFT_WAVES 8
+#endif
+__global__ __launch_bounds__(64, EVPLP_SHAFT_WAVES) void shaft_walk_kernel(GatherArgs a) {
+    __shared__ uint32_t s_list[kListLeaves * 64];
+    const int lane = threadIdx.x;
+    const uint32_t nvpl = *a.nvpl;
+    const uint32_t i = blockIdx.x / (uint32_t)a.band_supers, sb = blockIdx.x % (uint32_t)a.band_supers;
+    if (i >= nvpl) return;
+    const uint32_t tid = ((uint32_t)a.band_first_super + sb) * 64u + (uint32_t)lane;
+    const float4 *tbp = reinterpret_cast<const float4 *>(a.tile_bounds + tid);
+    const float4 t0 = tbp[0], t1 = tbp[1], t2 = tbp[2];
+    const uint32_t tflags = __float_as_uint(t0.w);
+    // the VPL: position and normal (first 32 bytes of the record), wave-uniform
+    const v8i ra = *reinterpret_cast<const v8i *>(a.vpls + i);
+    const V3 o = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])), vn = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6]));
+    const V3 lo = v3(t0), hi = v3(t1), tn = v3(t2);
+    bool live = (tflags & kTileLit) != 0u;
+    {
+        // cosine culls with a rounding margin (the per-pixel test of lighttracing.cu:284-288 is evaluated in fp32; a tile is
+        // only dropped when every pixel's cosine is negative by far more than that arithmetic can err):
+        //   VPL side:   max over the box of  n2 . (p - o)  <= -eps   ->  c2 = max(-n2 . v12, 0) = 0 for every pixel
+        //   pixel side: tiles with one common normal:  max of  n1 . (o - p)  <= -eps  ->  c1 = 0 for every pixel
+        const V3 c = (lo + hi) * 0.5f, h = (hi - lo) * 0.5f, co = c - o;
+        const V3 an2 = v3(fabsf(vn.x), fabsf(vn.y), fabsf(vn.z));
+        const float m2 = dot(vn, co) + dot(an2, h), s2 = dot(an2, v3(fabsf(co.x), fabsf(co.y), fabsf(co.z))) + dot(an2, h);
+        if (m2 < -1.0e-5f * s2) live = false;
+        if (tflags & kTileFlat) {
+            const V3 an1 = v3(fabsf(tn.x), fabsf(tn.y), fabsf(tn.z));
+            const float m1 = -dot(tn, co) + dot(an1, h), s1 = dot(an1, v3(fabsf(co.x), fabsf(co.y), fabsf(co.z))) + dot(an1, h);
+            if (m1 < -1.0e-5f * s1) live = false;
+        }
+    }
+    const bool skip = !live;
+    uint32_t cnt = 0u;
+    if (ballot64(live) != 0ull) {
+        // shaft constants in the segment's own parameter u = (t - tmin) / (tmax - tmin), as occluded_wave
+        const float tmin = 0.0001f, tmax = 1.0f - 0.0001f, ku = 1.0f / (tmax - tmin);
+        const float dead = __builtin_inff();
+        float rE[3], cE[3], rX[3], cX[3];
+        const float dl[3] = { lo.x - o.x, lo.y - o.y, lo.z - o.z }, dh[3] = { hi.x - o.x, hi.y - o.y, hi.z - o.z }, oo[3] = { o.x, o.y, o.z };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float il = safe_rcp(dl[k]), ih = safe_rcp(dh[k]);
+            const bool pos = dl[k] > 0.0f, neg = dh[k] < 0.0f;
+            const float e = pos ? ih : neg ? il : ih;
+            const float x = pos ? il : neg ? ih : 0.0f;
+            rE[k] = e * ku; cE[k] = live ? (-(oo[k] * e) - tmin) * ku : dead;
+            rX[k] = x * ku; cX[k] = (pos || neg) ? (-(oo[k] * x) - tmin) * ku : dead;
+        }
+        const v2f rEx = bc(rE[0]), rEy = bc(rE[1]), rEz = bc(rE[2]), aEx = bc(fabsf(rE[0])), aEy = bc(fabsf(rE[1])), aEz = bc(fabsf(rE[2]));
+        const v2f rXx = bc(rX[0]), rXy = bc(rX[1]), rXz = bc(rX[2]), aXx = bc(fabsf(rX[0])), aXy = bc(fabsf(rX[1])), aXz = bc(fabsf(rX[2]));
+        v2f cEx = bc(cE[0]), cEy = bc(cE[1]), cEz = bc(cE[2]);
+        const v2f cXx = bc(cX[0]), cXy = bc(cX[1]), cXz = bc(cX[2]);
+        int sp = 0, vstack = 0;
+        int32_t cur = 0;  // root is always an inner node
+        const char *node_base = reinterpret_cast<const char *>(a.sc.nodes);
+        for (;;) {
+            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
+            const v2f cx = pk(n[0], n[1]), cy = pk(n[2], n[3]), cz = pk(n[4], n[5]);
+            const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
+            const v2f enx = pk_fma(hx, -aEx, pk_fma(cx, rEx, cEx)), eny = pk_fma(hy, -aEy, pk_fma(cy, rEy, cEy)), enz = pk_fma(hz, -aEz, pk_fma(cz, rEz, cEz));
+            const v2f exx = pk_fma(hx, aXx, pk_fma(cx, rXx, cXx)), exy = pk_fma(hy, aXy, pk_fma(cy, rXy, cXy)), exz = pk_fma(hz, aXz, pk_fma(cz, rXz, cXz));
+            const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
+            const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
+            const bool h0 = tn0 < tf0, h1 = tn1 < tf1;
+            const unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
+            const int32_t c0 = n[12], c1 = n[13];
+            uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
+            // a leaf child is not entered: the lanes whose shaft meets its box put it on their list
+            bool over = false;
+            if (a0 != 0u && c0 < 0) {
+                if (h0) { if (cnt < (uint32_t)kListLeaves) s_list[cnt * 64u + (uint32_t)lane] = (uint32_t)c0; else over = true; cnt++; }
+                a0 = 0u;
+            }
+            if (a1 != 0u && c1 < 0) {
+                if (h1) { if (cnt < (uint32_t)kListLeaves) s_list[cnt * 64u + (uint32_t)lane] = (uint32_t)c1; else over = true; cnt++; }
+                a1 = 0u;
+            }
+            if (over) { cEx = bc(dead); cEy = bc(dead); cEz = bc(dead); }   // a full list ends its lane's walk (the gather walks the tree for it)
+            if ((a0 | a1) != 0u) {
+                if (a0 == 0u) { cur = c1; continue; }
+                if (a1 == 0u) { cur = c0; continue; }
+                const uint32_t p0 = (uint32_t)__builtin_popcountll(m0), p1 = (uint32_t)__builtin_popcountll(m1);
+                const bool first0 = p0 >= p1;
+                vstack = lane_write(first0 ? c1 : c0, sp, vstack);
+                sp++;
+                cur = first0 ? c0 : c1;
+                continue;
+            }
+            if (sp == 0) break;
+            sp--;
+            cur = lane_read(vstack, sp);
+        }
+    }
+    // list entry of (tile, VPL): 8 words per lane, two 16-byte stores
+    uint32_t w[kListWords];
+    w[0] = min(cnt, (uint32_t)kListLeaves) | (cnt > (uint32_t)kListLeaves ? kListOverflow : 0u) | (skip ? kListSkip : 0u);
+#pragma unroll
+    for (int k = 0; k < kListLeaves; k++) w[1 + k] = (uint32_t)k < cnt ? s_list[(uint32_t)k * 64u + (uint32_t)lane] : 0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(a.lists + ((size_t)i * ((size_t)a.band_supers * 64u) + (size_t)sb * 64u + (size_t)lane) * kListWords);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// exact any-hit test of the wave's segments (common origin o, per-lane direction d) against the triangles of ONE leaf block
+EV_DEV bool leaf_any_hit(const char *leaf_base, uint32_t leafref, V3 o, V3 d, float tmin, float tmax) {
+    const uint32_t id = ~leafref;
+    const uint32_t cnt = (id & 3u) + 1u;
+    const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
+    const v16i a = tp[0], b = tp[1];
+    Hit2 h = tri_pair_test(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
+                           pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]),
+                           o, d, tmin, tmax);
+    bool any = h.a | h.b;    // an empty slot B is all zeros: den = 0 -> never a hit
+    if (cnt > 2u) {
+        const v16i c = tp[2];
+        Hit2 g = tri_pair_test(pk(b[8], b[9]), pk(b[10], b[11]), pk(b[12], b[13]), pk(b[14], b[15]), pk(c[0], c[1]), pk(c[2], c[3]),
+                               pk(c[4], c[5]), pk(c[6], c[7]), pk(c[8], c[9]), pk(c[10], c[11]), pk(c[12], c[13]), pk(c[14], c[15]),
+                               o, d, tmin, tmax);
+        any = any | g.a | g.b;
+    }
+    return any;
+}
+
+// Phase 2.  One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.  Per VPL the wave reads the
+// (tile, VPL) list entry: skipped, a handful of leaves to test with the exact predicate, or "overflow" = walk the tree.
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
     const int lane = threadIdx.x;
-    const Item t = item_setup(a.st, lane);
+    const Item t = item_setup(a, lane);
     if (!t.has_tile) return;   // padding of the super-tile grid
     const uint32_t p = t.p;
 
@@ -137,52 +319,137 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     const bool valid = t.in_image && gp.w != 0.0f;      // stencil test, lighttracing.cu:354
 
     const uint32_t nvpl = *a.nvpl;
-    V3 result = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0;
-    for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
-        const Vpl v = fetch_vpl(a.vpls + i);
-        V3 v12 = v.pos - px.p1;                                         // :282
-        float c1 = fmaxf(dot(px.n1, v12), 0.0f);
-        float c2 = fmaxf(-dot(v.n, v12), 0.0f);
-        float c1c2 = c1 * c2;
-        bool active = valid && !(c1c2 <= 0.0f);                         // :288
-        if (ballot64(active) == 0ull) continue;
-        rays += active ? 1u : 0u;
-        // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
+    const int k = a.splits_per_wave;
+    const char *leaf_base = reinterpret_cast<const char *>(a.sc.leaves);
+    const uint32_t *list_row = a.lists ? a.lists + (size_t)t.tile_in_band * kListWords : nullptr;
+    const size_t list_stride = (size_t)a.band_supers * 64u * kListWords;    // words per VPL
+    __shared__ float s_lvl[6 * 192];
+    V3 total = v3(0.f, 0.f, 0.f);
+    uint32_t rays = 0, shaded = 0;
+    for (int jj = 0; jj < k; jj++) {
+        const uint32_t split = (uint32_t)(t.group * k + jj);
+        V3 result = v3(0.f, 0.f, 0.f);
+        for (uint32_t i = split; i < nvpl; i += kVplSplit) {
+            v8i L = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (list_row) {
+                L = *reinterpret_cast<const v8i *>(list_row + (size_t)i * list_stride);
 #if EVPLP_TRAVERSAL_STATS
-        WalkStats ws = { 0u, 0u, 0u };
-        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
-        if (lane == 0) {
-            atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
-            atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
-            atomicAdd(&a.counters->hist[32], 1ull);
-            atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
-            if (ballot64(active && !occ) == 0ull) atomicAdd(&a.counters->hist[34], 1ull);
-        }
-#else
-        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+                if (lane == 0) {
+                    if ((uint32_t)L[0] & kListSkip) atomicAdd(&a.counters->hist[48], 1ull);
+                    else if ((uint32_t)L[0] & kListOverflow) atomicAdd(&a.counters->hist[49], 1ull);
+                    else atomicAdd(&a.counters->hist[40 + ((uint32_t)L[0] & kListCountMask)], 1ull);
+                }
 #endif
-        if (active && !occ) result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2);
+                if ((uint32_t)L[0] & kListSkip) continue;
+            }
+            const Vpl v = fetch_vpl(a.vpls + i);
+            V3 v12 = v.pos - px.p1;                                         // :282
+            float c1 = fmaxf(dot(px.n1, v12), 0.0f);
+            float c2 = fmaxf(-dot(v.n, v12), 0.0f);
+            float c1c2 = c1 * c2;
+            bool active = valid && !(c1c2 <= 0.0f);                         // :288
+            unsigned long long alive = ballot64(active);
+            if (alive == 0ull) continue;
+            rays += active ? 1u : 0u;
+            // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
+            bool occ;
+            if (!list_row || ((uint32_t)L[0] & kListOverflow)) {
+#if EVPLP_TRAVERSAL_STATS
+                WalkStats ws = { 0u, 0u, 0u };
+                occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
+                if (lane == 0) {
+                    atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
+                    atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
+                    atomicAdd(&a.counters->hist[32], 1ull);
+                    atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
+                    if (ballot64(active && !occ) == 0ull) atomicAdd(&a.counters->hist[34], 1ull);
+                }
+#else
+                occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+#endif
+            } else {
+                occ = false;
+                const V3 d = -v12;
+                uint32_t n = (uint32_t)L[0] & kListCountMask;
+                int r1 = L[1], r2 = L[2], r3 = L[3], r4 = L[4], r5 = L[5], r6 = L[6], r7 = L[7];
+#if EVPLP_TRAVERSAL_STATS
+                uint32_t tested = 0;
+#endif
+                while (n != 0u) {
+                    const bool hit = leaf_any_hit(leaf_base, (uint32_t)r1, v.pos, d, 0.0001f, 1.0f - 0.0001f);
+#if EVPLP_TRAVERSAL_STATS
+                    tested++;
+#endif
+                    occ = occ || hit;
+                    alive &= ~ballot64(hit);
+                    if (alive == 0ull) break;
+                    r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7;
+                    n--;
+                }
+#if EVPLP_TRAVERSAL_STATS
+                if (lane == 0) { atomicAdd(&a.counters->hist[35], 1ull); atomicAdd(&a.counters->hist[36], (unsigned long long)tested); }
+#endif
+            }
+            if (active && !occ) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2); shaded++; }
+        }
+        // fold the split sums in the fixed balanced-tree order: a binary counter whose level j holds the sum of 2^j splits.
+        // The levels live in LDS ([level][component][lane], touched once per split): registers are what limits occupancy here.
+        {
+            int lev = 0;
+            while ((jj >> lev) & 1) {       // wave-uniform
+                float *q = s_lvl + lev * 192 + lane;
+                result = v3(q[0], q[64], q[128]) + result;
+                lev++;
+            }
+            float *q = s_lvl + lev * 192 + lane;
+            q[0] = result.x; q[64] = result.y; q[128] = result.z;
+        }
+        total = result;     // after the last jj (k - 1 = all ones) this is the sum of all k splits
     }
-    if (t.in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
-    // statistics: one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0) atomicAdd(&a.counters->rays, (unsigned long long)rays);
+    // per-lane statistics ride in the unused fourth component: shadow rays | unoccluded pairs << 16 (both < 65536 per item)
+    if (t.in_image) a.partial[(size_t)t.group * a.partial_stride + p] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (shaded << 16)));
 }
 
-// out = (sum of the kVplSplit partials in split order) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378)
+// out = (balanced-tree sum of the per-group partials) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378);
+// the shadow-ray / unoccluded-pair counts of the items are summed here too (64 counter shards, summed by the host)
 __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int stencil_test) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n = (size_t)a.st.W * a.st.local_rows;
-    if (i >= n) return;
-    const int ly = (int)(i / a.st.W);
-    if (a.st.global_row(ly) >= a.st.H) return;
-    if (stencil_test && a.g_pos[i].w == 0.0f) return;               // splatColor returns before writing (:354)
-    float4 s = a.partial[i];
-    for (int k = 1; k < kVplSplit; k++) { float4 q = a.partial[(size_t)k * a.partial_stride + i]; s.x += q.x; s.y += q.y; s.z += q.z; }
-    const float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
-    float4 old = a.out[i];
-    a.out[i] = make_float4(s.x / inv + acc * old.x, s.y / inv + acc * old.y, s.z / inv + acc * old.z, 0.0f + acc * old.w);
+    unsigned long long rays = 0ull, shaded = 0ull;
+    bool writes = i < n;
+    if (writes) {
+        const int ly = (int)(i / a.st.W);
+        if (a.st.global_row(ly) >= a.st.H) writes = false;
+        else if (stencil_test && a.g_pos[i].w == 0.0f) writes = false;      // splatColor returns before writing (:354)
+    }
+    if (writes) {
+        const int groups = kVplSplit / a.splits_per_wave;
+        V3 r = v3(0.f, 0.f, 0.f), lv0 = r, lv1 = r, lv2 = r, lv3 = r, lv4 = r, lv5 = r, lv6 = r;
+        for (int g = 0; g < groups; g++) {
+            float4 q = a.partial[(size_t)g * a.partial_stride + i];
+            const uint32_t st = __float_as_uint(q.w);
+            rays += st & 0xffffu; shaded += st >> 16;
+            r = v3(q.x, q.y, q.z);
+            // binary counter over g (level j holds the sum of 2^j consecutive partials): merge while the low bits of g are ones
+#define EV_MERGE(L, NEXT) if (((g >> L) & 1) == 0) lv##L = r; else { r = lv##L + r; NEXT }
+            EV_MERGE(0, EV_MERGE(1, EV_MERGE(2, EV_MERGE(3, EV_MERGE(4, EV_MERGE(5, EV_MERGE(6, ;)))))))
+#undef EV_MERGE
+        }
+        const float inv = (float)a.fp.num_vpl_light_paths, acc = (float)a.fp.do_accumulate;
+        float4 old = a.out[i];
+        a.out[i] = make_float4(r.x / inv + acc * old.x, r.y / inv + acc * old.y, r.z / inv + acc * old.z, 0.0f + acc * old.w);
+    }
+    __shared__ unsigned long long s_sum[2];
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0ull;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); shaded += __shfl_down(shaded, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum[0], rays); atomicAdd(&s_sum[1], shaded); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int shard = blockIdx.x & (kCounterShards - 1);
+        atomicAdd(&a.counters->shard_rays[shard], s_sum[0]);
+        atomicAdd(&a.counters->shard_shaded[shard], s_sum[1]);
+    }
 }
 
 // ------------------------------------------------------------------- light-subpath windows
@@ -404,7 +671,7 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, con
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
     const int lane = threadIdx.x;
     const int W = a.st.W;
-    const Item t = item_setup(a.st, lane);
+    const Item t = item_setup(a, lane);      // splits_per_wave = 1: group = split
     if (!t.has_tile) return;
     const uint32_t p = t.p;
     const bool in_image = t.in_image;
@@ -425,8 +692,8 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
     }
     const uint32_t nvpl = *a.nvpl;
     V3 result = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0;
-    for (uint32_t i = (uint32_t)t.split; i < nvpl; i += kVplSplit) {
+    uint32_t rays = 0, nlit = 0;
+    for (uint32_t i = (uint32_t)t.group; i < nvpl; i += kVplSplit) {
         const Vpl v = fetch_vpl(a.vpls + i);
         V3 v12 = v.pos - px.p1;                                       // :605
         float dist2 = dot(v12, v12);
@@ -438,6 +705,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
         bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
         if (ballot64(lit) == 0ull) continue;
         if (lit) {
+            nlit++;
             VslCtx c;
             float rdratio = a.fp.vsl_radius / dist;
             c.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
@@ -468,30 +736,28 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
             result = result + acc * vslm::rcp((float)num_samples);
         }
     }
-    if (in_image) a.partial[(size_t)t.split * a.partial_stride + p] = make_float4(result.x, result.y, result.z, 0.f);
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0) atomicAdd(&a.counters->rays, (unsigned long long)rays);
+    if (in_image) a.partial[(size_t)t.group * a.partial_stride + p] = make_float4(result.x, result.y, result.z, __uint_as_float(rays | (nlit << 16)));
 }
 
-static dim3 gather_grid(const StripDev &st) {
-    int tiles_x = (st.W + 7) / 8, tiles_y = (st.local_rows + 7) / 8;
-    int sx = (tiles_x + kSuper - 1) / kSuper, sy = (tiles_y + kSuper - 1) / kSuper;
-    int per_xcd = (sx * sy + 7) / 8;                          // super-tiles per XCD (rounded up)
-    return dim3(per_xcd * kSuperTiles * kVplSplit * 8);       // x tiles x kVplSplit items x 8 XCDs
+static dim3 gather_grid(const GatherArgs &a) {
+    const int groups = kVplSplit / a.splits_per_wave;
+    return dim3((unsigned)(a.band_supers * 64 * groups));       // (band tiles rounded to 8) x groups: tile = tile_j * 8 + xcd
 }
-static void launch_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
+void launch_tile_bounds(const GatherArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(tile_bounds_kernel, dim3((unsigned)(a.nsx * a.nsy * 64)), dim3(64), 0, s, a);
+}
+void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
     size_t n = (size_t)a.st.W * a.st.local_rows;
     hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, stencil_test);
 }
-void launch_gather_vpl(const GatherArgs &a, hipStream_t s, hipEvent_t dom_end) {
-    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a.st), dim3(64), 0, s, a);
-    if (dom_end) hipEventRecord(dom_end, s);
-    launch_reduce(a, 1, s);
+void launch_shaft_walk(const GatherArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(shaft_walk_kernel, dim3((unsigned)a.band_supers * a.max_vpls), dim3(64), 0, s, a);
 }
-void launch_gather_vsl(const GatherArgs &a, hipStream_t s, hipEvent_t dom_end) {
-    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a.st), dim3(64), 0, s, a);
-    if (dom_end) hipEventRecord(dom_end, s);
-    launch_reduce(a, 0, s);
+void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), 0, s, a);
+}
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), 0, s, a);
 }
 
 } // namespace evplp

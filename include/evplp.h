@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EVPLP_ABI_VERSION 1
+#define EVPLP_ABI_VERSION 2
 
 typedef enum evplp_status {
     EVPLP_OK = 0,
@@ -79,7 +79,10 @@ typedef struct evplp_config {
     uint32_t photons_per_path;   /* numMaxBounces + 1, rtcomphoton.h:116-117 */
     int32_t bvh_builder;         /* evplp_bvh_builder */
     int32_t deterministic;       /* 1: photon bins are accumulated in record order (bitwise reproducible) */
-    int32_t reserved[4];
+    int32_t gather_splits_per_wave; /* VPL gather work-item size: consecutive VPL splits (of 128) one wavefront sums; a power of two
+                                  * 1..32, 0 = automatic (16 / strip_count).  Results do not depend on it (fixed summation tree). */
+    int32_t gather_no_shaft_lists;  /* 1: every gather item walks the tree itself (no per-(tile, VPL) candidate lists); same results */
+    int32_t reserved[2];
 } evplp_config;
 
 /* rt/rtcommon.h:278-308 RtMaterial: three RGBA32F textures (a constant is a 1x1 texture,
@@ -133,8 +136,11 @@ typedef struct evplp_pass_stats {
     uint64_t pairs;          /* gather: (pixel, usable record) pairs; splat: (photon, covered pixel) pairs */
     uint64_t rays;           /* rays traced by the pass */
     uint64_t usable;         /* usable VPL / photon records consumed */
-    float dominant_kernel_ms;/* device time of the pass's dominant kernel alone */
+    float dominant_kernel_ms;/* device time of the pass's dominant kernel alone (summed over its launches) */
     uint32_t reserved[3];
+    uint64_t shaded;         /* gather: pairs that passed the cosine test AND the visibility test (contributions evaluated) */
+    uint32_t launches;       /* launches of the dominant kernel in the pass (the VPL gather runs one per band of tiles) */
+    uint32_t pad;
 } evplp_pass_stats;
 
 typedef enum evplp_pass {

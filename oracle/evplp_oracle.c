@@ -782,6 +782,38 @@ void evo_gather_vpl(const evo_scene *s, const evo_frame_params *fp, int32_t W, i
     if (pairs_out) *pairs_out = pairs;
 }
 
+/* Counting twin of evo_gather_vpl (test infrastructure for the product's statistics): shadow rays traced = pairs that pass the
+ * cosine test of lighttracing.cu:288, and pairs left after the any-hit test of :290-294.  rows may be any subset of image rows. */
+void evo_gather_vpl_counts(const evo_scene *s, const evo_frame_params *fp, int32_t W, const int32_t *rows, int32_t nrows,
+                           const float *g_pos, const float *g_nrm, const evo_record *records, uint64_t *rays_out, uint64_t *unoccluded_out) {
+    uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;
+    uint64_t rays = 0, lit = 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays, lit) num_threads(evo_get_threads())
+    for (int32_t r = 0; r < nrows; r++) {
+        int32_t y = rows[r];
+        for (int32_t x = 0; x < W; x++) {
+            size_t p = ((size_t)y * W + x) * 4;
+            if (g_pos[p + 3] == 0.0f) continue;
+            v3 p1 = ld3(g_pos + p), n1 = ld3(g_nrm + p);
+            for (uint32_t i = 0; i < nrec; i++) {
+                const evo_record *rec = &records[i];
+                if (!(rec->flags & EVO_USABLE_VPL)) continue;
+                v3 pv = ld3(rec->pos);
+                v3 v12 = sub(pv, p1);
+                float c1 = maxf(dot(n1, v12), 0.0f), c2 = maxf(-dot(ld3(rec->normal), v12), 0.0f);
+                float c1c2 = c1 * c2;
+                if (c1c2 <= 0.000f) continue;
+                rays++;
+                float o[3], d[3]; st3(o, pv); st3(d, neg(v12));
+                if (evo_occluded(s, o, d, 0.0001f, 1.0f - 0.0001f)) continue;
+                lit++;
+            }
+        }
+    }
+    if (rays_out) *rays_out = rays;
+    if (unoccluded_out) *unoccluded_out = lit;
+}
+
 /* -------------------------------------------------------------- VSL gather */
 /* lighttracing.cu:382-390 */
 static inline v3 square_to_solid_angle(float sx, float sy, float half_angle_max) {

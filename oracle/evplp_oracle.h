@@ -150,6 +150,9 @@ void evo_gather_vpl(const evo_scene *s, const evo_frame_params *fp, int32_t W, i
                     const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
                     const evo_record *records, float *out /* RGBA accumulate */,
                     uint64_t *pairs_out /* optional: evaluated (pixel, usable record) pairs */);
+/* counting twin: shadow rays traced / pairs left unoccluded over the given image rows (checks the product's statistics) */
+void evo_gather_vpl_counts(const evo_scene *s, const evo_frame_params *fp, int32_t W, const int32_t *rows, int32_t nrows,
+                           const float *g_pos, const float *g_nrm, const evo_record *records, uint64_t *rays_out, uint64_t *unoccluded_out);
 /* lighttracing.cu:596-722 */
 void evo_gather_vsl(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H,
                     int32_t row_begin, int32_t row_end,

@@ -85,6 +85,7 @@ def load():
     l.evo_trace_light_paths.argtypes = [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]
     l.evo_vpl_splat_pair.argtypes = [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, _P]
     l.evo_gather_vpl.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]
+    l.evo_gather_vpl_counts.argtypes = [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]
     l.evo_gather_vsl.argtypes = l.evo_gather_vpl.argtypes
     l.evo_gather_lvc.argtypes = l.evo_gather_vpl.argtypes
     l.evo_photon_frag.restype = C.c_int
@@ -169,6 +170,13 @@ class Scene:
         fn = self.lib.evo_gather_lvc if lvc else self.lib.evo_gather_vsl if vsl else self.lib.evo_gather_vpl
         fn(self.h, C.byref(fp), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), ptr(out), C.byref(pairs))
         return out, pairs.value
+
+    def gather_counts(self, fp, W, gbuf, records, rows):
+        """(shadow rays traced, unoccluded pairs) of the VPL gather over the given image rows."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        rays, lit = C.c_uint64(), C.c_uint64()
+        self.lib.evo_gather_vpl_counts(self.h, C.byref(fp), W, ptr(rows), rows.shape[0], ptr(gbuf[0]), ptr(gbuf[1]), ptr(records), C.byref(rays), C.byref(lit))
+        return rays.value, lit.value
 
     def path_trace(self, cam_pos, seed, max_bounces, W, H, gbuf, out=None, accumulate=True, rows=None):
         if out is None:

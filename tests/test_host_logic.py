@@ -23,12 +23,12 @@ def test_library_exports_every_declared_symbol(evplp):
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in include/evplp.h but not exported: {missing}"
     assert declared == set(evplp._SIGNATURES), declared ^ set(evplp._SIGNATURES)
-    assert lib.evplp_abi_version() == 1
+    assert lib.evplp_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(evplp):
     assert C.sizeof(evplp.FrameParams) == 64 and C.sizeof(evplp.Config) == 64
-    assert C.sizeof(evplp.Material) == 40 and C.sizeof(evplp.Camera) == 44 and C.sizeof(evplp.PassStats) == 48
+    assert C.sizeof(evplp.Material) == 40 and C.sizeof(evplp.Camera) == 44 and C.sizeof(evplp.PassStats) == 64
     assert evplp.RECORD_DTYPE.itemsize == 96
 
 
@@ -47,7 +47,7 @@ def test_create_rejects_bad_configs(evplp):
     cfg.abi_version = 99
     assert evplp.lib().evplp_create(C.byref(cfg), C.byref(h)) == evplp.ERR_INVALID
     assert b"ABI version" in evplp.lib().evplp_last_error(None)
-    cfg.abi_version = 1; cfg.res_x = cfg.res_y = 8; cfg.num_light_paths = 4; cfg.num_vpl_light_paths = 8; cfg.photons_per_path = 4
+    cfg.abi_version = 2; cfg.res_x = cfg.res_y = 8; cfg.num_light_paths = 4; cfg.num_vpl_light_paths = 8; cfg.photons_per_path = 4
     assert evplp.lib().evplp_create(C.byref(cfg), C.byref(h)) == evplp.ERR_INVALID
     assert b"num_vpl_light_paths" in evplp.lib().evplp_last_error(None)
     assert evplp.lib().evplp_create(None, C.byref(h)) == evplp.ERR_INVALID
