@@ -129,7 +129,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
-    hipFree(c->d_tile_bounds); hipFree(c->d_lists);
+    hipFree(c->d_tile_bounds); hipFree(c->d_vis);
     for (hipEvent_t ev : c->ev_band) hipEventDestroy(ev);
     hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
     hipFree(c->d_compact); hipFree(c->d_rect); hipFree(c->d_tile_z); hipFree(c->d_tile_pairs);
@@ -395,8 +395,8 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.splits_per_wave = 1;
     return EVPLP_OK;
 }
-// gather workspace (lazy): partial sums for `groups` groups, tile bounds, and -- for the VPL gather -- the shaft lists of one band
-static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t groups, bool want_lists, int *bands_out) {
+// gather workspace (lazy): partial sums for `groups` groups, tile bounds, and -- for the VPL gather -- the visibility masks of one band
+static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t groups, bool want_beams, int *bands_out) {
     const size_t px = (size_t)c->st.W * c->st.local_rows;
     if (c->partial_groups < groups) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -413,24 +413,24 @@ static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t group
     }
     a.tile_bounds = c->d_tile_bounds;
     int bands = 1;
-    if (want_lists) {
-        // one list entry (32 B) per (tile, VPL slot): the image is processed in bands of super-tiles whose lists fit the budget
+    if (want_beams) {
+        // one 8-byte occlusion mask per (tile, VPL slot): the image is processed in bands of super-tiles whose masks fit the budget
         size_t budget = (size_t)1 << 30;
-        if (const char *mb = std::getenv("EVPLP_LIST_MB")) budget = (size_t)std::max(1, atoi(mb)) << 20;
-        const size_t per_super = (size_t)a.max_vpls * 64 * kListWords * sizeof(uint32_t);
+        if (const char *mb = std::getenv("EVPLP_VIS_MB")) budget = (size_t)std::max(1, atoi(mb)) << 20;
+        const size_t per_super = (size_t)a.max_vpls * 64 * sizeof(unsigned long long);
         const int total = a.nsx * a.nsy;
         int per_band = (int)std::max<size_t>(1, std::min<size_t>((size_t)total, budget / per_super));
         bands = (total + per_band - 1) / per_band;
         per_band = (total + bands - 1) / bands;           // even bands
-        const size_t words = (size_t)per_band * per_super / sizeof(uint32_t);
-        if (c->list_words < words) {
+        const size_t words = (size_t)per_band * per_super / sizeof(unsigned long long);
+        if (c->vis_words < words) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_lists); c->d_lists = nullptr; c->list_words = 0;
-            hipError_t e = hipMalloc((void **)&c->d_lists, words * sizeof(uint32_t));
-            if (e != hipSuccess) { c->set_error("gather: cannot allocate %zu bytes of shaft lists: %s", words * sizeof(uint32_t), hipGetErrorString(e)); return EVPLP_ERR_OOM; }
-            c->list_words = words;
+            hipFree(c->d_vis); c->d_vis = nullptr; c->vis_words = 0;
+            hipError_t e = hipMalloc((void **)&c->d_vis, words * sizeof(unsigned long long));
+            if (e != hipSuccess) { c->set_error("gather: cannot allocate %zu bytes of visibility masks: %s", words * sizeof(unsigned long long), hipGetErrorString(e)); return EVPLP_ERR_OOM; }
+            c->vis_words = words;
         }
-        a.lists = c->d_lists;
+        a.vis = c->d_vis;
         a.band_supers = per_band;
     }
     while (c->ev_band.size() < (size_t)bands * 2) {
@@ -463,19 +463,19 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         while (k > 1 && ((size_t)a.max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
     }
     a.splits_per_wave = k;
-    const bool want_lists = !vsl && !c->cfg.gather_no_shaft_lists && std::getenv("EVPLP_NO_SHAFT_LISTS") == nullptr;
+    const bool want_beams = !vsl && !c->cfg.gather_no_beams && std::getenv("EVPLP_NO_BEAMS") == nullptr;
     int bands = 1;
-    if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k), want_lists, &bands))) return rc;
+    if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k), want_beams, &bands))) return rc;
     if ((rc = pass_begin(c, pass))) return rc;
     const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
     launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
-    if (want_lists) launch_tile_bounds(a, c->stream);
+    if (want_beams) launch_tile_bounds(a, c->stream);
     const int total = a.nsx * a.nsy, per_band = a.band_supers;
     for (int b = 0; b < bands; b++) {
         a.band_first_super = b * per_band;
         a.band_supers = std::min(per_band, total - a.band_first_super);
         if (a.band_supers <= 0) { bands = b; break; }
-        if (want_lists) launch_shaft_walk(a, c->stream);
+        if (want_beams) launch_beam_visibility(a, c->stream);
         HIP_TRY(c, hipEventRecord(c->ev_band[2 * b], c->stream));
         if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl_items(a, c->stream);
         HIP_TRY(c, hipEventRecord(c->ev_band[2 * b + 1], c->stream));

@@ -284,6 +284,7 @@ EV_DEV v2f pk_max(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
 // Exact test of a PAIR of triangles with packed fp32 (half 0 = triangle A, half 1 = B): the same
 // operations in the same order as tri_test, two triangles per instruction.  r[0..23] = the 24 dwords
 // of a TriPair.  Returns the two hit flags.
+EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 struct Hit2 { bool a, b; };
 EV_DEV Hit2 tri_pair_test(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, v2f e1x, v2f e1y, v2f e1z, v2f nx, v2f ny, v2f nz,
                           V3 o, V3 d, float tmin, float tmax) {
@@ -303,6 +304,54 @@ EV_DEV Hit2 tri_pair_test(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, 
     return h;
 }
 
+// Any-hit of a PAIR of triangles for a whole wave, with a plane-distance pre-test in front of the exact predicate.
+// In real arithmetic the hit distance is t = N / den with N = n . (p0 - o) -- the same for every lane, the origin is shared --
+// and den = n . d, and the predicate evaluates it as  sum n_k * fl(w_k * fl(1 / den))  (w = p0 - o): its result differs from
+// N / den by at most ~5 eps S / |den|, S = sum |n_k w_k|.  So  t in (tmin, tmax)  is impossible when  N - tmin den  and
+// N - tmax den  have the same sign beyond M = 32 eps S, and a pair none of whose live lanes can pass needs no division,
+// cross products or barycentrics: 11 instructions instead of ~60.  That rejects the triangles a segment does not reach
+// and, above all, the coplanar neighbours of the surfaces the segment starts and ends on (t ~ 0 and t ~ 1).  S = 0 (an
+// empty slot, or every n_k w_k = 0) makes t exactly 0 or NaN: rejected too.  Lanes that pass take the exact test unchanged,
+// so the result is bit-identical to tri_pair_test for every lane in `alive`.
+struct PairOps { v2f p0x, p0y, p0z, e0x, e0y, e0z, e1x, e1y, e1z, nx, ny, nz; };
+EV_DEV bool tri_pair_any(const PairOps &T, V3 o, V3 d, float tmin, float tmax, unsigned long long alive, uint32_t *exact_runs = nullptr) {
+    bool maybe;
+    {
+        const v2f wx = T.p0x - bc(o.x), wy = T.p0y - bc(o.y), wz = T.p0z - bc(o.z);
+        const v2f tx = T.nx * wx, ty = T.ny * wy, tz = T.nz * wz;
+        const v2f N = tx + ty + tz;
+        const v2f S = pk_max(tx, -tx) + pk_max(ty, -ty) + pk_max(tz, -tz);
+        const v2f M = S * bc(32.0f * 5.9604645e-8f);
+        const v2f den = pk_fma(T.nz, bc(d.z), pk_fma(T.ny, bc(d.y), T.nx * bc(d.x)));
+        const v2f f1 = pk_fma(den, bc(-tmin), N), f2 = pk_fma(den, bc(-tmax), N);
+        const v2f mn = pk_min(f1, f2), mx = pk_max(f1, f2);
+        maybe = !((mn.x >= M.x) | (mx.x <= -M.x)) | !((mn.y >= M.y) | (mx.y <= -M.y));
+    }
+    if ((ballot64(maybe) & alive) == 0ull) return false;
+    if (exact_runs) (*exact_runs)++;
+    Hit2 h = tri_pair_test(T.p0x, T.p0y, T.p0z, T.e0x, T.e0y, T.e0z, T.e1x, T.e1y, T.e1z, T.nx, T.ny, T.nz, o, d, tmin, tmax);
+    return h.a | h.b;
+}
+// the (up to) two pairs of one 192-byte leaf block, fetched with three s_load_dwordx16
+struct LeafOps { PairOps A, B; uint32_t cnt; };
+EV_DEV LeafOps fetch_leaf(const char *leaf_base, uint32_t leafref) {
+    const uint32_t id = ~leafref;
+    LeafOps L; L.cnt = (id & 3u) + 1u;
+    const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
+    const v16i a = tp[0], b = tp[1];
+    L.A.p0x = pk(a[0], a[1]); L.A.p0y = pk(a[2], a[3]); L.A.p0z = pk(a[4], a[5]); L.A.e0x = pk(a[6], a[7]); L.A.e0y = pk(a[8], a[9]); L.A.e0z = pk(a[10], a[11]);
+    L.A.e1x = pk(a[12], a[13]); L.A.e1y = pk(a[14], a[15]); L.A.e1z = pk(b[0], b[1]); L.A.nx = pk(b[2], b[3]); L.A.ny = pk(b[4], b[5]); L.A.nz = pk(b[6], b[7]);
+    if (L.cnt > 2u) {
+        const v16i c = tp[2];
+        L.B.p0x = pk(b[8], b[9]); L.B.p0y = pk(b[10], b[11]); L.B.p0z = pk(b[12], b[13]); L.B.e0x = pk(b[14], b[15]); L.B.e0y = pk(c[0], c[1]); L.B.e0z = pk(c[2], c[3]);
+        L.B.e1x = pk(c[4], c[5]); L.B.e1y = pk(c[6], c[7]); L.B.e1z = pk(c[8], c[9]); L.B.nx = pk(c[10], c[11]); L.B.ny = pk(c[12], c[13]); L.B.nz = pk(c[14], c[15]);
+    } else {
+        const v2f z = bc(0.0f);
+        L.B.p0x = L.B.p0y = L.B.p0z = L.B.e0x = L.B.e0y = L.B.e0z = L.B.e1x = L.B.e1y = L.B.e1z = L.B.nx = L.B.ny = L.B.nz = z;
+    }
+    return L;
+}
+
 // Stack-in-a-VGPR helpers: entry k of the wave's stack is lane k of one register.  A push is a
 // compare + select against the lane id (this clang has no v_writelane builtin), a pop is v_readlane
 // with a scalar lane index; neither touches memory.
@@ -317,7 +366,6 @@ EV_DEV int lane_read(int v, int slot) { return __builtin_amdgcn_readlane(v, slot
 // scalar stack pointer: no memory latency on either).  It holds at most one entry per tree level and
 // evplp_build_accel rejects trees deeper than 62 levels, so 64 entries always suffice.  Replaces rtTrace(..., ray type 1) + rtMaterialAnyHit,
 // rt/lighttracing.cu:184-188,290-294.  Returns true for lanes whose segment is occluded.
-EV_DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // [0, 1] clamp that the backend folds into the clamp modifier of the instruction producing x
 EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
@@ -388,22 +436,12 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             const uint32_t id = (uint32_t)~cur;
             const uint32_t cnt = (id & 3u) + 1u;
             // a leaf block is two triangle pairs (192 B); fetch all of it before testing
-            const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
-            const v16i a = tp[0], b = tp[1];
+            const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cur);
 #if EVPLP_TRAVERSAL_STATS
             if (ws) { ws->leaves++; ws->pairs += cnt > 2u ? 2u : 1u; }
 #endif
-            Hit2 h = tri_pair_test(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
-                                   pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]),
-                                   o, d, tmin, tmax);
-            bool any = h.a | h.b;    // an empty slot B is all zeros: den = 0 -> never a hit
-            if (cnt > 2u) {
-                const v16i c = tp[2];
-                Hit2 g = tri_pair_test(pk(b[8], b[9]), pk(b[10], b[11]), pk(b[12], b[13]), pk(b[14], b[15]), pk(c[0], c[1]), pk(c[2], c[3]),
-                                       pk(c[4], c[5]), pk(c[6], c[7]), pk(c[8], c[9]), pk(c[10], c[11]), pk(c[12], c[13]), pk(c[14], c[15]),
-                                       o, d, tmin, tmax);
-                any = any | g.a | g.b;
-            }
+            bool any = tri_pair_any(L.A, o, d, tmin, tmax, alive);    // an empty slot B is all zeros: never a hit
+            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, alive);
             const unsigned long long hm = ballot64(any) & alive;
             if (hm != 0ull) {
                 hitm |= hm;

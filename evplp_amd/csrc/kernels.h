@@ -24,8 +24,9 @@ struct PassCounters {
     unsigned long long aux;
     // EVPLP_TRAVERSAL_STATS builds only (tools/traversal_stats.py): histogram of leaf blocks tested per (wave, VPL) walk
     // ([31] = 31 or more), [32] = walks, [33] = triangle pairs tested, [34] = walks that ended with every lane occluded,
-    // [35] = (tile, VPL) items served from a shaft list, [36] = leaf blocks tested from lists, [40 + n] = lists of n leaves,
-    // [48] = list entries flagged skip, [49] = flagged overflow
+    // beam_visibility_kernel: [35] = (super-tile, VPL) beams walked, [36] = node visits, [37] = leaf blocks met by some shaft,
+    // [38] = (tile, leaf) exact tests run with pixel lanes, [39] = triangle pairs passed to the exact predicate, [40] = pairs
+    // rejected by the plane-distance pre-test, [41] = tiles that ended fully occluded, [42] = (tile, VPL) pairs culled by the cosine bounds
     unsigned long long hist[64];
     // gather: shadow rays / unoccluded pairs, summed by gather_reduce_kernel into 64 shards (one device-scope atomic per
     // workgroup; a single word saturates near 90 atomics per microsecond)
@@ -37,18 +38,11 @@ constexpr int kCounterShards = 64;
 // receiver cosine of lighttracing.cu:284 exactly 0, such a pixel never traces a shadow ray), written once per frame.
 struct TileBound {
     float lo[3]; uint32_t flags;      // AABB of the positions
-    float hi[3]; float pad0;
-    float n[3]; float pad1;           // the common normal when every lit pixel of the tile has the same one (kTileFlat)
+    float hi[3]; uint32_t lit_lo;     // lit_lo | lit_hi << 32: bit l = pixel (l & 7, l >> 3) of the tile is lit
+    float n[3]; uint32_t lit_hi;      // n: the common normal when every lit pixel of the tile has the same one (kTileFlat)
 };
 static_assert(sizeof(TileBound) == 48, "TileBound must be 48 bytes");
 constexpr uint32_t kTileLit = 1u, kTileFlat = 2u;
-// Candidate list of one (tile, VPL) shaft, written by shaft_walk_kernel and consumed by gather_vpl_kernel: 32 bytes = one
-// s_load_dwordx8.  word 0 = number of leaf references (0..kListLeaves) | flags, words 1..7 = leaf references (~child id).
-constexpr int kListLeaves = 7;
-constexpr int kListWords = 8;
-constexpr uint32_t kListCountMask = 0xfu;
-constexpr uint32_t kListOverflow = 0x100u;   // more than kListLeaves leaves met the shaft: the gather walks the tree itself
-constexpr uint32_t kListSkip = 0x200u;       // no pixel of the tile can pass the cosine test against this VPL (or the tile has no lit pixel)
 
 struct GatherArgs {
     SceneDev sc; StripDev st;
@@ -64,7 +58,8 @@ struct GatherArgs {
     PassCounters *counters;
     // tile enumeration: super-tiles of (1 << super_w_log2) x (64 >> super_w_log2) tiles, tile id = super-tile * 64 + lane
     TileBound *tile_bounds;           // [nsx * nsy * 64]
-    uint32_t *lists;                  // [max usable VPLs][band_supers * 64][kListWords]; null: no shaft lists (walk per item)
+    unsigned long long *vis;          // [max usable VPLs][band_supers * 64] occlusion mask of every (tile, VPL): bit l = the shadow ray of
+                                      // pixel l is blocked (or the pixel cannot be lit); null: every gather item walks the tree itself
     int32_t super_w_log2, nsx, nsy;
     int32_t band_first_super, band_supers;   // the super-tiles this launch covers
     int32_t splits_per_wave;          // k: a wave sums k consecutive splits (a power of two <= 32) and folds them in tree order
@@ -119,9 +114,9 @@ void launch_primary(const PrimaryArgs &a, hipStream_t s);
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s);
 void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
                         uint32_t *count_out, hipStream_t s);
-// VPL gather = tile bounds, then per band of super-tiles: shaft lists (when a.lists) + the gather items, then one reduce
+// VPL gather = tile bounds, then per band of super-tiles: beam visibility (when a.vis) + the gather items, then one reduce
 void launch_tile_bounds(const GatherArgs &a, hipStream_t s);
-void launch_shaft_walk(const GatherArgs &a, hipStream_t s);
+void launch_beam_visibility(const GatherArgs &a, hipStream_t s);
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s);
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
 void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s);

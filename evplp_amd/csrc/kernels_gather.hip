@@ -160,38 +160,45 @@ __global__ __launch_bounds__(64) void tile_bounds_kernel(GatherArgs a) {
     if (lane == 0) {
         TileBound tb;
         for (int k = 0; k < 3; k++) { tb.lo[k] = lo[k]; tb.hi[k] = hi[k]; tb.n[k] = n[k]; }
-        tb.flags = flags; tb.pad0 = tb.pad1 = 0.f;
+        tb.flags = flags; tb.lit_lo = (uint32_t)lm; tb.lit_hi = (uint32_t)(lm >> 32);
         a.tile_bounds[tid] = tb;
     }
 }
 
-// Phase 1: one wave = (super-tile, VPL), lane = tile.  Every lane carries the SHAFT of its tile -- the union of the segments
-// from the VPL to every point of the tile's position box, o + t (p - o), p in [lo, hi], t in [tmin, tmax] -- and the wave
-// walks the tree once for all 64 shafts (the packet walk of occluded_wave with lanes = tiles): a node visit costs 18 vector
-// instructions for 64 (tile, VPL) pairs instead of 15 per pair.  Leaves met by a lane's shaft are appended to that lane's
-// list (LDS, [slot][lane]).  A ray of the tile can only hit a triangle whose (padded) leaf box its segment meets, hence a
-// leaf on the list: testing the listed leaves' triangles with the exact predicate gives the same visibility bits as the
-// walk.  Per axis the shaft occupies o + t [dlo, dhi] (dlo = lo - o, dhi = hi - o) and meets the node slab [ctr - hal, ctr + hal]
-// while  t dhi >= ctr - hal - o  and  t dlo <= ctr + hal - o:
+// Phase 1, the beam pass: one wave = (super-tile of 64 tiles, VPL).  While it walks the tree a lane is a TILE and carries
+// the SHAFT of its tile -- the union of the segments from the VPL to every point of the tile's position box,
+// o + t (p - o), p in [lo, hi], t in [tmin, tmax] -- so one node visit (18 vector instructions, the two-child packed slab test of
+// occluded_wave with separate entry / exit reciprocals) serves 64 (tile, VPL) pairs instead of one.  Per axis the shaft occupies
+// o + t [dlo, dhi] (dlo = lo - o, dhi = hi - o) and meets the node slab [ctr - hal, ctr + hal] while  t dhi >= ctr - hal - o  and
+// t dlo <= ctr + hal - o:
 //   dlo > 0          entry (ctr - o - hal) / dhi,  exit (ctr - o + hal) / dlo
 //   dhi < 0          entry (ctr - o + hal) / dlo,  exit (ctr - o - hal) / dhi
-//   dlo <= 0 <= dhi  the tile's extent straddles the origin on this axis: only the entry (ctr - o - hal) / dhi is kept and
-//                    the exit is +inf (conservative; rare -- the VPL coordinate has to fall inside the tile's few cm)
-// i.e.  entry = ctr rE + cE - hal |rE|,  exit = ctr rX + cX + hal |rX|  with per-lane constants: the two-child packed
-// slab test of occluded_wave with separate reciprocals for entry and exit.
-#ifndef EVPLP_SHAFT_WAVES
-#define EVPLP_SHAFT_WAVES 8
+//   dlo <= 0 <= dhi  the tile's extent straddles the origin on this axis: only the entry (ctr - o - hal) / dhi is kept, the exit is
+//                    +inf (conservative; rare -- the VPL coordinate has to fall inside the tile's few centimetres)
+// i.e.  entry = ctr rE + cE - hal |rE|,  exit = ctr rX + cX + hal |rX|  with per-lane constants.
+// A leaf is not entered.  For every tile whose shaft meets the leaf's (padded) box the wave switches roles -- lane = PIXEL of
+// that tile -- and runs the exact any-hit predicate on the leaf's triangles for the tile's 64 shadow segments, OR-ing the hits
+// into the tile's 64-bit occlusion mask (kept in the tile's own lane).  A segment can only hit a triangle whose leaf box it
+// meets, and then its tile's shaft meets that box too: every (segment, triangle) pair that can hit is tested with the same
+// predicate as the per-item walk, so the masks are bit-identical to it.  A tile whose lit pixels are all occluded stops
+// driving the walk.  The gather then reads one 8-byte mask per (tile, VPL) and never touches the tree.
+#ifndef EVPLP_BEAM_WAVES
+#define EVPLP_BEAM_WAVES 6
 #endif
-__global__ __launch_bounds__(64, EVPLP_SHAFT_WAVES) void shaft_walk_kernel(GatherArgs a) {
-    __shared__ uint32_t s_list[kListLeaves * 64];
+__global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(GatherArgs a) {
     const int lane = threadIdx.x;
     const uint32_t nvpl = *a.nvpl;
-    const uint32_t i = blockIdx.x / (uint32_t)a.band_supers, sb = blockIdx.x % (uint32_t)a.band_supers;
-    if (i >= nvpl) return;
-    const uint32_t tid = ((uint32_t)a.band_first_super + sb) * 64u + (uint32_t)lane;
+    // super-tiles are dealt to XCDs (block b runs on XCD b % 8): the beams of one super-tile stay on one XCD, whose L2 then
+    // holds the super-tile's G-buffer positions for all its VPLs
+    const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+    const uint32_t i = j % a.max_vpls, sb = (j / a.max_vpls) * 8u + xcd;
+    if (i >= nvpl || sb >= (uint32_t)a.band_supers) return;
+    const uint32_t st = (uint32_t)a.band_first_super + sb;
+    const uint32_t tid = st * 64u + (uint32_t)lane;
     const float4 *tbp = reinterpret_cast<const float4 *>(a.tile_bounds + tid);
     const float4 t0 = tbp[0], t1 = tbp[1], t2 = tbp[2];
     const uint32_t tflags = __float_as_uint(t0.w);
+    const uint32_t lit_lo = __float_as_uint(t1.w), lit_hi = __float_as_uint(t2.w);
     // the VPL: position and normal (first 32 bytes of the record), wave-uniform
     const v8i ra = *reinterpret_cast<const v8i *>(a.vpls + i);
     const V3 o = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])), vn = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6]));
@@ -203,17 +210,22 @@ __global__ __launch_bounds__(64, EVPLP_SHAFT_WAVES) void shaft_walk_kernel(Gathe
         //   VPL side:   max over the box of  n2 . (p - o)  <= -eps   ->  c2 = max(-n2 . v12, 0) = 0 for every pixel
         //   pixel side: tiles with one common normal:  max of  n1 . (o - p)  <= -eps  ->  c1 = 0 for every pixel
         const V3 c = (lo + hi) * 0.5f, h = (hi - lo) * 0.5f, co = c - o;
+        const V3 aco = v3(fabsf(co.x), fabsf(co.y), fabsf(co.z));
         const V3 an2 = v3(fabsf(vn.x), fabsf(vn.y), fabsf(vn.z));
-        const float m2 = dot(vn, co) + dot(an2, h), s2 = dot(an2, v3(fabsf(co.x), fabsf(co.y), fabsf(co.z))) + dot(an2, h);
+        const float m2 = dot(vn, co) + dot(an2, h), s2 = dot(an2, aco) + dot(an2, h);
         if (m2 < -1.0e-5f * s2) live = false;
         if (tflags & kTileFlat) {
             const V3 an1 = v3(fabsf(tn.x), fabsf(tn.y), fabsf(tn.z));
-            const float m1 = -dot(tn, co) + dot(an1, h), s1 = dot(an1, v3(fabsf(co.x), fabsf(co.y), fabsf(co.z))) + dot(an1, h);
+            const float m1 = -dot(tn, co) + dot(an1, h), s1 = dot(an1, aco) + dot(an1, h);
             if (m1 < -1.0e-5f * s1) live = false;
         }
     }
-    const bool skip = !live;
-    uint32_t cnt = 0u;
+    // occlusion mask of this lane's tile; a tile that cannot be lit reports "everything blocked" (the gather skips it)
+    uint32_t occ_lo = live ? 0u : 0xffffffffu, occ_hi = occ_lo;
+#if EVPLP_TRAVERSAL_STATS
+    uint32_t st_nodes = 0, st_leaves = 0, st_tests = 0, st_exact = 0, st_pairs = 0, st_dead = 0;
+    const uint32_t st_culled = (uint32_t)__builtin_popcountll(ballot64(!live && (tflags & kTileLit) != 0u));
+#endif
     if (ballot64(live) != 0ull) {
         // shaft constants in the segment's own parameter u = (t - tmin) / (tmax - tmin), as occluded_wave
         const float tmin = 0.0001f, tmax = 1.0f - 0.0001f, ku = 1.0f / (tmax - tmin);
@@ -233,32 +245,74 @@ __global__ __launch_bounds__(64, EVPLP_SHAFT_WAVES) void shaft_walk_kernel(Gathe
         const v2f rXx = bc(rX[0]), rXy = bc(rX[1]), rXz = bc(rX[2]), aXx = bc(fabsf(rX[0])), aXy = bc(fabsf(rX[1])), aXz = bc(fabsf(rX[2]));
         v2f cEx = bc(cE[0]), cEy = bc(cE[1]), cEz = bc(cE[2]);
         const v2f cXx = bc(cX[0]), cXy = bc(cX[1]), cXz = bc(cX[2]);
+        // pixel role: where this lane's pixel sits inside a tile, and the super-tile's origin in tiles
+        const int swl = a.super_w_log2, sw = 1 << swl;
+        const int stx = (int)(st % (uint32_t)a.nsx), sty = (int)(st / (uint32_t)a.nsx);
+        const int px_x = lane & 7, px_y = lane >> 3;
+        const int W = a.st.W, max_row = a.st.local_rows - 1;
+        const char *leaf_base = reinterpret_cast<const char *>(a.sc.leaves);
         int sp = 0, vstack = 0;
         int32_t cur = 0;  // root is always an inner node
         const char *node_base = reinterpret_cast<const char *>(a.sc.nodes);
         for (;;) {
             const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
+#if EVPLP_TRAVERSAL_STATS
+            st_nodes++;
+#endif
             const v2f cx = pk(n[0], n[1]), cy = pk(n[2], n[3]), cz = pk(n[4], n[5]);
             const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
             const v2f enx = pk_fma(hx, -aEx, pk_fma(cx, rEx, cEx)), eny = pk_fma(hy, -aEy, pk_fma(cy, rEy, cEy)), enz = pk_fma(hz, -aEz, pk_fma(cz, rEz, cEz));
             const v2f exx = pk_fma(hx, aXx, pk_fma(cx, rXx, cXx)), exy = pk_fma(hy, aXy, pk_fma(cy, rXy, cXy)), exz = pk_fma(hz, aXz, pk_fma(cz, rXz, cXz));
             const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
             const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
-            const bool h0 = tn0 < tf0, h1 = tn1 < tf1;
-            const unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
+            unsigned long long m0 = ballot64(tn0 < tf0), m1 = ballot64(tn1 < tf1);
             const int32_t c0 = n[12], c1 = n[13];
-            uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
-            // a leaf child is not entered: the lanes whose shaft meets its box put it on their list
-            bool over = false;
-            if (a0 != 0u && c0 < 0) {
-                if (h0) { if (cnt < (uint32_t)kListLeaves) s_list[cnt * 64u + (uint32_t)lane] = (uint32_t)c0; else over = true; cnt++; }
-                a0 = 0u;
+            // leaf children: exact tests with pixel lanes for every tile whose shaft meets the leaf box
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const int32_t cc = side ? c1 : c0;
+                unsigned long long m = side ? m1 : m0;
+                if (cc >= 0 || m == 0ull) continue;
+                if (side) m1 = 0ull; else m0 = 0ull;
+                const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cc);
+#if EVPLP_TRAVERSAL_STATS
+                st_leaves++;
+#endif
+                while (m != 0ull) {
+                    const int t = (int)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    // the tile's pixels that still need an answer (its lit pixels that no triangle has blocked yet)
+                    const unsigned long long occ_t = (unsigned long long)(uint32_t)lane_read((int)occ_lo, t) | ((unsigned long long)(uint32_t)lane_read((int)occ_hi, t) << 32);
+                    const unsigned long long lit_t = (unsigned long long)(uint32_t)lane_read((int)lit_lo, t) | ((unsigned long long)(uint32_t)lane_read((int)lit_hi, t) << 32);
+                    const unsigned long long need = lit_t & ~occ_t;
+                    if (need == 0ull) continue;
+                    const int tx = (stx << swl) + (t & (sw - 1)), ty = sty * (64 >> swl) + (t >> swl);
+                    const int x = min(tx * 8 + px_x, W - 1), ly = min(ty * 8 + px_y, max_row);
+                    const float4 gp = a.g_pos[(size_t)ly * W + x];
+                    const V3 d = v3(gp) - o;                       // == -(v.pos - p1) bit for bit (Ray(o, -v12), lighttracing.cu:292)
+#if EVPLP_TRAVERSAL_STATS
+                    st_tests++; st_pairs += L.cnt > 2u ? 2u : 1u;
+                    bool hit = tri_pair_any(L.A, o, d, tmin, tmax, need, &st_exact);
+                    if (L.cnt > 2u) hit = hit | tri_pair_any(L.B, o, d, tmin, tmax, need, &st_exact);
+#else
+                    bool hit = tri_pair_any(L.A, o, d, tmin, tmax, need);
+                    if (L.cnt > 2u) hit = hit | tri_pair_any(L.B, o, d, tmin, tmax, need);
+#endif
+                    const unsigned long long hm = ballot64(hit) & need;
+                    if (hm != 0ull) {
+                        const bool mine = lane == t;
+                        occ_lo = mine ? (occ_lo | (uint32_t)hm) : occ_lo;
+                        occ_hi = mine ? (occ_hi | (uint32_t)(hm >> 32)) : occ_hi;
+                        if ((need & ~hm) == 0ull) {               // every lit pixel of the tile is blocked: its shaft leaves the walk
+                            if (mine) { cEx = bc(dead); cEy = bc(dead); cEz = bc(dead); }
+#if EVPLP_TRAVERSAL_STATS
+                            st_dead++;
+#endif
+                        }
+                    }
+                }
             }
-            if (a1 != 0u && c1 < 0) {
-                if (h1) { if (cnt < (uint32_t)kListLeaves) s_list[cnt * 64u + (uint32_t)lane] = (uint32_t)c1; else over = true; cnt++; }
-                a1 = 0u;
-            }
-            if (over) { cEx = bc(dead); cEy = bc(dead); cEz = bc(dead); }   // a full list ends its lane's walk (the gather walks the tree for it)
+            const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
             if ((a0 | a1) != 0u) {
                 if (a0 == 0u) { cur = c1; continue; }
                 if (a1 == 0u) { cur = c0; continue; }
@@ -274,39 +328,24 @@ __global__ __launch_bounds__(64, EVPLP_SHAFT_WAVES) void shaft_walk_kernel(Gathe
             cur = lane_read(vstack, sp);
         }
     }
-    // list entry of (tile, VPL): 8 words per lane, two 16-byte stores
-    uint32_t w[kListWords];
-    w[0] = min(cnt, (uint32_t)kListLeaves) | (cnt > (uint32_t)kListLeaves ? kListOverflow : 0u) | (skip ? kListSkip : 0u);
-#pragma unroll
-    for (int k = 0; k < kListLeaves; k++) w[1 + k] = (uint32_t)k < cnt ? s_list[(uint32_t)k * 64u + (uint32_t)lane] : 0u;
-    uint4 *dst = reinterpret_cast<uint4 *>(a.lists + ((size_t)i * ((size_t)a.band_supers * 64u) + (size_t)sb * 64u + (size_t)lane) * kListWords);
-    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-
-// exact any-hit test of the wave's segments (common origin o, per-lane direction d) against the triangles of ONE leaf block
-EV_DEV bool leaf_any_hit(const char *leaf_base, uint32_t leafref, V3 o, V3 d, float tmin, float tmax) {
-    const uint32_t id = ~leafref;
-    const uint32_t cnt = (id & 3u) + 1u;
-    const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
-    const v16i a = tp[0], b = tp[1];
-    Hit2 h = tri_pair_test(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
-                           pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]),
-                           o, d, tmin, tmax);
-    bool any = h.a | h.b;    // an empty slot B is all zeros: den = 0 -> never a hit
-    if (cnt > 2u) {
-        const v16i c = tp[2];
-        Hit2 g = tri_pair_test(pk(b[8], b[9]), pk(b[10], b[11]), pk(b[12], b[13]), pk(b[14], b[15]), pk(c[0], c[1]), pk(c[2], c[3]),
-                               pk(c[4], c[5]), pk(c[6], c[7]), pk(c[8], c[9]), pk(c[10], c[11]), pk(c[12], c[13]), pk(c[14], c[15]),
-                               o, d, tmin, tmax);
-        any = any | g.a | g.b;
+    // pixels that are not lit can never be shaded: report them blocked, so "all ones" = nothing to shade for this (tile, VPL)
+    occ_lo |= ~lit_lo; occ_hi |= ~lit_hi;
+    a.vis[(size_t)i * ((size_t)a.band_supers * 64u) + (size_t)sb * 64u + (size_t)lane] = (unsigned long long)occ_lo | ((unsigned long long)occ_hi << 32);
+#if EVPLP_TRAVERSAL_STATS
+    if (lane == 0) {
+        atomicAdd(&a.counters->hist[35], 1ull); atomicAdd(&a.counters->hist[36], (unsigned long long)st_nodes);
+        atomicAdd(&a.counters->hist[37], (unsigned long long)st_leaves); atomicAdd(&a.counters->hist[38], (unsigned long long)st_tests);
+        atomicAdd(&a.counters->hist[39], (unsigned long long)st_exact); atomicAdd(&a.counters->hist[40], (unsigned long long)(st_pairs - st_exact));
+        atomicAdd(&a.counters->hist[41], (unsigned long long)st_dead); atomicAdd(&a.counters->hist[42], (unsigned long long)st_culled);
     }
-    return any;
+#endif
 }
 
-// Phase 2.  One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.  Per VPL the wave reads the
-// (tile, VPL) list entry: skipped, a handful of leaves to test with the exact predicate, or "overflow" = walk the tree.
-__global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
+// Phase 2.  One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.  With the beam pass the wave reads the
+// (tile, VPL) occlusion mask (one s_load_dwordx2) and only shades; without it (a.vis == nullptr) it walks the tree itself.
+template <bool kBeam>
+__global__ __launch_bounds__(64, kBeam ? 8 : EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
+    __shared__ float s_lvl[6 * 192];
     const int lane = threadIdx.x;
     const Item t = item_setup(a, lane);
     if (!t.has_tile) return;   // padding of the super-tile grid
@@ -320,40 +359,30 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
 
     const uint32_t nvpl = *a.nvpl;
     const int k = a.splits_per_wave;
-    const char *leaf_base = reinterpret_cast<const char *>(a.sc.leaves);
-    const uint32_t *list_row = a.lists ? a.lists + (size_t)t.tile_in_band * kListWords : nullptr;
-    const size_t list_stride = (size_t)a.band_supers * 64u * kListWords;    // words per VPL
-    __shared__ float s_lvl[6 * 192];
+    const unsigned long long *vis_row = kBeam ? a.vis + t.tile_in_band : nullptr;
+    const size_t vis_stride = (size_t)a.band_supers * 64u;    // masks per VPL
+    const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     V3 total = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, shaded = 0;
     for (int jj = 0; jj < k; jj++) {
         const uint32_t split = (uint32_t)(t.group * k + jj);
         V3 result = v3(0.f, 0.f, 0.f);
         for (uint32_t i = split; i < nvpl; i += kVplSplit) {
-            v8i L = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            if (list_row) {
-                L = *reinterpret_cast<const v8i *>(list_row + (size_t)i * list_stride);
-#if EVPLP_TRAVERSAL_STATS
-                if (lane == 0) {
-                    if ((uint32_t)L[0] & kListSkip) atomicAdd(&a.counters->hist[48], 1ull);
-                    else if ((uint32_t)L[0] & kListOverflow) atomicAdd(&a.counters->hist[49], 1ull);
-                    else atomicAdd(&a.counters->hist[40 + ((uint32_t)L[0] & kListCountMask)], 1ull);
-                }
-#endif
-                if ((uint32_t)L[0] & kListSkip) continue;
-            }
             const Vpl v = fetch_vpl(a.vpls + i);
             V3 v12 = v.pos - px.p1;                                         // :282
             float c1 = fmaxf(dot(px.n1, v12), 0.0f);
             float c2 = fmaxf(-dot(v.n, v12), 0.0f);
             float c1c2 = c1 * c2;
             bool active = valid && !(c1c2 <= 0.0f);                         // :288
-            unsigned long long alive = ballot64(active);
-            if (alive == 0ull) continue;
+            if (ballot64(active) == 0ull) continue;
             rays += active ? 1u : 0u;
             // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
             bool occ;
-            if (!list_row || ((uint32_t)L[0] & kListOverflow)) {
+            if (kBeam) {
+                const unsigned long long m = vis_row[(size_t)i * vis_stride];
+                occ = (((uint32_t)m & bit_lo) | ((uint32_t)(m >> 32) & bit_hi)) != 0u;
+                if (ballot64(active && !occ) == 0ull) continue;
+            } else {
 #if EVPLP_TRAVERSAL_STATS
                 WalkStats ws = { 0u, 0u, 0u };
                 occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
@@ -366,28 +395,6 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 }
 #else
                 occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
-#endif
-            } else {
-                occ = false;
-                const V3 d = -v12;
-                uint32_t n = (uint32_t)L[0] & kListCountMask;
-                int r1 = L[1], r2 = L[2], r3 = L[3], r4 = L[4], r5 = L[5], r6 = L[6], r7 = L[7];
-#if EVPLP_TRAVERSAL_STATS
-                uint32_t tested = 0;
-#endif
-                while (n != 0u) {
-                    const bool hit = leaf_any_hit(leaf_base, (uint32_t)r1, v.pos, d, 0.0001f, 1.0f - 0.0001f);
-#if EVPLP_TRAVERSAL_STATS
-                    tested++;
-#endif
-                    occ = occ || hit;
-                    alive &= ~ballot64(hit);
-                    if (alive == 0ull) break;
-                    r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7;
-                    n--;
-                }
-#if EVPLP_TRAVERSAL_STATS
-                if (lane == 0) { atomicAdd(&a.counters->hist[35], 1ull); atomicAdd(&a.counters->hist[36], (unsigned long long)tested); }
 #endif
             }
             if (active && !occ) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2); shaded++; }
@@ -750,11 +757,13 @@ void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) 
     size_t n = (size_t)a.st.W * a.st.local_rows;
     hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, stencil_test);
 }
-void launch_shaft_walk(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(shaft_walk_kernel, dim3((unsigned)a.band_supers * a.max_vpls), dim3(64), 0, s, a);
+void launch_beam_visibility(const GatherArgs &a, hipStream_t s) {
+    const unsigned per_xcd = ((unsigned)a.band_supers + 7u) / 8u;       // super-tiles per XCD (rounded up)
+    hipLaunchKernelGGL(beam_visibility_kernel, dim3(per_xcd * a.max_vpls * 8u), dim3(64), 0, s, a);
 }
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), 0, s, a);
+    if (a.vis) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), 0, s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), 0, s, a);

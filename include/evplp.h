@@ -81,7 +81,8 @@ typedef struct evplp_config {
     int32_t deterministic;       /* 1: photon bins are accumulated in record order (bitwise reproducible) */
     int32_t gather_splits_per_wave; /* VPL gather work-item size: consecutive VPL splits (of 128) one wavefront sums; a power of two
                                   * 1..32, 0 = automatic (16 / strip_count).  Results do not depend on it (fixed summation tree). */
-    int32_t gather_no_shaft_lists;  /* 1: every gather item walks the tree itself (no per-(tile, VPL) candidate lists); same results */
+    int32_t gather_no_beams;     /* 1: every gather item walks the tree itself instead of reading the (tile, VPL) occlusion masks of the
+                                  * beam pass (super-tile packets); same results, slower -- kept as the cross-check of the beam pass */
     int32_t reserved[2];
 } evplp_config;
 

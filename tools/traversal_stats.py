@@ -17,13 +17,13 @@ ap.add_argument("--tris", type=int, default=331000)
 ap.add_argument("--paths", type=int, default=1024)
 ap.add_argument("--scene", default="easy")
 ap.add_argument("--out", default="")
-ap.add_argument("--no-lists", action="store_true", help="every item walks the tree (round-1 behaviour)")
+ap.add_argument("--no-beams", action="store_true", help="every item walks the tree itself (round-1 behaviour)")
 ap.add_argument("--k", type=int, default=0)
 a = ap.parse_args()
 d = "/tmp/evplp_stats_%s" % a.scene
 jp = ev.synth_scene(d, "conf", a.tris, 1234, a.res, a.res, style=a.scene)
 P = 4
-c = ev.Context(a.res, a.res, a.paths, a.paths, P, shaft_lists=not a.no_lists, gather_splits_per_wave=a.k)
+c = ev.Context(a.res, a.res, a.paths, a.paths, P, beams=not a.no_beams, gather_splits_per_wave=a.k)
 c.load_scene_json(jp)
 cam = c.camera()
 fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=a.paths, num_vpl_light_paths=a.paths, photons_per_path=P, do_accumulate=0)
@@ -42,8 +42,11 @@ out = {
     "walks_fully_occluded_frac": all_occ / max(walks, 1),
     "leaf_blocks_per_walk_hist": (hist / max(walks, 1)).round(4).tolist(),
     "kernel_ms_with_counters": st["dominant_kernel_ms"], "launches": st["launches"], "shaded": st["shaded"],
-    "list_items": int(raw[4 + 35]), "list_leaf_blocks_tested_per_item": int(raw[4 + 36]) / max(int(raw[4 + 35]), 1),
-    "list_len_hist": [int(x) for x in raw[4 + 40:4 + 48]], "list_skip": int(raw[4 + 48]), "list_overflow": int(raw[4 + 49]),
+    "beam": {"beams": int(raw[4 + 35]), "node_visits_per_beam": int(raw[4 + 36]) / max(int(raw[4 + 35]), 1),
+             "leaf_blocks_per_beam": int(raw[4 + 37]) / max(int(raw[4 + 35]), 1), "tile_leaf_tests_per_beam": int(raw[4 + 38]) / max(int(raw[4 + 35]), 1),
+             "tile_leaf_tests_per_tile_vpl": int(raw[4 + 38]) / max(int(raw[4 + 35]) * 64, 1),
+             "pairs_exact": int(raw[4 + 39]), "pairs_rejected_by_pretest": int(raw[4 + 40]),
+             "tiles_fully_occluded_per_beam": int(raw[4 + 41]) / max(int(raw[4 + 35]), 1), "tiles_cosine_culled_per_beam": int(raw[4 + 42]) / max(int(raw[4 + 35]), 1)},
 }
 print(json.dumps(out, indent=1))
 if a.out:
