@@ -393,6 +393,8 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.nsx = (tiles_x + (1 << swl) - 1) >> swl; a.nsy = (tiles_y + sh - 1) / sh;
     a.band_first_super = 0; a.band_supers = a.nsx * a.nsy;
     a.splits_per_wave = 1;
+    a.fat_ratio = 24.0f;
+    if (const char *e = std::getenv("EVPLP_FAT_RATIO")) a.fat_ratio = (float)atof(e);
     return EVPLP_OK;
 }
 // gather workspace (lazy): partial sums for `groups` groups, tile bounds, and -- for the VPL gather -- the visibility masks of one band
@@ -408,7 +410,7 @@ static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t group
     a.partial = c->d_partial;
     const size_t ntid = (size_t)a.nsx * a.nsy * 64;
     if (!c->d_tile_bounds) {
-        hipError_t e = hipMalloc((void **)&c->d_tile_bounds, sizeof(TileBound) * ntid);
+        hipError_t e = hipMalloc((void **)&c->d_tile_bounds, sizeof(SubBound) * ntid * kSubs);
         if (e != hipSuccess) { c->set_error("gather: cannot allocate tile bounds: %s", hipGetErrorString(e)); return EVPLP_ERR_OOM; }
     }
     a.tile_bounds = c->d_tile_bounds;
@@ -475,8 +477,8 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         a.band_first_super = b * per_band;
         a.band_supers = std::min(per_band, total - a.band_first_super);
         if (a.band_supers <= 0) { bands = b; break; }
-        if (want_beams) launch_beam_visibility(a, c->stream);
         HIP_TRY(c, hipEventRecord(c->ev_band[2 * b], c->stream));
+        if (want_beams) launch_beam_visibility(a, c->stream);
         if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl_items(a, c->stream);
         HIP_TRY(c, hipEventRecord(c->ev_band[2 * b + 1], c->stream));
     }

@@ -42,7 +42,7 @@ struct evplp_context {
     float *d_rgb = nullptr;
     // gather workspace, allocated on the first gather (path-tracing / photon-only contexts never pay for it)
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
-    evplp::TileBound *d_tile_bounds = nullptr;                  // [nsx * nsy * 64]
+    evplp::SubBound *d_tile_bounds = nullptr;                   // [nsx * nsy * 64][kSubs]
     unsigned long long *d_vis = nullptr; size_t vis_words = 0;  // (tile, VPL) occlusion masks of one band of super-tiles
     std::vector<hipEvent_t> ev_band;                            // begin/end pairs around the gather kernel of every band
     int32_t gather_launches[EVPLP_PASS_COUNT] = {};

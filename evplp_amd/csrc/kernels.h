@@ -34,15 +34,23 @@ struct PassCounters {
 };
 constexpr int kCounterShards = 64;
 
-// Bounds of the lit part of one 8x8-pixel tile of the G-buffer (pixels with a non-zero normal: a zero normal makes the
-// receiver cosine of lighttracing.cu:284 exactly 0, such a pixel never traces a shadow ray), written once per frame.
-struct TileBound {
-    float lo[3]; uint32_t flags;      // AABB of the positions
-    float hi[3]; uint32_t lit_lo;     // lit_lo | lit_hi << 32: bit l = pixel (l & 7, l >> 3) of the tile is lit
-    float n[3]; uint32_t lit_hi;      // n: the common normal when every lit pixel of the tile has the same one (kTileFlat)
+// The beam pass bounds the pixels of a tile by up to kSubs position boxes ("sub-tiles").  A tile's lit pixels (non-zero normal:
+// a zero normal makes the receiver cosine of lighttracing.cu:284 exactly 0, such a pixel never traces a shadow ray) are sorted by
+// their distance to the camera and cut into kSubs groups -- at depth discontinuities where there are any, at the middle of the
+// depth range otherwise -- so that a tile seen at a grazing angle (metres deep, centimetres wide) or holding a silhouette edge is
+// still covered by compact boxes.  Written once per frame by tile_clusters_kernel.
+constexpr int kSubs = 4;
+struct SubBound {
+    float lo[3]; uint32_t flags;      // AABB of the member pixels' positions
+    float hi[3]; uint32_t mem_lo;     // mem_lo | mem_hi << 32: bit l = pixel (l & 7, l >> 3) of the tile belongs to this sub-tile
+    float n[3]; uint32_t mem_hi;      // n: the common normal when every member has the same one (kTileFlat)
 };
-static_assert(sizeof(TileBound) == 48, "TileBound must be 48 bytes");
+static_assert(sizeof(SubBound) == 48, "SubBound must be 48 bytes");
 constexpr uint32_t kTileLit = 1u, kTileFlat = 2u;
+// kTileFat (set on every sub-tile of the tile): some sub-tile still spans far more space than neighbouring surface points would;
+// its shaft would meet hundreds of leaves, so the tile is left out of the beam pass and its items walk the tree with their 64
+// exact segments instead.
+constexpr uint32_t kTileFat = 4u;
 
 struct GatherArgs {
     SceneDev sc; StripDev st;
@@ -57,14 +65,14 @@ struct GatherArgs {
     size_t partial_stride;            // W * local_rows
     PassCounters *counters;
     // tile enumeration: super-tiles of (1 << super_w_log2) x (64 >> super_w_log2) tiles, tile id = super-tile * 64 + lane
-    TileBound *tile_bounds;           // [nsx * nsy * 64]
+    SubBound *tile_bounds;            // [nsx * nsy * 64][kSubs]
     unsigned long long *vis;          // [max usable VPLs][band_supers * 64] occlusion mask of every (tile, VPL): bit l = the shadow ray of
                                       // pixel l is blocked (or the pixel cannot be lit); null: every gather item walks the tree itself
     int32_t super_w_log2, nsx, nsy;
     int32_t band_first_super, band_supers;   // the super-tiles this launch covers
     int32_t splits_per_wave;          // k: a wave sums k consecutive splits (a power of two <= 32) and folds them in tree order
-    uint32_t max_vpls;                // allocated VPL slots (grid bound of shaft_walk_kernel)
-    int32_t pad1;
+    uint32_t max_vpls;                // allocated VPL slots (grid bound of beam_visibility_kernel)
+    float fat_ratio;                  // a sub-tile is fat when its box extent exceeds fat_ratio x 8 x the smallest spacing of adjacent lit pixels
 };
 #ifndef EVPLP_VPL_SPLIT
 #define EVPLP_VPL_SPLIT 128

@@ -133,8 +133,9 @@ EV_DEV Vpl fetch_vpl(const evplp_record *r) {
 }
 
 // ---------------------------------------------------------------------------------- shaft lists
-// Phase 0: bounds of the lit pixels of every tile (one wave per tile id).
-__global__ __launch_bounds__(64) void tile_bounds_kernel(GatherArgs a) {
+// Phase 0: sub-tile boxes of every tile (one wave per tile id; see SubBound).
+__global__ __launch_bounds__(64) void tile_clusters_kernel(GatherArgs a) {
+    __shared__ float s_z[64];
     const int lane = threadIdx.x;
     const uint32_t tid = blockIdx.x;
     const TileXY xy = tile_of(a, tid);
@@ -145,70 +146,140 @@ __global__ __launch_bounds__(64) void tile_bounds_kernel(GatherArgs a) {
     float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), gn = gp;
     if (in_image) { gp = a.g_pos[p]; gn = a.g_nrm[p]; }
     const bool lit = in_image && gp.w != 0.0f && (gn.x != 0.0f || gn.y != 0.0f || gn.z != 0.0f);
-    const float big = 3.0e38f;
-    float lo[3] = { lit ? gp.x : big, lit ? gp.y : big, lit ? gp.z : big }, hi[3] = { lit ? gp.x : -big, lit ? gp.y : -big, lit ? gp.z : -big };
-    for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
     const unsigned long long lm = ballot64(lit);
-    uint32_t flags = 0u; float n[3] = { 0.f, 0.f, 0.f };
-    if (lm != 0ull) {
-        flags = kTileLit;
-        const int first = (int)__ffsll((long long)lm) - 1;
-        n[0] = __shfl(gn.x, first); n[1] = __shfl(gn.y, first); n[2] = __shfl(gn.z, first);
-        if (ballot64(lit && (gn.x != n[0] || gn.y != n[1] || gn.z != n[2])) == 0ull) flags |= kTileFlat;
+    const int nlit = (int)__builtin_popcountll(lm);
+    const float big = 3.0e38f;
+    // sort key: squared distance to the camera; rank among the lit pixels (ties by lane)
+    const V3 cp = v3(gp) - v3(a.fp.camera_pos);
+    const float z = lit ? dot(cp, cp) : big;
+    int rank = 0;
+    for (int j = 0; j < 64; j++) {
+        const float zj = __shfl(z, j);
+        rank += (zj < z || (zj == z && j < lane)) ? 1 : 0;
     }
-    if (lane == 0) {
-        TileBound tb;
-        for (int k = 0; k < 3; k++) { tb.lo[k] = lo[k]; tb.hi[k] = hi[k]; tb.n[k] = n[k]; }
-        tb.flags = flags; tb.lit_lo = (uint32_t)lm; tb.lit_hi = (uint32_t)(lm >> 32);
-        a.tile_bounds[tid] = tb;
+    s_z[rank] = z;                                    // ranks are a permutation of 0..63; lit pixels come first
+    __builtin_amdgcn_wave_barrier();
+    // three cuts: always split the group with the largest depth extent, at its largest gap when that gap is a real
+    // discontinuity (> 30 % of the group's extent), at the middle of its depth range otherwise
+    int cut[kSubs + 1] = { 0, nlit, nlit, nlit, nlit };      // group g = ranks [cut[g], cut[g + 1]); unused groups are empty
+    const float zr = s_z[lane], zr1 = s_z[min(lane + 1, 63)];
+    for (int step = 1; step < kSubs; step++) {
+        int best = -1; float best_ext = 0.0f;
+        for (int g = 0; g < step; g++) {
+            const int ga = cut[g], gb = cut[g + 1];
+            if (gb - ga < 2) continue;
+            const float e = s_z[gb - 1] - s_z[ga];
+            if (e > best_ext) { best_ext = e; best = g; }
+        }
+        if (best < 0) break;
+        const int ga = cut[best], gb = cut[best + 1];
+        const bool inside = lane >= ga && lane + 1 < gb;
+        float gap = inside ? zr1 - zr : -1.0f, gmax = gap;
+        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
+        int c;
+        if (gmax > 0.3f * best_ext) c = (int)__builtin_ctzll(ballot64(inside && gap == gmax)) + 1;
+        else {
+            const float mid = 0.5f * (s_z[ga] + s_z[gb - 1]);
+            c = ga + (int)__builtin_popcountll(ballot64(lane >= ga && lane < gb && zr < mid));
+        }
+        c = max(ga + 1, min(c, gb - 1));
+        for (int g = step; g > best + 1; g--) cut[g] = cut[g - 1];      // insert the cut, keep the groups ordered by depth
+        cut[best + 1] = c; cut[step + 1] = nlit;
+        for (int g = step + 1; g <= kSubs; g++) cut[g] = max(cut[g], cut[g - 1]);
     }
+    // smallest spacing of horizontally / vertically adjacent lit pixels (the scale a compact box is measured against)
+    float s2 = big;
+    {
+        const float rx = __shfl_down(gp.x, 1), ry = __shfl_down(gp.y, 1), rz = __shfl_down(gp.z, 1);
+        const float ux = __shfl_down(gp.x, 8), uy = __shfl_down(gp.y, 8), uz = __shfl_down(gp.z, 8);
+        const bool lit_r = ((lm >> ((lane + 1) & 63)) & 1ull) != 0ull && (lane & 7) != 7;
+        const bool lit_u = ((lm >> ((lane + 8) & 63)) & 1ull) != 0ull && lane < 56;
+        if (lit && lit_r) s2 = fminf(s2, (rx - gp.x) * (rx - gp.x) + (ry - gp.y) * (ry - gp.y) + (rz - gp.z) * (rz - gp.z));
+        if (lit && lit_u) s2 = fminf(s2, (ux - gp.x) * (ux - gp.x) + (uy - gp.y) * (uy - gp.y) + (uz - gp.z) * (uz - gp.z));
+    }
+    for (int off = 32; off > 0; off >>= 1) s2 = fminf(s2, __shfl_xor(s2, off));
+    const float lim = a.fat_ratio * 8.0f;
+    SubBound mine; bool any_fat = false;
+    for (int g = 0; g < kSubs; g++) {
+        const bool mem = lit && rank >= cut[g] && rank < cut[g + 1];
+        const unsigned long long mm = ballot64(mem);
+        float lo[3] = { mem ? gp.x : big, mem ? gp.y : big, mem ? gp.z : big }, hi[3] = { mem ? gp.x : -big, mem ? gp.y : -big, mem ? gp.z : -big };
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+        uint32_t flags = 0u; float n[3] = { 0.f, 0.f, 0.f };
+        if (mm != 0ull) {
+            flags = kTileLit;
+            const int first = (int)__builtin_ctzll(mm);
+            n[0] = __shfl(gn.x, first); n[1] = __shfl(gn.y, first); n[2] = __shfl(gn.z, first);
+            if (ballot64(mem && (gn.x != n[0] || gn.y != n[1] || gn.z != n[2])) == 0ull) flags |= kTileFlat;
+            const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+            if (ext > 0.0f && (s2 >= big || ext * ext > lim * lim * s2)) any_fat = true;
+        }
+        if (lane == g) {
+            for (int k = 0; k < 3; k++) { mine.lo[k] = lo[k]; mine.hi[k] = hi[k]; mine.n[k] = n[k]; }
+            mine.flags = flags; mine.mem_lo = (uint32_t)mm; mine.mem_hi = (uint32_t)(mm >> 32);
+        }
+    }
+    if (lane < kSubs) {
+        if (any_fat) mine.flags |= kTileFat;
+        a.tile_bounds[(size_t)tid * kSubs + lane] = mine;
+    }
+#if EVPLP_TRAVERSAL_STATS
+    if (lane == 0 && nlit > 0) { atomicAdd(&a.counters->hist[44], 1ull); if (any_fat) atomicAdd(&a.counters->hist[43], 1ull); }
+#endif
 }
 
-// Phase 1, the beam pass: one wave = (super-tile of 64 tiles, VPL).  While it walks the tree a lane is a TILE and carries
-// the SHAFT of its tile -- the union of the segments from the VPL to every point of the tile's position box,
+// Phase 1, the beam pass: one wave = (16 tiles of a super-tile, VPL).  While it walks the tree a lane is a SUB-TILE (kSubs boxes
+// per tile, SubBound) and carries the SHAFT of its box -- the union of the segments from the VPL to every point of the box,
 // o + t (p - o), p in [lo, hi], t in [tmin, tmax] -- so one node visit (18 vector instructions, the two-child packed slab test of
-// occluded_wave with separate entry / exit reciprocals) serves 64 (tile, VPL) pairs instead of one.  Per axis the shaft occupies
+// occluded_wave with separate entry / exit reciprocals) serves 16 (tile, VPL) pairs instead of one.  Per axis the shaft occupies
 // o + t [dlo, dhi] (dlo = lo - o, dhi = hi - o) and meets the node slab [ctr - hal, ctr + hal] while  t dhi >= ctr - hal - o  and
 // t dlo <= ctr + hal - o:
 //   dlo > 0          entry (ctr - o - hal) / dhi,  exit (ctr - o + hal) / dlo
 //   dhi < 0          entry (ctr - o + hal) / dlo,  exit (ctr - o - hal) / dhi
-//   dlo <= 0 <= dhi  the tile's extent straddles the origin on this axis: only the entry (ctr - o - hal) / dhi is kept, the exit is
-//                    +inf (conservative; rare -- the VPL coordinate has to fall inside the tile's few centimetres)
+//   dlo <= 0 <= dhi  the box straddles the origin on this axis: only the entry (ctr - o - hal) / dhi is kept, the exit is +inf
+//                    (conservative; rare -- the VPL coordinate has to fall inside the box's few centimetres)
 // i.e.  entry = ctr rE + cE - hal |rE|,  exit = ctr rX + cX + hal |rX|  with per-lane constants.
-// A leaf is not entered.  For every tile whose shaft meets the leaf's (padded) box the wave switches roles -- lane = PIXEL of
-// that tile -- and runs the exact any-hit predicate on the leaf's triangles for the tile's 64 shadow segments, OR-ing the hits
-// into the tile's 64-bit occlusion mask (kept in the tile's own lane).  A segment can only hit a triangle whose leaf box it
-// meets, and then its tile's shaft meets that box too: every (segment, triangle) pair that can hit is tested with the same
-// predicate as the per-item walk, so the masks are bit-identical to it.  A tile whose lit pixels are all occluded stops
-// driving the walk.  The gather then reads one 8-byte mask per (tile, VPL) and never touches the tree.
+// A leaf is not entered.  For every tile one of whose shafts meets the leaf's (padded) box the wave switches roles -- lane =
+// PIXEL of that tile -- and runs the exact any-hit predicate on the leaf's triangles for the tile's shadow segments, OR-ing the
+// hits into the tile's 64-bit occlusion mask (kept in the lane of the tile's first sub-tile).  A segment can only hit a
+// triangle whose leaf box it meets, and then the shaft of its sub-tile meets that box too: every (segment, triangle) pair that
+// can hit is tested with the same predicate as the per-item walk, so the masks are bit-identical to it.  A tile whose lit pixels
+// are all occluded stops driving the walk.  The gather then reads one 8-byte mask per (tile, VPL) and never touches the tree.
 #ifndef EVPLP_BEAM_WAVES
 #define EVPLP_BEAM_WAVES 6
 #endif
+constexpr int kBeamTiles = 64 / kSubs;      // tiles per beam wave
 __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(GatherArgs a) {
     const int lane = threadIdx.x;
     const uint32_t nvpl = *a.nvpl;
     // super-tiles are dealt to XCDs (block b runs on XCD b % 8): the beams of one super-tile stay on one XCD, whose L2 then
     // holds the super-tile's G-buffer positions for all its VPLs
     const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
-    const uint32_t i = j % a.max_vpls, sb = (j / a.max_vpls) * 8u + xcd;
+    const uint32_t part = j % (uint32_t)kSubs, j2 = j / (uint32_t)kSubs;            // which 16 tiles of the super-tile
+    const uint32_t i = j2 % a.max_vpls, sb = (j2 / a.max_vpls) * 8u + xcd;
     if (i >= nvpl || sb >= (uint32_t)a.band_supers) return;
     const uint32_t st = (uint32_t)a.band_first_super + sb;
-    const uint32_t tid = st * 64u + (uint32_t)lane;
-    const float4 *tbp = reinterpret_cast<const float4 *>(a.tile_bounds + tid);
+    const int tl = (int)part * kBeamTiles + (lane / kSubs);                          // this lane's tile inside the super-tile (0..63)
+    const int first_lane = lane & ~(kSubs - 1);                                      // lane of the tile's first sub-tile: owns the tile's mask
+    const uint32_t tid = st * 64u + (uint32_t)tl;
+    const float4 *tbp = reinterpret_cast<const float4 *>(a.tile_bounds + (size_t)tid * kSubs + (lane & (kSubs - 1)));
     const float4 t0 = tbp[0], t1 = tbp[1], t2 = tbp[2];
     const uint32_t tflags = __float_as_uint(t0.w);
-    const uint32_t lit_lo = __float_as_uint(t1.w), lit_hi = __float_as_uint(t2.w);
+    const uint32_t mem_lo = __float_as_uint(t1.w), mem_hi = __float_as_uint(t2.w);
+    // lit pixels of the whole tile = union of its sub-tiles' members (every lane of the tile gets it)
+    uint32_t lit_lo = mem_lo, lit_hi = mem_hi;
+    for (int off = 1; off < kSubs; off <<= 1) { lit_lo |= (uint32_t)__shfl_xor((int)lit_lo, off); lit_hi |= (uint32_t)__shfl_xor((int)lit_hi, off); }
     // the VPL: position and normal (first 32 bytes of the record), wave-uniform
     const v8i ra = *reinterpret_cast<const v8i *>(a.vpls + i);
     const V3 o = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])), vn = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6]));
     const V3 lo = v3(t0), hi = v3(t1), tn = v3(t2);
-    bool live = (tflags & kTileLit) != 0u;
+    bool live = (tflags & kTileLit) != 0u && (tflags & kTileFat) == 0u;    // fat tiles are served by the per-item walk
     {
-        // cosine culls with a rounding margin (the per-pixel test of lighttracing.cu:284-288 is evaluated in fp32; a tile is
-        // only dropped when every pixel's cosine is negative by far more than that arithmetic can err):
-        //   VPL side:   max over the box of  n2 . (p - o)  <= -eps   ->  c2 = max(-n2 . v12, 0) = 0 for every pixel
-        //   pixel side: tiles with one common normal:  max of  n1 . (o - p)  <= -eps  ->  c1 = 0 for every pixel
+        // cosine culls with a rounding margin (the per-pixel test of lighttracing.cu:284-288 is evaluated in fp32; a box is
+        // only dropped when every member's cosine is negative by far more than that arithmetic can err):
+        //   VPL side:   max over the box of  n2 . (p - o)  <= -eps   ->  c2 = max(-n2 . v12, 0) = 0 for every member
+        //   pixel side: boxes with one common normal:  max of  n1 . (o - p)  <= -eps  ->  c1 = 0 for every member
         const V3 c = (lo + hi) * 0.5f, h = (hi - lo) * 0.5f, co = c - o;
         const V3 aco = v3(fabsf(co.x), fabsf(co.y), fabsf(co.z));
         const V3 an2 = v3(fabsf(vn.x), fabsf(vn.y), fabsf(vn.z));
@@ -220,11 +291,14 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
             if (m1 < -1.0e-5f * s1) live = false;
         }
     }
-    // occlusion mask of this lane's tile; a tile that cannot be lit reports "everything blocked" (the gather skips it)
-    uint32_t occ_lo = live ? 0u : 0xffffffffu, occ_hi = occ_lo;
+    // pixels that can still be lit by this VPL = members of the live sub-tiles; everything else is reported blocked:
+    // unlit pixels, members of culled sub-tiles (their cosine product is 0), and -- for the gather's skip test -- whole culled tiles
+    uint32_t want_lo = live ? mem_lo : 0u, want_hi = live ? mem_hi : 0u;
+    for (int off = 1; off < kSubs; off <<= 1) { want_lo |= (uint32_t)__shfl_xor((int)want_lo, off); want_hi |= (uint32_t)__shfl_xor((int)want_hi, off); }
+    uint32_t occ_lo = ~want_lo, occ_hi = ~want_hi;      // the tile's mask (authoritative copy in the tile's first lane)
 #if EVPLP_TRAVERSAL_STATS
     uint32_t st_nodes = 0, st_leaves = 0, st_tests = 0, st_exact = 0, st_pairs = 0, st_dead = 0;
-    const uint32_t st_culled = (uint32_t)__builtin_popcountll(ballot64(!live && (tflags & kTileLit) != 0u));
+    const uint32_t st_culled = (uint32_t)__builtin_popcountll(ballot64(!live && (tflags & kTileLit) != 0u && (tflags & kTileFat) == 0u));
 #endif
     if (ballot64(live) != 0ull) {
         // shaft constants in the segment's own parameter u = (t - tmin) / (tmax - tmin), as occluded_wave
@@ -265,9 +339,10 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
             const v2f exx = pk_fma(hx, aXx, pk_fma(cx, rXx, cXx)), exy = pk_fma(hy, aXy, pk_fma(cy, rXy, cXy)), exz = pk_fma(hz, aXz, pk_fma(cz, rXz, cXz));
             const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
             const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
-            unsigned long long m0 = ballot64(tn0 < tf0), m1 = ballot64(tn1 < tf1);
+            const bool h0 = tn0 < tf0, h1 = tn1 < tf1;
+            unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
             const int32_t c0 = n[12], c1 = n[13];
-            // leaf children: exact tests with pixel lanes for every tile whose shaft meets the leaf box
+            // leaf children: exact tests with pixel lanes for every tile one of whose shafts meets the leaf box
 #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const int32_t cc = side ? c1 : c0;
@@ -275,17 +350,26 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
                 if (cc >= 0 || m == 0ull) continue;
                 if (side) m1 = 0ull; else m0 = 0ull;
                 const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cc);
+                // pixels of the sub-tiles whose shafts met the box, per tile (OR over the tile's lanes)
+                const bool hs = side ? h1 : h0;
+                uint32_t hit_lo = hs ? mem_lo : 0u, hit_hi = hs ? mem_hi : 0u;
+                for (int off = 1; off < kSubs; off <<= 1) { hit_lo |= (uint32_t)__shfl_xor((int)hit_lo, off); hit_hi |= (uint32_t)__shfl_xor((int)hit_hi, off); }
+                // one bit per tile: its first lane
+                unsigned long long mt = m;
+                for (int off = 1; off < kSubs; off <<= 1) mt |= mt >> off;
+                mt &= 0x1111111111111111ull;
 #if EVPLP_TRAVERSAL_STATS
                 st_leaves++;
 #endif
-                while (m != 0ull) {
-                    const int t = (int)__builtin_ctzll(m);
-                    m &= m - 1ull;
-                    // the tile's pixels that still need an answer (its lit pixels that no triangle has blocked yet)
-                    const unsigned long long occ_t = (unsigned long long)(uint32_t)lane_read((int)occ_lo, t) | ((unsigned long long)(uint32_t)lane_read((int)occ_hi, t) << 32);
-                    const unsigned long long lit_t = (unsigned long long)(uint32_t)lane_read((int)lit_lo, t) | ((unsigned long long)(uint32_t)lane_read((int)lit_hi, t) << 32);
-                    const unsigned long long need = lit_t & ~occ_t;
+                while (mt != 0ull) {
+                    const int fl = (int)__builtin_ctzll(mt);       // first lane of the tile
+                    mt &= mt - 1ull;
+                    // the tile's pixels that still need an answer: members of the shafts that met the box, not blocked yet
+                    const unsigned long long occ_t = (unsigned long long)(uint32_t)lane_read((int)occ_lo, fl) | ((unsigned long long)(uint32_t)lane_read((int)occ_hi, fl) << 32);
+                    const unsigned long long hit_t = (unsigned long long)(uint32_t)lane_read((int)hit_lo, fl) | ((unsigned long long)(uint32_t)lane_read((int)hit_hi, fl) << 32);
+                    const unsigned long long need = hit_t & ~occ_t;
                     if (need == 0ull) continue;
+                    const int t = (int)part * kBeamTiles + fl / kSubs;
                     const int tx = (stx << swl) + (t & (sw - 1)), ty = sty * (64 >> swl) + (t >> swl);
                     const int x = min(tx * 8 + px_x, W - 1), ly = min(ty * 8 + px_y, max_row);
                     const float4 gp = a.g_pos[(size_t)ly * W + x];
@@ -300,10 +384,10 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
 #endif
                     const unsigned long long hm = ballot64(hit) & need;
                     if (hm != 0ull) {
-                        const bool mine = lane == t;
+                        const bool mine = first_lane == fl;       // every lane of the tile keeps the mask up to date
                         occ_lo = mine ? (occ_lo | (uint32_t)hm) : occ_lo;
                         occ_hi = mine ? (occ_hi | (uint32_t)(hm >> 32)) : occ_hi;
-                        if ((need & ~hm) == 0ull) {               // every lit pixel of the tile is blocked: its shaft leaves the walk
+                        if ((~(occ_t | hm)) == 0ull) {             // every pixel of the tile is blocked: its shafts leave the walk
                             if (mine) { cEx = bc(dead); cEy = bc(dead); cEz = bc(dead); }
 #if EVPLP_TRAVERSAL_STATS
                             st_dead++;
@@ -328,9 +412,8 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
             cur = lane_read(vstack, sp);
         }
     }
-    // pixels that are not lit can never be shaded: report them blocked, so "all ones" = nothing to shade for this (tile, VPL)
-    occ_lo |= ~lit_lo; occ_hi |= ~lit_hi;
-    a.vis[(size_t)i * ((size_t)a.band_supers * 64u) + (size_t)sb * 64u + (size_t)lane] = (unsigned long long)occ_lo | ((unsigned long long)occ_hi << 32);
+    if ((lane & (kSubs - 1)) == 0)
+        a.vis[(size_t)i * ((size_t)a.band_supers * 64u) + (size_t)sb * 64u + (size_t)tl] = (unsigned long long)occ_lo | ((unsigned long long)occ_hi << 32);
 #if EVPLP_TRAVERSAL_STATS
     if (lane == 0) {
         atomicAdd(&a.counters->hist[35], 1ull); atomicAdd(&a.counters->hist[36], (unsigned long long)st_nodes);
@@ -349,6 +432,11 @@ __global__ __launch_bounds__(64, kBeam ? 8 : EVPLP_GATHER_WAVES) void gather_vpl
     const int lane = threadIdx.x;
     const Item t = item_setup(a, lane);
     if (!t.has_tile) return;   // padding of the super-tile grid
+    // with the beam pass two launches cover the image: <true> shades the tiles the beams served, <false> walks for the fat tiles
+    if (a.vis) {
+        const uint32_t tflags = a.tile_bounds[((size_t)a.band_first_super * 64u + t.tile_in_band) * kSubs].flags;
+        if (((tflags & kTileFat) != 0u) == kBeam) return;
+    }
     const uint32_t p = t.p;
 
     Pixel px;
@@ -751,7 +839,7 @@ static dim3 gather_grid(const GatherArgs &a) {
     return dim3((unsigned)(a.band_supers * 64 * groups));       // (band tiles rounded to 8) x groups: tile = tile_j * 8 + xcd
 }
 void launch_tile_bounds(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(tile_bounds_kernel, dim3((unsigned)(a.nsx * a.nsy * 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(tile_clusters_kernel, dim3((unsigned)(a.nsx * a.nsy * 64)), dim3(64), 0, s, a);
 }
 void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
     size_t n = (size_t)a.st.W * a.st.local_rows;
@@ -759,11 +847,11 @@ void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) 
 }
 void launch_beam_visibility(const GatherArgs &a, hipStream_t s) {
     const unsigned per_xcd = ((unsigned)a.band_supers + 7u) / 8u;       // super-tiles per XCD (rounded up)
-    hipLaunchKernelGGL(beam_visibility_kernel, dim3(per_xcd * a.max_vpls * 8u), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(beam_visibility_kernel, dim3(per_xcd * a.max_vpls * 8u * (unsigned)kSubs), dim3(64), 0, s, a);
 }
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
     if (a.vis) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), 0, s, a);      // everything without the beam pass, the fat tiles with it
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), 0, s, a);

@@ -44,9 +44,10 @@ out = {
     "kernel_ms_with_counters": st["dominant_kernel_ms"], "launches": st["launches"], "shaded": st["shaded"],
     "beam": {"beams": int(raw[4 + 35]), "node_visits_per_beam": int(raw[4 + 36]) / max(int(raw[4 + 35]), 1),
              "leaf_blocks_per_beam": int(raw[4 + 37]) / max(int(raw[4 + 35]), 1), "tile_leaf_tests_per_beam": int(raw[4 + 38]) / max(int(raw[4 + 35]), 1),
-             "tile_leaf_tests_per_tile_vpl": int(raw[4 + 38]) / max(int(raw[4 + 35]) * 64, 1),
+             "tile_leaf_tests_per_tile_vpl": int(raw[4 + 38]) / max(int(raw[4 + 35]) * 16, 1), "node_visits_per_tile_vpl": int(raw[4 + 36]) / max(int(raw[4 + 35]) * 16, 1),
              "pairs_exact": int(raw[4 + 39]), "pairs_rejected_by_pretest": int(raw[4 + 40]),
-             "tiles_fully_occluded_per_beam": int(raw[4 + 41]) / max(int(raw[4 + 35]), 1), "tiles_cosine_culled_per_beam": int(raw[4 + 42]) / max(int(raw[4 + 35]), 1)},
+             "tiles_fully_occluded_per_beam": int(raw[4 + 41]) / max(int(raw[4 + 35]), 1), "tiles_cosine_culled_per_beam": int(raw[4 + 42]) / max(int(raw[4 + 35]), 1),
+             "lit_tiles": int(raw[4 + 44]), "fat_tiles": int(raw[4 + 43])},
 }
 print(json.dumps(out, indent=1))
 if a.out:
