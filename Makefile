@@ -33,7 +33,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 
 $(BUILD)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(HOSTFLAGS) -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $< -o $@
+	$(HIPCC) $(HOSTFLAGS) $(EXTRA_HIPFLAGS) -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $< -o $@
 
 $(OUT)/evplp-render: $(CSRC)/host/driver_main.cpp $(OUT)/libevplp_hip.so
 	g++ -O2 -std=c++17 -Iinclude -o $@ $< -L$(OUT) -levplp_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib

@@ -110,6 +110,7 @@ _SIGNATURES = {
     "evplp_upload": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
+    "evplp_debug_buffer": (C.c_int, [_P, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -344,6 +345,11 @@ class Context:
     def debug_counters(self, which: int) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint64)
         n = self._check(self._lib.evplp_debug_counters(self._h, which, _ptr(out), out.size))
+        return out[:n]
+
+    def debug_buffer(self, capacity: int = 1 << 22) -> np.ndarray:
+        out = np.zeros(capacity, dtype=np.uint32)
+        n = self._check(self._lib.evplp_debug_buffer(self._h, _ptr(out), out.size))
         return out[:n]
 
     # -- strips

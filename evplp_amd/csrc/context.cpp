@@ -129,7 +129,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
-    hipFree(c->d_tile_bounds); hipFree(c->d_vis);
+    hipFree(c->d_tile_bounds); hipFree(c->d_vis); hipFree(c->d_dbg);
     for (hipEvent_t ev : c->ev_band) hipEventDestroy(ev);
     hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
     hipFree(c->d_compact); hipFree(c->d_rect); hipFree(c->d_tile_z); hipFree(c->d_tile_pairs);
@@ -414,6 +414,11 @@ static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t group
         if (e != hipSuccess) { c->set_error("gather: cannot allocate tile bounds: %s", hipGetErrorString(e)); return EVPLP_ERR_OOM; }
     }
     a.tile_bounds = c->d_tile_bounds;
+#if defined(EVPLP_TRAVERSAL_STATS) && EVPLP_TRAVERSAL_STATS
+    if (!c->d_dbg) { c->dbg_words = ntid + a.max_vpls; if (hipMalloc((void **)&c->d_dbg, c->dbg_words * sizeof(uint32_t)) != hipSuccess) c->d_dbg = nullptr; }
+    if (c->d_dbg) hipMemsetAsync(c->d_dbg, 0, c->dbg_words * sizeof(uint32_t), c->stream);
+    a.dbg = c->d_dbg;
+#endif
     int bands = 1;
     if (want_beams) {
         // one 8-byte occlusion mask per (tile, VPL slot): the image is processed in bands of super-tiles whose masks fit the budget
@@ -629,6 +634,18 @@ extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, si
     HIP_TRY(c, hipMemcpyAsync(c->buf[which], src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EVPLP_OK;
+}
+
+// diagnostic builds: per-tile-id and per-VPL exact-test counts of the last beam pass (returns words written, 0 when absent)
+extern "C" int evplp_debug_buffer(evplp_context *c, uint32_t *out, int32_t capacity) {
+    CTX_CHECK(c);
+    if (!out || capacity <= 0) { c->set_error("evplp_debug_buffer: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (!c->d_dbg) return 0;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int n = (int)std::min<size_t>((size_t)capacity, c->dbg_words);
+    HIP_TRY(c, hipMemcpy(out, c->d_dbg, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 // raw device counters of a pass (diagnostic builds fill the histogram part; see kernels.h PassCounters)

@@ -44,6 +44,7 @@ struct evplp_context {
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
     evplp::SubBound *d_tile_bounds = nullptr;                   // [nsx * nsy * 64][kSubs]
     unsigned long long *d_vis = nullptr; size_t vis_words = 0;  // (tile, VPL) occlusion masks of one band of super-tiles
+    uint32_t *d_dbg = nullptr; size_t dbg_words = 0;            // diagnostic builds only
     std::vector<hipEvent_t> ev_band;                            // begin/end pairs around the gather kernel of every band
     int32_t gather_launches[EVPLP_PASS_COUNT] = {};
     // splat workspace

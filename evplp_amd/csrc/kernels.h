@@ -72,6 +72,7 @@ struct GatherArgs {
     int32_t band_first_super, band_supers;   // the super-tiles this launch covers
     int32_t splits_per_wave;          // k: a wave sums k consecutive splits (a power of two <= 32) and folds them in tree order
     uint32_t max_vpls;                // allocated VPL slots (grid bound of beam_visibility_kernel)
+    uint32_t *dbg;                    // EVPLP_TRAVERSAL_STATS builds: [tile ids] + [max_vpls] exact-test counts of the beam pass; else null
     float fat_ratio;                  // a sub-tile is fat when its box extent exceeds fat_ratio x 8 x the smallest spacing of adjacent lit pixels
 };
 #ifndef EVPLP_VPL_SPLIT

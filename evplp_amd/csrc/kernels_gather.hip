@@ -237,9 +237,11 @@ __global__ __launch_bounds__(64) void tile_clusters_kernel(GatherArgs a) {
 // t dlo <= ctr + hal - o:
 //   dlo > 0          entry (ctr - o - hal) / dhi,  exit (ctr - o + hal) / dlo
 //   dhi < 0          entry (ctr - o + hal) / dlo,  exit (ctr - o - hal) / dhi
-//   dlo <= 0 <= dhi  the box straddles the origin on this axis: only the entry (ctr - o - hal) / dhi is kept, the exit is +inf
-//                    (conservative; rare -- the VPL coordinate has to fall inside the box's few centimetres)
-// i.e.  entry = ctr rE + cE - hal |rE|,  exit = ctr rX + cX + hal |rX|  with per-lane constants.
+//   dlo <= 0 <= dhi  the box straddles the origin on this axis (the VPL's coordinate lies inside the box's range: common for the
+//                    metre-wide boxes of surfaces seen at grazing angles): the cross-section widens to both sides, both conditions
+//                    are ENTRY conditions -- (ctr - o - hal) / dhi and (ctr - o + hal) / dlo -- and there is no exit
+// i.e.  entry = max(ctr rE + cE - hal |rE|, ctr rF + cF - hal |rF|),  exit = ctr rX + cX + hal |rX|  with per-lane constants
+// (the second entry form is -inf off the straddling case; waves without a straddling lane skip it: 18 instead of 26 instructions).
 // A leaf is not entered.  For every tile one of whose shafts meets the leaf's (padded) box the wave switches roles -- lane =
 // PIXEL of that tile -- and runs the exact any-hit predicate on the leaf's triangles for the tile's shadow segments, OR-ing the
 // hits into the tile's 64-bit occlusion mask (kept in the lane of the tile's first sub-tile).  A segment can only hit a
@@ -284,11 +286,11 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
         const V3 aco = v3(fabsf(co.x), fabsf(co.y), fabsf(co.z));
         const V3 an2 = v3(fabsf(vn.x), fabsf(vn.y), fabsf(vn.z));
         const float m2 = dot(vn, co) + dot(an2, h), s2 = dot(an2, aco) + dot(an2, h);
-        if (m2 < -1.0e-5f * s2) live = false;
+        if (m2 <= -1.0e-5f * s2) live = false;      // (s2 = 0: every product n2_k (p_k - o_k) is exactly 0 for every member -> c2 = 0)
         if (tflags & kTileFlat) {
             const V3 an1 = v3(fabsf(tn.x), fabsf(tn.y), fabsf(tn.z));
             const float m1 = -dot(tn, co) + dot(an1, h), s1 = dot(an1, aco) + dot(an1, h);
-            if (m1 < -1.0e-5f * s1) live = false;
+            if (m1 <= -1.0e-5f * s1) live = false;
         }
     }
     // pixels that can still be lit by this VPL = members of the live sub-tiles; everything else is reported blocked:
@@ -297,28 +299,36 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
     for (int off = 1; off < kSubs; off <<= 1) { want_lo |= (uint32_t)__shfl_xor((int)want_lo, off); want_hi |= (uint32_t)__shfl_xor((int)want_hi, off); }
     uint32_t occ_lo = ~want_lo, occ_hi = ~want_hi;      // the tile's mask (authoritative copy in the tile's first lane)
 #if EVPLP_TRAVERSAL_STATS
-    uint32_t st_nodes = 0, st_leaves = 0, st_tests = 0, st_exact = 0, st_pairs = 0, st_dead = 0;
+    uint32_t st_nodes = 0, st_leaves = 0, st_tests = 0, st_exact = 0, st_pairs = 0, st_dead = 0, my_tests = 0;
     const uint32_t st_culled = (uint32_t)__builtin_popcountll(ballot64(!live && (tflags & kTileLit) != 0u && (tflags & kTileFat) == 0u));
 #endif
     if (ballot64(live) != 0ull) {
         // shaft constants in the segment's own parameter u = (t - tmin) / (tmax - tmin), as occluded_wave
         const float tmin = 0.0001f, tmax = 1.0f - 0.0001f, ku = 1.0f / (tmax - tmin);
         const float dead = __builtin_inff();
-        float rE[3], cE[3], rX[3], cX[3];
+        float rE[3], cE[3], rX[3], cX[3], rF[3], cF[3];
         const float dl[3] = { lo.x - o.x, lo.y - o.y, lo.z - o.z }, dh[3] = { hi.x - o.x, hi.y - o.y, hi.z - o.z }, oo[3] = { o.x, o.y, o.z };
+        bool straddles = false;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float il = safe_rcp(dl[k]), ih = safe_rcp(dh[k]);
-            const bool pos = dl[k] > 0.0f, neg = dh[k] < 0.0f;
-            const float e = pos ? ih : neg ? il : ih;
+            const bool pos = dl[k] > 0.0f, neg = dh[k] < 0.0f, mid = !(pos || neg);
+            // straddling: dlo <= 0 <= dhi, the reciprocals keep those signs even when an end is exactly (+-)0
+            const float e = pos ? ih : neg ? il : fabsf(ih);
             const float x = pos ? il : neg ? ih : 0.0f;
+            const float f = -fabsf(il);
             rE[k] = e * ku; cE[k] = live ? (-(oo[k] * e) - tmin) * ku : dead;
-            rX[k] = x * ku; cX[k] = (pos || neg) ? (-(oo[k] * x) - tmin) * ku : dead;
+            rX[k] = x * ku; cX[k] = mid ? dead : (-(oo[k] * x) - tmin) * ku;
+            rF[k] = mid ? f * ku : 0.0f; cF[k] = mid ? (-(oo[k] * f) - tmin) * ku : -dead;
+            straddles = straddles || (mid && live);
         }
+        const bool any_straddle = ballot64(straddles) != 0ull;                 // wave-uniform
         const v2f rEx = bc(rE[0]), rEy = bc(rE[1]), rEz = bc(rE[2]), aEx = bc(fabsf(rE[0])), aEy = bc(fabsf(rE[1])), aEz = bc(fabsf(rE[2]));
         const v2f rXx = bc(rX[0]), rXy = bc(rX[1]), rXz = bc(rX[2]), aXx = bc(fabsf(rX[0])), aXy = bc(fabsf(rX[1])), aXz = bc(fabsf(rX[2]));
+        const v2f rFx = bc(rF[0]), rFy = bc(rF[1]), rFz = bc(rF[2]), aFx = bc(fabsf(rF[0])), aFy = bc(fabsf(rF[1])), aFz = bc(fabsf(rF[2]));
         v2f cEx = bc(cE[0]), cEy = bc(cE[1]), cEz = bc(cE[2]);
         const v2f cXx = bc(cX[0]), cXy = bc(cX[1]), cXz = bc(cX[2]);
+        const v2f cFx = bc(cF[0]), cFy = bc(cF[1]), cFz = bc(cF[2]);
         // pixel role: where this lane's pixel sits inside a tile, and the super-tile's origin in tiles
         const int swl = a.super_w_log2, sw = 1 << swl;
         const int stx = (int)(st % (uint32_t)a.nsx), sty = (int)(st / (uint32_t)a.nsx);
@@ -337,8 +347,13 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
             const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
             const v2f enx = pk_fma(hx, -aEx, pk_fma(cx, rEx, cEx)), eny = pk_fma(hy, -aEy, pk_fma(cy, rEy, cEy)), enz = pk_fma(hz, -aEz, pk_fma(cz, rEz, cEz));
             const v2f exx = pk_fma(hx, aXx, pk_fma(cx, rXx, cXx)), exy = pk_fma(hy, aXy, pk_fma(cy, rXy, cXy)), exz = pk_fma(hz, aXz, pk_fma(cz, rXz, cXz));
-            const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
-            const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
+            float e0 = fmaxf(fmaxf(enx.x, eny.x), enz.x), e1 = fmaxf(fmaxf(enx.y, eny.y), enz.y);
+            if (any_straddle) {
+                const v2f fx = pk_fma(hx, -aFx, pk_fma(cx, rFx, cFx)), fy = pk_fma(hy, -aFy, pk_fma(cy, rFy, cFy)), fz = pk_fma(hz, -aFz, pk_fma(cz, rFz, cFz));
+                e0 = fmaxf(e0, fmaxf(fmaxf(fx.x, fy.x), fz.x)); e1 = fmaxf(e1, fmaxf(fmaxf(fx.y, fy.y), fz.y));
+            }
+            const float tn0 = clamp01(e0), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
+            const float tn1 = clamp01(e1), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
             const bool h0 = tn0 < tf0, h1 = tn1 < tf1;
             unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
             const int32_t c0 = n[12], c1 = n[13];
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
                     const float4 gp = a.g_pos[(size_t)ly * W + x];
                     const V3 d = v3(gp) - o;                       // == -(v.pos - p1) bit for bit (Ray(o, -v12), lighttracing.cu:292)
 #if EVPLP_TRAVERSAL_STATS
-                    st_tests++; st_pairs += L.cnt > 2u ? 2u : 1u;
+                    st_tests++; st_pairs += L.cnt > 2u ? 2u : 1u; if (first_lane == fl) my_tests++;
                     bool hit = tri_pair_any(L.A, o, d, tmin, tmax, need, &st_exact);
                     if (L.cnt > 2u) hit = hit | tri_pair_any(L.B, o, d, tmin, tmax, need, &st_exact);
 #else
@@ -420,7 +435,9 @@ __global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(G
         atomicAdd(&a.counters->hist[37], (unsigned long long)st_leaves); atomicAdd(&a.counters->hist[38], (unsigned long long)st_tests);
         atomicAdd(&a.counters->hist[39], (unsigned long long)st_exact); atomicAdd(&a.counters->hist[40], (unsigned long long)(st_pairs - st_exact));
         atomicAdd(&a.counters->hist[41], (unsigned long long)st_dead); atomicAdd(&a.counters->hist[42], (unsigned long long)st_culled);
+        if (a.dbg) atomicAdd(&a.dbg[(size_t)a.nsx * a.nsy * 64 + i], st_tests);
     }
+    if (a.dbg && (lane & (kSubs - 1)) == 0) atomicAdd(&a.dbg[tid], my_tests);
 #endif
 }
 

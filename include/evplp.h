@@ -224,6 +224,8 @@ int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out
 /* Raw device-side counters of the last run of `pass` (rays, node visits, pairs, aux, then the traversal histogram that
  * only -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds fill).  Returns the number of 64-bit words written. */
 int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_t capacity);
+/* -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds: exact-test counts of the last beam pass per tile id, then per VPL; 0 words otherwise */
+int evplp_debug_buffer(evplp_context *ctx, uint32_t *out, int32_t capacity);
 /* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
 int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
 

@@ -1,16 +1,16 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r2e; mkdir -p $O
+O=gpurun_out/r2f; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $O/pytest_parity.log 2>&1; echo "rc=$?" >> $O/pytest_parity.log
 tail -4 $O/pytest_parity.log
-for fr in 6 12 24; do
+for fr in 24; do
 for sc in easy hard; do
   EVPLP_FAT_RATIO=$fr timeout 300 python3 tools/traversal_stats.py --scene $sc --out $O/stats_${sc}_fr$fr.json > $O/stats_${sc}_fr$fr.log 2>&1
   python3 -c "
 import json
 d=json.load(open('$O/stats_${sc}_fr$fr.json')); b=d['beam']; print('$sc fat_ratio $fr', {k:(round(v,2) if isinstance(v,float) else v) for k,v in b.items()}, 'walks',d['walks'],'nodes/walk',round(d['node_visits_per_walk'],1), 'ms', round(d['kernel_ms_with_counters'],1))"
 done; done
-for fr in 6 12 24; do
+for fr in 24; do
 for sc in hard easy; do
 EVPLP_FAT_RATIO=$fr timeout 600 python3 bench.py --steps 5 --warmup 1 --scene $sc --no-cpu-baseline --no-extras > $O/bench_ir_${sc}_fr$fr.jsonl 2> $O/bench_ir_${sc}_fr$fr.err
 python3 -c "

@@ -49,6 +49,28 @@ out = {
              "tiles_fully_occluded_per_beam": int(raw[4 + 41]) / max(int(raw[4 + 35]), 1), "tiles_cosine_culled_per_beam": int(raw[4 + 42]) / max(int(raw[4 + 35]), 1),
              "lit_tiles": int(raw[4 + 44]), "fat_tiles": int(raw[4 + 43])},
 }
+dbg = c.debug_buffer()
+if dbg.size:
+    # per-tile heat map of the beam pass's (tile, leaf) tests, summed over the VPLs, as an image (tile ids are super-tile swizzled)
+    ntid = dbg.size - (a.paths * P)
+    per_tile, per_vpl = dbg[:ntid].astype(np.float64), dbg[ntid:].astype(np.float64)
+    tiles = a.res // 8
+    img = np.zeros((tiles, tiles), np.float64)
+    tid = np.arange(ntid); st_, l = tid >> 6, tid & 63
+    nsx = (tiles + 7) // 8
+    tx, ty = (st_ % nsx) * 8 + (l & 7), (st_ // nsx) * 8 + (l >> 3)
+    ok = (tx < tiles) & (ty < tiles)
+    img[ty[ok], tx[ok]] = per_tile[ok]
+    out["beam"]["per_tile_tests_percentiles"] = [float(np.percentile(per_tile[ok], q)) for q in (10, 50, 90, 99, 100)]
+    out["beam"]["per_vpl_tests_percentiles"] = [float(np.percentile(per_vpl[:int(st['usable'])], q)) for q in (10, 50, 90, 99, 100)]
+    srt = np.sort(per_tile[ok])[::-1]
+    out["beam"]["share_of_tests_in_top_1pct_10pct_tiles"] = [float(srt[:len(srt) // 100].sum() / max(srt.sum(), 1)), float(srt[:len(srt) // 10].sum() / max(srt.sum(), 1))]
+    v = np.log1p(img) / max(np.log1p(img).max(), 1e-9)
+    os.makedirs("gpurun_out", exist_ok=True)
+    ev.save_image("gpurun_out/beam_tests_%s.png" % a.scene, np.repeat(np.repeat(np.stack([v, v, v], -1)[::-1], 4, 0), 4, 1).astype(np.float32))
+    np.save("gpurun_out/beam_tests_%s.npy" % a.scene, img.astype(np.float32))
+    vs = np.argsort(per_vpl[:int(st['usable'])])[::-1][:8]
+    out["beam"]["heaviest_vpls"] = [[int(k), float(per_vpl[k])] for k in vs]
 print(json.dumps(out, indent=1))
 if a.out:
     json.dump(out, open(a.out, "w"), indent=1)
