@@ -49,7 +49,7 @@ class Config(C.Structure):
                 ("strip_rank", C.c_int32), ("strip_count", C.c_int32), ("strip_rows", C.c_int32),
                 ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
                 ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("gather_splits_per_wave", C.c_int32),
-                ("gather_no_beams", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("reserved", C.c_int32 * 3)]
 
 
 class Material(C.Structure):
@@ -110,7 +110,6 @@ _SIGNATURES = {
     "evplp_upload": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
-    "evplp_debug_buffer": (C.c_int, [_P, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -181,15 +180,14 @@ class Context:
 
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
-                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0,
-                 beams: bool = True):
+                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0):
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.strip_rank = strip_rank; cfg.strip_count = strip_count; cfg.strip_rows = strip_rows
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths
         cfg.photons_per_path = photons_per_path; cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
-        cfg.gather_splits_per_wave = gather_splits_per_wave; cfg.gather_no_beams = 0 if beams else 1
+        cfg.gather_splits_per_wave = gather_splits_per_wave
         self.cfg = cfg
         h = C.c_void_p()
         rc = self._lib.evplp_create(C.byref(cfg), C.byref(h))
@@ -345,11 +343,6 @@ class Context:
     def debug_counters(self, which: int) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint64)
         n = self._check(self._lib.evplp_debug_counters(self._h, which, _ptr(out), out.size))
-        return out[:n]
-
-    def debug_buffer(self, capacity: int = 1 << 22) -> np.ndarray:
-        out = np.zeros(capacity, dtype=np.uint32)
-        n = self._check(self._lib.evplp_debug_buffer(self._h, _ptr(out), out.size))
         return out[:n]
 
     # -- strips

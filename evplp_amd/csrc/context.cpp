@@ -129,8 +129,6 @@ extern "C" void evplp_destroy(evplp_context *c) {
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
-    hipFree(c->d_tile_bounds); hipFree(c->d_vis); hipFree(c->d_dbg);
-    for (hipEvent_t ev : c->ev_band) hipEventDestroy(ev);
     hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
     hipFree(c->d_compact); hipFree(c->d_rect); hipFree(c->d_tile_z); hipFree(c->d_tile_pairs);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -383,22 +381,15 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.out = (float4 *)c->buf[EVPLP_BUF_VPL_ACCUM];
     a.partial_stride = (size_t)c->st.W * c->st.local_rows;
     a.counters = &c->d_counters[pass];
-    a.max_vpls = std::max<uint32_t>(c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1u);
-    // tile enumeration: super-tiles of SW x SH tiles, SH = the tile rows a row strip keeps adjacent (8 for a whole image)
-    const int tiles_x = (c->st.W + 7) / 8, tiles_y = (c->st.local_rows + 7) / 8;
+    a.splits_per_wave = 1;
+    // tile blocks: as many tile rows as a row strip keeps adjacent, at most 8
     int sh = 8;
     if (c->st.strip_count > 1) { sh = 1; while (sh * 2 <= std::min(8, c->st.strip_rows / 8) && (c->st.strip_rows / 8) % (sh * 2) == 0) sh *= 2; }
-    int swl = 0; while ((64 >> swl) > sh) swl++;
-    a.super_w_log2 = swl;
-    a.nsx = (tiles_x + (1 << swl) - 1) >> swl; a.nsy = (tiles_y + sh - 1) / sh;
-    a.band_first_super = 0; a.band_supers = a.nsx * a.nsy;
-    a.splits_per_wave = 1;
-    a.fat_ratio = 24.0f;
-    if (const char *e = std::getenv("EVPLP_FAT_RATIO")) a.fat_ratio = (float)atof(e);
+    a.block_h_log2 = sh == 8 ? 3 : sh == 4 ? 2 : sh == 2 ? 1 : 0;
     return EVPLP_OK;
 }
-// gather workspace (lazy): partial sums for `groups` groups, tile bounds, and -- for the VPL gather -- the visibility masks of one band
-static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t groups, bool want_beams, int *bands_out) {
+// gather workspace (lazy: path-tracing / photon-only contexts never pay for it): per-item partial sums for `groups` groups
+static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t groups) {
     const size_t px = (size_t)c->st.W * c->st.local_rows;
     if (c->partial_groups < groups) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -408,42 +399,6 @@ static int ensure_gather_workspace(evplp_context *c, GatherArgs &a, size_t group
         c->partial_groups = groups;
     }
     a.partial = c->d_partial;
-    const size_t ntid = (size_t)a.nsx * a.nsy * 64;
-    if (!c->d_tile_bounds) {
-        hipError_t e = hipMalloc((void **)&c->d_tile_bounds, sizeof(SubBound) * ntid * kSubs);
-        if (e != hipSuccess) { c->set_error("gather: cannot allocate tile bounds: %s", hipGetErrorString(e)); return EVPLP_ERR_OOM; }
-    }
-    a.tile_bounds = c->d_tile_bounds;
-#if defined(EVPLP_TRAVERSAL_STATS) && EVPLP_TRAVERSAL_STATS
-    if (!c->d_dbg) { c->dbg_words = ntid + a.max_vpls; if (hipMalloc((void **)&c->d_dbg, c->dbg_words * sizeof(uint32_t)) != hipSuccess) c->d_dbg = nullptr; }
-    if (c->d_dbg) hipMemsetAsync(c->d_dbg, 0, c->dbg_words * sizeof(uint32_t), c->stream);
-    a.dbg = c->d_dbg;
-#endif
-    int bands = 1;
-    if (want_beams) {
-        // one 8-byte occlusion mask per (tile, VPL slot): the image is processed in bands of super-tiles whose masks fit the budget
-        size_t budget = (size_t)1 << 30;
-        if (const char *mb = std::getenv("EVPLP_VIS_MB")) budget = (size_t)std::max(1, atoi(mb)) << 20;
-        const size_t per_super = (size_t)a.max_vpls * 64 * sizeof(unsigned long long);
-        const int total = a.nsx * a.nsy;
-        int per_band = (int)std::max<size_t>(1, std::min<size_t>((size_t)total, budget / per_super));
-        bands = (total + per_band - 1) / per_band;
-        per_band = (total + bands - 1) / bands;           // even bands
-        const size_t words = (size_t)per_band * per_super / sizeof(unsigned long long);
-        if (c->vis_words < words) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_vis); c->d_vis = nullptr; c->vis_words = 0;
-            hipError_t e = hipMalloc((void **)&c->d_vis, words * sizeof(unsigned long long));
-            if (e != hipSuccess) { c->set_error("gather: cannot allocate %zu bytes of visibility masks: %s", words * sizeof(unsigned long long), hipGetErrorString(e)); return EVPLP_ERR_OOM; }
-            c->vis_words = words;
-        }
-        a.vis = c->d_vis;
-        a.band_supers = per_band;
-    }
-    while (c->ev_band.size() < (size_t)bands * 2) {
-        hipEvent_t ev; HIP_TRY(c, hipEventCreate(&ev)); c->ev_band.push_back(ev);
-    }
-    *bands_out = bands;
     return EVPLP_OK;
 }
 static int check_fp(evplp_context *c, const evplp_frame_params *fp, const char *name) {
@@ -461,33 +416,23 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     if ((rc = check_fp(c, fp, name))) return rc;
     if (fp->num_vpl_light_paths == 0) { c->set_error("%s: num_vpl_light_paths is 0 (the reference disables the pass, rtcomphoton.h:200-203)", name); return EVPLP_ERR_INVALID; }
     GatherArgs a; fill_gather_args(c, fp, a, pass);
-    // work-item size: k consecutive splits per wavefront.  One GPU: 16 (8 partials per pixel, 131 k items at 1024^2); row
-    // strips keep the item count per GPU up with smaller k.  The per-item statistics need (VPLs per split) * k < 65536.
+    // work-item size: k consecutive splits per wavefront (fixed summation tree: the result does not depend on k).  The per-item
+    // statistics need (VPLs per split) * k < 65536.
     int k = 1;
     if (!vsl) {
-        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : std::max(1, 16 / std::max(1, c->st.strip_count));
+        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : kDefaultSplitsPerWave;
         if (const char *e = std::getenv("EVPLP_GATHER_K")) { int v = atoi(e); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k = v; }
-        while (k > 1 && ((size_t)a.max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
+        const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
+        while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
     }
     a.splits_per_wave = k;
-    const bool want_beams = !vsl && !c->cfg.gather_no_beams && std::getenv("EVPLP_NO_BEAMS") == nullptr;
-    int bands = 1;
-    if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k), want_beams, &bands))) return rc;
+    if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k)))) return rc;
     if ((rc = pass_begin(c, pass))) return rc;
     const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
     launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
-    if (want_beams) launch_tile_bounds(a, c->stream);
-    const int total = a.nsx * a.nsy, per_band = a.band_supers;
-    for (int b = 0; b < bands; b++) {
-        a.band_first_super = b * per_band;
-        a.band_supers = std::min(per_band, total - a.band_first_super);
-        if (a.band_supers <= 0) { bands = b; break; }
-        HIP_TRY(c, hipEventRecord(c->ev_band[2 * b], c->stream));
-        if (want_beams) launch_beam_visibility(a, c->stream);
-        if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl_items(a, c->stream);
-        HIP_TRY(c, hipEventRecord(c->ev_band[2 * b + 1], c->stream));
-    }
-    c->gather_launches[pass] = bands;
+    HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
+    if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl_items(a, c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
     launch_gather_reduce(a, vsl ? 0 : 1, c->stream);
     c->pass_has_dom[pass] = true;
     return pass_end(c, pass);
@@ -636,18 +581,6 @@ extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, si
     return EVPLP_OK;
 }
 
-// diagnostic builds: per-tile-id and per-VPL exact-test counts of the last beam pass (returns words written, 0 when absent)
-extern "C" int evplp_debug_buffer(evplp_context *c, uint32_t *out, int32_t capacity) {
-    CTX_CHECK(c);
-    if (!out || capacity <= 0) { c->set_error("evplp_debug_buffer: bad arguments"); return EVPLP_ERR_INVALID; }
-    if (!c->d_dbg) return 0;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const int n = (int)std::min<size_t>((size_t)capacity, c->dbg_words);
-    HIP_TRY(c, hipMemcpy(out, c->d_dbg, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
-    return n;
-}
-
 // raw device counters of a pass (diagnostic builds fill the histogram part; see kernels.h PassCounters)
 extern "C" int evplp_debug_counters(evplp_context *c, int32_t pass, uint64_t *out, int32_t capacity) {
     CTX_CHECK(c);
@@ -669,12 +602,7 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipEventSynchronize(c->ev_end[pass]));
     HIP_TRY(c, hipEventElapsedTime(&out->ms, c->ev_begin[pass], c->ev_end[pass]));
-    const bool is_gather = pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL;
-    if (is_gather) {
-        float sum = 0.f;
-        for (int b = 0; b < c->gather_launches[pass]; b++) { float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_band[2 * b], c->ev_band[2 * b + 1])); sum += ms; }
-        out->dominant_kernel_ms = sum; out->launches = (uint32_t)c->gather_launches[pass];
-    } else if (c->pass_has_dom[pass]) { HIP_TRY(c, hipEventElapsedTime(&out->dominant_kernel_ms, c->ev_dom_begin[pass], c->ev_dom_end[pass])); out->launches = 1; }
+    if (c->pass_has_dom[pass]) { HIP_TRY(c, hipEventElapsedTime(&out->dominant_kernel_ms, c->ev_dom_begin[pass], c->ev_dom_end[pass])); out->launches = 1; }
     else { out->dominant_kernel_ms = out->ms; out->launches = 1; }
     PassCounters pc; uint32_t scal[16];
     HIP_TRY(c, hipMemcpy(&pc, &c->d_counters[pass], sizeof(pc), hipMemcpyDeviceToHost));

@@ -42,11 +42,7 @@ struct evplp_context {
     float *d_rgb = nullptr;
     // gather workspace, allocated on the first gather (path-tracing / photon-only contexts never pay for it)
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
-    evplp::SubBound *d_tile_bounds = nullptr;                   // [nsx * nsy * 64][kSubs]
-    unsigned long long *d_vis = nullptr; size_t vis_words = 0;  // (tile, VPL) occlusion masks of one band of super-tiles
-    uint32_t *d_dbg = nullptr; size_t dbg_words = 0;            // diagnostic builds only
-    std::vector<hipEvent_t> ev_band;                            // begin/end pairs around the gather kernel of every band
-    int32_t gather_launches[EVPLP_PASS_COUNT] = {};
+
     // splat workspace
     int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0, last_bin_entries = 0, last_bin_max = 0;
     uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;

@@ -372,7 +372,7 @@ EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 #ifndef EVPLP_TRAVERSAL_STATS
 #define EVPLP_TRAVERSAL_STATS 0    // 1: count node visits / leaf blocks / triangle pairs per walk (diagnostic build, tools/traversal_stats.py)
 #endif
-struct WalkStats { uint32_t nodes, leaves, pairs; };
+struct WalkStats { uint32_t nodes, leaves, pairs, exact; };
 
 EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
@@ -440,8 +440,13 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
 #if EVPLP_TRAVERSAL_STATS
             if (ws) { ws->leaves++; ws->pairs += cnt > 2u ? 2u : 1u; }
 #endif
-            bool any = tri_pair_any(L.A, o, d, tmin, tmax, alive);    // an empty slot B is all zeros: never a hit
-            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, alive);
+#if EVPLP_TRAVERSAL_STATS
+            uint32_t *ex = ws ? &ws->exact : nullptr;
+#else
+            uint32_t *ex = nullptr;
+#endif
+            bool any = tri_pair_any(L.A, o, d, tmin, tmax, alive, ex);    // an empty slot B is all zeros: never a hit
+            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, alive, ex);
             const unsigned long long hm = ballot64(any) & alive;
             if (hm != 0ull) {
                 hitm |= hm;

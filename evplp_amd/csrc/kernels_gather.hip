@@ -78,37 +78,30 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
     return v.flux * x;
 }
 
-// Tile enumeration.  Tiles are grouped into super-tiles of SW x SH tiles (SW * SH = 64, SH = as many tile rows as a row
-// strip keeps adjacent); tile id = super-tile * 64 + (ty % SH) * SW + tx % SW.  One launch covers a band of super-tiles.
-struct TileXY { int tx, ty; bool exists; };
-EV_DEV TileXY tile_of(const GatherArgs &a, uint32_t tid) {
-    const int tiles_x = (a.st.W + 7) >> 3, tiles_y = (a.st.local_rows + 7) >> 3;
-    const int swl = a.super_w_log2, sw = 1 << swl;
-    const int st = (int)(tid >> 6), l = (int)(tid & 63u);
-    const int stx = st % a.nsx, sty = st / a.nsx;
-    TileXY t;
-    t.tx = (stx << swl) + (l & (sw - 1)); t.ty = sty * (64 >> swl) + (l >> swl);
-    t.exists = sty < a.nsy && t.tx < tiles_x && t.ty < tiles_y;
-    return t;
-}
 // Item order.  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; speed only, never
-// correctness).  All items of a tile run back to back on one XCD (they share the tile's G-buffer lines, its shaft lists
-// and BVH neighbourhood in that L2); consecutive TILES go to different XCDs (item cost varies by 5x across the image --
+// correctness).  All items of a tile run back to back on one XCD (they share the tile's G-buffer lines and BVH
+// neighbourhood in that L2); consecutive TILES go to different XCDs (item cost varies by 5x across the image --
 // furniture silhouettes vs open floor -- and balance beats L2 locality: per-XCD super-tiles of 2x2 / 4x4 tiles
-// measured 3 % / 13 % slower in round 1).
-struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p, tile_in_band; };   // p: pixel index in the strip (W * local_rows < 2^32)
+// measured 3 % / 13 % slower in round 1).  Tiles are enumerated block by block -- 8 x SH tiles, SH = as many tile rows
+// as a row strip keeps adjacent (8 for a whole image) -- so that the tiles in flight at one time are 2-D neighbours and
+// walk the same part of the tree: 101.7 ms against 113.9 ms for row-major order (cfg2, hard scene).
+struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   // p: pixel index in the strip (W * local_rows < 2^32)
 EV_DEV Item item_setup(const GatherArgs &a, int lane) {
     const StripDev &st = a.st;
+    const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
     const int groups = kVplSplit / a.splits_per_wave;
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int tile_j = j / groups;
+    const int tile = tile_j * 8 + xcd;                 // index in block order
+    const int shl = a.block_h_log2, sh = 1 << shl;     // block = 8 x sh tiles
+    const int per_block = 8 << shl, nbx = (tiles_x + 7) >> 3, nby = (tiles_y + sh - 1) >> shl;
+    const int blk = tile / per_block, l = tile - blk * per_block;
+    const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * sh + (l >> 3);
     Item t;
     t.group = j - tile_j * groups;
-    t.tile_in_band = (uint32_t)(tile_j * 8 + xcd);
-    const TileXY xy = tile_of(a, (uint32_t)a.band_first_super * 64u + t.tile_in_band);
-    t.has_tile = t.tile_in_band < (uint32_t)a.band_supers * 64u && xy.exists;
-    t.x = xy.tx * 8 + (lane & 7); t.ly = xy.ty * 8 + (lane >> 3);
+    t.has_tile = blk < nbx * nby && tx < tiles_x && ty < tiles_y;
+    t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
     const int cly = max(min(t.ly, st.local_rows - 1), 0);
     t.gy = st.global_row(cly);
     t.in_image = t.has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
@@ -117,7 +110,7 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
 }
 
 #ifndef EVPLP_GATHER_WAVES
-#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups)
+#define EVPLP_GATHER_WAVES 6   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene: 6 = 110.8 / 52.9 ms, 7 = 113.9 / 54.2, 8 = 121.2 / 55.8
 #endif
 typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -132,328 +125,12 @@ EV_DEV Vpl fetch_vpl(const evplp_record *r) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------- shaft lists
-// Phase 0: sub-tile boxes of every tile (one wave per tile id; see SubBound).
-__global__ __launch_bounds__(64) void tile_clusters_kernel(GatherArgs a) {
-    __shared__ float s_z[64];
-    const int lane = threadIdx.x;
-    const uint32_t tid = blockIdx.x;
-    const TileXY xy = tile_of(a, tid);
-    const int x = xy.tx * 8 + (lane & 7), ly = xy.ty * 8 + (lane >> 3);
-    const int cly = max(min(ly, a.st.local_rows - 1), 0);
-    const bool in_image = xy.exists && x < a.st.W && ly < a.st.local_rows && a.st.global_row(cly) < a.st.H;
-    const size_t p = (size_t)cly * a.st.W + min(x, a.st.W - 1);
-    float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), gn = gp;
-    if (in_image) { gp = a.g_pos[p]; gn = a.g_nrm[p]; }
-    const bool lit = in_image && gp.w != 0.0f && (gn.x != 0.0f || gn.y != 0.0f || gn.z != 0.0f);
-    const unsigned long long lm = ballot64(lit);
-    const int nlit = (int)__builtin_popcountll(lm);
-    const float big = 3.0e38f;
-    // sort key: squared distance to the camera; rank among the lit pixels (ties by lane)
-    const V3 cp = v3(gp) - v3(a.fp.camera_pos);
-    const float z = lit ? dot(cp, cp) : big;
-    int rank = 0;
-    for (int j = 0; j < 64; j++) {
-        const float zj = __shfl(z, j);
-        rank += (zj < z || (zj == z && j < lane)) ? 1 : 0;
-    }
-    s_z[rank] = z;                                    // ranks are a permutation of 0..63; lit pixels come first
-    __builtin_amdgcn_wave_barrier();
-    // three cuts: always split the group with the largest depth extent, at its largest gap when that gap is a real
-    // discontinuity (> 30 % of the group's extent), at the middle of its depth range otherwise
-    int cut[kSubs + 1] = { 0, nlit, nlit, nlit, nlit };      // group g = ranks [cut[g], cut[g + 1]); unused groups are empty
-    const float zr = s_z[lane], zr1 = s_z[min(lane + 1, 63)];
-    for (int step = 1; step < kSubs; step++) {
-        int best = -1; float best_ext = 0.0f;
-        for (int g = 0; g < step; g++) {
-            const int ga = cut[g], gb = cut[g + 1];
-            if (gb - ga < 2) continue;
-            const float e = s_z[gb - 1] - s_z[ga];
-            if (e > best_ext) { best_ext = e; best = g; }
-        }
-        if (best < 0) break;
-        const int ga = cut[best], gb = cut[best + 1];
-        const bool inside = lane >= ga && lane + 1 < gb;
-        float gap = inside ? zr1 - zr : -1.0f, gmax = gap;
-        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
-        int c;
-        if (gmax > 0.3f * best_ext) c = (int)__builtin_ctzll(ballot64(inside && gap == gmax)) + 1;
-        else {
-            const float mid = 0.5f * (s_z[ga] + s_z[gb - 1]);
-            c = ga + (int)__builtin_popcountll(ballot64(lane >= ga && lane < gb && zr < mid));
-        }
-        c = max(ga + 1, min(c, gb - 1));
-        for (int g = step; g > best + 1; g--) cut[g] = cut[g - 1];      // insert the cut, keep the groups ordered by depth
-        cut[best + 1] = c; cut[step + 1] = nlit;
-        for (int g = step + 1; g <= kSubs; g++) cut[g] = max(cut[g], cut[g - 1]);
-    }
-    // smallest spacing of horizontally / vertically adjacent lit pixels (the scale a compact box is measured against)
-    float s2 = big;
-    {
-        const float rx = __shfl_down(gp.x, 1), ry = __shfl_down(gp.y, 1), rz = __shfl_down(gp.z, 1);
-        const float ux = __shfl_down(gp.x, 8), uy = __shfl_down(gp.y, 8), uz = __shfl_down(gp.z, 8);
-        const bool lit_r = ((lm >> ((lane + 1) & 63)) & 1ull) != 0ull && (lane & 7) != 7;
-        const bool lit_u = ((lm >> ((lane + 8) & 63)) & 1ull) != 0ull && lane < 56;
-        if (lit && lit_r) s2 = fminf(s2, (rx - gp.x) * (rx - gp.x) + (ry - gp.y) * (ry - gp.y) + (rz - gp.z) * (rz - gp.z));
-        if (lit && lit_u) s2 = fminf(s2, (ux - gp.x) * (ux - gp.x) + (uy - gp.y) * (uy - gp.y) + (uz - gp.z) * (uz - gp.z));
-    }
-    for (int off = 32; off > 0; off >>= 1) s2 = fminf(s2, __shfl_xor(s2, off));
-    const float lim = a.fat_ratio * 8.0f;
-    SubBound mine; bool any_fat = false;
-    for (int g = 0; g < kSubs; g++) {
-        const bool mem = lit && rank >= cut[g] && rank < cut[g + 1];
-        const unsigned long long mm = ballot64(mem);
-        float lo[3] = { mem ? gp.x : big, mem ? gp.y : big, mem ? gp.z : big }, hi[3] = { mem ? gp.x : -big, mem ? gp.y : -big, mem ? gp.z : -big };
-        for (int off = 32; off > 0; off >>= 1)
-            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
-        uint32_t flags = 0u; float n[3] = { 0.f, 0.f, 0.f };
-        if (mm != 0ull) {
-            flags = kTileLit;
-            const int first = (int)__builtin_ctzll(mm);
-            n[0] = __shfl(gn.x, first); n[1] = __shfl(gn.y, first); n[2] = __shfl(gn.z, first);
-            if (ballot64(mem && (gn.x != n[0] || gn.y != n[1] || gn.z != n[2])) == 0ull) flags |= kTileFlat;
-            const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-            if (ext > 0.0f && (s2 >= big || ext * ext > lim * lim * s2)) any_fat = true;
-        }
-        if (lane == g) {
-            for (int k = 0; k < 3; k++) { mine.lo[k] = lo[k]; mine.hi[k] = hi[k]; mine.n[k] = n[k]; }
-            mine.flags = flags; mine.mem_lo = (uint32_t)mm; mine.mem_hi = (uint32_t)(mm >> 32);
-        }
-    }
-    if (lane < kSubs) {
-        if (any_fat) mine.flags |= kTileFat;
-        a.tile_bounds[(size_t)tid * kSubs + lane] = mine;
-    }
-#if EVPLP_TRAVERSAL_STATS
-    if (lane == 0 && nlit > 0) { atomicAdd(&a.counters->hist[44], 1ull); if (any_fat) atomicAdd(&a.counters->hist[43], 1ull); }
-#endif
-}
-
-// Phase 1, the beam pass: one wave = (16 tiles of a super-tile, VPL).  While it walks the tree a lane is a SUB-TILE (kSubs boxes
-// per tile, SubBound) and carries the SHAFT of its box -- the union of the segments from the VPL to every point of the box,
-// o + t (p - o), p in [lo, hi], t in [tmin, tmax] -- so one node visit (18 vector instructions, the two-child packed slab test of
-// occluded_wave with separate entry / exit reciprocals) serves 16 (tile, VPL) pairs instead of one.  Per axis the shaft occupies
-// o + t [dlo, dhi] (dlo = lo - o, dhi = hi - o) and meets the node slab [ctr - hal, ctr + hal] while  t dhi >= ctr - hal - o  and
-// t dlo <= ctr + hal - o:
-//   dlo > 0          entry (ctr - o - hal) / dhi,  exit (ctr - o + hal) / dlo
-//   dhi < 0          entry (ctr - o + hal) / dlo,  exit (ctr - o - hal) / dhi
-//   dlo <= 0 <= dhi  the box straddles the origin on this axis (the VPL's coordinate lies inside the box's range: common for the
-//                    metre-wide boxes of surfaces seen at grazing angles): the cross-section widens to both sides, both conditions
-//                    are ENTRY conditions -- (ctr - o - hal) / dhi and (ctr - o + hal) / dlo -- and there is no exit
-// i.e.  entry = max(ctr rE + cE - hal |rE|, ctr rF + cF - hal |rF|),  exit = ctr rX + cX + hal |rX|  with per-lane constants
-// (the second entry form is -inf off the straddling case; waves without a straddling lane skip it: 18 instead of 26 instructions).
-// A leaf is not entered.  For every tile one of whose shafts meets the leaf's (padded) box the wave switches roles -- lane =
-// PIXEL of that tile -- and runs the exact any-hit predicate on the leaf's triangles for the tile's shadow segments, OR-ing the
-// hits into the tile's 64-bit occlusion mask (kept in the lane of the tile's first sub-tile).  A segment can only hit a
-// triangle whose leaf box it meets, and then the shaft of its sub-tile meets that box too: every (segment, triangle) pair that
-// can hit is tested with the same predicate as the per-item walk, so the masks are bit-identical to it.  A tile whose lit pixels
-// are all occluded stops driving the walk.  The gather then reads one 8-byte mask per (tile, VPL) and never touches the tree.
-#ifndef EVPLP_BEAM_WAVES
-#define EVPLP_BEAM_WAVES 6
-#endif
-constexpr int kBeamTiles = 64 / kSubs;      // tiles per beam wave
-__global__ __launch_bounds__(64, EVPLP_BEAM_WAVES) void beam_visibility_kernel(GatherArgs a) {
-    const int lane = threadIdx.x;
-    const uint32_t nvpl = *a.nvpl;
-    // super-tiles are dealt to XCDs (block b runs on XCD b % 8): the beams of one super-tile stay on one XCD, whose L2 then
-    // holds the super-tile's G-buffer positions for all its VPLs
-    const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
-    const uint32_t part = j % (uint32_t)kSubs, j2 = j / (uint32_t)kSubs;            // which 16 tiles of the super-tile
-    const uint32_t i = j2 % a.max_vpls, sb = (j2 / a.max_vpls) * 8u + xcd;
-    if (i >= nvpl || sb >= (uint32_t)a.band_supers) return;
-    const uint32_t st = (uint32_t)a.band_first_super + sb;
-    const int tl = (int)part * kBeamTiles + (lane / kSubs);                          // this lane's tile inside the super-tile (0..63)
-    const int first_lane = lane & ~(kSubs - 1);                                      // lane of the tile's first sub-tile: owns the tile's mask
-    const uint32_t tid = st * 64u + (uint32_t)tl;
-    const float4 *tbp = reinterpret_cast<const float4 *>(a.tile_bounds + (size_t)tid * kSubs + (lane & (kSubs - 1)));
-    const float4 t0 = tbp[0], t1 = tbp[1], t2 = tbp[2];
-    const uint32_t tflags = __float_as_uint(t0.w);
-    const uint32_t mem_lo = __float_as_uint(t1.w), mem_hi = __float_as_uint(t2.w);
-    // lit pixels of the whole tile = union of its sub-tiles' members (every lane of the tile gets it)
-    uint32_t lit_lo = mem_lo, lit_hi = mem_hi;
-    for (int off = 1; off < kSubs; off <<= 1) { lit_lo |= (uint32_t)__shfl_xor((int)lit_lo, off); lit_hi |= (uint32_t)__shfl_xor((int)lit_hi, off); }
-    // the VPL: position and normal (first 32 bytes of the record), wave-uniform
-    const v8i ra = *reinterpret_cast<const v8i *>(a.vpls + i);
-    const V3 o = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])), vn = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6]));
-    const V3 lo = v3(t0), hi = v3(t1), tn = v3(t2);
-    bool live = (tflags & kTileLit) != 0u && (tflags & kTileFat) == 0u;    // fat tiles are served by the per-item walk
-    {
-        // cosine culls with a rounding margin (the per-pixel test of lighttracing.cu:284-288 is evaluated in fp32; a box is
-        // only dropped when every member's cosine is negative by far more than that arithmetic can err):
-        //   VPL side:   max over the box of  n2 . (p - o)  <= -eps   ->  c2 = max(-n2 . v12, 0) = 0 for every member
-        //   pixel side: boxes with one common normal:  max of  n1 . (o - p)  <= -eps  ->  c1 = 0 for every member
-        const V3 c = (lo + hi) * 0.5f, h = (hi - lo) * 0.5f, co = c - o;
-        const V3 aco = v3(fabsf(co.x), fabsf(co.y), fabsf(co.z));
-        const V3 an2 = v3(fabsf(vn.x), fabsf(vn.y), fabsf(vn.z));
-        const float m2 = dot(vn, co) + dot(an2, h), s2 = dot(an2, aco) + dot(an2, h);
-        if (m2 <= -1.0e-5f * s2) live = false;      // (s2 = 0: every product n2_k (p_k - o_k) is exactly 0 for every member -> c2 = 0)
-        if (tflags & kTileFlat) {
-            const V3 an1 = v3(fabsf(tn.x), fabsf(tn.y), fabsf(tn.z));
-            const float m1 = -dot(tn, co) + dot(an1, h), s1 = dot(an1, aco) + dot(an1, h);
-            if (m1 <= -1.0e-5f * s1) live = false;
-        }
-    }
-    // pixels that can still be lit by this VPL = members of the live sub-tiles; everything else is reported blocked:
-    // unlit pixels, members of culled sub-tiles (their cosine product is 0), and -- for the gather's skip test -- whole culled tiles
-    uint32_t want_lo = live ? mem_lo : 0u, want_hi = live ? mem_hi : 0u;
-    for (int off = 1; off < kSubs; off <<= 1) { want_lo |= (uint32_t)__shfl_xor((int)want_lo, off); want_hi |= (uint32_t)__shfl_xor((int)want_hi, off); }
-    uint32_t occ_lo = ~want_lo, occ_hi = ~want_hi;      // the tile's mask (authoritative copy in the tile's first lane)
-#if EVPLP_TRAVERSAL_STATS
-    uint32_t st_nodes = 0, st_leaves = 0, st_tests = 0, st_exact = 0, st_pairs = 0, st_dead = 0, my_tests = 0;
-    const uint32_t st_culled = (uint32_t)__builtin_popcountll(ballot64(!live && (tflags & kTileLit) != 0u && (tflags & kTileFat) == 0u));
-#endif
-    if (ballot64(live) != 0ull) {
-        // shaft constants in the segment's own parameter u = (t - tmin) / (tmax - tmin), as occluded_wave
-        const float tmin = 0.0001f, tmax = 1.0f - 0.0001f, ku = 1.0f / (tmax - tmin);
-        const float dead = __builtin_inff();
-        float rE[3], cE[3], rX[3], cX[3], rF[3], cF[3];
-        const float dl[3] = { lo.x - o.x, lo.y - o.y, lo.z - o.z }, dh[3] = { hi.x - o.x, hi.y - o.y, hi.z - o.z }, oo[3] = { o.x, o.y, o.z };
-        bool straddles = false;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float il = safe_rcp(dl[k]), ih = safe_rcp(dh[k]);
-            const bool pos = dl[k] > 0.0f, neg = dh[k] < 0.0f, mid = !(pos || neg);
-            // straddling: dlo <= 0 <= dhi, the reciprocals keep those signs even when an end is exactly (+-)0
-            const float e = pos ? ih : neg ? il : fabsf(ih);
-            const float x = pos ? il : neg ? ih : 0.0f;
-            const float f = -fabsf(il);
-            rE[k] = e * ku; cE[k] = live ? (-(oo[k] * e) - tmin) * ku : dead;
-            rX[k] = x * ku; cX[k] = mid ? dead : (-(oo[k] * x) - tmin) * ku;
-            rF[k] = mid ? f * ku : 0.0f; cF[k] = mid ? (-(oo[k] * f) - tmin) * ku : -dead;
-            straddles = straddles || (mid && live);
-        }
-        const bool any_straddle = ballot64(straddles) != 0ull;                 // wave-uniform
-        const v2f rEx = bc(rE[0]), rEy = bc(rE[1]), rEz = bc(rE[2]), aEx = bc(fabsf(rE[0])), aEy = bc(fabsf(rE[1])), aEz = bc(fabsf(rE[2]));
-        const v2f rXx = bc(rX[0]), rXy = bc(rX[1]), rXz = bc(rX[2]), aXx = bc(fabsf(rX[0])), aXy = bc(fabsf(rX[1])), aXz = bc(fabsf(rX[2]));
-        const v2f rFx = bc(rF[0]), rFy = bc(rF[1]), rFz = bc(rF[2]), aFx = bc(fabsf(rF[0])), aFy = bc(fabsf(rF[1])), aFz = bc(fabsf(rF[2]));
-        v2f cEx = bc(cE[0]), cEy = bc(cE[1]), cEz = bc(cE[2]);
-        const v2f cXx = bc(cX[0]), cXy = bc(cX[1]), cXz = bc(cX[2]);
-        const v2f cFx = bc(cF[0]), cFy = bc(cF[1]), cFz = bc(cF[2]);
-        // pixel role: where this lane's pixel sits inside a tile, and the super-tile's origin in tiles
-        const int swl = a.super_w_log2, sw = 1 << swl;
-        const int stx = (int)(st % (uint32_t)a.nsx), sty = (int)(st / (uint32_t)a.nsx);
-        const int px_x = lane & 7, px_y = lane >> 3;
-        const int W = a.st.W, max_row = a.st.local_rows - 1;
-        const char *leaf_base = reinterpret_cast<const char *>(a.sc.leaves);
-        int sp = 0, vstack = 0;
-        int32_t cur = 0;  // root is always an inner node
-        const char *node_base = reinterpret_cast<const char *>(a.sc.nodes);
-        for (;;) {
-            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
-#if EVPLP_TRAVERSAL_STATS
-            st_nodes++;
-#endif
-            const v2f cx = pk(n[0], n[1]), cy = pk(n[2], n[3]), cz = pk(n[4], n[5]);
-            const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
-            const v2f enx = pk_fma(hx, -aEx, pk_fma(cx, rEx, cEx)), eny = pk_fma(hy, -aEy, pk_fma(cy, rEy, cEy)), enz = pk_fma(hz, -aEz, pk_fma(cz, rEz, cEz));
-            const v2f exx = pk_fma(hx, aXx, pk_fma(cx, rXx, cXx)), exy = pk_fma(hy, aXy, pk_fma(cy, rXy, cXy)), exz = pk_fma(hz, aXz, pk_fma(cz, rXz, cXz));
-            float e0 = fmaxf(fmaxf(enx.x, eny.x), enz.x), e1 = fmaxf(fmaxf(enx.y, eny.y), enz.y);
-            if (any_straddle) {
-                const v2f fx = pk_fma(hx, -aFx, pk_fma(cx, rFx, cFx)), fy = pk_fma(hy, -aFy, pk_fma(cy, rFy, cFy)), fz = pk_fma(hz, -aFz, pk_fma(cz, rFz, cFz));
-                e0 = fmaxf(e0, fmaxf(fmaxf(fx.x, fy.x), fz.x)); e1 = fmaxf(e1, fmaxf(fmaxf(fx.y, fy.y), fz.y));
-            }
-            const float tn0 = clamp01(e0), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
-            const float tn1 = clamp01(e1), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
-            const bool h0 = tn0 < tf0, h1 = tn1 < tf1;
-            unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
-            const int32_t c0 = n[12], c1 = n[13];
-            // leaf children: exact tests with pixel lanes for every tile one of whose shafts meets the leaf box
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const int32_t cc = side ? c1 : c0;
-                unsigned long long m = side ? m1 : m0;
-                if (cc >= 0 || m == 0ull) continue;
-                if (side) m1 = 0ull; else m0 = 0ull;
-                const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cc);
-                // pixels of the sub-tiles whose shafts met the box, per tile (OR over the tile's lanes)
-                const bool hs = side ? h1 : h0;
-                uint32_t hit_lo = hs ? mem_lo : 0u, hit_hi = hs ? mem_hi : 0u;
-                for (int off = 1; off < kSubs; off <<= 1) { hit_lo |= (uint32_t)__shfl_xor((int)hit_lo, off); hit_hi |= (uint32_t)__shfl_xor((int)hit_hi, off); }
-                // one bit per tile: its first lane
-                unsigned long long mt = m;
-                for (int off = 1; off < kSubs; off <<= 1) mt |= mt >> off;
-                mt &= 0x1111111111111111ull;
-#if EVPLP_TRAVERSAL_STATS
-                st_leaves++;
-#endif
-                while (mt != 0ull) {
-                    const int fl = (int)__builtin_ctzll(mt);       // first lane of the tile
-                    mt &= mt - 1ull;
-                    // the tile's pixels that still need an answer: members of the shafts that met the box, not blocked yet
-                    const unsigned long long occ_t = (unsigned long long)(uint32_t)lane_read((int)occ_lo, fl) | ((unsigned long long)(uint32_t)lane_read((int)occ_hi, fl) << 32);
-                    const unsigned long long hit_t = (unsigned long long)(uint32_t)lane_read((int)hit_lo, fl) | ((unsigned long long)(uint32_t)lane_read((int)hit_hi, fl) << 32);
-                    const unsigned long long need = hit_t & ~occ_t;
-                    if (need == 0ull) continue;
-                    const int t = (int)part * kBeamTiles + fl / kSubs;
-                    const int tx = (stx << swl) + (t & (sw - 1)), ty = sty * (64 >> swl) + (t >> swl);
-                    const int x = min(tx * 8 + px_x, W - 1), ly = min(ty * 8 + px_y, max_row);
-                    const float4 gp = a.g_pos[(size_t)ly * W + x];
-                    const V3 d = v3(gp) - o;                       // == -(v.pos - p1) bit for bit (Ray(o, -v12), lighttracing.cu:292)
-#if EVPLP_TRAVERSAL_STATS
-                    st_tests++; st_pairs += L.cnt > 2u ? 2u : 1u; if (first_lane == fl) my_tests++;
-                    bool hit = tri_pair_any(L.A, o, d, tmin, tmax, need, &st_exact);
-                    if (L.cnt > 2u) hit = hit | tri_pair_any(L.B, o, d, tmin, tmax, need, &st_exact);
-#else
-                    bool hit = tri_pair_any(L.A, o, d, tmin, tmax, need);
-                    if (L.cnt > 2u) hit = hit | tri_pair_any(L.B, o, d, tmin, tmax, need);
-#endif
-                    const unsigned long long hm = ballot64(hit) & need;
-                    if (hm != 0ull) {
-                        const bool mine = first_lane == fl;       // every lane of the tile keeps the mask up to date
-                        occ_lo = mine ? (occ_lo | (uint32_t)hm) : occ_lo;
-                        occ_hi = mine ? (occ_hi | (uint32_t)(hm >> 32)) : occ_hi;
-                        if ((~(occ_t | hm)) == 0ull) {             // every pixel of the tile is blocked: its shafts leave the walk
-                            if (mine) { cEx = bc(dead); cEy = bc(dead); cEz = bc(dead); }
-#if EVPLP_TRAVERSAL_STATS
-                            st_dead++;
-#endif
-                        }
-                    }
-                }
-            }
-            const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
-            if ((a0 | a1) != 0u) {
-                if (a0 == 0u) { cur = c1; continue; }
-                if (a1 == 0u) { cur = c0; continue; }
-                const uint32_t p0 = (uint32_t)__builtin_popcountll(m0), p1 = (uint32_t)__builtin_popcountll(m1);
-                const bool first0 = p0 >= p1;
-                vstack = lane_write(first0 ? c1 : c0, sp, vstack);
-                sp++;
-                cur = first0 ? c0 : c1;
-                continue;
-            }
-            if (sp == 0) break;
-            sp--;
-            cur = lane_read(vstack, sp);
-        }
-    }
-    if ((lane & (kSubs - 1)) == 0)
-        a.vis[(size_t)i * ((size_t)a.band_supers * 64u) + (size_t)sb * 64u + (size_t)tl] = (unsigned long long)occ_lo | ((unsigned long long)occ_hi << 32);
-#if EVPLP_TRAVERSAL_STATS
-    if (lane == 0) {
-        atomicAdd(&a.counters->hist[35], 1ull); atomicAdd(&a.counters->hist[36], (unsigned long long)st_nodes);
-        atomicAdd(&a.counters->hist[37], (unsigned long long)st_leaves); atomicAdd(&a.counters->hist[38], (unsigned long long)st_tests);
-        atomicAdd(&a.counters->hist[39], (unsigned long long)st_exact); atomicAdd(&a.counters->hist[40], (unsigned long long)(st_pairs - st_exact));
-        atomicAdd(&a.counters->hist[41], (unsigned long long)st_dead); atomicAdd(&a.counters->hist[42], (unsigned long long)st_culled);
-        if (a.dbg) atomicAdd(&a.dbg[(size_t)a.nsx * a.nsy * 64 + i], st_tests);
-    }
-    if (a.dbg && (lane & (kSubs - 1)) == 0) atomicAdd(&a.dbg[tid], my_tests);
-#endif
-}
-
-// Phase 2.  One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.  With the beam pass the wave reads the
-// (tile, VPL) occlusion mask (one s_load_dwordx2) and only shades; without it (a.vis == nullptr) it walks the tree itself.
-template <bool kBeam>
-__global__ __launch_bounds__(64, kBeam ? 8 : EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
+// One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
+__global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
     __shared__ float s_lvl[6 * 192];
     const int lane = threadIdx.x;
     const Item t = item_setup(a, lane);
-    if (!t.has_tile) return;   // padding of the super-tile grid
-    // with the beam pass two launches cover the image: <true> shades the tiles the beams served, <false> walks for the fat tiles
-    if (a.vis) {
-        const uint32_t tflags = a.tile_bounds[((size_t)a.band_first_super * 64u + t.tile_in_band) * kSubs].flags;
-        if (((tflags & kTileFat) != 0u) == kBeam) return;
-    }
+    if (!t.has_tile) return;   // padding of the block grid
     const uint32_t p = t.p;
 
     Pixel px;
@@ -464,9 +141,6 @@ __global__ __launch_bounds__(64, kBeam ? 8 : EVPLP_GATHER_WAVES) void gather_vpl
 
     const uint32_t nvpl = *a.nvpl;
     const int k = a.splits_per_wave;
-    const unsigned long long *vis_row = kBeam ? a.vis + t.tile_in_band : nullptr;
-    const size_t vis_stride = (size_t)a.band_supers * 64u;    // masks per VPL
-    const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     V3 total = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, shaded = 0;
     for (int jj = 0; jj < k; jj++) {
@@ -483,19 +157,16 @@ __global__ __launch_bounds__(64, kBeam ? 8 : EVPLP_GATHER_WAVES) void gather_vpl
             rays += active ? 1u : 0u;
             // Ray(photon.mPosition, -v12, 1, 0.0001, 1 - 0.0001)  :292
             bool occ;
-            if (kBeam) {
-                const unsigned long long m = vis_row[(size_t)i * vis_stride];
-                occ = (((uint32_t)m & bit_lo) | ((uint32_t)(m >> 32) & bit_hi)) != 0u;
-                if (ballot64(active && !occ) == 0ull) continue;
-            } else {
+            {
 #if EVPLP_TRAVERSAL_STATS
-                WalkStats ws = { 0u, 0u, 0u };
+                WalkStats ws = { 0u, 0u, 0u, 0u };
                 occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
                 if (lane == 0) {
                     atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
                     atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
                     atomicAdd(&a.counters->hist[32], 1ull);
                     atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
+                    atomicAdd(&a.counters->hist[35], (unsigned long long)ws.exact);
                     if (ballot64(active && !occ) == 0ull) atomicAdd(&a.counters->hist[34], 1ull);
                 }
 #else
@@ -853,22 +524,16 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
 
 static dim3 gather_grid(const GatherArgs &a) {
     const int groups = kVplSplit / a.splits_per_wave;
-    return dim3((unsigned)(a.band_supers * 64 * groups));       // (band tiles rounded to 8) x groups: tile = tile_j * 8 + xcd
-}
-void launch_tile_bounds(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(tile_clusters_kernel, dim3((unsigned)(a.nsx * a.nsy * 64)), dim3(64), 0, s, a);
+    const int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8, sh = 1 << a.block_h_log2;
+    const int tiles = ((tiles_x + 7) / 8) * ((tiles_y + sh - 1) / sh) * 8 * sh;      // whole blocks
+    return dim3((unsigned)(tiles * groups));                     // tile = tile_j * 8 + xcd
 }
 void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
     size_t n = (size_t)a.st.W * a.st.local_rows;
     hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, stencil_test);
 }
-void launch_beam_visibility(const GatherArgs &a, hipStream_t s) {
-    const unsigned per_xcd = ((unsigned)a.band_supers + 7u) / 8u;       // super-tiles per XCD (rounded up)
-    hipLaunchKernelGGL(beam_visibility_kernel, dim3(per_xcd * a.max_vpls * 8u * (unsigned)kSubs), dim3(64), 0, s, a);
-}
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
-    if (a.vis) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), 0, s, a);      // everything without the beam pass, the fat tiles with it
+    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), 0, s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), 0, s, a);

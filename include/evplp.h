@@ -80,10 +80,8 @@ typedef struct evplp_config {
     int32_t bvh_builder;         /* evplp_bvh_builder */
     int32_t deterministic;       /* 1: photon bins are accumulated in record order (bitwise reproducible) */
     int32_t gather_splits_per_wave; /* VPL gather work-item size: consecutive VPL splits (of 128) one wavefront sums; a power of two
-                                  * 1..32, 0 = automatic (16 / strip_count).  Results do not depend on it (fixed summation tree). */
-    int32_t gather_no_beams;     /* 1: every gather item walks the tree itself instead of reading the (tile, VPL) occlusion masks of the
-                                  * beam pass (super-tile packets); same results, slower -- kept as the cross-check of the beam pass */
-    int32_t reserved[2];
+                                  * 1..32, 0 = the library's default.  Results do not depend on it (fixed summation tree). */
+    int32_t reserved[3];
 } evplp_config;
 
 /* rt/rtcommon.h:278-308 RtMaterial: three RGBA32F textures (a constant is a 1x1 texture,
@@ -140,7 +138,7 @@ typedef struct evplp_pass_stats {
     float dominant_kernel_ms;/* device time of the pass's dominant kernel alone (summed over its launches) */
     uint32_t reserved[3];
     uint64_t shaded;         /* gather: pairs that passed the cosine test AND the visibility test (contributions evaluated) */
-    uint32_t launches;       /* launches of the dominant kernel in the pass (the VPL gather runs one per band of tiles) */
+    uint32_t launches;       /* launches of the dominant kernel in the pass */
     uint32_t pad;
 } evplp_pass_stats;
 
@@ -224,8 +222,6 @@ int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out
 /* Raw device-side counters of the last run of `pass` (rays, node visits, pairs, aux, then the traversal histogram that
  * only -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds fill).  Returns the number of 64-bit words written. */
 int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_t capacity);
-/* -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds: exact-test counts of the last beam pass per tile id, then per VPL; 0 words otherwise */
-int evplp_debug_buffer(evplp_context *ctx, uint32_t *out, int32_t capacity);
 /* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
 int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
 

@@ -17,13 +17,12 @@ ap.add_argument("--tris", type=int, default=331000)
 ap.add_argument("--paths", type=int, default=1024)
 ap.add_argument("--scene", default="easy")
 ap.add_argument("--out", default="")
-ap.add_argument("--no-beams", action="store_true", help="every item walks the tree itself (round-1 behaviour)")
 ap.add_argument("--k", type=int, default=0)
 a = ap.parse_args()
 d = "/tmp/evplp_stats_%s" % a.scene
 jp = ev.synth_scene(d, "conf", a.tris, 1234, a.res, a.res, style=a.scene)
 P = 4
-c = ev.Context(a.res, a.res, a.paths, a.paths, P, beams=not a.no_beams, gather_splits_per_wave=a.k)
+c = ev.Context(a.res, a.res, a.paths, a.paths, P, gather_splits_per_wave=a.k)
 c.load_scene_json(jp)
 cam = c.camera()
 fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=a.paths, num_vpl_light_paths=a.paths, photons_per_path=P, do_accumulate=0)
@@ -42,35 +41,8 @@ out = {
     "walks_fully_occluded_frac": all_occ / max(walks, 1),
     "leaf_blocks_per_walk_hist": (hist / max(walks, 1)).round(4).tolist(),
     "kernel_ms_with_counters": st["dominant_kernel_ms"], "launches": st["launches"], "shaded": st["shaded"],
-    "beam": {"beams": int(raw[4 + 35]), "node_visits_per_beam": int(raw[4 + 36]) / max(int(raw[4 + 35]), 1),
-             "leaf_blocks_per_beam": int(raw[4 + 37]) / max(int(raw[4 + 35]), 1), "tile_leaf_tests_per_beam": int(raw[4 + 38]) / max(int(raw[4 + 35]), 1),
-             "tile_leaf_tests_per_tile_vpl": int(raw[4 + 38]) / max(int(raw[4 + 35]) * 16, 1), "node_visits_per_tile_vpl": int(raw[4 + 36]) / max(int(raw[4 + 35]) * 16, 1),
-             "pairs_exact": int(raw[4 + 39]), "pairs_rejected_by_pretest": int(raw[4 + 40]),
-             "tiles_fully_occluded_per_beam": int(raw[4 + 41]) / max(int(raw[4 + 35]), 1), "tiles_cosine_culled_per_beam": int(raw[4 + 42]) / max(int(raw[4 + 35]), 1),
-             "lit_tiles": int(raw[4 + 44]), "fat_tiles": int(raw[4 + 43])},
+    "tri_pairs_to_exact_predicate_per_walk": int(raw[4 + 35]) / max(walks, 1),
 }
-dbg = c.debug_buffer()
-if dbg.size:
-    # per-tile heat map of the beam pass's (tile, leaf) tests, summed over the VPLs, as an image (tile ids are super-tile swizzled)
-    ntid = dbg.size - (a.paths * P)
-    per_tile, per_vpl = dbg[:ntid].astype(np.float64), dbg[ntid:].astype(np.float64)
-    tiles = a.res // 8
-    img = np.zeros((tiles, tiles), np.float64)
-    tid = np.arange(ntid); st_, l = tid >> 6, tid & 63
-    nsx = (tiles + 7) // 8
-    tx, ty = (st_ % nsx) * 8 + (l & 7), (st_ // nsx) * 8 + (l >> 3)
-    ok = (tx < tiles) & (ty < tiles)
-    img[ty[ok], tx[ok]] = per_tile[ok]
-    out["beam"]["per_tile_tests_percentiles"] = [float(np.percentile(per_tile[ok], q)) for q in (10, 50, 90, 99, 100)]
-    out["beam"]["per_vpl_tests_percentiles"] = [float(np.percentile(per_vpl[:int(st['usable'])], q)) for q in (10, 50, 90, 99, 100)]
-    srt = np.sort(per_tile[ok])[::-1]
-    out["beam"]["share_of_tests_in_top_1pct_10pct_tiles"] = [float(srt[:len(srt) // 100].sum() / max(srt.sum(), 1)), float(srt[:len(srt) // 10].sum() / max(srt.sum(), 1))]
-    v = np.log1p(img) / max(np.log1p(img).max(), 1e-9)
-    os.makedirs("gpurun_out", exist_ok=True)
-    ev.save_image("gpurun_out/beam_tests_%s.png" % a.scene, np.repeat(np.repeat(np.stack([v, v, v], -1)[::-1], 4, 0), 4, 1).astype(np.float32))
-    np.save("gpurun_out/beam_tests_%s.npy" % a.scene, img.astype(np.float32))
-    vs = np.argsort(per_vpl[:int(st['usable'])])[::-1][:8]
-    out["beam"]["heaviest_vpls"] = [[int(k), float(per_vpl[k])] for k in vs]
 print(json.dumps(out, indent=1))
 if a.out:
     json.dump(out, open(a.out, "w"), indent=1)
