@@ -27,6 +27,9 @@ $(LIBSO): $(HIP_OBJS) $(CPP_OBJS)
 stats:
 	$(MAKE) VARIANT=stats EXTRA_HIPFLAGS=-DEVPLP_TRAVERSAL_STATS=1 $(OUT)/libevplp_hip_stats.so
 
+# the feeders (G-buffer, light tracing) are compiled without floating-point contraction: every operation rounds as in the oracle,
+# so G-buffers and light-path records can be compared bit for bit; the hot kernels keep contraction (radiance is toleranced)
+$(BUILD)/kernels_trace.o: HIPFLAGS += -ffp-contract=off
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

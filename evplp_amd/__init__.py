@@ -414,7 +414,7 @@ def decode_image(path: str):
     return out, ch.value
 
 
-SCENE_STYLES = {"easy": 0, "hard": 1}
+SCENE_STYLES = {"easy": 0, "hard": 1, "textured": 2}
 
 
 def synth_scene(out_dir: str, name: str = "conference_synth", target_triangles: int = 331000, seed: int = 1234,

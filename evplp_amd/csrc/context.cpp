@@ -386,6 +386,7 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     int sh = 8;
     if (c->st.strip_count > 1) { sh = 1; while (sh * 2 <= std::min(8, c->st.strip_rows / 8) && (c->st.strip_rows / 8) % (sh * 2) == 0) sh *= 2; }
     a.block_h_log2 = sh == 8 ? 3 : sh == 4 ? 2 : sh == 2 ? 1 : 0;
+    if (const char *e = std::getenv("EVPLP_TILE_BLOCK_LOG2")) a.block_h_log2 = std::max(0, std::min(atoi(e), a.block_h_log2));   // developer knob: 0 = rows of 8 tiles
     return EVPLP_OK;
 }
 // gather workspace (lazy: path-tracing / photon-only contexts never pay for it): per-item partial sums for `groups` groups

@@ -8,6 +8,7 @@
 // contracted; it is compared under a stated tolerance.
 #pragma once
 #include "evplp_types.h"
+#include "ev_math.h"
 
 namespace evplp {
 
@@ -33,6 +34,34 @@ EV_DEV V3 normalize(V3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv;
 EV_DEV V3 reflect(V3 i, V3 n) { float d = dot(n, i); return i - (n * 2.0f) * d; }
 EV_DEV V3 faceforward(V3 n, V3 i, V3 nref) { return n * copysignf(1.0f, dot(i, nref)); }
 EV_DEV float max_color(V3 c) { return fmaxf(fmaxf(c.x, c.y), c.z); }
+// (a.x b.x + a.y b.y) + a.z b.z with every product and sum rounded on its own (the oracle's dot under -ffp-contract=off): used
+// where a SIGN decides something discrete -- the cosine test of lighttracing.cu:284-288 -- so that the set of pairs that trace a
+// shadow ray is identical on CPU and GPU, not just the radiance within a tolerance
+EV_DEV V3 cross_exact(V3 a, V3 b) {
+#pragma clang fp contract(off)
+    const float x0 = a.y * b.z, x1 = a.z * b.y, y0 = a.z * b.x, y1 = a.x * b.z, z0 = a.x * b.y, z1 = a.y * b.x;
+    return v3(x0 - x1, y0 - y1, z0 - z1);
+}
+EV_DEV float dot_exact(V3 a, V3 b);
+// optixu normalize with the oracle's roundings: v * (1 / sqrt((x x + y y) + z z)), IEEE sqrt and division
+EV_DEV V3 normalize_exact(V3 v) {
+#pragma clang fp contract(off)
+    const float d = dot_exact(v, v);
+    const float inv = 1.0f / __builtin_sqrtf(d);
+    return v3(v.x * inv, v.y * inv, v.z * inv);
+}
+// a + b * t, product and sum rounded separately
+EV_DEV V3 madd_exact(V3 a, V3 b, float t) {
+#pragma clang fp contract(off)
+    const float x = b.x * t, y = b.y * t, z = b.z * t;
+    return v3(a.x + x, a.y + y, a.z + z);
+}
+EV_DEV float dot_exact(V3 a, V3 b) {
+#pragma clang fp contract(off)
+    const float x = a.x * b.x, y = a.y * b.y, z = a.z * b.z;
+    const float xy = x + y;
+    return xy + z;
+}
 
 // ---------------------------------------------------------------------------------- EXACT
 // optix::intersect_triangle_branchless (OptiX SDK 4.1.1 optixu_math_namespace.h) as called by
@@ -102,7 +131,10 @@ EV_DEV float rng_uniform(Rng &r) { return (float)((rng_u32(r) >> 8) + 1u) * (1.0
 // -------------------------------------------------------------------------------- textures
 // tex2D, RT_FILTER_LINEAR / RT_WRAP_REPEAT / normalised coordinates (rt/rtcommon.h:223-245)
 EV_DEV int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+// Every operation rounded on its own, in the oracle's order (contract off): texels feed discrete decisions downstream (lobe
+// selection and Russian roulette of the light paths, lighttracing.cu:141-166), so they are reproduced bit for bit.
 EV_DEV float4 tex2d(const SceneDev &sc, int id, float u, float v) {
+#pragma clang fp contract(off)
     TexDesc t = sc.textures[id];
     const float4 *px = sc.tex_pool + t.offset;
     if (t.w == 1 && t.h == 1) return px[0];
@@ -115,20 +147,21 @@ EV_DEV float4 tex2d(const SceneDev &sc, int id, float u, float v) {
     float4 p01 = px[(size_t)y1 * t.w + x0], p11 = px[(size_t)y1 * t.w + x1];
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     float4 r;
-    r.x = w00 * p00.x + w10 * p10.x + w01 * p01.x + w11 * p11.x;
-    r.y = w00 * p00.y + w10 * p10.y + w01 * p01.y + w11 * p11.y;
-    r.z = w00 * p00.z + w10 * p10.z + w01 * p01.z + w11 * p11.z;
-    r.w = w00 * p00.w + w10 * p10.w + w01 * p01.w + w11 * p11.w;
+    r.x = ((w00 * p00.x + w10 * p10.x) + w01 * p01.x) + w11 * p11.x;
+    r.y = ((w00 * p00.y + w10 * p10.y) + w01 * p01.y) + w11 * p11.y;
+    r.z = ((w00 * p00.z + w10 * p10.z) + w01 * p01.z) + w11 * p11.z;
+    r.w = ((w00 * p00.w + w10 * p10.w) + w01 * p01.w) + w11 * p11.w;
     return r;
 }
 // material fetch at a hit (rt/lighttracing.cu:131-133, shaders/deferred.frag:18-21)
 EV_DEV void material_at(const SceneDev &sc, const TriAttr &ta, float beta, float gamma, V3 &kd, V3 &ks, float &ns) {
+#pragma clang fp contract(off)
     const Material &m = sc.materials[ta.material];
     kd = v3(m.kd); ks = v3(m.ks); ns = m.ns;
     if (m.tex_kd >= 0 || m.tex_ks >= 0 || m.tex_ns >= 0) {
         float w0 = 1.0f - beta - gamma;  // rt/triangleintersect.cu:36
-        float u = ta.uv[2] * beta + ta.uv[4] * gamma + ta.uv[0] * w0;
-        float v = ta.uv[3] * beta + ta.uv[5] * gamma + ta.uv[1] * w0;
+        float u = (ta.uv[2] * beta + ta.uv[4] * gamma) + ta.uv[0] * w0;
+        float v = (ta.uv[3] * beta + ta.uv[5] * gamma) + ta.uv[1] * w0;
         if (m.tex_kd >= 0) { float4 c = tex2d(sc, m.tex_kd, u, v); kd = v3(c.x, c.y, c.z); }
         if (m.tex_ks >= 0) { float4 c = tex2d(sc, m.tex_ks, u, v); ks = v3(c.x, c.y, c.z); }
         if (m.tex_ns >= 0) { float4 c = tex2d(sc, m.tex_ns, u, v); ns = c.x; }
@@ -199,7 +232,8 @@ EV_DEV V3 lambert_sample(V3 &out, float &pdfw, V3 normal, V3 rho_d, Rng &rng) {
     float u2 = rng_uniform(rng);
     float r = sqrtf(u1);
     float phi = 2.0f * EV_PI * u2;
-    V3 p; p.x = r * cosf(phi); p.y = r * sinf(phi);
+    float sp, cp; evm_sincosf(phi, &sp, &cp);          // shared with the oracle bit for bit (ev_math.h)
+    V3 p; p.x = r * cp; p.y = r * sp;
     p.z = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
     Onb o = onb_make(normal);
     out = onb_inverse(o, p);
@@ -211,17 +245,17 @@ EV_DEV V3 phong_sample(V3 &out, float &pdfw, V3 in, V3 normal, V3 rho_s, float e
     V3 r = reflect(-in, normal);
     float sx = rng_uniform(rng);
     float sy = rng_uniform(rng);
-    float cos_t = powf(sx, 1.f / (e + 1.f));
+    float cos_t = evm_powf(sx, 1.f / (e + 1.f));
     float sin_t = sqrtf(1.0f - cos_t * cos_t);
     float phi = 2.f * EV_PI * sy;
-    float cp = cosf(phi), sp = sinf(phi);
+    float sp, cp; evm_sincosf(phi, &sp, &cp);
     V3 p = v3(sin_t * cp, sin_t * sp, cos_t);
     Onb o = onb_make(r);
     out = onb_inverse(o, p);
     float unsafe_cos = dot(out, normal);
     float cos_n = fmaxf(unsafe_cos, 0.f);
     float cos_r = fmaxf(dot(out, r), 0.f);
-    if (unsafe_cos > 0.0f) pdfw = (e + 1.0f) * 0.5f * powf(cos_r, e) * EV_INV_PI;
+    if (unsafe_cos > 0.0f) pdfw = (e + 1.0f) * 0.5f * evm_powf(cos_r, e) * EV_INV_PI;
     else pdfw = 0.0f;
     return rho_s * ((e + 2.0f) / (e + 1.0f) * cos_n);
 }

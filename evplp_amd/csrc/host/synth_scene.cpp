@@ -9,6 +9,7 @@
 // wound (outward for objects, inward for the room): back-face hits end light paths
 // (rt/lighttracing.cu:124).
 #include "../../../include/evplp.h"
+#include "images.hpp"
 #include "json.hpp"
 
 #include <cmath>
@@ -285,7 +286,7 @@ size_t write_patches(FILE *f, const std::vector<Patch> &patches, size_t target_t
 }
 } // namespace
 
-static int synth_furnished(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed, int32_t res_x, int32_t res_y) {
+static int synth_furnished(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed, int32_t res_x, int32_t res_y, bool textured) {
     std::string base = std::string(out_dir) + "/" + name;
     Builder B; int nobj = 0;
     Rng32 rng{ seed * 747796405u + 2891336453u };
@@ -433,11 +434,34 @@ static int synth_furnished(const char *out_dir, const char *name, int32_t target
     f = std::fopen((base + ".mtl").c_str(), "w");
     if (!f) return EVPLP_ERR_IO;
     Rng32 mr{ seed * 2654435761u + 12345u };
+    // style 2: image textures (map_Kd, one map_Ks / map_Ns) on the room shell and the table, like the reference's living room
+    // (scene/livingroom/*.jpg through map_Kd): PNG files written with the product's own writer, decoded by its own decoder
+    const int ntex = 3;
+    if (textured) {
+        const int TW = 128, TH = 128;
+        std::vector<float> img((size_t)TW * TH * 3);
+        for (int tex = 0; tex < ntex; tex++) {
+            Rng32 tr{ seed * 97u + (uint32_t)tex * 7919u + 1u };
+            for (int y = 0; y < TH; y++) for (int x = 0; x < TW; x++) {
+                float *q = &img[((size_t)y * TW + x) * 3];
+                const bool check = (((x >> 3) + (y >> 3)) & 1) != 0;
+                const float n = 0.85f + 0.15f * tr.next();
+                if (tex == 0) { q[0] = (check ? 0.55f : 0.25f) * n; q[1] = (check ? 0.5f : 0.22f) * n; q[2] = (check ? 0.45f : 0.2f) * n; }          // checker floor / walls
+                else if (tex == 1) { const float g = 0.35f + 0.25f * std::sin(0.37f * (float)x + 2.0f * std::sin(0.11f * (float)y)); q[0] = 1.6f * g * n; q[1] = 1.0f * g * n; q[2] = 0.55f * g * n; }   // wood grain
+                else { const float g = check ? 0.30f : 0.02f; q[0] = q[1] = q[2] = g; }                                                                   // specular mask / exponent map
+            }
+            const std::string tp = base + "_tex" + std::to_string(tex) + ".png";
+            if (evplp::save_image(tp.c_str(), TW, TH, img.data()) != EVPLP_OK) return EVPLP_ERR_IO;
+        }
+    }
     for (int i = 0; i < nobj; i++) {
         float kd[3] = { 0.2f + 0.6f * mr.next(), 0.2f + 0.6f * mr.next(), 0.2f + 0.6f * mr.next() };
         bool glossy = (i % 5) == 4;
-        std::fprintf(f, "newmtl obj%d\nKd %.9g %.9g %.9g\nKs %.9g %.9g %.9g\nNs %.9g\n\n", i, kd[0], kd[1], kd[2],
+        std::fprintf(f, "newmtl obj%d\nKd %.9g %.9g %.9g\nKs %.9g %.9g %.9g\nNs %.9g\n", i, kd[0], kd[1], kd[2],
                      glossy ? 0.2f : 0.f, glossy ? 0.2f : 0.f, glossy ? 0.2f : 0.f, glossy ? 20.f : 0.f);
+        if (textured && i < 6) std::fprintf(f, "map_Kd %s_tex0.png\n", name);                               // room shell
+        if (textured && i == 6) std::fprintf(f, "map_Kd %s_tex1.png\nmap_Ks %s_tex2.png\nNs 40\n", name, name);   // table: wood + specular mask
+        std::fprintf(f, "\n");
     }
     std::fclose(f);
     f = std::fopen((base + "_lights.obj").c_str(), "w");
@@ -450,9 +474,9 @@ static int synth_furnished(const char *out_dir, const char *name, int32_t target
 }
 
 extern "C" int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed, int32_t res_x, int32_t res_y, int32_t style) {
-    if (!out_dir || !name || target_triangles < 12 || res_x <= 0 || res_y <= 0 || style < 0 || style > 1) return EVPLP_ERR_INVALID;
+    if (!out_dir || !name || target_triangles < 12 || res_x <= 0 || res_y <= 0 || style < 0 || style > 2) return EVPLP_ERR_INVALID;
     mkdir(out_dir, 0755);
-    return style == 0 ? synth_boxes(out_dir, name, target_triangles, seed, res_x, res_y) : synth_furnished(out_dir, name, target_triangles, seed, res_x, res_y);
+    return style == 0 ? synth_boxes(out_dir, name, target_triangles, seed, res_x, res_y) : synth_furnished(out_dir, name, target_triangles, seed, res_x, res_y, style == 2);
 }
 extern "C" int evplp_synth_scene(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed, int32_t res_x, int32_t res_y) {
     return evplp_synth_scene_ex(out_dir, name, target_triangles, seed, res_x, res_y, 0);

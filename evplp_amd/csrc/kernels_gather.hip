@@ -149,8 +149,8 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         for (uint32_t i = split; i < nvpl; i += kVplSplit) {
             const Vpl v = fetch_vpl(a.vpls + i);
             V3 v12 = v.pos - px.p1;                                         // :282
-            float c1 = fmaxf(dot(px.n1, v12), 0.0f);
-            float c2 = fmaxf(-dot(v.n, v12), 0.0f);
+            float c1 = fmaxf(dot_exact(px.n1, v12), 0.0f);
+            float c2 = fmaxf(-dot_exact(v.n, v12), 0.0f);
             float c1c2 = c1 * c2;
             bool active = valid && !(c1c2 <= 0.0f);                         // :288
             if (ballot64(active) == 0ull) continue;
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(64, EVPLP_LVC_WAVES) void gather_lvc_kernel(GatherA
             pairs++;
             const Vpl v = load_vpl(reinterpret_cast<const float4 *>(r));
             V3 v12 = v.pos - px.p1;
-            float c1 = fmaxf(dot(px.n1, v12), 0.0f);
-            float c2 = fmaxf(-dot(v.n, v12), 0.0f);
+            float c1 = fmaxf(dot_exact(px.n1, v12), 0.0f);
+            float c2 = fmaxf(-dot_exact(v.n, v12), 0.0f);
             float c1c2 = c1 * c2;
             if (c1c2 <= 0.0f) continue;
             rays++;

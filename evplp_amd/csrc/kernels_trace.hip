@@ -54,7 +54,8 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
         const float w0 = 1.0f - b - g;
         V3 P = v3((p1.x * b + p2.x * g) + p0.x * w0, (p1.y * b + p2.y * g) + p0.y * w0, (p1.z * b + p2.z * g) + p0.z * w0);
-        V3 N = normalize(cross(p1 - p0, p2 - p0));  // deferred.geom:16-18 flat winding normal
+        V3 N = normalize_exact(cross_exact(p1 - p0, p2 - p0));  // deferred.geom:16-18 flat winding normal; the oracle's roundings: the
+                                                                // sign of n1 . v12 decides which pairs trace a shadow ray (lighttracing.cu:284-288)
         V3 kd, ks; float ns;
         material_at(a.sc, ta, b, g, kd, ks, ns);
         pos = make_float4(P.x, P.y, P.z, 1.0f);
@@ -113,12 +114,13 @@ __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTr
         if (tri < 0) break;  // no miss program in the reference; a miss ends the path here
         const TriAttr &ta = a.sc.attrs[tri];
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
-        V3 gn = normalize(cross(p0 - p2, p1 - p0));       // triangleintersect.cu:31
-        V3 wgn = normalize(gn);                           // :115
-        V3 ffn = faceforward(wgn, -next_dir, wgn);        // :116
-        V3 hit_pos = next_pos + next_dir * t;             // :120
+        // geometry of the hit with the oracle's roundings (record positions and normals feed the cosine and visibility tests)
+        V3 gn = normalize_exact(cross_exact(p0 - p2, p1 - p0));   // triangleintersect.cu:31
+        V3 wgn = normalize_exact(gn);                     // :115
+        V3 ffn = wgn * copysignf(1.0f, dot_exact(-next_dir, wgn));   // :116 faceforward(wgn, -next_dir, wgn)
+        V3 hit_pos = madd_exact(next_pos, next_dir, t);   // :120
         const Material &m = a.sc.materials[ta.material];
-        if (dot(gn, next_dir) > 0.f || m.light[0] > 0.01f) break;  // :124-128
+        if (dot_exact(gn, next_dir) > 0.f || m.light[0] > 0.01f) break;  // :124-128
         V3 kd, ks; float ns;
         material_at(a.sc, ta, b, g, kd, ks, ns);
         float max_l = max_color(kd), max_p = max_color(ks);

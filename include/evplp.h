@@ -256,7 +256,8 @@ int evplp_synth_scene(const char *out_dir, const char *name, int32_t target_tria
                       int32_t res_x, int32_t res_y);
 /* style 0: the room of tessellated boxes above ("easy"); style 1: the same room, light and camera furnished with curved and
  * thin parts (ellipsoid cushions, cylinder legs, rotated clutter, ~2400 small occluders) -- closer to what the real
- * conference model (curved chairs, scene/conference/conference_exported.obj, an LFS stub) asks of an any-hit walk. */
+ * conference model (curved chairs, scene/conference/conference_exported.obj, an LFS stub) asks of an any-hit walk;
+ * style 2: style 1 with image textures (map_Kd / map_Ks PNG files next to the OBJ) on the room shell and the table. */
 int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_triangles, uint32_t seed,
                          int32_t res_x, int32_t res_y, int32_t style);
 /* main() + LoadScene + RtComPhoton::render (main.cpp:87-121, rtcomphoton.h:107-223): parse the

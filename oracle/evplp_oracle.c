@@ -10,6 +10,9 @@
  * to the HIP kernels, which are written to the same operation order.
  */
 #include "evplp_oracle.h"
+/* sin / cos / pow of the direction sampling: one implementation shared with the kernels, so that light-path records can be compared
+ * bit for bit (see the header; checked against libm in tests/test_oracle_selfcheck.py) */
+#include "../evplp_amd/csrc/ev_math.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -64,7 +67,8 @@ static inline v3 onb_inverse(const onb_t *o, v3 p) {
 static inline v3 cosine_sample_hemisphere(float u1, float u2) {
     float r = sqrtf(u1);
     float phi = 2.0f * EVO_PI * u2;
-    v3 p; p.x = r * cosf(phi); p.y = r * sinf(phi);
+    float sp, cp; evm_sincosf(phi, &sp, &cp);
+    v3 p; p.x = r * cp; p.y = r * sp;
     p.z = sqrtf(maxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
     return p;
 }
@@ -485,20 +489,22 @@ static inline v3 phong_sample(v3 *out, float *pdfw, v3 in, v3 normal, v3 rho_s, 
     v3 r = reflect(neg(in), normal);
     float sx = evo_rng_uniform(rng);
     float sy = evo_rng_uniform(rng);
-    float cos_t = powf(sx, 1.f / (e + 1.f));
+    float cos_t = evm_powf(sx, 1.f / (e + 1.f));
     float sin_t = sqrtf(1.0f - cos_t * cos_t);
     float phi = 2.f * EVO_PI * sy;
-    float cp = cosf(phi), sp = sinf(phi);
+    float sp, cp; evm_sincosf(phi, &sp, &cp);
     v3 p = V3(sin_t * cp, sin_t * sp, cos_t);
     onb_t o = onb_make(r);
     *out = onb_inverse(&o, p);
     float unsafe_cos = dot(*out, normal);
     float cos_n = maxf(unsafe_cos, 0.f);
     float cos_r = maxf(dot(*out, r), 0.f);
-    if (unsafe_cos > 0.0f) *pdfw = (e + 1.0f) * 0.5f * powf(cos_r, e) * EVO_INV_PI;
+    if (unsafe_cos > 0.0f) *pdfw = (e + 1.0f) * 0.5f * evm_powf(cos_r, e) * EVO_INV_PI;
     else *pdfw = 0.0f;
     return muls(rho_s, (e + 2.0f) / (e + 1.0f) * cos_n);
 }
+void evo_math_sincos(float x, float *s, float *c) { evm_sincosf(x, s, c); }
+float evo_math_pow(float x, float y) { return evm_powf(x, y); }
 float evo_phong_eval_f(const float out[3], const float in[3], const float n[3], float e) { return phong_eval_f(ld3(out), ld3(in), ld3(n), e); }
 float evo_lambert_pdf_a(const float n1[3], const float n2[3], const float v12[3]) { return lambert_pdf_a(ld3(n1), ld3(n2), ld3(v12)); }
 float evo_phong_pdf_a(const float n1[3], const float n2[3], const float v12[3], const float in[3], const float rs[3], float e) {

@@ -115,6 +115,9 @@ uint32_t evo_rng_u32(evo_rng *r);
 float evo_rng_uniform(evo_rng *r); /* (0,1] like curand_uniform */
 
 /* ---- BRDF helpers rt/rtmaterial.cuh (exported for unit tests) ---- */
+/* the shared direction-sampling math (evplp_amd/csrc/ev_math.h), exported for the accuracy check against libm */
+void evo_math_sincos(float x, float *s, float *c);
+float evo_math_pow(float x, float y);
 float evo_phong_eval_f(const float out[3], const float in[3], const float n[3], float e);
 float evo_lambert_pdf_a(const float n1[3], const float n2[3], const float v12[3]);
 float evo_phong_pdf_a(const float n1[3], const float n2[3], const float v12[3], const float in[3],

@@ -73,6 +73,9 @@ def load():
     l.evo_rng_u32.argtypes = [_P]
     l.evo_rng_uniform.restype = C.c_float
     l.evo_rng_uniform.argtypes = [_P]
+    l.evo_math_sincos.argtypes = [C.c_float, _P, _P]
+    l.evo_math_pow.restype = C.c_float
+    l.evo_math_pow.argtypes = [C.c_float, C.c_float]
     l.evo_phong_eval_f.restype = C.c_float
     l.evo_phong_eval_f.argtypes = [_P, _P, _P, C.c_float]
     l.evo_lambert_pdf_a.restype = C.c_float

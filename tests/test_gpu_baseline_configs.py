@@ -1,0 +1,244 @@
+"""The five BASELINE.json configurations at their own sizes, on the furnished ("hard") stand-in scene, against the oracle.
+
+The oracle cannot render whole frames at these sizes in test time, so every comparison is on image rows: a product context
+that owns a row STRIP of the frame (the multi-GPU partition, include/evplp.h) renders exactly the rows the oracle is asked for,
+with the full record set.  Checked per configuration: the image rows (stated tolerance), the shadow-ray and unoccluded-pair
+counts (identical = identical cosine tests and visibility bits), and size-independent properties where they apply.
+
+  #1  path tracing, 256 x 256, 16 iterations x 1 spp, through evplp_render_json          (rt/rtpt/rtpt2.h:575-719)
+  #2  Instant Radiosity, 1024^2, 1024 light paths x 4 = 4096 VPL record slots, all six misModes (lighttracing.cu:275-379)
+  #3  EVPLP = #2 + 500 000 light paths splatted: tests/test_gpu_end_to_end.py::test_full_size_photon_splat_rows (easy scene)
+      and here on the hard scene for the default balance mode
+  #4  progressive photon mapping, 1920 x 1080, 300 000 light paths, 20 iterations through evplp_render_json on the textured
+      scene, against the oracle loop on sampled rows                                      (rtcomphoton.h:1033-1063)
+  #5  progressive VSL gather + photons, 2048^2, 4096 VPL paths = 16 384 record slots      (lighttracing.cu:596-722, rtcomphoton.h:205-218)
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as oa
+import scenes
+from test_gpu_end_to_end import MT19937, jitter_of, oracle_pt, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+P = 4
+
+
+@pytest.fixture(scope="module")
+def hard_scene(evplp, tmp_path_factory):
+    d = tmp_path_factory.mktemp("conf_hard")
+    jp = evplp.synth_scene(str(d), "conference_synth", 331000, 1234, 1024, 1024, style="hard")
+    sd, _ = scenes.load_obj_scene(jp)
+    return jp, sd, oa.Scene(sd)
+
+
+def strip_inputs(c, evplp):
+    """G-buffer planes and records of a strip context, scattered into full-frame arrays at the strip's rows."""
+    rows = c.global_rows(); ok = rows < c.H
+    planes = []
+    for b in (evplp.BUF_GBUF_POSITION, evplp.BUF_GBUF_NORMAL, evplp.BUF_GBUF_DIFFUSE, evplp.BUF_GBUF_PHONG):
+        full = np.zeros((c.H, c.W, 4), np.float32)
+        full[rows[ok]] = c.download(b)[ok]
+        planes.append(full)
+    return rows[ok], ok, planes
+
+
+def row_blocks(rows):
+    """contiguous [r0, r1) runs of a sorted row list (the oracle takes row ranges)"""
+    rows = np.sort(rows); out = []; start = prev = int(rows[0])
+    for r in rows[1:]:
+        r = int(r)
+        if r != prev + 1:
+            out.append((start, prev + 1)); start = r
+        prev = r
+    out.append((start, prev + 1))
+    return out
+
+
+def test_config1_path_tracer_256_16spp(evplp, tmp_path):
+    jp = evplp.synth_scene(str(tmp_path), "room", 30000, 5, 256, 256, style="hard")
+    root = json.load(open(jp))
+    block = dict(rngOffset=0, numMaxIteration=16, timeLimitMs=1e9, frameMode="accumulate", outputFilename="pt.pfm", statFilename="pt_stat.json",
+                 useJitter=True, useStat=True, numSamplePerPixel=1, numMaxBounces=3)
+    root.pop("photonfam"); root["pt"] = block
+    json.dump(root, open(jp, "w"))
+    evplp.render_json(jp)
+    got = evplp.load_pfm(str(tmp_path / "pt.pfm"))
+    ref, _ = oracle_pt(jp, block)
+    assert json.load(open(tmp_path / "pt_stat.json"))["numIterations"] == 16
+    # paths make discrete choices on values that differ in the last ulps between glibc and ocml: a bounded fraction of pixels
+    # takes another path in some iteration, the rest agree to fp32 round-off; image energy agrees
+    scale = ref.max()
+    bad = (np.abs(got - ref) > 2e-4 * np.maximum(np.abs(ref), 1e-3 * scale)).any(-1)
+    assert bad.mean() <= 16 * 8e-3, bad.mean()
+    assert abs(got.sum() / ref.sum() - 1.0) <= 5e-3
+    assert rel_l2(got[~bad], ref[~bad]) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", ["one", "balance", "max", "power2", "geometryClamp", "geometryBrdfClamp"])
+def test_config2_instant_radiosity_1024_all_modes(evplp, hard_scene, mode):
+    jp, sd, osc = hard_scene
+    W = H = 1024; N = 1024
+    count = 32                                   # this strip = 32 rows spread over the frame (4 blocks of 8 rows)
+    with evplp.Context(W, H, N, N, P, strip_rank=5, strip_count=count, strip_rows=8) as c:
+        c.load_scene_json(jp)
+        bsr, total, _ = c.scene_metrics()
+        c.primary((0.0, 0.0)); c.trace_light_paths(0)
+        kw = dict(camera_pos=sd.cam_origin, mis_mode=mode, pdf_mc=(1.0 / math.pi) / (0.003 * bsr) ** 2, clamping_value=1.0 / total,
+                  photon_radius=0.003 * bsr, num_light_paths=N, num_vpl_light_paths=N, photons_per_path=P)
+        c.gather_vpl(evplp.frame_params(**kw))
+        st = c.pass_stats(evplp.PASS_GATHER_VPL)
+        rows, ok, gbuf = strip_inputs(c, evplp)
+        got = c.download(evplp.BUF_VPL_ACCUM)[ok]
+        rec = c.download(evplp.BUF_RECORDS)
+    okw = dict(kw); okw["mis_mode"] = evplp.MIS_MODES[mode]
+    out = np.zeros((H, W, 4), np.float32)
+    for r0, r1 in row_blocks(rows):
+        osc.gather(oa.frame_params(**okw), W, H, gbuf, rec, out=out, rows=(r0, r1))
+    ref = out[rows]
+    assert ref[..., :3].max() > 0 and st["usable"] > 2500
+    assert rel_l2(got[..., :3], ref[..., :3]) <= 1e-5
+    scale = ref[..., :3].max()
+    assert (np.abs(got[..., :3] - ref[..., :3]) <= 2e-4 * np.maximum(np.abs(ref[..., :3]), 1e-3 * scale)).all()
+    if mode == "one":
+        assert (st["rays"], st["shaded"]) == osc.gather_counts(oa.frame_params(**okw), W, gbuf, rec, rows)
+
+
+def test_config3_evplp_hard_scene_rows(evplp, hard_scene):
+    jp, sd, osc = hard_scene
+    W = H = 1024; N, NV = 500000, 1024
+    with evplp.Context(W, H, N, NV, P, strip_rank=9, strip_count=64, strip_rows=8, deterministic=True) as c:
+        c.load_scene_json(jp)
+        bsr, total, _ = c.scene_metrics(); r = 0.003 * bsr
+        jitter = (0.0004, -0.0003)
+        kw = dict(camera_pos=sd.cam_origin, mis_mode="balance", pdf_mc=(NV / N) / math.pi / (r * r), photon_radius=r, clamping_value=1.0 / total,
+                  num_light_paths=N, num_vpl_light_paths=NV, photons_per_path=P, jitter=jitter)
+        c.primary(jitter); c.trace_light_paths(3)
+        c.gather_vpl(evplp.frame_params(**kw))
+        c.splat_photons(evplp.frame_params(**kw), clear=True)
+        rows, ok, gbuf = strip_inputs(c, evplp)
+        vpl = c.download(evplp.BUF_VPL_ACCUM)[ok]; pm = c.download(evplp.BUF_PHOTON_ACCUM)[ok]
+        rec = c.download(evplp.BUF_RECORDS)
+        pairs = c.pass_stats(evplp.PASS_SPLAT)["pairs"]
+    # 2 M record slots, every byte as the oracle traces them
+    assert rec.tobytes() == osc.trace_light_paths(3, N, P).tobytes()
+    okw = dict(kw); okw["mis_mode"] = 1
+    ovpl = np.zeros((H, W, 4), np.float32); opm = np.zeros((H, W, 4), np.float32); opairs = 0
+    for r0, r1 in row_blocks(rows):
+        osc.gather(oa.frame_params(**okw), W, H, gbuf, rec, out=ovpl, rows=(r0, r1))
+        _, n = oa.splat(oa.frame_params(**okw), W, H, gbuf, rec, out=opm, rows=(r0, r1)); opairs += n
+    assert (rec["flags"] & 2).astype(bool).sum() > 1_000_000 and opairs > 1000 and pairs == opairs
+    for got, ref in ((vpl, ovpl[rows]), (pm, opm[rows])):
+        assert ref[..., :3].max() > 0
+        assert rel_l2(got[..., :3], ref[..., :3]) <= 1e-5
+        assert (np.abs(got[..., :3] - ref[..., :3]) <= 2e-4 * np.maximum(np.abs(ref[..., :3]), 1e-3 * ref[..., :3].max()) + 1e-9).all()
+
+
+def test_config4_progressive_photon_mapping_1080p_loop(evplp, tmp_path):
+    """The whole technique loop at its own size through evplp_render_json, against the same loop driven over the oracle on
+    sampled rows (the oracle's primary / splat passes take row ranges; light tracing is always complete)."""
+    W, H, NL, ITER = 1920, 1080, 300000, 20
+    jp = evplp.synth_scene(str(tmp_path), "living", 120000, 11, W, H, style="textured")
+    root = json.load(open(jp))
+    block = dict(rngOffset=7, numMaxIteration=ITER, timeLimitMs=1e9, frameMode="accumulate", misMode="one", numLightPaths=NL, numVplLightPaths=0,
+                 numMaxBounces=3, radiusPercentage=0.003, DoProgressive=True, AlphaProgressive=0.7, useJitter=True, useStat=True,
+                 combinedFilename="c.pfm", weightedPhotonFilename="pm.pfm", weightedVplFilename="vpl.pfm", statFilename="stat.json")
+    root["photonfam"] = block
+    json.dump(root, open(jp, "w"))
+    evplp.render_json(jp)
+    got = evplp.load_pfm(str(tmp_path / "pm.pfm"))          # top-down rows, final.frag composite of the photon image / iterations
+    assert json.load(open(tmp_path / "stat.json"))["numIterations"] == ITER
+    # ---- the oracle loop on 6 rows
+    sd, _ = scenes.load_obj_scene(jp, decode=lambda p: evplp.decode_image(p)[0])
+    assert len(sd.textures) == 3
+    # fovx -> fovy (rtcommon.h:559) goes through tanf / atanf: take the product's value, numpy's float32 tan differs from libm's by an ulp
+    with evplp.Context(W, H, 1, 0, 1) as c0:
+        c0.load_scene_json(jp)
+        assert abs(c0.camera().fovy / sd.fovy - 1.0) < 1e-6
+        sd.fovy = c0.camera().fovy
+    osc = oa.Scene(sd); l = oa.load()
+    import ctypes as C
+    f32 = np.float32
+    bsr = f32(l.evo_scene_bounding_sphere_radius(osc.h))
+    radius = f32(bsr * f32(block["radiusPercentage"]))
+    inv_pi = f32(0.318309886183790671537767526745028724068919291480912897495)
+    pdf_mc = f32(f32(0) / f32(NL) * inv_pi / f32(radius * radius))
+    clamp = f32(1.0) / f32(l.evo_scene_total_area(osc.h)); clamp_start = clamp
+    rows = [37, 300, 541, 700, 905, 1079]                      # y = 0 bottom
+    pm = np.zeros((H, W, 4), np.float32)
+    rng = MT19937(block["rngOffset"])
+    for it in range(ITER):
+        jitter = jitter_of(rng, W, H)
+        rec = osc.trace_light_paths(it + block["rngOffset"], NL, P)
+        kw = dict(camera_pos=sd.cam_origin, mis_mode=0, pdf_mc=float(pdf_mc), clamping_value=float(clamp), photon_radius=float(radius),
+                  num_light_paths=NL, num_vpl_light_paths=0, photons_per_path=P, do_accumulate=1, rng_seed=it + block["rngOffset"], jitter=jitter)
+        g = [np.zeros((H, W, 4), np.float32) for _ in range(5)]
+        for y in rows:
+            gy = osc.primary(W, H, jitter, rows=(y, y + 1))
+            for k in range(5):
+                g[k][y] = gy[k][y]
+        for y in rows:
+            oa.splat(oa.frame_params(**kw), W, H, g, rec, out=pm, rows=(y, y + 1))
+        r, c_, p_, vr, vi = (C.c_float(x) for x in (radius, clamp, pdf_mc, 0.0, 0.0))
+        l.evo_progressive_step(it + 1, 0.7, float(clamp_start), 0, NL, C.byref(r), C.byref(c_), C.byref(p_), 0, C.byref(vr), C.byref(vi))
+        radius, clamp, pdf_mc = f32(r.value), f32(c_.value), f32(p_.value)
+    ref = pm[rows][..., :3] / np.float32(ITER)
+    mine = got[[H - 1 - y for y in rows]]                      # the saved image is flipped (FlipY, rtcomphoton.h:1124-1127)
+    assert ref.max() > 0 and (ref.sum(-1) > 0).mean() > 0.5
+    # G-buffer and light-path records are bit-identical to the oracle's (feeders without contraction, shared direction-sampling
+    # math); the fragment arithmetic is toleranced and the bins are accumulated in atomic-cursor order (not deterministic mode)
+    assert rel_l2(mine, ref) <= 5e-6, rel_l2(mine, ref)
+    assert (np.abs(mine - ref) <= 2e-4 * np.maximum(ref, 1e-3 * ref.max()) + 1e-9).all()
+
+
+def test_config5_progressive_vsl_and_photons_2048(evplp, tmp_path_factory):
+    """2048^2, 4096 VPL light paths (16 384 record slots, forceVsl), 300 000 light paths of photons: two iterations of the
+    progressive schedule on a strip of 8 rows (count 256 = one 8-row block per rank), the oracle on two of those rows."""
+    d = tmp_path_factory.mktemp("buddha_like")
+    W = H = 2048; NL, NV = 300000, 4096
+    jp = evplp.synth_scene(str(d), "statue", 331000, 77, W, H, style="hard")
+    sd, _ = scenes.load_obj_scene(jp)
+    osc = oa.Scene(sd); l = oa.load()
+    import ctypes as C
+    with evplp.Context(W, H, NL, NV, P, strip_rank=100, strip_count=256, strip_rows=8, deterministic=True) as c:
+        c.load_scene_json(jp)
+        bsr, total, _ = c.scene_metrics()
+        radius = 0.003 * bsr; vsl_r = max(0.05 * bsr, 0.008)
+        sched = dict(radius=radius, clamp=1.0 / total, pdf_mc=(NV / NL) / math.pi / radius ** 2, vsl_r=vsl_r, vsl_i=1.0 / (math.pi * vsl_r ** 2))
+        clamp_start = sched["clamp"]
+        rows_all = c.global_rows(); ok = rows_all < H
+        check = [int(rows_all[ok][1]), int(rows_all[ok][6])]
+        ovsl = np.zeros((H, W, 4), np.float32); opm = np.zeros((H, W, 4), np.float32)
+        rng = MT19937(3)
+        for it in range(2):
+            jitter = jitter_of(rng, W, H)
+            kw = dict(camera_pos=sd.cam_origin, mis_mode="one", pdf_mc=sched["pdf_mc"], clamping_value=sched["clamp"], photon_radius=sched["radius"],
+                      vsl_radius=sched["vsl_r"], vsl_inv_pi_radius2=sched["vsl_i"], num_light_paths=NL, num_vpl_light_paths=NV, photons_per_path=P,
+                      do_accumulate=1, rng_seed=it + 3, jitter=jitter)
+            c.primary(jitter); c.trace_light_paths(it + 3)
+            c.gather_vsl(evplp.frame_params(**kw))
+            c.splat_photons(evplp.frame_params(**kw))
+            st = c.pass_stats(evplp.PASS_GATHER_VSL)
+            assert st["usable"] > 10000                      # ~12 k of the 16 384 slots are usable VPLs
+            rows, _, gbuf = strip_inputs(c, evplp)
+            rec = c.download(evplp.BUF_RECORDS)
+            okw = dict(kw); okw["mis_mode"] = 0
+            for y in check:
+                osc.gather(oa.frame_params(**okw), W, H, gbuf, rec, out=ovsl, vsl=True, rows=(y, y + 1))
+                oa.splat(oa.frame_params(**okw), W, H, gbuf, rec, out=opm, rows=(y, y + 1))
+            r, cc, p_, vr, vi = evplp.progressive_step(it + 1, 0.7, clamp_start, NV, NL, sched["radius"], sched["clamp"], sched["pdf_mc"], True, sched["vsl_r"], sched["vsl_i"])
+            sched.update(radius=r, clamp=cc, pdf_mc=p_, vsl_r=vr, vsl_i=vi)
+        vsl = np.zeros((H, W, 4), np.float32); pm = np.zeros((H, W, 4), np.float32)
+        vsl[rows_all[ok]] = c.download(evplp.BUF_VPL_ACCUM)[ok]; pm[rows_all[ok]] = c.download(evplp.BUF_PHOTON_ACCUM)[ok]
+    gv, rv = vsl[check][..., :3], ovsl[check][..., :3]
+    gp, rp = pm[check][..., :3], opm[check][..., :3]
+    assert rv.max() > 0 and rp.max() > 0
+    # VSL estimators: Monte-Carlo sums whose terms branch on thresholds; hardware transcendentals on the GPU side
+    assert rel_l2(gv, rv) <= 1e-3, rel_l2(gv, rv)
+    assert (np.abs(gv - rv) <= 2e-2 * np.maximum(rv, 1e-2 * rv.max())).mean() >= 0.999
+    assert rel_l2(gp, rp) <= 1e-5

@@ -95,9 +95,9 @@ def test_light_tracing_records(ctx, oscene, evplp):
     assert np.array_equal(got["flags"], ref["flags"]), "path structure differs (closest hit / RNG stream)"
     used = ref["flags"] != 0
     assert used.sum() > NPATHS
-    for f in ("pos", "normal", "flux", "flux_dir", "rho_d", "rho_s"):
-        assert np.allclose(got[f][used], ref[f][used], rtol=2e-4, atol=2e-5), f
-    assert np.allclose(got["p_select_lambert"][used], ref["p_select_lambert"][used], rtol=1e-6)
+    # the feeders are compiled without contraction and sample directions with the shared ev_math.h: every field of every
+    # record is the oracle's, bit for bit
+    assert got.tobytes() == ref.tobytes()
     # a sliced trace (multi-GPU: each rank a range of paths) writes the same records
     ctx.upload(evplp.BUF_RECORDS, np.zeros_like(got))
     ctx.trace_light_paths(5, 0, NPATHS // 2)

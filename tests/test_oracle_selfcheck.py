@@ -251,3 +251,29 @@ def test_photon_fragment_known_answers(oracle):
     for mode, wp in ((1, mix_a / (mix_a + pdf_mc)), (3, mix_a ** 2 / (mix_a ** 2 + pdf_mc ** 2))):
         wv = {1: pdf_mc / (pdf_mc + mix_a), 3: pdf_mc ** 2 / (pdf_mc ** 2 + mix_a ** 2)}[mode]
         assert abs(wp + wv - 1.0) < 1e-12
+
+
+def test_shared_direction_sampling_math_against_libm(oracle):
+    """evplp_amd/csrc/ev_math.h (one sin / cos / pow for the oracle AND the kernels, so that light-path records compare bit for
+    bit) is an independent implementation: check it against double-precision libm over the ranges the samplers use."""
+    import ctypes as C
+    rng = np.random.RandomState(5)
+    s, c = C.c_float(), C.c_float()
+    xs = np.concatenate([rng.rand(20000).astype(np.float32) * np.float32(6.2831855), np.linspace(0, 6.2831855, 5001, dtype=np.float32)])
+    worst = 0.0
+    for x in xs:
+        oracle.evo_math_sincos(float(x), C.byref(s), C.byref(c))
+        for got, ref in ((s.value, math.sin(float(x))), (c.value, math.cos(float(x)))):
+            worst = max(worst, abs(got - ref) / max(float(np.spacing(np.float32(abs(ref)))), 2.0 ** -30))
+    assert worst <= 2.0, worst                       # ulps of the result (absolute 2^-30 floor at the zero crossings)
+    worst = 0.0
+    for _ in range(20000):
+        x = float(np.float32(rng.rand())); y = float(np.float32(rng.choice([rng.rand(), 1.0 / (1.0 + rng.rand() * 100.0), rng.rand() * 200.0])))
+        if x <= 0.0:
+            continue
+        got, ref = oracle.evo_math_pow(x, y), x ** y
+        if ref > 1e-37:
+            worst = max(worst, abs(got - ref) / float(np.spacing(np.float32(ref))))
+    assert worst <= 0.51, worst
+    assert oracle.evo_math_pow(0.0, 2.0) == 0.0 and oracle.evo_math_pow(0.3, 0.0) == 1.0 and oracle.evo_math_pow(1.0, 77.0) == 1.0
+    assert oracle.evo_math_pow(0.25, 0.5) == 0.5
