@@ -106,7 +106,12 @@ def test_config2_instant_radiosity_1024_all_modes(evplp, hard_scene, mode):
     scale = ref[..., :3].max()
     assert (np.abs(got[..., :3] - ref[..., :3]) <= 2e-4 * np.maximum(np.abs(ref[..., :3]), 1e-3 * scale)).all()
     if mode == "one":
-        assert (st["rays"], st["shaded"]) == osc.gather_counts(oa.frame_params(**okw), W, gbuf, rec, rows)
+        # The cosine test is exact: the same pairs trace a shadow ray.  The any-hit predicate is exact too, but for a segment within
+        # ~1 degree of a triangle's plane (den = n . d ~ 0) it can accept a "hit" millimetres outside the triangle -- outside every
+        # padded box -- and then whether the triangle is tested at all depends on which leaves a traversal visits.  The oracle has
+        # its own tree: such pairs may differ (tools/debug_vis.py found 1 in 7e7: a 4 mm plant-leaf edge seen edge-on, cos 3.8e-5).
+        rays, lit = osc.gather_counts(oa.frame_params(**okw), W, gbuf, rec, rows)
+        assert st["rays"] == rays and abs(st["shaded"] - lit) <= max(2, rays // 20_000_000), (st["shaded"], lit)
 
 
 def test_config3_evplp_hard_scene_rows(evplp, hard_scene):
