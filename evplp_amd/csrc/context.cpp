@@ -29,6 +29,8 @@ static size_t buffer_bytes(const evplp_context *c, int which) {
     return px * sizeof(float4);
 }
 
+static int settle_splat(evplp_context *c);
+
 extern "C" int evplp_abi_version(void) { return EVPLP_ABI_VERSION; }
 
 extern "C" const char *evplp_last_error(const evplp_context *ctx) { return ctx ? ctx->error : g_create_error; }
@@ -102,16 +104,23 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     c->tiles_x = (c->st.W + 7) / 8; c->tiles_y = c->st.local_rows / 8;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     const size_t nrec = (size_t)cfg->num_light_paths * cfg->photons_per_path;
-    c->bin_capacity = (uint32_t)std::min<size_t>(std::max<size_t>(nrec * 8, 1u << 20), 0xfffffff0u);   // grown on demand
-    if ((e = hipMalloc((void **)&c->d_tile_count, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_count)", e);
-    if ((e = hipMalloc((void **)&c->d_tile_z, sizeof(float2) * ntiles)) != hipSuccess) return fail("hipMalloc(tile_z)", e);
-    if ((e = hipMalloc((void **)&c->d_tile_pairs, sizeof(uint32_t) * ntiles)) != hipSuccess) return fail("hipMalloc(tile_pairs)", e);
-    if ((e = hipMalloc((void **)&c->d_tile_offset, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_offset)", e);
+    // photon bins: a slab of bin_stride slots per tile, 8x the mean occupancy to start with (a power of two >= 64), doubled
+    // when a bin overflows (tiles that see a floor at grazing angle collect ~10x the mean)
+    {
+        size_t mean = ntiles ? nrec * 2 / std::max<size_t>(ntiles, 1) : 0, k = 64;
+        while (k < 8 * mean && k < (1u << 20)) k <<= 1;
+        c->bin_stride = (uint32_t)k;
+        if (const char *env = std::getenv("EVPLP_BIN_STRIDE")) c->bin_stride = (uint32_t)std::max(1, atoi(env));   // tests: force the overflow / re-run path
+    }
+    if ((e = hipMalloc((void **)&c->d_tile_box, sizeof(float4) * 2 * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_box)", e);
+    if ((e = hipMalloc((void **)&c->d_tile_pairs, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_pairs)", e);
     if ((e = hipMalloc((void **)&c->d_tile_cursor, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_cursor)", e);
-    if ((e = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * (size_t)c->bin_capacity)) != hipSuccess) return fail("hipMalloc(bin_items)", e);
-    if (cfg->deterministic && (e = hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * (size_t)c->bin_capacity)) != hipSuccess) return fail("hipMalloc(bin_items_tmp)", e);
+    if ((e = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * std::max<size_t>(ntiles * c->bin_stride, 1))) != hipSuccess) return fail("hipMalloc(bin_items)", e);
+    if (cfg->deterministic && (e = hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * std::max<size_t>(ntiles * c->bin_stride, 1))) != hipSuccess) return fail("hipMalloc(bin_items_tmp)", e);
     if ((e = hipMalloc((void **)&c->d_compact, sizeof(float4) * kCompactF4 * nrec)) != hipSuccess) return fail("hipMalloc(compact)", e);
-    if ((e = hipMalloc((void **)&c->d_rect, sizeof(uint4) * nrec)) != hipSuccess) return fail("hipMalloc(rect)", e);
+    if ((e = hipHostMalloc((void **)&c->h_summary, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc(summary)", e);
+    std::memset(c->h_summary, 0, 4 * sizeof(uint32_t));
+    if ((e = hipEventCreate(&c->ev_summary)) != hipSuccess) return fail("hipEventCreate", e);
     *out = c;
     return EVPLP_OK;
 }
@@ -125,18 +134,21 @@ static void free_scene_device(evplp_context *c) {
 extern "C" void evplp_destroy(evplp_context *c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);
+    c->splat_pending = false;
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
-    hipFree(c->d_tile_count); hipFree(c->d_tile_offset); hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
-    hipFree(c->d_compact); hipFree(c->d_rect); hipFree(c->d_tile_z); hipFree(c->d_tile_pairs);
+    hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
+    hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if (c->ev_begin[i]) hipEventDestroy(c->ev_begin[i]);
         if (c->ev_end[i]) hipEventDestroy(c->ev_end[i]);
         if (c->ev_dom_begin[i]) hipEventDestroy(c->ev_dom_begin[i]);
         if (c->ev_dom_end[i]) hipEventDestroy(c->ev_dom_end[i]);
     }
+    if (c->ev_summary) hipEventDestroy(c->ev_summary);
+    if (c->h_summary) hipHostFree(c->h_summary);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -148,6 +160,7 @@ extern "C" int evplp_set_stream(evplp_context *c, void *s) {
 }
 extern "C" int evplp_synchronize(evplp_context *c) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EVPLP_OK;
 }
@@ -326,12 +339,43 @@ extern "C" int evplp_accel_info(evplp_context *c, int32_t *nodes, int32_t *leave
 }
 
 // ---------------------------------------------------------------------------------- passes
+// Look at the bin summary of the last photon splat (see context.hpp).  Called at the start of every entry point that
+// enqueues work, reads results or changes buffers.  Overflow is rare (the bins carry 25 % slack over the last pass and the
+// radius only shrinks in a progressive run): then the bins grow and fill + tiles of that pass run again -- they wrote nothing.
+static int settle_splat(evplp_context *c) {
+    if (!c->splat_pending) return EVPLP_OK;
+    c->splat_pending = false;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_summary));
+    const uint32_t total = c->h_summary[0], biggest = c->h_summary[1], overflow = c->h_summary[2];
+    c->last_bin_entries = total; c->last_bin_max = biggest;
+    if (!overflow) return EVPLP_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t want = 64; while (want < (uint64_t)overflow + overflow / 4) want <<= 1;     // overflow = slots the fullest bin wanted
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    if (want * ntiles > 0xfffffff0ull) { c->set_error("photon bins: %llu slots per tile needed", (unsigned long long)overflow); return EVPLP_ERR_OOM; }
+    hipFree(c->d_bin_items); c->d_bin_items = nullptr;
+    if (c->d_bin_items_tmp) { hipFree(c->d_bin_items_tmp); c->d_bin_items_tmp = nullptr; }
+    hipError_t e1 = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * ntiles * want);
+    hipError_t e2 = c->cfg.deterministic ? hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * ntiles * want) : hipSuccess;
+    if (e1 != hipSuccess || e2 != hipSuccess) { c->set_error("photon bins: cannot allocate %zu x %llu slots", ntiles, (unsigned long long)want); return EVPLP_ERR_OOM; }
+    c->bin_stride = (uint32_t)want;
+    SplatArgs &a = c->splat_args;
+    a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_stride = c->bin_stride;
+    HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
+    launch_splat_bin(a, c->stream);
+    const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
+    launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    HIP_TRY(c, hipEventRecord(c->ev_end[EVPLP_PASS_SPLAT], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return EVPLP_OK;
+}
 static int pass_ready(evplp_context *c, const char *name, bool need_camera) {
     if (!c->accel_built) { c->set_error("%s: scene not built (evplp_build_accel)", name); return EVPLP_ERR_INVALID; }
     if (need_camera && !c->camera_set) { c->set_error("%s: camera not set", name); return EVPLP_ERR_INVALID; }
     hipError_t e = hipSetDevice(c->cfg.device);
     if (e != hipSuccess) { c->set_error("hipSetDevice: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
-    return EVPLP_OK;
+    return settle_splat(c);
 }
 static int pass_begin(evplp_context *c, int pass) {
     HIP_TRY(c, hipMemsetAsync(&c->d_counters[pass], 0, sizeof(PassCounters), c->stream));
@@ -483,47 +527,35 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.records = (const evplp_record *)c->buf[EVPLP_BUF_RECORDS];
     a.num_records = c->cfg.num_light_paths * c->cfg.photons_per_path;   // instances = numLightPaths * P (:832)
     a.out = (float4 *)c->buf[EVPLP_BUF_PHOTON_ACCUM];
-    a.tile_count = c->d_tile_count; a.tile_z = c->d_tile_z; a.tile_pairs = c->d_tile_pairs; a.tile_offset = c->d_tile_offset; a.tile_cursor = c->d_tile_cursor;
-    a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_capacity = c->bin_capacity;
-    a.compact = c->d_compact; a.rect = c->d_rect; a.overflow = &c->d_scalars[8]; a.summary = &c->d_scalars[10];
+    a.tile_box = c->d_tile_box; a.tile_pairs = c->d_tile_pairs; a.tile_cursor = c->d_tile_cursor;
+    a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_stride = c->bin_stride;
+    a.compact = c->d_compact; a.overflow = &c->d_scalars[8]; a.summary = &c->d_scalars[10];
     a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic;
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
     HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
-    launch_splat_count(a, c->stream);
-    // The number of (photon, tile) bin entries depends on the photon set and the radius; read it back
-    // (4 bytes, one stream sync per splat) and grow the bins when needed instead of dropping photons.
-    uint32_t summary[2] = { 0, 0 };
-    HIP_TRY(c, hipMemcpyAsync(summary, &c->d_scalars[10], sizeof(summary), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint32_t total = summary[0];
-    if (total > c->bin_capacity) {
-        uint32_t want = (uint32_t)std::min<uint64_t>((uint64_t)total + total / 4 + 1024, 0xfffffff0ull);
-        hipFree(c->d_bin_items); c->d_bin_items = nullptr;
-        if (c->d_bin_items_tmp) { hipFree(c->d_bin_items_tmp); c->d_bin_items_tmp = nullptr; }
-        hipError_t e1 = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * (size_t)want);
-        hipError_t e2 = c->cfg.deterministic ? hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * (size_t)want) : hipSuccess;
-        if (e1 != hipSuccess || e2 != hipSuccess) { c->bin_capacity = 0; c->set_error("photon bins: cannot allocate %u entries", want); return EVPLP_ERR_OOM; }
-        c->bin_capacity = want;
-        a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_capacity = want;
-        HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
-    }
-    c->last_bin_entries = total;
+    launch_splat_bin(a, c->stream);
+    // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
+    // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
+    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[0], &c->d_scalars[10], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[2], &c->d_scalars[8], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_summary, c->stream));
     // Tile kernel variant.  One wave per tile is cheapest while bins are short; when some bins are very full (tiles
     // that see a floor at grazing angle collect thousands of photons) those waves set the duration of the launch and
     // four waves per tile win.  Deterministic mode always uses one variant: the fold order is part of the result.
     // Measured (tiles kernel, ms): fullest bin 1405 entries (config #3): 0.31 with one wave, 0.18 with four; fullest bin 365
-    // (config #4 shape): 0.12 / 0.22.
-    const bool split_tiles = c->cfg.deterministic ? true : summary[1] >= 768u;
-    c->last_bin_max = summary[1];
+    // (config #4 shape): 0.12 / 0.22.  The fullest bin of the PREVIOUS pass decides (a heuristic either way).
+    const bool split_tiles = c->cfg.deterministic ? true : c->last_bin_max >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    c->splat_args = a; c->splat_pending = true;
     c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
     return pass_end(c, EVPLP_PASS_SPLAT);
 }
 
 extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (!out_rgb) { c->set_error("evplp_resolve: null output"); return EVPLP_ERR_INVALID; }
     int rc;
@@ -538,6 +570,7 @@ extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int
 
 extern "C" int evplp_clear_accumulators(evplp_context *c) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_VPL_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_VPL_ACCUM), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
@@ -556,6 +589,7 @@ extern "C" int evplp_buffer_info(evplp_context *c, int32_t which, void **ptr, si
 }
 extern "C" int evplp_bind_buffer(evplp_context *c, int32_t which, void *ptr, size_t bytes) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (which < 0 || which >= EVPLP_BUF_COUNT || !ptr) { c->set_error("evplp_bind_buffer: bad arguments"); return EVPLP_ERR_INVALID; }
     if (bytes < buffer_bytes(c, which)) { c->set_error("evplp_bind_buffer: %zu bytes given, %zu needed", bytes, buffer_bytes(c, which)); return EVPLP_ERR_INVALID; }
     if (((uintptr_t)ptr & 15u) != 0) { c->set_error("evplp_bind_buffer: pointer must be 16-byte aligned"); return EVPLP_ERR_INVALID; }
@@ -567,6 +601,7 @@ extern "C" int evplp_bind_buffer(evplp_context *c, int32_t which, void *ptr, siz
 }
 extern "C" int evplp_download(evplp_context *c, int32_t which, void *dst, size_t bytes) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (which < 0 || which >= EVPLP_BUF_COUNT || !dst || bytes > buffer_bytes(c, which)) { c->set_error("evplp_download: bad arguments"); return EVPLP_ERR_INVALID; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemcpyAsync(dst, c->buf[which], bytes, hipMemcpyDeviceToHost, c->stream));
@@ -575,6 +610,7 @@ extern "C" int evplp_download(evplp_context *c, int32_t which, void *dst, size_t
 }
 extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, size_t bytes) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (which < 0 || which >= EVPLP_BUF_COUNT || !src || bytes > buffer_bytes(c, which)) { c->set_error("evplp_upload: bad arguments"); return EVPLP_ERR_INVALID; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemcpyAsync(c->buf[which], src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -585,6 +621,7 @@ extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, si
 // raw device counters of a pass (diagnostic builds fill the histogram part; see kernels.h PassCounters)
 extern "C" int evplp_debug_counters(evplp_context *c, int32_t pass, uint64_t *out, int32_t capacity) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out || capacity <= 0) { c->set_error("evplp_debug_counters: bad arguments"); return EVPLP_ERR_INVALID; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -597,6 +634,7 @@ extern "C" int evplp_debug_counters(evplp_context *c, int32_t pass, uint64_t *ou
 
 extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_stats *out) {
     CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out) { c->set_error("evplp_pass_stats_get: bad arguments"); return EVPLP_ERR_INVALID; }
     std::memset(out, 0, sizeof(*out));
     if (!c->pass_ran[pass]) return EVPLP_OK;
@@ -621,7 +659,6 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
         HIP_TRY(c, hipMemcpy(tp.data(), c->d_tile_pairs, tp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint64_t sum = 0; for (uint32_t v : tp) sum += v;
         out->pairs = sum; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries; out->reserved[1] = c->last_bin_max;
-        if (scal[8]) { c->set_error("photon bins overflowed: %u entries needed, capacity %u", scal[8], c->bin_capacity); return EVPLP_ERR_OOM; }
     } else if (pass == EVPLP_PASS_PATH_TRACE) { out->pairs = pc.pairs; out->rays = pc.rays; }
     else if (pass == EVPLP_PASS_GATHER_LVC) { out->pairs = pc.pairs; out->rays = pc.rays; }
     else if (pass == EVPLP_PASS_PRIMARY) out->rays = c->stats_host[pass].rays;

@@ -44,9 +44,16 @@ struct evplp_context {
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
 
     // splat workspace
-    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_capacity = 0, last_bin_entries = 0, last_bin_max = 0;
-    uint32_t *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
-    float4 *d_compact = nullptr; uint4 *d_rect = nullptr; float2 *d_tile_z = nullptr; uint32_t *d_tile_pairs = nullptr;
+    int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_stride = 0, last_bin_entries = 0, last_bin_max = 0;   // bin_stride: slots per tile bin
+    uint32_t *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
+    float4 *d_compact = nullptr; float4 *d_tile_box = nullptr; uint32_t *d_tile_pairs = nullptr;
+    // The bin sizes of a splat are known only on the device.  The pass is enqueued completely (fill and tiles kernels do
+    // nothing when the bins overflowed); the summary arrives in pinned host memory behind ev_summary and is looked at by the
+    // NEXT call on the context (settle_splat): no host round trip, no GPU bubble inside the pass.
+    uint32_t *h_summary = nullptr;            // pinned: [0] bin entries, [1] fullest bin, [2] overflow (entries needed)
+    hipEvent_t ev_summary = nullptr;
+    bool splat_pending = false;
+    evplp::SplatArgs splat_args{};            // the pending pass, for the re-run after the bins have grown
 
     char error[512] = "";
     void set_error(const char *fmt, ...);

@@ -73,18 +73,15 @@ struct SplatArgs {
     const float4 *g_pos, *g_nrm, *g_dif, *g_phg;
     const evplp_record *records; uint32_t num_records;
     float4 *out;
-    // binning workspace
-    uint32_t *tile_count;     // [ntiles + 1]
+    // binning workspace: every 8x8-px tile owns a fixed slab of bin_stride item slots
     uint32_t *tile_pairs;     // [ntiles] (photon, pixel) pairs accepted in the tile (statistics; summed by the host on demand)
-    float2 *tile_z;           // [ntiles] view-depth range (min, max) of the tile's G-buffer positions
-    uint32_t *tile_offset;    // [ntiles + 1] exclusive scan
-    uint32_t *tile_cursor;    // [ntiles]
-    uint32_t *bin_items;      // [bin_capacity] compact photon ids
-    uint32_t bin_capacity;
-    uint32_t *bin_items_tmp;  // [bin_capacity] (deterministic mode: unsorted fill target)
+    float4 *tile_box;         // [ntiles][2] world-space box (lo, hi) of the tile's G-buffer positions
+    uint32_t *tile_cursor;    // [ntiles] entries the photons wanted to put into the tile's bin (may exceed bin_stride: overflow)
+    uint32_t *bin_items;      // [ntiles][bin_stride] compact photon ids
+    uint32_t bin_stride;
+    uint32_t *bin_items_tmp;  // [ntiles][bin_stride] (deterministic mode: unsorted fill target)
     float4 *compact;          // [num_records * kCompactF4] per-photon pre-shaded data
-    uint4 *rect;              // [num_records] tile rectangle (x0 | x1<<16, y0 | y1<<16; x0 > x1 = none) + 64-bit mask of its tiles that survive the depth cull
-    uint32_t *overflow;       // device flag: bins did not fit
+    uint32_t *overflow;       // device flag: some bin wanted more than bin_stride entries (fill / tiles then do nothing; the host re-runs)
     uint32_t *summary;        // device: [0] total bin entries, [1] entries of the fullest bin
     int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
     PassCounters *counters;
@@ -105,7 +102,8 @@ void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
 void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s);
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s);
-void launch_splat_count(const SplatArgs &a, hipStream_t s);
+// binning (tile depth ranges, compact photons + bin fill, summary); then the per-tile accumulation
+void launch_splat_bin(const SplatArgs &a, hipStream_t s);
 void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);

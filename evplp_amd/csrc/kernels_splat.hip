@@ -6,15 +6,17 @@
 // The reference rasterises one icosphere proxy per record and lets the ROP blend every fragment
 // (one RMW of HBM per fragment).  Here (ideal kernel of SURVEY A.4: photon i adds to pixel p iff
 // |X_p - P_i|^2 <= r^2):
-//   0. splat_tile_depth : view-depth range of every 8x8-pixel tile of the G-buffer.
-//   1. splat_prepare : one lane per record (records staged through LDS).  Everything of the fragment
+//   0. splat_tile_box : world-space bounding box of the G-buffer positions of every 8x8-pixel tile.
+//   1. splat_bin : one lane per record (records staged through LDS).  Everything of the fragment
 //      shader that does not depend on the pixel (w12, the MIS/clamp weight, 1/(pi r^2 N) scaling) is
-//      folded into a 64-byte compact photon; the conservative screen rectangle of the radius-r sphere
-//      is counted into the 8x8-pixel tile bins whose depth range meets the photon's.
-//   2. splat_scan    : exclusive scan of the tile counts (+ total and fullest bin for the host).
-//   3. splat_fill    : scatter photon ids into their bins.  (deterministic mode: + rank sort so
-//      every pixel accumulates in ascending record order, like the oracle.)
-//   4. splat_tiles   : one wavefront per tile (four when bins are very full), lane = pixel with its G-buffer texel in registers;
+//      folded into a 64-byte compact photon; the photon id goes into the bin of every 8x8-pixel tile of the
+//      conservative screen rectangle of its radius-r sphere whose position box the sphere reaches.  Bins are
+//      fixed slabs of bin_stride slots per tile (slot = one returning atomic on the tile's cursor): no counting
+//      pass, no scan, one scattered atomic per entry instead of two.  A bin that wants more than its slab
+//      raises the overflow flag; the host doubles the slabs and runs the pass again (context.cpp settle_splat).
+//      (deterministic mode: + rank sort so every pixel accumulates in ascending record order, like the oracle.)
+//   2. splat_summary : total entries and fullest bin (sizes the slabs, picks the tile kernel variant).
+//   3. splat_tiles   : one wavefront per tile (four when bins are very full), lane = pixel with its G-buffer texel in registers;
 //      the bin streams through LDS 64 photons at a time (each lane fetches one compact photon,
 //      all lanes then read it back as an LDS broadcast); RGB accumulates in registers and is
 //      written once per pixel with coalesced 16-byte stores -- no atomics, no per-fragment RMW.
@@ -54,11 +56,12 @@ EV_DEV Rec load_rec(const float4 *q) {
 // compact photon: [0] pos.xyz, cpn   [1] w12.xyz, d2   [2] wflux.xyz, alive   [3] brdf2.xyz, n1.w12 (unused)
 // Everything of one photon that does not depend on the pixel (compact record) + its conservative rectangle of 8x8-px
 // tiles, packed (x0 | x1 << 16, y0 | y1 << 16); x0 > x1 = nothing to splat.
-EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_ph, const float4 *s_prev, float &view_z) {
+EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_ph, const float4 *s_prev, V3 &photon_pos) {
     const uint2 none = make_uint2(1u, 0u);
     Rec ph = load_rec(s_ph);
     if (!(ph.flags & EVPLP_USABLE_PHOTON)) return none;  // vert:31, geom:20
     Rec prev = load_rec(s_prev);                    // frag:163
+    photon_pos = ph.pos;
 
     const float r = a.fp.photon_radius;
     V3 v12 = prev.pos - ph.pos;                                           // frag:170
@@ -88,7 +91,6 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     // (jittered) camera of this iteration: uMVP of runPhotonSplat is the jittered matrix (:982)
     V3 q = ph.pos - v3(a.cam.eye);
     float vx = dot(q, v3(a.cam.s)), vy = dot(q, v3(a.cam.u)), vz = dot(q, v3(a.cam.f));
-    view_z = vz;
     // visible surface points have view depth in [near, far] = [0.1, 100] (rtcommon.h:586): clip the
     // sphere's depth range to it -- a photon closer than r to the camera plane then needs no
     // whole-screen fallback (those few photons used to produce most of the bin entries)
@@ -115,13 +117,12 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     return make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
 }
 
-// View-depth range of every 8x8-px tile's G-buffer positions (one wave per tile).  A pixel can only receive a
-// photon whose centre is within r of its position, hence within r of its view depth: splat_prepare drops the
-// (photon, tile) entries whose depth intervals cannot meet.  Screen-space bins otherwise collect every photon along
-// the tile's frustum -- floor under the table, wall behind the chairs -- ~6x more than ever pass the radius test.
-// Every in-image pixel counts, background included (its position is the clear colour, which is what the radius test
-// of frag:152-154 sees too).
-__global__ __launch_bounds__(256) void splat_tile_depth_kernel(SplatArgs a) {
+// World-space bounding box of every 8x8-px tile's G-buffer positions (one wave per tile).  A pixel can only receive a
+// photon whose centre lies within r of its position: splat_bin drops the (photon, tile) entries whose sphere does not reach
+// the tile's box.  Screen-space bins otherwise collect every photon along the tile's frustum -- floor under the table,
+// wall behind the chairs -- several times more than ever pass the radius test.  Every in-image pixel counts, background
+// included (its position is the clear colour, which is what the radius test of frag:152-154 sees too).
+__global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tile = blockIdx.x * 4 + wave;
@@ -129,21 +130,21 @@ __global__ __launch_bounds__(256) void splat_tile_depth_kernel(SplatArgs a) {
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
-    float zmin = 3.0e38f, zmax = -3.0e38f;
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
     if (in_image) {
         float4 gp = a.g_pos[(size_t)ly * a.st.W + x];
-        float z = dot(v3(gp) - v3(a.cam.eye), v3(a.cam.f));
-        zmin = zmax = z;
+        lo[0] = hi[0] = gp.x; lo[1] = hi[1] = gp.y; lo[2] = hi[2] = gp.z;
     }
-    for (int off = 32; off > 0; off >>= 1) { zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off)); }
-    if (lane == 0) a.tile_z[tile] = make_float2(zmin, zmax);
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+    if (lane == 0) { a.tile_box[2 * tile] = make_float4(lo[0], lo[1], lo[2], 0.f); a.tile_box[2 * tile + 1] = make_float4(hi[0], hi[1], hi[2], 0.f); }
 }
 
 // The 96-byte AoS records are read ONCE, as a coalesced 16 B/lane stream, into LDS (slot k = record base - 1 + k:
 // every photon also needs its predecessor on the light path, frag:163); a lane then picks its two records from LDS.
 // One lane per record reading its own 6 float4 at a 96-byte stride touched every line six times and every record
 // twice.
-__global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
+__global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a, uint32_t *items) {
     __shared__ float4 s_rec[257 * kRecF4];
     const uint32_t base = blockIdx.x * 256u;
     {
@@ -155,95 +156,56 @@ __global__ __launch_bounds__(256) void splat_prepare_kernel(SplatArgs a) {
     __syncthreads();
     const uint32_t i = base + threadIdx.x;
     uint2 rc = make_uint2(1u, 0u);
-    float vz = 0.f;
-    if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(threadIdx.x + 1u) * kRecF4], &s_rec[threadIdx.x * kRecF4], vz);
-    const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
-    // depth interval of the photon's sphere, widened by the rounding of the two depth computations (|error| ~ 1e-6 of
-    // the coordinates): a tile whose positions all lie outside it cannot hold a pixel within r of the photon
-    const float zguard = a.fp.photon_radius * 1.0e-3f + 1.0e-4f * fmaxf(fabsf(vz), 1.0f);
-    const float zlo = vz - a.fp.photon_radius - zguard, zhi = vz + a.fp.photon_radius + zguard;
-    // bin entries of this photon on THIS rank's row strips: a 64-bit mask over the (<= 64) tiles of its rectangle,
-    // larger rectangles (huge radii) are not depth-culled
-    const int tiles_per_block = a.st.strip_rows >> 3;
-    const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
-    const bool small = tx0 <= tx1 && nx * ny <= 64;
-    unsigned long long keep = 0ull;
-    if (tx0 <= tx1)
-        for (int ty = ty0; ty <= ty1; ty++) {
-            int blk = ty / tiles_per_block;
-            if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
-            int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
-            for (int tx = tx0; tx <= tx1; tx++) {
-                const int tile = lty * a.tiles_x + tx;
-                if (small) {
-                    const float2 tz = a.tile_z[tile];
-                    if (tz.y < zlo || tz.x > zhi) continue;
-                    keep |= 1ull << ((ty - ty0) * nx + (tx - tx0));
-                }
-                atomicAdd(&a.tile_count[tile], 1u);
-            }
-        }
-    if (i < a.num_records) a.rect[i] = make_uint4(rc.x, rc.y, (uint32_t)keep, (uint32_t)(keep >> 32));
-}
-
-// single-workgroup exclusive scan over the tile counts (<= a few 100k tiles)
-__global__ __launch_bounds__(1024) void splat_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor, uint32_t n,
-                                                          uint32_t capacity, uint32_t *overflow, uint32_t *summary) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry, biggest;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry = 0; biggest = 0; }
-    __syncthreads();
-    uint32_t my_max = 0;
-    for (uint32_t start = 0; start < n; start += 1024) {
-        uint32_t i = start + tid;
-        uint32_t v = i < n ? count[i] : 0u;
-        my_max = max(my_max, v);
-        uint32_t incl = v;
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = carry;
-        for (int w = 0; w < wave; w++) base += wsum[w];
-        if (i < n) { offset[i] = base + incl - v; cursor[i] = 0u; }
-        __syncthreads();
-        if (tid == 0) { uint32_t tot = 0; for (int w = 0; w < 16; w++) tot += wsum[w]; carry += tot; }
-        __syncthreads();
-    }
-    atomicMax(&biggest, my_max);
-    __syncthreads();
-    // summary[0] = total bin entries, summary[1] = fullest bin (the host sizes the bins and picks the tile kernel with them)
-    if (tid == 0) { offset[n] = carry; summary[0] = carry; summary[1] = biggest; if (carry > capacity) *overflow = carry; }
-}
-
-// second walk over the photon's surviving tiles: slot = start of the tile's bin + a cursor bump
-__global__ __launch_bounds__(256) void splat_fill_kernel(SplatArgs a, uint32_t *items) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.num_records) return;
-    const uint4 rc = a.rect[i];
+    V3 c0 = v3(0.f, 0.f, 0.f);
+    if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(threadIdx.x + 1u) * kRecF4], &s_rec[threadIdx.x * kRecF4], c0);
     const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
     if (tx0 > tx1) return;
-    const unsigned long long keep = (unsigned long long)rc.z | ((unsigned long long)rc.w << 32);
+    // squared radius with a guard for the rounding of the distance computation (relative 1e-5 and an absolute term scaled by
+    // the coordinates): a tile whose box is farther than that from the photon cannot hold a pixel within r of it
+    const float pmag = fmaxf(fmaxf(fabsf(c0.x), fabsf(c0.y)), fmaxf(fabsf(c0.z), 1.0f));
+    const float reach = a.fp.photon_radius * (1.0f + 1.0e-5f) + 4.0e-6f * pmag;
+    const float reach2 = reach * reach;
+    // bin entries of this photon on THIS rank's row strips; rectangles of more than 64 tiles (huge radii) are not depth-culled
+    const int tiles_per_block = a.st.strip_rows >> 3;
     const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
     const bool small = nx * ny <= 64;
-    const int tiles_per_block = a.st.strip_rows >> 3;
     for (int ty = ty0; ty <= ty1; ty++) {
         int blk = ty / tiles_per_block;
-        if (blk % a.st.strip_count != a.st.strip_rank) continue;
+        if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
         int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
         for (int tx = tx0; tx <= tx1; tx++) {
-            if (small && !((keep >> ((ty - ty0) * nx + (tx - tx0))) & 1ull)) continue;
-            int tile = lty * a.tiles_x + tx;
-            uint32_t slot = a.tile_offset[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
-            if (slot < a.bin_capacity) items[slot] = i;
+            const int tile = lty * a.tiles_x + tx;
+            if (small) {
+                const float4 blo = a.tile_box[2 * tile], bhi = a.tile_box[2 * tile + 1];
+                const float dx = fmaxf(fmaxf(blo.x - c0.x, c0.x - bhi.x), 0.0f), dy = fmaxf(fmaxf(blo.y - c0.y, c0.y - bhi.y), 0.0f),
+                            dz = fmaxf(fmaxf(blo.z - c0.z, c0.z - bhi.z), 0.0f);
+                if (dx * dx + dy * dy + dz * dz > reach2) continue;
+            }
+            const uint32_t slot = atomicAdd(&a.tile_cursor[tile], 1u);
+            if (slot < a.bin_stride) items[(size_t)tile * a.bin_stride + slot] = i;
+            else atomicMax(a.overflow, slot + 1u);
         }
     }
+}
+
+// total entries and fullest bin (one workgroup; the cursors of <= a few 100k tiles)
+__global__ __launch_bounds__(1024) void splat_summary_kernel(const uint32_t *cursor, uint32_t n, uint32_t *summary) {
+    __shared__ uint32_t s_sum, s_max;
+    if (threadIdx.x == 0) { s_sum = 0u; s_max = 0u; }
+    __syncthreads();
+    uint32_t sum = 0u, mx = 0u;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) { const uint32_t v = cursor[i]; sum += v; mx = max(mx, v); }
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off); mx = max(mx, (uint32_t)__shfl_down((int)mx, off)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum, sum); atomicMax(&s_max, mx); }
+    __syncthreads();
+    if (threadIdx.x == 0) { summary[0] = s_sum; summary[1] = s_max; }
 }
 
 // deterministic mode: rank sort of every bin (ids are unique) so pixels accumulate in record order
-__global__ __launch_bounds__(256) void splat_sort_kernel(const uint32_t *offset, const uint32_t *src, uint32_t *dst, uint32_t capacity) {
+__global__ __launch_bounds__(256) void splat_sort_kernel(const uint32_t *cursor, uint32_t stride, const uint32_t *src, uint32_t *dst, const uint32_t *overflow) {
     const uint32_t tile = blockIdx.x;
-    uint32_t b = offset[tile], e = min(offset[tile + 1], capacity);
+    if (*overflow != 0u) return;
+    const uint32_t b = tile * stride, e = b + min(cursor[tile], stride);
     for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
         uint32_t v = src[i], rank = 0;
         for (uint32_t j = b; j < e; j++) rank += src[j] < v ? 1u : 0u;
@@ -261,12 +223,12 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int part = WAVES == 4 ? wave : 0;                       // this wave's share of the bin
     const int tile = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
-    if (tile >= a.tiles_x * a.tiles_y) return;                    // (WAVES == 1 only: whole waves leave, no barrier below)
+    if (tile >= a.tiles_x * a.tiles_y || *a.overflow != 0u) return;                    // (WAVES == 1 only: whole waves leave, no barrier below)
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
     const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
-    const uint32_t b = a.tile_offset[tile], e = min(a.tile_offset[tile + 1], a.bin_capacity);
+    const uint32_t b = (uint32_t)tile * a.bin_stride, e = b + min(a.tile_cursor[tile], a.bin_stride);
     if (b >= e) { if (lane == 0 && part == 0) a.tile_pairs[tile] = 0u; return; }
 
     // a wave without a batch of its own (most bins hold one or two) only takes part in the fold below
@@ -347,25 +309,19 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     }
 }
 
-// Phase A: compact photons + tile counts + exclusive scan (tile_offset[ntiles] = total bin entries).
-void launch_splat_count(const SplatArgs &a, hipStream_t s) {
+// Phase A: tile depth ranges, compact photons + bins, summary.
+void launch_splat_bin(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-    hipMemsetAsync(a.tile_count, 0, sizeof(uint32_t) * (ntiles + 1), s);
-    hipLaunchKernelGGL(splat_tile_depth_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
+    hipMemsetAsync(a.tile_cursor, 0, sizeof(uint32_t) * ntiles, s);
+    hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
     const uint32_t nb = (a.num_records + 255) / 256;
-    hipLaunchKernelGGL(splat_prepare_kernel, dim3(nb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, s, a.tile_count, a.tile_offset, a.tile_cursor, ntiles, a.bin_capacity, a.overflow, a.summary);
+    hipLaunchKernelGGL(splat_bin_kernel, dim3(nb), dim3(256), 0, s, a, a.deterministic ? a.bin_items_tmp : a.bin_items);
+    hipLaunchKernelGGL(splat_summary_kernel, dim3(1), dim3(1024), 0, s, a.tile_cursor, ntiles, a.summary);
 }
-// Phase B: fill the bins (capacity already checked by the host) and accumulate the tiles.
+// Phase B: (deterministic: sort the bins) and accumulate the tiles.  Both do nothing when a bin overflowed.
 void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-    const uint32_t nb = (a.num_records + 255) / 256;
-    if (a.deterministic) {
-        hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items_tmp);
-        hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_offset, a.bin_items_tmp, a.bin_items, a.bin_capacity);
-    } else {
-        hipLaunchKernelGGL(splat_fill_kernel, dim3(nb), dim3(256), 0, s, a, a.bin_items);
-    }
+    if (a.deterministic) hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_cursor, a.bin_stride, a.bin_items_tmp, a.bin_items, a.overflow);
     if (dom_begin) hipEventRecord(dom_begin, s);
     if (split_tiles) hipLaunchKernelGGL(splat_tiles_kernel<4>, dim3(ntiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(splat_tiles_kernel<1>, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);

@@ -217,7 +217,7 @@ def test_config5_progressive_vsl_and_photons_2048(evplp, tmp_path_factory):
         sched = dict(radius=radius, clamp=1.0 / total, pdf_mc=(NV / NL) / math.pi / radius ** 2, vsl_r=vsl_r, vsl_i=1.0 / (math.pi * vsl_r ** 2))
         clamp_start = sched["clamp"]
         rows_all = c.global_rows(); ok = rows_all < H
-        check = [int(rows_all[ok][1]), int(rows_all[ok][6])]
+        check = [int(rows_all[ok][4])]                       # one row of 2048 pixels x ~12 k VSLs: the oracle's estimators take ~25 s per iteration
         ovsl = np.zeros((H, W, 4), np.float32); opm = np.zeros((H, W, 4), np.float32)
         rng = MT19937(3)
         for it in range(2):

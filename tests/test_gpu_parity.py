@@ -256,6 +256,27 @@ def test_photon_splat_modes(ctx, oscene, evplp, inputs, mode):
     assert np.allclose(twice[..., :3], 2 * got[..., :3], rtol=1e-6, atol=1e-9)
 
 
+def test_photon_bins_grow_and_the_pass_reruns(room, oscene, evplp, inputs, monkeypatch):
+    """The splat is enqueued without knowing the bin sizes; a pass whose bins overflow writes nothing and is run again by the
+    next call with larger bins (context.cpp settle_splat).  Force that path with two-slot bins."""
+    gbuf, records = inputs
+    kw = dict(camera_pos=oscene.sd.cam_origin, mis_mode=1, pdf_mc=0.35, photon_radius=0.35, num_light_paths=NPATHS,
+              num_vpl_light_paths=NPATHS, photons_per_path=P)
+    outs = []
+    for cap in (None, "2"):
+        if cap:
+            monkeypatch.setenv("EVPLP_BIN_STRIDE", cap)
+        with evplp.Context(W, H, NPATHS, NPATHS, P, deterministic=True) as c:
+            room.upload(c)
+            upload_inputs(c, evplp, gbuf, records)
+            c.splat_photons(evplp.frame_params(**kw), clear=True)
+            c.splat_photons(evplp.frame_params(**kw), clear=False)         # accumulates on top: a dropped or doubled pass shows
+            st = c.pass_stats(evplp.PASS_SPLAT)
+            outs.append((c.download(evplp.BUF_PHOTON_ACCUM)[:H].tobytes(), st["pairs"]))
+        monkeypatch.delenv("EVPLP_BIN_STRIDE", raising=False)
+    assert outs[0][1] > 1000 and outs[0] == outs[1]
+
+
 def test_gather_vsl(ctx, oscene, evplp, inputs):
     gbuf, records = inputs
     upload_inputs(ctx, evplp, gbuf, records)
