@@ -279,9 +279,11 @@ class Context:
     def synchronize(self):
         self._check(self._lib.evplp_synchronize(self._h))
 
-    def primary(self, jitter=(0.0, 0.0), clear_light=False):
+    def primary(self, jitter=(0.0, 0.0), clear_light=False, light_unoccluded=False, light_skip=False):
+        """clear_light / light_unoccluded / light_skip = EVPLP_LIGHT_CLEAR / _UNOCCLUDED / _SKIP (include/evplp.h)."""
         j = (C.c_float * 2)(float(jitter[0]), float(jitter[1]))
-        self._check(self._lib.evplp_primary(self._h, C.byref(j), int(clear_light)))
+        flags = (1 if clear_light else 0) | (2 if light_unoccluded else 0) | (4 if light_skip else 0)
+        self._check(self._lib.evplp_primary(self._h, C.byref(j), flags))
 
     def trace_light_paths(self, rng_seed: int, path_begin: int = 0, path_count: Optional[int] = None):
         if path_count is None:

@@ -31,6 +31,8 @@ static size_t buffer_bytes(const evplp_context *c, int which) {
 
 static int settle_splat(evplp_context *c);
 
+namespace evplp { void set_context_error(evplp_context *ctx, const char *text) { if (ctx) ctx->set_error("%s", text ? text : ""); } }
+
 extern "C" int evplp_abi_version(void) { return EVPLP_ABI_VERSION; }
 
 extern "C" const char *evplp_last_error(const evplp_context *ctx) { return ctx ? ctx->error : g_create_error; }

@@ -41,6 +41,9 @@ HostScene load_scene(const Json &root, const std::string &json_path);
 // uploads through the C ABI (textures, materials, meshes, light, camera) and builds the accel
 int upload_scene(evplp_context *ctx, const HostScene &scene);
 
+// stores `text` as the context's last error (defined in context.cpp; the host side has no access to evplp_context otherwise)
+void set_context_error(evplp_context *ctx, const char *text);
+
 std::string dirname_of(const std::string &path);
 std::string join_path(const std::string &dir, const std::string &rel);
 std::string read_text_file(const std::string &path);

@@ -126,7 +126,7 @@ private:
             if (num_iterations == num_max_iteration) break;                                   // :610-613
             float jitter[2] = { 0.f, 0.f };
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :618-624
-            check(h, evplp_primary(h, jitter, clear_every_frame ? 1 : 0), "primary");        // :626-629, 633-643
+            check(h, evplp_primary(h, jitter, clear_every_frame ? (EVPLP_LIGHT_CLEAR | EVPLP_LIGHT_UNOCCLUDED) : 0), "primary");        // :626-629, 633-643
             check(h, evplp_path_trace(h, scene.camera.origin, (uint32_t)num_iterations + rng_offset, (uint32_t)num_max_bounce,
                                       clear_every_frame ? 0 : 1), "path trace");             // :631
             num_iterations++;
@@ -273,7 +273,8 @@ private:
             float jitter[2] = { 0.f, 0.f };
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :946-952
             evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
-            if (do_deferred) check(h, evplp_primary(h, jitter, (do_light_render && frame_mode == 2) ? 1 : 0), "primary");   // :954-960, 985-995
+            const int light_flags = !do_light_render ? EVPLP_LIGHT_SKIP : frame_mode == 2 ? (EVPLP_LIGHT_CLEAR | EVPLP_LIGHT_UNOCCLUDED) : 0;   // :985-995
+            if (do_deferred) check(h, evplp_primary(h, jitter, light_flags), "primary");   // :954-960
             if (do_light_tracing) check(h, evplp_trace_light_paths(h, (uint32_t)num_iterations + rng_offset, 0, (uint32_t)num_light_paths), "light tracing");  // :962-966
             if (do_vpl_splat) check(h, lvc ? evplp_gather_lvc(h, &fp) : force_vsl ? evplp_gather_vsl(h, &fp) : evplp_gather_vpl(h, &fp), "gather");  // :968-972
             // radius 0 (radiusPercentage 0 of the VPL-only configs): the proxy spheres are degenerate, nothing is drawn
@@ -356,8 +357,8 @@ extern "C" int evplp_load_scene_json(evplp_context *ctx, const char *json_path) 
         Json root = Json::parse(read_text_file(json_path));
         HostScene scene = load_scene(root, json_path);
         return upload_scene(ctx, scene);
-    } catch (const JsonError &) { return EVPLP_ERR_PARSE; }
-    catch (const std::exception &) { return EVPLP_ERR_IO; }
+    } catch (const JsonError &e) { set_context_error(ctx, e.what()); return EVPLP_ERR_PARSE; }
+    catch (const std::exception &e) { set_context_error(ctx, e.what()); return EVPLP_ERR_IO; }   // e.g. a Git-LFS pointer instead of a mesh, a missing file
 }
 
 extern "C" int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap) {

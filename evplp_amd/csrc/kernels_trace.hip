@@ -41,10 +41,12 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     int32_t tri = closest_wave(a.sc, eye, dj, 0.1f, 100.0f, 1, in_image, t, b, g);
     // the light mesh only matters in front of (or at) the scene hit (depth LEQUAL): bound its walk by that depth --
     // both directions have camera-space z = -1, so t is the view depth on either ray
-    const float light_far = tri >= 0 ? fminf(t * 1.000001f + 1.0e-30f, 100.0f) : 100.0f;
+    const bool light_unoccluded = (a.clear_light & EVPLP_LIGHT_UNOCCLUDED) != 0;      // wave-uniform
+    const float light_far = (tri >= 0 && !light_unoccluded) ? fminf(t * 1.000001f + 1.0e-30f, 100.0f) : 100.0f;
     int32_t ltri = a.sc.light_count > 0 ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl) : -1;
     if (!in_image) return;
     bool use_light = ltri >= 0 && (tri < 0 || tl <= t);  // depth LEQUAL, light mesh drawn last
+    const bool light_visible = light_unoccluded ? ltri >= 0 : use_light;              // the emitter IMAGE (rtcomphoton.h:985-995)
     if (use_light) { tri = ltri; b = bl; g = gl; }
 
     float4 pos = make_float4(0.f, 0.f, 0.f, 1.f);  // clear colour (0,0,0,1) rtcomphoton.h:885
@@ -64,8 +66,10 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
         phg = make_float4(ks.x, ks.y, ks.z, ns);
     }
     a.g_pos[p] = pos; a.g_nrm[p] = nrm; a.g_dif[p] = dif; a.g_phg[p] = phg;
-    if (use_light) a.g_light[p] = make_float4(a.sc.light_unscaled[0], a.sc.light_unscaled[1], a.sc.light_unscaled[2], 0.f);
-    else if (a.clear_light) a.g_light[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(a.clear_light & EVPLP_LIGHT_SKIP)) {
+        if (light_visible) a.g_light[p] = make_float4(a.sc.light_unscaled[0], a.sc.light_unscaled[1], a.sc.light_unscaled[2], 0.f);
+        else if (a.clear_light & EVPLP_LIGHT_CLEAR) a.g_light[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // lighttracing.cu:93-96

@@ -183,8 +183,14 @@ int evplp_scene_metrics(evplp_context *ctx, float *bounding_sphere_radius, float
 
 /* ---- the per-iteration passes of RtComPhoton::run() (rtcomphoton.h:936-1068) ---- */
 /* [deferredShading] + [lightRender]: runDeferredProgram (:710-754) + runLightProgram (:839-855);
- * jitter = (2u-1)/res NDC translation (:949); light plane is cleared iff clear_light != 0 (:990-993). */
-int evplp_primary(evplp_context *ctx, const float jitter[2], int32_t clear_light);
+ * jitter = (2u-1)/res NDC translation (:949).  light_flags (evplp_light_flags) restate :985-995:
+ *   EVPLP_LIGHT_CLEAR       cleareveryframe: pixels that do not show the emitter are written 0 (glClear of the light framebuffer);
+ *   EVPLP_LIGHT_UNOCCLUDED  cleareveryframe also clears the depth buffer the light pass shares with the deferred pass
+ *                           (GL_DEPTH_BUFFER_BIT, :992): the emitter image is then NOT depth-tested against the scene;
+ *   EVPLP_LIGHT_SKIP        run.lightRender = false: the light image is not touched at all.
+ * The G-buffer itself is always depth-correct. */
+enum evplp_light_flags { EVPLP_LIGHT_CLEAR = 1, EVPLP_LIGHT_UNOCCLUDED = 2, EVPLP_LIGHT_SKIP = 4 };
+int evplp_primary(evplp_context *ctx, const float jitter[2], int32_t light_flags);
 /* [lightTracing]: launch(LightTrace, numLightPaths) (:869-881).  Traces paths
  * [path_begin, path_begin+path_count) into the record buffer (multi-GPU: each rank a slice). */
 int evplp_trace_light_paths(evplp_context *ctx, uint32_t rng_seed, uint32_t path_begin, uint32_t path_count);

@@ -557,7 +557,7 @@ static inline v3 cam_dir(const cam_basis *b, float ndcx, float ndcy) {
  * the un-jittered one (rtcomphoton.h:720-727); depth LEQUAL, light mesh drawn last. */
 void evo_primary(const evo_scene *s, const evo_camera *cam, int32_t W, int32_t H, const float jitter[2],
                  int32_t row_begin, int32_t row_end,
-                 float *g_pos, float *g_nrm, float *g_dif, float *g_phg, float *g_light) {
+                 float *g_pos, float *g_nrm, float *g_dif, float *g_phg, float *g_light, int32_t light_unoccluded) {
     cam_basis cb = cam_make(cam);
 #pragma omp parallel for schedule(dynamic, 4) num_threads(evo_get_threads())
     for (int32_t y = row_begin; y < row_end; y++) {
@@ -584,10 +584,12 @@ void evo_primary(const evo_scene *s, const evo_camera *cam, int32_t W, int32_t H
                 v3 N = normalize(cross(sub(p1, p0), sub(p2, p0)));
                 v3 kd, ks; float ns; material_at(s, tri, b, g, &kd, &ks, &ns);
                 st3(pos, P); st3(nrm, N); st3(dif, kd); st3(phg, ks); phg[3] = ns;
-                if (use_light) {
-                    /* light.frag:7-10 with uLightIntensity = unscaled I (rtcomphoton.h:845) */
-                    lig[0] = s->light_unscaled[0]; lig[1] = s->light_unscaled[1]; lig[2] = s->light_unscaled[2];
-                }
+            }
+            /* the emitter image: depth-tested against the scene unless the frame mode cleared the shared depth buffer before the
+             * light pass (cleareveryframe, rtcomphoton.h:989-994) */
+            if (light_unoccluded ? ltri >= 0 : use_light) {
+                /* light.frag:7-10 with uLightIntensity = unscaled I (rtcomphoton.h:845) */
+                lig[0] = s->light_unscaled[0]; lig[1] = s->light_unscaled[1]; lig[2] = s->light_unscaled[2];
             }
             memcpy(g_pos + p, pos, 16); memcpy(g_nrm + p, nrm, 16); memcpy(g_dif + p, dif, 16); memcpy(g_phg + p, phg, 16);
             if (g_light) memcpy(g_light + p, lig, 16);

@@ -132,7 +132,8 @@ float evo_phong_pdf_w(const float n1[3], const float v12[3], const float in[3], 
  * Rows [row_begin,row_end) of the full W x H image are written at their global offset. */
 void evo_primary(const evo_scene *s, const evo_camera *cam, int32_t W, int32_t H,
                  const float jitter[2], int32_t row_begin, int32_t row_end,
-                 float *g_pos, float *g_nrm, float *g_dif, float *g_phg, float *g_light);
+                 float *g_pos, float *g_nrm, float *g_dif, float *g_phg, float *g_light,
+                 int32_t light_unoccluded /* 1: the emitter image is not depth-tested (cleareveryframe, rtcomphoton.h:989-994) */);
 
 /* lighttracing.cu:192-250 + 113-182 */
 void evo_trace_light_paths(const evo_scene *s, uint32_t rng_seed, uint32_t path_begin, uint32_t path_count,

@@ -84,7 +84,7 @@ def load():
     l.evo_phong_pdf_a.argtypes = [_P, _P, _P, _P, _P, C.c_float]
     l.evo_phong_pdf_w.restype = C.c_float
     l.evo_phong_pdf_w.argtypes = [_P, _P, _P, _P, C.c_float]
-    l.evo_primary.argtypes = [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]
+    l.evo_primary.argtypes = [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32]
     l.evo_trace_light_paths.argtypes = [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]
     l.evo_vpl_splat_pair.argtypes = [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, _P]
     l.evo_gather_vpl.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]
@@ -151,12 +151,12 @@ class Scene:
         c.fovy = sd.fovy; c.aspect = sd.aspect
         return c
 
-    def primary(self, W, H, jitter=(0.0, 0.0), rows=None):
+    def primary(self, W, H, jitter=(0.0, 0.0), rows=None, light_unoccluded=False):
         planes = [np.zeros((H, W, 4), dtype=np.float32) for _ in range(5)]
         j = f3(jitter)
         cam = self.camera()
         r0, r1 = rows if rows else (0, H)
-        self.lib.evo_primary(self.h, C.byref(cam), W, H, ptr(j), r0, r1, *[ptr(p) for p in planes])
+        self.lib.evo_primary(self.h, C.byref(cam), W, H, ptr(j), r0, r1, *[ptr(p) for p in planes], int(light_unoccluded))
         return planes
 
     def trace_light_paths(self, seed, npaths, P, begin=0, count=None, records=None):

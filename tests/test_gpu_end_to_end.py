@@ -67,7 +67,7 @@ def oracle_pt(json_path, block):
 
     while n_it != block["numMaxIteration"]:
         jitter = jitter_of(rng, W, H) if block["useJitter"] else (0.0, 0.0)
-        g = osc.primary(W, H, jitter)
+        g = osc.primary(W, H, jitter, light_unoccluded=not accumulate)      # cleareveryframe clears the depth buffer the light pass shares
         lit = g[4][..., 0] > 0
         if not accumulate:
             light[:] = 0
@@ -117,9 +117,10 @@ def oracle_technique(json_path, block, lvc=False):
         jitter = (0.0, 0.0)
         if block["useJitter"]:
             jitter = jitter_of(rng, W, H)
-        g = osc.primary(W, H, jitter)
-        lit = g[4][..., 0] > 0
-        if not accumulate:
+        do_light = block.get("run", {}).get("lightRender", True)
+        g = osc.primary(W, H, jitter, light_unoccluded=not accumulate)      # rtcomphoton.h:985-995
+        lit = (g[4][..., 0] > 0) & do_light
+        if not accumulate and do_light:
             light[:] = 0
         light[lit] = g[4][lit]
         rec = osc.trace_light_paths(n_it + block["rngOffset"], nl, P)
@@ -606,3 +607,6 @@ def test_api_misuse_is_reported(evplp):
             c.splat_photons(evplp.frame_params(camera_pos=(0, 0, 0), num_light_paths=4, num_vpl_light_paths=4, photons_per_path=2, photon_radius=0.0))
         with pytest.raises(evplp.EvplpError):
             c.trace_light_paths(0, 2, 10)
+        with pytest.raises(evplp.EvplpError) as e:
+            c.load_scene_json("/nonexistent/scene.json")                              # the message names the file
+        assert e.value.status == evplp.ERR_IO and "/nonexistent/scene.json" in str(e.value)

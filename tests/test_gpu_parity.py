@@ -88,6 +88,26 @@ def test_primary_gbuffer(room, oscene, evplp, builder):
     assert (ref[4][..., 0] > 0).any(), "the light should be visible in this view"
 
 
+def test_light_image_flags(room, oscene, evplp):
+    """rtcomphoton.h:985-995: run.lightRender = false leaves the light image alone; cleareveryframe clears the depth buffer the
+    light pass shares with the deferred pass, so the emitter is drawn without a depth test."""
+    with evplp.Context(W, H, NPATHS, NPATHS, P) as c:
+        room.upload(c)
+        c.clear_accumulators()
+        c.primary((0.0, 0.0), light_skip=True)
+        assert not c.download(evplp.BUF_LIGHT)[:H].any()
+        c.primary((0.0, 0.0), clear_light=True)
+        tested = c.download(evplp.BUF_LIGHT)[:H]
+        gb = [c.download(b)[:H] for b in (evplp.BUF_GBUF_POSITION, evplp.BUF_GBUF_NORMAL)]
+        c.primary((0.0, 0.0), clear_light=True, light_unoccluded=True)
+        free = c.download(evplp.BUF_LIGHT)[:H]
+        gb2 = [c.download(b)[:H] for b in (evplp.BUF_GBUF_POSITION, evplp.BUF_GBUF_NORMAL)]
+    ref_t = oscene.primary(W, H, (0.0, 0.0))[4]; ref_f = oscene.primary(W, H, (0.0, 0.0), light_unoccluded=True)[4]
+    assert np.array_equal(tested, ref_t) and np.array_equal(free, ref_f)
+    assert (free[..., 0] > 0).sum() >= (tested[..., 0] > 0).sum() > 0
+    assert all(np.array_equal(a, b) for a, b in zip(gb, gb2)), "the G-buffer stays depth-correct"
+
+
 def test_light_tracing_records(ctx, oscene, evplp):
     ctx.trace_light_paths(5)
     got = ctx.download(evplp.BUF_RECORDS)
