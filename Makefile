@@ -8,7 +8,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functio
 HOSTFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-unused-value -ffp-contract=off
 
 HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip $(CSRC)/kernels_pt.hip
-CPP_SRCS = $(CSRC)/context.cpp $(CSRC)/bvh_build.cpp $(wildcard $(CSRC)/host/*.cpp)
+CPP_SRCS = $(CSRC)/context.cpp $(CSRC)/group.cpp $(CSRC)/bvh_build.cpp $(wildcard $(CSRC)/host/*.cpp)
 # VARIANT selects a separate object directory and library name (developer builds, e.g. `make stats`)
 VARIANT ?=
 BUILD = build$(if $(VARIANT),/$(VARIANT),)
@@ -21,7 +21,7 @@ all: $(OUT)/libevplp_hip.so $(OUT)/evplp-render oracle
 
 $(LIBSO): $(HIP_OBJS) $(CPP_OBJS)
 	@mkdir -p $(OUT)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 # diagnostic build with traversal counters (nodes / leaf blocks / triangle pairs per walk): tools/traversal_stats.py
 stats:

@@ -70,6 +70,10 @@ class FrameParams(C.Structure):
                 ("do_accumulate", C.c_uint32), ("rng_seed", C.c_uint32), ("jitter", C.c_float * 2)]
 
 
+class GroupConfig(C.Structure):
+    _fields_ = [("n_ranks", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("strip_rows", C.c_int32), ("use_rccl", C.c_int32)]
+
+
 class PassStats(C.Structure):
     _fields_ = [("ms", C.c_float), ("pairs", C.c_uint64), ("rays", C.c_uint64), ("usable", C.c_uint64),
                 ("dominant_kernel_ms", C.c_float), ("reserved", C.c_uint32 * 3), ("shaded", C.c_uint64), ("launches", C.c_uint32),
@@ -111,6 +115,20 @@ _SIGNATURES = {
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "evplp_group_create": (C.c_int, [C.POINTER(Config), _P, C.POINTER(_P)]),
+    "evplp_group_destroy": (None, [_P]),
+    "evplp_group_last_error": (C.c_char_p, [_P]),
+    "evplp_group_size": (C.c_int, [_P]),
+    "evplp_group_context": (_P, [_P, C.c_int32]),
+    "evplp_group_load_scene_json": (C.c_int, [_P, C.c_char_p]),
+    "evplp_group_clear_accumulators": (C.c_int, [_P]),
+    "evplp_group_primary": (C.c_int, [_P, C.POINTER(C.c_float * 2), C.c_int32]),
+    "evplp_group_trace_light_paths": (C.c_int, [_P, C.c_uint32]),
+    "evplp_group_gather": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
+    "evplp_group_splat_photons": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
+    "evplp_group_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
+    "evplp_group_synchronize": (C.c_int, [_P]),
+    "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "evplp_save_image": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P]),
@@ -352,6 +370,68 @@ class Context:
         """Global image row of every local row (>= H for padding rows)."""
         from . import strips
         return strips.global_rows(self.H, self.cfg.strip_rank, self.cfg.strip_count, self.cfg.strip_rows)
+
+
+class Group:
+    """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
+
+    def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=8,
+                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH):
+        self._lib = lib()
+        cfg = Config()
+        cfg.abi_version = ABI_VERSION; cfg.res_x = res_x; cfg.res_y = res_y
+        cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths; cfg.photons_per_path = photons_per_path
+        cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
+        gc = GroupConfig(); gc.n_ranks = n_ranks; gc.strip_rows = strip_rows; gc.use_rccl = int(use_rccl)
+        self._devs = (C.c_int32 * n_ranks)(*devices) if devices is not None else None
+        gc.devices = C.cast(self._devs, C.POINTER(C.c_int32)) if self._devs is not None else None
+        h = C.c_void_p()
+        rc = self._lib.evplp_group_create(C.byref(cfg), C.byref(gc), C.byref(h))
+        if rc != OK:
+            raise EvplpError(rc, self._lib.evplp_group_last_error(None).decode())
+        self._h = h; self.W, self.H, self.n = res_x, res_y, n_ranks
+
+    def _check(self, rc):
+        if rc < 0:
+            raise EvplpError(rc, self._lib.evplp_group_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.evplp_group_destroy(self._h); self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def load_scene_json(self, path):
+        self._check(self._lib.evplp_group_load_scene_json(self._h, path.encode()))
+
+    def clear_accumulators(self):
+        self._check(self._lib.evplp_group_clear_accumulators(self._h))
+
+    def primary(self, jitter=(0.0, 0.0), light_flags=0):
+        j = (C.c_float * 2)(float(jitter[0]), float(jitter[1]))
+        self._check(self._lib.evplp_group_primary(self._h, C.byref(j), light_flags))
+
+    def trace_light_paths(self, seed):
+        self._check(self._lib.evplp_group_trace_light_paths(self._h, seed))
+
+    def gather(self, fp, kind=0):
+        self._check(self._lib.evplp_group_gather(self._h, C.byref(fp), kind))
+
+    def splat_photons(self, fp, clear=False):
+        self._check(self._lib.evplp_group_splat_photons(self._h, C.byref(fp), int(clear)))
+
+    def synchronize(self):
+        self._check(self._lib.evplp_group_synchronize(self._h))
+
+    def resolve(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
+        out = np.empty((self.H, self.W, 3), dtype=np.float32)
+        self._check(self._lib.evplp_group_resolve(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma), _ptr(out)))
+        return out
 
 
 def progressive_step(n: int, alpha: float, clamp_start: float, n_vpl: int, n_light: int, radius: float, clamp: float,

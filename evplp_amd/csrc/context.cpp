@@ -555,16 +555,25 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     return pass_end(c, EVPLP_PASS_SPLAT);
 }
 
-extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
+// [finalize] composite of this context's strip into d_rgb (device); evplp_resolve downloads it, the group all-gathers it
+namespace evplp {
+int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
     CTX_CHECK(c);
     { int rc_ = settle_splat(c); if (rc_) return rc_; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    if (!out_rgb) { c->set_error("evplp_resolve: null output"); return EVPLP_ERR_INVALID; }
     int rc;
     if ((rc = pass_begin(c, EVPLP_PASS_RESOLVE))) return rc;
     launch_resolve(c->st, (const float4 *)c->buf[EVPLP_BUF_VPL_ACCUM], (const float4 *)c->buf[EVPLP_BUF_PHOTON_ACCUM],
                    (const float4 *)c->buf[EVPLP_BUF_LIGHT], vs, ps, ls, mask_emitter, gamma, c->d_rgb, c->stream);
-    if ((rc = pass_end(c, EVPLP_PASS_RESOLVE))) return rc;
+    return pass_end(c, EVPLP_PASS_RESOLVE);
+}
+} // namespace evplp
+
+extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
+    CTX_CHECK(c);
+    if (!out_rgb) { c->set_error("evplp_resolve: null output"); return EVPLP_ERR_INVALID; }
+    int rc = evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma);
+    if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_rgb, sizeof(float) * 3 * (size_t)c->st.W * c->st.local_rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EVPLP_OK;

@@ -30,12 +30,38 @@ const std::map<std::string, int> kMisModes = { { "one", 0 }, { "balance", 1 }, {
                                                { "geometryClamp", 4 }, { "geometryBrdfClamp", 5 } }; // :1199-1206
 constexpr float kInvPi = 0.318309886183790671537767526745028724068919291480912897495f;
 
-struct Ctx {   // RAII for the C handle
-    evplp_context *h = nullptr;
-    ~Ctx() { if (h) evplp_destroy(h); }
+// The techniques always run on an evplp_group (one rank = the reference's single device); the `device` block of the technique
+// JSON asks for more ranks: {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool} (build-only key, include/evplp.h).
+struct Grp {   // RAII for the C handle
+    evplp_group *g = nullptr;
+    ~Grp() { if (g) evplp_group_destroy(g); }
 };
-void check(evplp_context *h, int rc, const char *what) {
-    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + evplp_last_error(h));
+void check(evplp_group *g, int rc, const char *what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + evplp_group_last_error(g));
+}
+void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int device) {
+    evplp_group_config gc; std::memset(&gc, 0, sizeof(gc));
+    gc.n_ranks = 1; gc.strip_rows = 8;
+    bool virt = false;
+    if (json.has("device")) {
+        const Json &d = json.at("device");
+        if (d.has("gpus")) gc.n_ranks = (int)d.at("gpus").as_int("device.gpus");
+        if (d.has("virtual")) virt = d.at("virtual").as_bool("device.virtual");
+        if (d.has("stripRows")) gc.strip_rows = (int)d.at("stripRows").as_int("device.stripRows");
+        if (d.has("rccl")) gc.use_rccl = d.at("rccl").as_bool("device.rccl") ? 1 : 0;
+    }
+    if (gc.n_ranks < 1 || gc.n_ranks > 64) throw JsonError("device.gpus: must be 1..64");
+    std::vector<int32_t> devs((size_t)gc.n_ranks);
+    for (int r = 0; r < gc.n_ranks; r++) devs[(size_t)r] = virt ? device : device + r;
+    gc.devices = devs.data();
+    int rc = evplp_group_create(&cfg, &gc, &grp.g);
+    if (rc < 0) throw std::runtime_error(std::string("evplp_group_create: ") + evplp_group_last_error(nullptr));
+}
+void upload_scene_group(evplp_group *g, const HostScene &scene) {
+    for (int r = 0; r < evplp_group_size(g); r++) {
+        evplp_context *h = evplp_group_context(g, r);
+        if (upload_scene(h, scene) < 0) throw std::runtime_error(std::string("scene upload: ") + evplp_last_error(h));
+    }
 }
 // Output files named in the technique block.  The shipped scene files carry the authors' Windows paths
 // ("C://result/conference/3_pm.pfm"): off Windows a drive-letter path keeps only its file name and lands next to
@@ -57,7 +83,8 @@ std::vector<float> flip_y(const std::vector<float> &rgb, int w, int h) {
     return out;
 }
 // build-only additions to the stat file: per-pass device times of the last iteration
-void add_pass_times(evplp_context *h, Json &st) {
+void add_pass_times(evplp_group *g, Json &st) {
+    evplp_context *h = evplp_group_context(g, 0);
     const char *names[EVPLP_PASS_COUNT] = { "primaryMs", "lightTraceMs", "gatherVplMs", "gatherVslMs", "splatMs", "resolveMs", "pathTraceMs", "gatherLvcMs" };
     for (int p = 0; p < EVPLP_PASS_COUNT; p++) { evplp_pass_stats ps; if (evplp_pass_stats_get(h, p, &ps) == EVPLP_OK && ps.ms > 0) st.set(names[p], Json::number(ps.ms)); }
 }
@@ -105,39 +132,37 @@ public:
         cfg.strip_rank = 0; cfg.strip_count = 1; cfg.strip_rows = 8;
         cfg.num_light_paths = 1; cfg.num_vpl_light_paths = 1; cfg.photons_per_path = 1;   // no light sub-paths in this technique
         cfg.bvh_builder = bvh_builder;
-        Ctx ctx;
-        int rc = evplp_create(&cfg, &ctx.h);
-        if (rc < 0) throw std::runtime_error(std::string("evplp_create: ") + evplp_last_error(nullptr));
-        check(ctx.h, upload_scene(ctx.h, scene), "scene upload");
-        run(ctx.h, scene, res_x, res_y);
+        Grp grp; create_group(grp, cfg, json, device);
+        upload_scene_group(grp.g, scene);
+        run(grp.g, scene, res_x, res_y);
     }
 
 private:
     // rtpt2.h:575-719
-    void run(evplp_context *h, const HostScene &scene, int W, int H) {
+    void run(evplp_group *h, const HostScene &scene, int W, int H) {
         JitterSampler sampler(rng_offset);
-        check(h, evplp_clear_accumulators(h), "clear");
+        check(h, evplp_group_clear_accumulators(h), "clear");
         int num_iterations = 0;
         auto t0 = std::chrono::steady_clock::now();
         auto elapsed_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-        std::vector<float> rgb((size_t)W * evplp_local_rows(h) * 3);
+        std::vector<float> rgb((size_t)W * H * 3);
         const bool clear_every_frame = frame_mode == 2;
         for (;;) {
             if (num_iterations == num_max_iteration) break;                                   // :610-613
             float jitter[2] = { 0.f, 0.f };
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :618-624
-            check(h, evplp_primary(h, jitter, clear_every_frame ? (EVPLP_LIGHT_CLEAR | EVPLP_LIGHT_UNOCCLUDED) : 0), "primary");        // :626-629, 633-643
-            check(h, evplp_path_trace(h, scene.camera.origin, (uint32_t)num_iterations + rng_offset, (uint32_t)num_max_bounce,
-                                      clear_every_frame ? 0 : 1), "path trace");             // :631
+            check(h, evplp_group_primary(h, jitter, clear_every_frame ? (EVPLP_LIGHT_CLEAR | EVPLP_LIGHT_UNOCCLUDED) : 0), "primary");        // :626-629, 633-643
+            check(h, evplp_group_path_trace(h, scene.camera.origin, (uint32_t)num_iterations + rng_offset, (uint32_t)num_max_bounce,
+                                            clear_every_frame ? 0 : 1), "path trace");       // :631
             num_iterations++;
             if (write_every_frame) {                                                          // :669-689
                 size_t i = output_filename.find_last_of('.');
                 save(h, W, H, num_iterations, output_filename.substr(0, i) + "_" + std::to_string(num_iterations) + output_filename.substr(i), rgb);
             }
-            if (time_limit_ms < 1e8f) check(h, evplp_synchronize(h), "sync");
+            if (time_limit_ms < 1e8f) check(h, evplp_group_synchronize(h), "sync");
             if (elapsed_ms() >= time_limit_ms) break;                                         // :667
         }
-        check(h, evplp_synchronize(h), "sync");
+        check(h, evplp_group_synchronize(h), "sync");
         float time = elapsed_ms();
         if (use_stat) {                                                                       // :694-704
             Json st = Json::object();
@@ -150,11 +175,10 @@ private:
         save(h, W, H, num_iterations, output_filename, rgb);                                  // :706-719
     }
     // clear-every-frame: the composite as shown (masked emitter); accumulate: light image + path-traced image / n
-    void save(evplp_context *h, int W, int H, int n, const std::string &path, std::vector<float> &rgb) {
-        if (frame_mode == 2) check(h, evplp_resolve(h, 1.0f, 0.0f, 1.0f, 1, 0, rgb.data()), "resolve");
-        else check(h, evplp_resolve(h, 1.0f / (float)std::max(n, 1), 0.0f, 1.0f, 0, 0, rgb.data()), "resolve");
-        std::vector<float> img(rgb.begin(), rgb.begin() + (size_t)W * H * 3);
-        std::vector<float> top = flip_y(img, W, H);
+    void save(evplp_group *h, int W, int H, int n, const std::string &path, std::vector<float> &rgb) {
+        if (frame_mode == 2) check(h, evplp_group_resolve(h, 1.0f, 0.0f, 1.0f, 1, 0, rgb.data()), "resolve");
+        else check(h, evplp_group_resolve(h, 1.0f / (float)std::max(n, 1), 0.0f, 1.0f, 0, 0, rgb.data()), "resolve");
+        std::vector<float> top = flip_y(rgb, W, H);
         if (save_image(path.c_str(), W, H, top.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + path);
     }
 
@@ -224,12 +248,12 @@ public:
         cfg.strip_rank = 0; cfg.strip_count = 1; cfg.strip_rows = 8;
         cfg.num_light_paths = (uint32_t)num_light_paths; cfg.num_vpl_light_paths = (uint32_t)num_vpl_light_paths;
         cfg.photons_per_path = (uint32_t)photons_per_path; cfg.bvh_builder = bvh_builder;
-        Ctx ctx;
-        int rc = evplp_create(&cfg, &ctx.h);
-        if (rc < 0) throw std::runtime_error(std::string("evplp_create: ") + evplp_last_error(nullptr));
-        check(ctx.h, upload_scene(ctx.h, scene), "scene upload");
+        if (json.has("deterministic")) cfg.deterministic = json.at("deterministic").as_bool("deterministic") ? 1 : 0;   // build-only key
+        Grp grp; create_group(grp, cfg, json, device);
+        upload_scene_group(grp.g, scene);
         float bsr = 0.f, total_area = 0.f, light_area = 0.f;
-        check(ctx.h, evplp_scene_metrics(ctx.h, &bsr, &total_area, &light_area), "scene metrics");
+        { evplp_context *h0 = evplp_group_context(grp.g, 0);
+          if (evplp_scene_metrics(h0, &bsr, &total_area, &light_area) < 0) throw std::runtime_error(std::string("scene metrics: ") + evplp_last_error(h0)); }
 
         photon_radius = bsr * radius_percentage;                                                                 // :118-119
         pdf_mc = (float)num_vpl_light_paths / (float)num_light_paths * kInvPi / (photon_radius * photon_radius); // :120
@@ -243,7 +267,7 @@ public:
             if (vsl_radius <= 0.008f) { vsl_radius = std::max(vsl_radius, 0.008f); std::printf("warning : vslRadius is too small. clamped vslRadius\n"); }
             vsl_inv_pi_radius2 = kInvPi / (vsl_radius * vsl_radius);
         }
-        run(ctx.h, scene, res_x, res_y);
+        run(grp.g, scene, res_x, res_y);
     }
 
 private:
@@ -260,29 +284,29 @@ private:
     }
 
     // rtcomphoton.h:883-1133
-    void run(evplp_context *h, const HostScene &scene, int W, int H) {
+    void run(evplp_group *h, const HostScene &scene, int W, int H) {
         JitterSampler sampler(rng_offset);
-        check(h, evplp_clear_accumulators(h), "clear");
+        check(h, evplp_group_clear_accumulators(h), "clear");
         int num_iterations = 0;
         auto t0 = std::chrono::steady_clock::now();
         auto elapsed_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         float prev_timing = 0.f;
-        std::vector<float> rgb((size_t)W * evplp_local_rows(h) * 3);
+        std::vector<float> rgb((size_t)W * H * 3);
         for (;;) {
             if (num_iterations == num_max_iteration) break;                                   // :938-941
             float jitter[2] = { 0.f, 0.f };
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :946-952
             evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
             const int light_flags = !do_light_render ? EVPLP_LIGHT_SKIP : frame_mode == 2 ? (EVPLP_LIGHT_CLEAR | EVPLP_LIGHT_UNOCCLUDED) : 0;   // :985-995
-            if (do_deferred) check(h, evplp_primary(h, jitter, light_flags), "primary");   // :954-960
-            if (do_light_tracing) check(h, evplp_trace_light_paths(h, (uint32_t)num_iterations + rng_offset, 0, (uint32_t)num_light_paths), "light tracing");  // :962-966
-            if (do_vpl_splat) check(h, lvc ? evplp_gather_lvc(h, &fp) : force_vsl ? evplp_gather_vsl(h, &fp) : evplp_gather_vpl(h, &fp), "gather");  // :968-972
+            if (do_deferred) check(h, evplp_group_primary(h, jitter, light_flags), "primary");   // :954-960
+            if (do_light_tracing) check(h, evplp_group_trace_light_paths(h, (uint32_t)num_iterations + rng_offset), "light tracing");  // :962-966
+            if (do_vpl_splat) check(h, evplp_group_gather(h, &fp, lvc ? 2 : force_vsl ? 1 : 0), "gather");  // :968-972
             // radius 0 (radiusPercentage 0 of the VPL-only configs): the proxy spheres are degenerate, nothing is drawn
-            if (do_photon_splat && photon_radius > 0.0f) check(h, evplp_splat_photons(h, &fp, frame_mode == 2 ? 1 : 0), "photon splat");    // :974-983
+            if (do_photon_splat && photon_radius > 0.0f) check(h, evplp_group_splat_photons(h, &fp, frame_mode == 2 ? 1 : 0), "photon splat");    // :974-983
             // [finalize] renders to the window in the reference (:997-1004); headless: nothing to present
             num_iterations++;
             if (num_iterations % 20 == 0) {                                                   // :1008-1031
-                check(h, evplp_synchronize(h), "sync");
+                check(h, evplp_group_synchronize(h), "sync");
                 float cur = elapsed_ms();
                 std::printf("numIter: %d | raduis: %g | clamping: %g | timing: %g\n", num_iterations, photon_radius, clamping_value, cur - prev_timing);
                 if (target_rendering_time != -1.f) {
@@ -295,10 +319,10 @@ private:
                 evplp_progressive_step(num_iterations, alpha_progressive, clamping_start, (uint32_t)num_vpl_light_paths, (uint32_t)num_light_paths,
                                        &photon_radius, &clamping_value, &pdf_mc, force_vsl ? 1 : 0, &vsl_radius, &vsl_inv_pi_radius2);
             if (write_every_frame) dump_frame(h, W, H, num_iterations, rgb);                  // :1079-1102
-            if (time_limit_ms < 1e8f) check(h, evplp_synchronize(h), "sync");                 // a wall-clock limit needs finished frames
+            if (time_limit_ms < 1e8f) check(h, evplp_group_synchronize(h), "sync");           // a wall-clock limit needs finished frames
             if (elapsed_ms() >= time_limit_ms) break;                                         // :1065
         }
-        check(h, evplp_synchronize(h), "sync");
+        check(h, evplp_group_synchronize(h), "sync");
         float time = elapsed_ms();
         if (use_stat) {                                                                       // :1109-1119
             Json st = Json::object();
@@ -312,9 +336,8 @@ private:
         float param = frame_mode == 2 ? 1.0f : 1.0f / (float)std::max(num_iterations, 1);     // :1122
         // :1124-1132: three composites, un-masked sums, FlipY, Save
         auto compose = [&](float vs, float ps, float ls) {
-            check(h, evplp_resolve(h, vs, ps, ls, 0, 0, rgb.data()), "resolve");
-            std::vector<float> img(rgb.begin(), rgb.begin() + (size_t)W * H * 3);
-            return flip_y(img, W, H);
+            check(h, evplp_group_resolve(h, vs, ps, ls, 0, 0, rgb.data()), "resolve");
+            return flip_y(rgb, W, H);
         };
         std::vector<float> combined = compose(param, param, 1.0f);
         std::vector<float> vpl = compose(param, 0.0f, 1.0f);
@@ -324,11 +347,10 @@ private:
         if (save_image(weighted_photon_filename.c_str(), W, H, pm.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + weighted_photon_filename);
     }
 
-    void dump_frame(evplp_context *h, int W, int H, int iter, std::vector<float> &rgb) {
+    void dump_frame(evplp_group *h, int W, int H, int iter, std::vector<float> &rgb) {
         float param = frame_mode == 2 ? 1.0f : 1.0f / (float)iter;                            // :1088
-        check(h, evplp_resolve(h, param, param, 1.0f, 0, 0, rgb.data()), "resolve");
-        std::vector<float> img(rgb.begin(), rgb.begin() + (size_t)W * H * 3);
-        std::vector<float> top = flip_y(img, W, H);
+        check(h, evplp_group_resolve(h, param, param, 1.0f, 0, 0, rgb.data()), "resolve");
+        std::vector<float> top = flip_y(rgb, W, H);
         size_t i = weighted_photon_filename.find_last_of('.');                                // :1097-1101
         std::string path = weighted_photon_filename.substr(0, i) + "_" + std::to_string(iter) + weighted_photon_filename.substr(i);
         if (save_image(path.c_str(), W, H, top.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + path);

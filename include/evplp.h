@@ -231,6 +231,39 @@ int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_
 /* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
 int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
 
+/* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread drives
+ * n_ranks contexts, one per GPU of the node, that own interleaved row strips of the image (see the top of this file); scene and
+ * BVH are replicated; light-path sets of >= 16 384 paths are traced 1/n per rank and shared by an in-place all-gather of the
+ * record buffers, smaller ones are traced by every rank; every rank gathers / splats its own rows; evplp_group_resolve
+ * composites the strips where they are and all-gathers them, so that every GPU holds the frame.  The collectives are RCCL
+ * (ncclAllGather over xGMI; librccl is opened at run time).  Ranks that all share ONE device ("virtual ranks": tests, one-GPU
+ * boxes) exchange by device copies instead.  Per-pixel results do not depend on the partition.  Every call enqueues on all
+ * ranks and returns; a failing rank's message is in evplp_group_last_error. ---- */
+typedef struct evplp_group evplp_group;
+typedef struct evplp_group_config {
+    int32_t n_ranks;          /* contexts = row-strip ranks, 1..64 */
+    const int32_t *devices;   /* HIP ordinal of every rank; NULL = 0, 1, .. n_ranks-1.  All distinct (RCCL) or all equal (virtual ranks) */
+    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 8 */
+    int32_t use_rccl;         /* 1: a single-rank group goes through RCCL too (otherwise it needs no exchange at all) */
+} evplp_group_config;
+/* cfg: as for evplp_create; device / strip_* are set per rank by the group */
+int evplp_group_create(const evplp_config *cfg, const evplp_group_config *gcfg, evplp_group **out);
+void evplp_group_destroy(evplp_group *g);
+const char *evplp_group_last_error(const evplp_group *g);   /* g may be NULL: error of a failed create */
+int evplp_group_size(const evplp_group *g);
+evplp_context *evplp_group_context(evplp_group *g, int32_t rank);   /* scene upload by hand, per-rank buffers and statistics */
+int evplp_group_load_scene_json(evplp_group *g, const char *json_path);
+int evplp_group_clear_accumulators(evplp_group *g);
+int evplp_group_primary(evplp_group *g, const float jitter[2], int32_t light_flags);
+int evplp_group_trace_light_paths(evplp_group *g, uint32_t rng_seed);
+int evplp_group_gather(evplp_group *g, const evplp_frame_params *fp, int32_t kind);   /* 0 evplp_gather_vpl, 1 _vsl, 2 _lvc */
+int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int32_t clear);
+int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
+int evplp_group_synchronize(evplp_group *g);
+/* evplp_resolve for the whole frame: out_rgb = HOST pointer, res_y * res_x * 3 floats, y = 0 bottom */
+int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, float light_scale,
+                        int32_t mask_emitter, int32_t gamma, float *out_rgb);
+
 /* ---- host side of the reference interface (no GPU needed for these) ---- */
 /* Progressive schedule, rtcomphoton.h:1033-1063; call after numIterations++ */
 void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clamp_start,
@@ -268,7 +301,10 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
                          int32_t res_x, int32_t res_y, int32_t style);
 /* main() + LoadScene + RtComPhoton::render (main.cpp:87-121, rtcomphoton.h:107-223): parse the
  * scene JSON, load OBJ/MTL, run the `photonfam` technique, write the three images + stat file.
- * json_overrides: optional JSON object text merged over the `photonfam` block (may be NULL). */
+ * json_overrides: optional JSON object text merged over the technique block (may be NULL).
+ * Build-only keys of a technique block: "bvhBuilder": "sah" | "lbvh"; "deterministic": bool (photon bins accumulated in record
+ * order); "device": {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool} -- run on an evplp_group of N row-strip ranks
+ * (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a single rank goes through RCCL too). */
 int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap);
 
 #ifdef __cplusplus

@@ -1,0 +1,98 @@
+"""evplp_group (include/evplp.h): the multi-GPU entry of the C ABI, on the one GPU a test box has.
+
+Ranks that share a device ("virtual ranks") run the whole partitioned path -- strips, split light tracing + in-place record
+all-gather, strip composites + frame all-gather, host assembly -- with device copies standing in for RCCL; a single-rank group
+with use_rccl drives the same steps through ncclCommInitAll / ncclAllGather.  Per-pixel results must not depend on the
+partition: every group image is compared bit for bit with the single-context image."""
+import json
+import math
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+W, H, P = 96, 64, 4
+
+
+def frame(evplp, runner, sd, bsr, total, NL, NV, vsl=False):
+    r = 0.05 * bsr
+    kw = dict(camera_pos=sd.cam_origin, mis_mode="balance", pdf_mc=(NV / NL) / math.pi / (r * r), clamping_value=1.0 / total, photon_radius=r,
+              vsl_radius=0.1 * bsr, vsl_inv_pi_radius2=1.0 / (math.pi * (0.1 * bsr) ** 2), num_light_paths=NL, num_vpl_light_paths=NV, photons_per_path=P,
+              do_accumulate=1, rng_seed=4, jitter=(0.002, -0.001))
+    return evplp.frame_params(**kw)
+
+
+@pytest.mark.parametrize("NL", [64, 16384])           # small sets are traced by every rank, large ones split + all-gathered
+def test_virtual_ranks_equal_the_single_context(evplp, tmp_path, NL):
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H, style="hard")
+    sd, _ = scenes.load_obj_scene(jp)
+    NV = 32
+    images = {}
+    for n in (1, 2, 4):
+        with evplp.Group(W, H, NL, NV, P, n, devices=[0] * n, deterministic=True) as g:
+            g.load_scene_json(jp)
+            c0 = evplp.lib().evplp_group_context(g._h, 0)
+            import ctypes as C
+            r_, t_, l_ = C.c_float(), C.c_float(), C.c_float()
+            evplp.lib().evplp_scene_metrics(c0, C.byref(r_), C.byref(t_), C.byref(l_))
+            fp = frame(evplp, g, sd, r_.value, t_.value, NL, NV)
+            g.clear_accumulators()
+            for it in range(2):
+                g.primary((0.002, -0.001)); g.trace_light_paths(4 + it)
+                g.gather(fp, 0); g.splat_photons(fp)
+            images[n] = g.resolve(0.5, 0.5, 1.0)
+    # the single CONTEXT (no group at all)
+    with evplp.Context(W, H, NL, NV, P, deterministic=True) as c:
+        c.load_scene_json(jp)
+        bsr, total, _ = c.scene_metrics()
+        fp = frame(evplp, c, sd, bsr, total, NL, NV)
+        c.clear_accumulators()
+        for it in range(2):
+            c.primary((0.002, -0.001)); c.trace_light_paths(4 + it)
+            c.gather_vpl(fp); c.splat_photons(fp)
+        ref = c.resolve(0.5, 0.5, 1.0)[:H]
+    assert ref.max() > 0
+    for n, img in images.items():
+        assert img.tobytes() == ref.tobytes(), f"{n} ranks differ from the single context"
+
+
+def test_single_rank_group_through_rccl(evplp, tmp_path):
+    """ncclCommInitAll + ncclAllGather with one rank: the RCCL code path itself (communicator, streams, in-place gather)."""
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H)
+    with evplp.Group(W, H, 16384, 32, P, 1, use_rccl=True, deterministic=True) as g:
+        g.load_scene_json(jp)
+        fp = evplp.frame_params(camera_pos=(15.56, -4.79, 4.37), mis_mode="one", num_light_paths=16384, num_vpl_light_paths=32, photons_per_path=P)
+        g.primary(); g.trace_light_paths(1); g.gather(fp, 0)
+        a = g.resolve(1.0, 0.0, 1.0)
+    with evplp.Context(W, H, 16384, 32, P, deterministic=True) as c:
+        c.load_scene_json(jp)
+        c.primary(); c.trace_light_paths(1); c.gather_vpl(fp)
+        b = c.resolve(1.0, 0.0, 1.0)[:H]
+    assert a.max() > 0 and a.tobytes() == b.tobytes()
+
+
+def test_render_json_on_a_group_of_virtual_ranks(evplp, tmp_path):
+    """The technique loop on 4 strip ranks (JSON `device` block) writes the same files as on one."""
+    outs = {}
+    for n in (1, 4):
+        d = tmp_path / f"n{n}"; d.mkdir()
+        jp = evplp.synth_scene(str(d), "room", 3000, 3, 80, 56, style="hard")
+        root = json.load(open(jp))
+        root["photonfam"].update(numMaxIteration=3, numLightPaths=2000, numVplLightPaths=40, radiusPercentage=0.05, misMode="balance", DoProgressive=True,
+                                 deterministic=True, device=dict(gpus=n, virtual=True), combinedFilename="c.pfm", weightedPhotonFilename="pm.pfm",
+                                 weightedVplFilename="vpl.pfm", statFilename="s.json", run=dict(photonSplat=True))
+        json.dump(root, open(jp, "w"))
+        evplp.render_json(jp)
+        outs[n] = [open(d / f, "rb").read() for f in ("c.pfm", "pm.pfm", "vpl.pfm")]
+    assert outs[1] == outs[4]
+
+
+def test_group_errors_are_reported(evplp):
+    with pytest.raises(evplp.EvplpError) as e:
+        evplp.Group(16, 16, 4, 4, 2, 2, devices=[0, 0], use_rccl=True)
+    assert "distinct device" in str(e.value)
+    with pytest.raises(evplp.EvplpError):
+        evplp.Group(16, 16, 4, 4, 2, 0)
