@@ -129,6 +129,7 @@ _SIGNATURES = {
     "evplp_group_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_group_synchronize": (C.c_int, [_P]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
+    "evplp_jitter_sequence": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "evplp_save_image": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P]),
@@ -432,6 +433,14 @@ class Group:
         out = np.empty((self.H, self.W, 3), dtype=np.float32)
         self._check(self._lib.evplp_group_resolve(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma), _ptr(out)))
         return out
+
+
+def jitter_sequence(rng_offset: int, count: int, res_x: int, res_y: int) -> np.ndarray:
+    out = np.zeros((count, 2), dtype=np.float32)
+    rc = lib().evplp_jitter_sequence(rng_offset, count, res_x, res_y, _ptr(out))
+    if rc != OK:
+        raise EvplpError(rc, "evplp_jitter_sequence")
+    return out
 
 
 def progressive_step(n: int, alpha: float, clamp_start: float, n_vpl: int, n_light: int, radius: float, clamp: float,

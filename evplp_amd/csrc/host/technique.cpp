@@ -88,15 +88,20 @@ void add_pass_times(evplp_group *g, Json &st) {
     const char *names[EVPLP_PASS_COUNT] = { "primaryMs", "lightTraceMs", "gatherVplMs", "gatherVslMs", "splatMs", "resolveMs", "pathTraceMs", "gatherLvcMs" };
     for (int p = 0; p < EVPLP_PASS_COUNT; p++) { evplp_pass_stats ps; if (evplp_pass_stats_get(h, p, &ps) == EVPLP_OK && ps.ms > 0) st.set(names[p], Json::number(ps.ms)); }
 }
-// IndependentSampler(mRngOffset) -> std::mt19937 (common/rng.h:9-44); the float mapping of
-// std::uniform_real_distribution is implementation-defined, so a fixed one is used: u = (x >> 8) * 2^-24.
+// IndependentSampler(mRngOffset).nextVec2() (common/rng.h:9-44, sampler/independent.h:37-40) as the reference's own headers
+// behave when compiled here with g++ 11 / libstdc++ (pinned by tests/golden/jitter.npz, generated from oracle/_ref):
+//   * std::uniform_real_distribution<float>(0, 1) over std::mt19937 = generate_canonical<float, 24>: float(x) / 2^32 with the
+//     32-bit draw x converted to float by round-to-nearest, and a result of 1.0 replaced by the float below it;
+//   * Vec2(nextFloat(), nextFloat()): g++ evaluates the two arguments right to left, so .y takes the FIRST draw.
+// Both are implementation-defined in C++; the authors built with MSVC, whose library and argument order may differ --
+// statistically equivalent, but a different jitter sequence.
 struct JitterSampler {
     std::mt19937 rng;
     explicit JitterSampler(uint32_t seed) : rng(seed) {}
-    float next() { return (float)(rng() >> 8) * (1.0f / 16777216.0f); }
-    // ndc jitter (2 u - 1) / resolution, x first then y (rtcomphoton.h:946-952, rtpt2.h:617-623)
+    float next() { float u = (float)(uint32_t)rng() / 4294967296.0f; return u >= 1.0f ? 0.99999994f : u; }
+    // ndc jitter (2 u - 1) * invResolution (rtcomphoton.h:946-952, rtpt2.h:617-623)
     void next_jitter(int W, int H, float jitter[2]) {
-        float ux = next(), uy = next();
+        float uy = next(), ux = next();
         jitter[0] = (2.0f * ux - 1.0f) * (1.0f / (float)W); jitter[1] = (2.0f * uy - 1.0f) * (1.0f / (float)H);
     }
 };
@@ -371,6 +376,13 @@ private:
 };
 
 } // namespace evplp
+
+extern "C" int evplp_jitter_sequence(uint32_t rng_offset, int32_t count, int32_t res_x, int32_t res_y, float *out_ndc_xy) {
+    if (count < 0 || res_x <= 0 || res_y <= 0 || (count > 0 && !out_ndc_xy)) return EVPLP_ERR_INVALID;
+    evplp::JitterSampler s(rng_offset);
+    for (int32_t i = 0; i < count; i++) s.next_jitter(res_x, res_y, out_ndc_xy + 2 * (size_t)i);
+    return EVPLP_OK;
+}
 
 extern "C" int evplp_load_scene_json(evplp_context *ctx, const char *json_path) {
     using namespace evplp;

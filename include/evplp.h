@@ -265,6 +265,10 @@ int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, flo
                         int32_t mask_emitter, int32_t gamma, float *out_rgb);
 
 /* ---- host side of the reference interface (no GPU needed for these) ---- */
+/* The anti-aliasing jitters of the first `count` iterations of a technique run with this rngOffset: NDC translations (x, y) =
+ * (2 u - 1) / resolution with u = IndependentSampler(rngOffset).nextVec2() (rtcomphoton.h:887, 946-952) -- the reference's own
+ * sampler headers as they behave under g++ / libstdc++ (tests/golden/jitter.npz); out_ndc_xy: 2 * count floats. */
+int evplp_jitter_sequence(uint32_t rng_offset, int32_t count, int32_t res_x, int32_t res_y, float *out_ndc_xy);
 /* Progressive schedule, rtcomphoton.h:1033-1063; call after numIterations++ */
 void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clamp_start,
                             uint32_t n_vpl_paths, uint32_t n_light_paths,

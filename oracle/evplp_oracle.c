@@ -503,6 +503,7 @@ static inline v3 phong_sample(v3 *out, float *pdfw, v3 in, v3 normal, v3 rho_s, 
     else *pdfw = 0.0f;
     return muls(rho_s, (e + 2.0f) / (e + 1.0f) * cos_n);
 }
+float evo_tri_area(const float v9[9]) { return tri_area(v9); }
 void evo_math_sincos(float x, float *s, float *c) { evm_sincosf(x, s, c); }
 float evo_math_pow(float x, float y) { return evm_powf(x, y); }
 float evo_phong_eval_f(const float out[3], const float in[3], const float n[3], float e) { return phong_eval_f(ld3(out), ld3(in), ld3(n), e); }

@@ -115,6 +115,8 @@ uint32_t evo_rng_u32(evo_rng *r);
 float evo_rng_uniform(evo_rng *r); /* (0,1] like curand_uniform */
 
 /* ---- BRDF helpers rt/rtmaterial.cuh (exported for unit tests) ---- */
+/* Triangle::ComputeArea (shapes/trianglemesh.cpp:13-19) as the light CDF and totalArea use it (rtcommon.h:501-531, 759-768) */
+float evo_tri_area(const float v9[9]);
 /* the shared direction-sampling math (evplp_amd/csrc/ev_math.h), exported for the accuracy check against libm */
 void evo_math_sincos(float x, float *s, float *c);
 float evo_math_pow(float x, float y);

@@ -66,3 +66,27 @@ float ref_bounding_sphere_radius(int nverts, const float *verts) {
 }
 
 }
+
+// ---- the jitter sampler and the triangle area feeding the light CDF (round 2 pins)
+#include "sampler/independent.h"
+extern "C" {
+// IndependentSampler(seed).nextVec2() n times, exactly as RtComPhoton::run draws its jitter (rtcomphoton.h:887, 949):
+// std::mt19937 through std::uniform_real_distribution<float> (common/rng.h:34) -- here libstdc++'s, the authors' was MSVC's --
+// with the two draws of nextVec2 passed as constructor arguments (sampler/independent.h:37-40: evaluation order unspecified).
+void ref_jitter_vec2(uint32_t seed, int n, float *out) {
+    IndependentSampler s(seed);
+    for (int i = 0; i < n; i++) { Vec2 v = s.nextVec2(); out[2 * i] = (float)v.x; out[2 * i + 1] = (float)v.y; }
+}
+// the NDC jitter itself: (2 u - 1) * invResolution (rtcomphoton.h:949)
+void ref_jitter_ndc(uint32_t seed, int n, float res_x, float res_y, float *out) {
+    IndependentSampler s(seed);
+    glm::vec2 inv_res(1.0f / res_x, 1.0f / res_y);
+    for (int i = 0; i < n; i++) { glm::vec2 j = (2.0f * glm::vec2(s.nextVec2()) - glm::vec2(1)) * inv_res; out[2 * i] = j.x; out[2 * i + 1] = j.y; }
+}
+// Triangle::ComputeArea (shapes/trianglemesh.cpp:13-19) cannot be compiled here (the file needs Assimp); this is its expression
+// on the vendored GLM: glm::length(glm::cross(b - a, c - a)) / 2.0f
+float ref_triangle_area(const float a[3], const float b[3], const float c[3]) {
+    glm::vec3 A(a[0], a[1], a[2]), B(b[0], b[1], b[2]), Cc(c[0], c[1], c[2]);
+    return glm::length(glm::cross(B - A, Cc - A)) / 2.0f;
+}
+}

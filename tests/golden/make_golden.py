@@ -224,6 +224,20 @@ def main():
     cam_out["bsr_points"] = pts
     cam_out["bsr_radius"] = np.float32(ref.ref_bounding_sphere_radius(pts.shape[0], P(pts)))
     np.savez(os.path.join(HERE, "camera.npz"), **cam_out)
+
+    # jitter sampler (common/rng.h + sampler/independent.h compiled as they are) and triangle areas (GLM expression of
+    # shapes/trianglemesh.cpp:13-19, the file itself needs Assimp)
+    jit = {"seeds": np.array([0, 1, 7, 12345, 4294967295], np.uint32), "n": np.int32(64), "res": np.array([1280, 720], np.int32)}
+    for sd in jit["seeds"]:
+        v = np.zeros(2 * 64, np.float32); j = np.zeros(2 * 64, np.float32)
+        ref.ref_jitter_vec2(C.c_uint32(int(sd)), 64, P(v)); ref.ref_jitter_ndc(C.c_uint32(int(sd)), 64, C.c_float(1280.0), C.c_float(720.0), P(j))
+        jit[f"vec2_{int(sd)}"] = v.reshape(64, 2); jit[f"ndc_{int(sd)}"] = j.reshape(64, 2)
+    np.savez(os.path.join(HERE, "jitter.npz"), **jit)
+    ref.ref_triangle_area.restype = C.c_float
+    tris = (rng.randn(300, 9) * np.repeat(10.0 ** rng.uniform(-3, 1.5, (300, 1)), 9, 1)).astype(np.float32)
+    tris[:20, 3:6] = tris[:20, 0:3] + (tris[:20, 6:9] - tris[:20, 0:3]) * np.float32(0.5) + np.float32(1e-4) * rng.randn(20, 3).astype(np.float32)   # skinny
+    areas = np.array([ref.ref_triangle_area(P(t[0:3].copy()), P(t[3:6].copy()), P(t[6:9].copy())) for t in tris], np.float32)
+    np.savez(os.path.join(HERE, "areas.npz"), tris=tris, areas=areas)
     print("wrote", os.listdir(HERE))
 
 

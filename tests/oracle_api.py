@@ -73,6 +73,8 @@ def load():
     l.evo_rng_u32.argtypes = [_P]
     l.evo_rng_uniform.restype = C.c_float
     l.evo_rng_uniform.argtypes = [_P]
+    l.evo_tri_area.restype = C.c_float
+    l.evo_tri_area.argtypes = [_P]
     l.evo_math_sincos.argtypes = [C.c_float, _P, _P]
     l.evo_math_pow.restype = C.c_float
     l.evo_math_pow.argtypes = [C.c_float, C.c_float]

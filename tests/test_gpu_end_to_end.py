@@ -40,8 +40,14 @@ class MT19937:
 
 
 def jitter_of(rng, W, H):
+    """IndependentSampler::nextVec2 as the reference's headers behave under g++ / libstdc++ (tests/golden/jitter.npz): float(x) / 2^32,
+    the first draw goes to .y"""
     f32 = np.float32
-    ux = f32(rng() >> 8) * f32(1.0 / 16777216.0); uy = f32(rng() >> 8) * f32(1.0 / 16777216.0)
+
+    def nxt():
+        u = f32(np.uint32(rng())) / f32(4294967296.0)
+        return f32(0.99999994) if u >= f32(1.0) else u
+    uy = nxt(); ux = nxt()
     return (float((f32(2) * ux - f32(1)) * (f32(1) / f32(W))), float((f32(2) * uy - f32(1)) * (f32(1) / f32(H))))
 
 

@@ -228,3 +228,34 @@ def test_texture_decoders_on_the_reference_assets_when_present(evplp):
         ref.ref_stbi_free(ptr)
         got, channels = evplp.decode_image(f)
         assert channels == ch.value and np.array_equal(got, want), f
+
+
+# ---- round 2 pins: the jitter sampler and the triangle area (tests/golden/jitter.npz, areas.npz from oracle/_ref)
+JIT = np.load(os.path.join(HERE, "golden", "jitter.npz"))
+AREAS = np.load(os.path.join(HERE, "golden", "areas.npz"))
+
+
+@pytest.mark.parametrize("seed", [int(s) for s in JIT["seeds"]])
+def test_jitter_sequence_matches_the_reference_sampler(seed, evplp):
+    """IndependentSampler(rngOffset).nextVec2() -> (2 u - 1) / resolution (rtcomphoton.h:887, 949), from the reference's own
+    common/rng.h + sampler/independent.h compiled with g++ / libstdc++ (both the float mapping of uniform_real_distribution and
+    the order of the two draws are implementation-defined: the authors' MSVC build may have drawn another sequence)."""
+    n = int(JIT["n"]); W, H = (int(v) for v in JIT["res"])
+    got = evplp.jitter_sequence(seed, n, W, H)
+    assert got.tobytes() == JIT[f"ndc_{seed}"].tobytes()
+    # the Python twin the oracle loops of the GPU tests use
+    from test_gpu_end_to_end import MT19937, jitter_of
+    rng = MT19937(seed)
+    twin = np.array([jitter_of(rng, W, H) for _ in range(n)], np.float32)
+    assert twin.tobytes() == JIT[f"ndc_{seed}"].tobytes()
+    # and the raw draws: .y takes the first one
+    rng = MT19937(seed)
+    first, second = np.float32(np.uint32(rng())) / np.float32(2 ** 32), np.float32(np.uint32(rng())) / np.float32(2 ** 32)
+    assert JIT[f"vec2_{seed}"][0, 1] == first and JIT[f"vec2_{seed}"][0, 0] == second
+
+
+def test_triangle_area_matches_the_reference_expression(oracle):
+    """glm::length(glm::cross(b - a, c - a)) / 2 (shapes/trianglemesh.cpp:13-19 on the vendored GLM) feeds the light CDF
+    (rtcommon.h:501-531), the light area and totalArea (default clamping value, :759-768)."""
+    for t, ref in zip(AREAS["tris"], AREAS["areas"]):
+        assert oracle.evo_tri_area(oa.ptr(np.ascontiguousarray(t))) == ref
