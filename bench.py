@@ -86,9 +86,31 @@ def spawn_ranks(a):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode(errors="replace"))
+    # wait for all ranks; if one dies the others would sit in the rendezvous / a collective until a timeout: stop them (these are
+    # this process's own children, by handle)
+    import threading
+    buf = []
+    t = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for i, p in enumerate(procs):
+            if p.poll() is not None and p.returncode != 0:
+                failed = i
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    rcs = [p.wait() for p in procs]
+    t.join(timeout=5)
+    sys.stdout.write((buf[0] if buf else b"").decode(errors="replace"))
     sys.stdout.flush()
     bad = [i for i, rc in enumerate(rcs) if rc != 0]
     if bad:

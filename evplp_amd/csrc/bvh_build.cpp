@@ -109,6 +109,7 @@ struct Builder {
     }
 
     // ---- binned SAH ---------------------------------------------------------------------
+    float sah_ct = 1.0f;
     int32_t sah_rec(int32_t first, int32_t count, int d) {
         depth = std::max(depth, d);
         if (count <= kMaxLeafTris && count <= 2) return make_leaf(first, count);
@@ -137,10 +138,12 @@ struct Builder {
                 if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
             }
         }
-        // leaf if cheaper (cost model: traversal 1.0, triangle 1.0) and it fits
+        // leaf if cheaper and it fits.  Cost model in units of one triangle test: a node visit of the packet walk costs
+        // sah_ct of them (20 vector + 27 scalar instructions and a dependent 64-byte fetch against ~25 vector instructions per
+        // triangle with the plane-distance pre-test)
         if (count <= kMaxLeafTris) {
             float leaf_cost = (float)count * bb.area();
-            if (best_axis < 0 || best_cost + 1.0f * bb.area() >= leaf_cost) return make_leaf(first, count);
+            if (best_axis < 0 || best_cost + sah_ct * bb.area() >= leaf_cost) return make_leaf(first, count);
         }
         int32_t mid;
         if (best_axis >= 0) {
@@ -191,6 +194,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     int32_t nvalid = (int32_t)B.ids.size();
     B.nodes.reserve((size_t)2 * std::max(nvalid, 1) + 2);
     int32_t root = -1;
+    if (const char *e = std::getenv("EVPLP_SAH_CT")) B.sah_ct = (float)atof(e);
     if (nvalid > 0) root = (builder == EVPLP_BVH_SAH) ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
 
     // conservative padding: the device slab test is inexact, the triangle test is exact; a padded

@@ -1,0 +1,67 @@
+"""bench.py on the GPU box: the JSON contract, the collective code path on one rank, strip assembly through the product."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env=None):
+    e = dict(os.environ); e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_line_contract_small():
+    d = run_bench(["--steps", "2", "--warmup", "1", "--res", "256", "--tris", "20000", "--no-cpu-baseline", "--no-extras"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "valu" and 0 < r["frac"] < 1 and r["kernel"] == "gather_vpl_kernel" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["config"]["shadow_rays_per_frame"] <= d["config"]["pairs_nominal_per_frame"]
+
+
+def test_bench_collective_path_on_one_rank():
+    """EVPLP_BENCH_FORCE_DIST=1: init_process_group("nccl") with one rank, the record all-gather (split light tracing) and the
+    framebuffer all-gather run through RCCL exactly as with N ranks; same value definition, n_gpus from the process group."""
+    a = run_bench(["--steps", "2", "--warmup", "1", "--res", "256", "--tris", "20000", "--no-cpu-baseline", "--no-extras"], {"EVPLP_BENCH_FORCE_DIST": "1"})
+    b = run_bench(["--steps", "2", "--warmup", "1", "--res", "256", "--tris", "20000", "--no-cpu-baseline", "--no-extras"])
+    assert a["n_gpus"] == 1 and a["config"]["shadow_rays_per_frame"] == b["config"]["shadow_rays_per_frame"]
+    assert a["config"]["usable_vpl_records"] == b["config"]["usable_vpl_records"]
+
+
+def test_bench_refuses_a_rank_count_it_cannot_start():
+    """--gpus 2 on a one-GPU box: bench.py starts two ranks itself; the second has no device and the parent reports failure
+    instead of silently measuring one GPU."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two GPUs")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--res", "128", "--tris", "5000",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=180)
+    assert p.returncode != 0
+
+
+def test_two_strip_contexts_assemble_to_the_single_frame(evplp, tmp_path):
+    from evplp_amd import strips
+    W, H, N, P = 96, 64, 48, 4
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H, style="hard")
+    fp = evplp.frame_params(camera_pos=(15.56, -4.79, 4.37), mis_mode="one", num_light_paths=N, num_vpl_light_paths=N, photons_per_path=P)
+
+    def render(rank, count):
+        with evplp.Context(W, H, N, N, P, strip_rank=rank, strip_count=count, strip_rows=8) as c:
+            c.load_scene_json(jp)
+            c.primary(); c.trace_light_paths(2); c.gather_vpl(fp)
+            return c.download(evplp.BUF_VPL_ACCUM)
+    gathered = np.stack([render(r, 2) for r in range(2)])            # what an all-gather of the two strips delivers
+    full = strips.assemble(gathered, H, 2, 8)
+    ref = render(0, 1)[:H]
+    assert ref[..., :3].max() > 0 and full.tobytes() == ref.tobytes()
