@@ -338,30 +338,14 @@ EV_DEV Hit2 tri_pair_test(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, 
     return h;
 }
 
-// Any-hit of a PAIR of triangles for a whole wave, with a plane-distance pre-test in front of the exact predicate.
-// In real arithmetic the hit distance is t = N / den with N = n . (p0 - o) -- the same for every lane, the origin is shared --
-// and den = n . d, and the predicate evaluates it as  sum n_k * fl(w_k * fl(1 / den))  (w = p0 - o): its result differs from
-// N / den by at most ~5 eps S / |den|, S = sum |n_k w_k|.  So  t in (tmin, tmax)  is impossible when  N - tmin den  and
-// N - tmax den  have the same sign beyond M = 32 eps S, and a pair none of whose live lanes can pass needs no division,
-// cross products or barycentrics: 11 instructions instead of ~60.  That rejects the triangles a segment does not reach
-// and, above all, the coplanar neighbours of the surfaces the segment starts and ends on (t ~ 0 and t ~ 1).  S = 0 (an
-// empty slot, or every n_k w_k = 0) makes t exactly 0 or NaN: rejected too.  Lanes that pass take the exact test unchanged,
-// so the result is bit-identical to tri_pair_test for every lane in `alive`.
+// Any-hit of a PAIR of triangles for a whole wave (exact predicate, tri_pair_test).
+// Measured and removed: a plane-distance pre-test in front of it (t = N / den with N = n . (p0 - o) common to all lanes; a pair
+// none of whose live lanes can have t in range skips the division, cross products and barycentrics).  It rejects the coplanar
+// neighbours of the surfaces a segment starts and ends on, but costs ~30 instructions per pair and only pays when EVERY live
+// lane is rejected: 39 % of the pairs on the box scene, 9 % on the furnished one -- 50.7 / 104.1 ms with it against
+// 49.6 / 97.0 ms without (cfg2).  The smaller box padding (bvh_build.cpp) already keeps segments out of those leaves.
 struct PairOps { v2f p0x, p0y, p0z, e0x, e0y, e0z, e1x, e1y, e1z, nx, ny, nz; };
-EV_DEV bool tri_pair_any(const PairOps &T, V3 o, V3 d, float tmin, float tmax, unsigned long long alive, uint32_t *exact_runs = nullptr) {
-    bool maybe;
-    {
-        const v2f wx = T.p0x - bc(o.x), wy = T.p0y - bc(o.y), wz = T.p0z - bc(o.z);
-        const v2f tx = T.nx * wx, ty = T.ny * wy, tz = T.nz * wz;
-        const v2f N = tx + ty + tz;
-        const v2f S = pk_max(tx, -tx) + pk_max(ty, -ty) + pk_max(tz, -tz);
-        const v2f M = S * bc(32.0f * 5.9604645e-8f);
-        const v2f den = pk_fma(T.nz, bc(d.z), pk_fma(T.ny, bc(d.y), T.nx * bc(d.x)));
-        const v2f f1 = pk_fma(den, bc(-tmin), N), f2 = pk_fma(den, bc(-tmax), N);
-        const v2f mn = pk_min(f1, f2), mx = pk_max(f1, f2);
-        maybe = !((mn.x >= M.x) | (mx.x <= -M.x)) | !((mn.y >= M.y) | (mx.y <= -M.y));
-    }
-    if ((ballot64(maybe) & alive) == 0ull) return false;
+EV_DEV bool tri_pair_any(const PairOps &T, V3 o, V3 d, float tmin, float tmax, uint32_t *exact_runs = nullptr) {
     if (exact_runs) (*exact_runs)++;
     Hit2 h = tri_pair_test(T.p0x, T.p0y, T.p0z, T.e0x, T.e0y, T.e0z, T.e1x, T.e1y, T.e1z, T.nx, T.ny, T.nz, o, d, tmin, tmax);
     return h.a | h.b;
@@ -379,10 +363,7 @@ EV_DEV LeafOps fetch_leaf(const char *leaf_base, uint32_t leafref) {
         const v16i c = tp[2];
         L.B.p0x = pk(b[8], b[9]); L.B.p0y = pk(b[10], b[11]); L.B.p0z = pk(b[12], b[13]); L.B.e0x = pk(b[14], b[15]); L.B.e0y = pk(c[0], c[1]); L.B.e0z = pk(c[2], c[3]);
         L.B.e1x = pk(c[4], c[5]); L.B.e1y = pk(c[6], c[7]); L.B.e1z = pk(c[8], c[9]); L.B.nx = pk(c[10], c[11]); L.B.ny = pk(c[12], c[13]); L.B.nz = pk(c[14], c[15]);
-    } else {
-        const v2f z = bc(0.0f);
-        L.B.p0x = L.B.p0y = L.B.p0z = L.B.e0x = L.B.e0y = L.B.e0z = L.B.e1x = L.B.e1y = L.B.e1z = L.B.nx = L.B.ny = L.B.nz = z;
-    }
+    }      // (else: pair B is never read, the callers test it only when cnt > 2)
     return L;
 }
 
@@ -458,7 +439,11 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if (a1 == 0u) { cur = c0; continue; }
             {
                 // both hit: descend into the child wanted by more lanes first, keep the other one on the stack
-                const uint32_t p0 = (uint32_t)__builtin_popcountll(m0), p1 = (uint32_t)__builtin_popcountll(m1);
+                // (scalar popcounts through inline asm: given __builtin_popcountll this compiler widens the counts to 64 bits and
+                // compares them with a VECTOR instruction, v_cmp_lt_u64 on a v_mov'd copy)
+                int p0, p1;
+                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(p0) : "s"(m0) : "scc");
+                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(p1) : "s"(m1) : "scc");
                 const bool first0 = p0 >= p1;
                 const int32_t oth = first0 ? c1 : c0;
                 vstack = lane_write(oth, sp, vstack);
@@ -479,8 +464,8 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
 #else
             uint32_t *ex = nullptr;
 #endif
-            bool any = tri_pair_any(L.A, o, d, tmin, tmax, alive, ex);    // an empty slot B is all zeros: never a hit
-            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, alive, ex);
+            bool any = tri_pair_any(L.A, o, d, tmin, tmax, ex);    // an empty slot B is all zeros: never a hit
+            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, ex);
             const unsigned long long hm = ballot64(any) & alive;
             if (hm != 0ull) {
                 hitm |= hm;

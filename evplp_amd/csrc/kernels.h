@@ -24,7 +24,6 @@ struct PassCounters {
     unsigned long long aux;
     // EVPLP_TRAVERSAL_STATS builds only (tools/traversal_stats.py): histogram of leaf blocks tested per (wave, VPL) walk
     // ([31] = 31 or more), [32] = walks, [33] = triangle pairs tested, [34] = walks that ended with every lane occluded,
-    // [35] = triangle pairs that went on to the exact predicate (the rest were rejected by the plane-distance pre-test)
     unsigned long long hist[64];
     // gather: shadow rays / unoccluded pairs, summed by gather_reduce_kernel into 64 shards (one device-scope atomic per
     // workgroup; a single word saturates near 90 atomics per microsecond)

@@ -84,7 +84,7 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
 // furniture silhouettes vs open floor -- and balance beats L2 locality: per-XCD super-tiles of 2x2 / 4x4 tiles
 // measured 3 % / 13 % slower in round 1).  Tiles are enumerated block by block -- 8 x SH tiles, SH = as many tile rows
 // as a row strip keeps adjacent (8 for a whole image) -- so that the tiles in flight at one time are 2-D neighbours and
-// walk the same part of the tree: 101.7 ms against 113.9 ms for row-major order (cfg2, hard scene).
+// walk the same part of the tree: 107.6 ms against 110.8 ms for row-major order (cfg2, hard scene, same GPU).
 struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   // p: pixel index in the strip (W * local_rows < 2^32)
 EV_DEV Item item_setup(const GatherArgs &a, int lane) {
     const StripDev &st = a.st;
@@ -110,7 +110,7 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
 }
 
 #ifndef EVPLP_GATHER_WAVES
-#define EVPLP_GATHER_WAVES 6   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene: 6 = 110.8 / 52.9 ms, 7 = 113.9 / 54.2, 8 = 121.2 / 55.8
+#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene: 5 = 106.0 / 54.3 ms, 6 = 94.3 / 48.7, 7 = 91.0 / 47.6, 8 = 94.6 / 50.0
 #endif
 typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -166,7 +166,6 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                     atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
                     atomicAdd(&a.counters->hist[32], 1ull);
                     atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
-                    atomicAdd(&a.counters->hist[35], (unsigned long long)ws.exact);
                     if (ballot64(active && !occ) == 0ull) atomicAdd(&a.counters->hist[34], 1ull);
                 }
 #else

@@ -41,7 +41,6 @@ out = {
     "walks_fully_occluded_frac": all_occ / max(walks, 1),
     "leaf_blocks_per_walk_hist": (hist / max(walks, 1)).round(4).tolist(),
     "kernel_ms_with_counters": st["dominant_kernel_ms"], "launches": st["launches"], "shaded": st["shaded"],
-    "tri_pairs_to_exact_predicate_per_walk": int(raw[4 + 35]) / max(walks, 1),
 }
 print(json.dumps(out, indent=1))
 if a.out:
