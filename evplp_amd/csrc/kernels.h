@@ -53,9 +53,11 @@ struct GatherArgs {
 // split summed in increasing i.  A constant, and a fixed tree: results must not depend on the GPU count or on splits_per_wave.
 constexpr int kVplSplit = EVPLP_VPL_SPLIT;
 #ifndef EVPLP_GATHER_K
-#define EVPLP_GATHER_K 1
+#define EVPLP_GATHER_K 4
 #endif
-constexpr int kDefaultSplitsPerWave = EVPLP_GATHER_K;   // measured on one GPU (hard scene, cfg2): k = 1 101.7 ms, k = 16 139.7 ms (long items: launch tail)
+// k = 4: 32 partial sums per pixel (512 MB at 1024^2 instead of 2 GB for k = 1) at the same speed (hard scene, cfg2, one GPU:
+// k = 1 113.9 ms, 2 114.3, 4 114.0 on one box); k = 16 was 38 % slower (long items: launch tail)
+constexpr int kDefaultSplitsPerWave = EVPLP_GATHER_K;
 
 struct PathTraceArgs {
     SceneDev sc; StripDev st;

@@ -1,0 +1,35 @@
+"""profiles/traffic_*.json from the PMC summaries of tools/prof_all.sh (FETCH_SIZE / WRITE_SIZE passes).
+usage: make_traffic_json.py <prof dir> <tag>"""
+import json, os, sys
+d, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ir = json.load(open(os.path.join(d, "pmc_ir_summary.json")))
+g = ir["evplp::gather_vpl_kernel"]
+f, w = g["FETCH_SIZE"] * 1024, g["WRITE_SIZE"] * 1024
+json.dump({
+    "config": "hard:1024x1024:1024:1",
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_all.sh {tag}) over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`, last launch; summary profiles/{tag}_bench_ir_pmc.txt",
+    "kernel": "evplp::gather_vpl_kernel", "FETCH_SIZE_KB": g["FETCH_SIZE"], "WRITE_SIZE_KB": g["WRITE_SIZE"],
+    "hbm_bytes_per_launch": f + w, "hbm_bytes_per_launch_if_fetch_x2": 2 * f + w,
+    "note": "FETCH_SIZE raw (MI355X_MICROARCH.md: it reads 1/2 of the bytes of wide 16 B/lane streams; this kernel reads 64-byte scalar node / leaf blocks, "
+            "an uncalibrated width, so the x2 figure is given beside it); fabric-side counters, Infinity-Cache hits included (nodes + leaves = 41 MB stay resident). "
+            "WRITE_SIZE = per-item partial sums (128 / splits_per_wave x 16 MB) + prologue register spills. Algorithmic bytes per launch = 1024*1024*(64+16+16) + n_vpl*96 = 101 MB.",
+    "l2_hit_rate": g["TCC_HIT_sum"] / (g["TCC_HIT_sum"] + g["TCC_MISS_sum"]),
+    "scalar_cache_hit_rate": g["SQC_DCACHE_HITS"] / (g["SQC_DCACHE_HITS"] + g["SQC_DCACHE_MISSES"]),
+    "valu_insts": g["SQ_INSTS_VALU"], "salu_insts": g["SQ_INSTS_SALU"], "lds_insts": g["SQ_INSTS_LDS"],
+}, open(os.path.join(ROOT, "profiles", "traffic_gather_vpl.json"), "w"), indent=1)
+ev = json.load(open(os.path.join(d, "pmc_evplp_summary.json")))
+tot_f = tot_w = 0.0; per = {}
+for k, v in ev.items():
+    if "splat" in k and "FETCH_SIZE" in v:
+        per[k] = {"FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"]}
+        if "tiles_kernel<1>" in k:      # the first frame's variant only
+            continue
+        tot_f += v["FETCH_SIZE"] * 1024; tot_w += v["WRITE_SIZE"] * 1024
+json.dump({
+    "config": "evplp:hard:1024x1024:1",
+    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/prof_all.sh {tag}) over `python3 bench.py --workload evplp --steps 2 --warmup 1 ...`, last launch of every splat kernel; summary profiles/{tag}_bench_evplp_pmc.txt",
+    "kernels": per, "hbm_bytes_per_pass": tot_f + tot_w, "hbm_bytes_per_pass_if_fetch_x2": 2 * tot_f + tot_w,
+    "algorithmic_bytes_per_pass": 2000000 * 96 + 1024 * 1024 * (64 + 24),
+}, open(os.path.join(ROOT, "profiles", "traffic_splat.json"), "w"), indent=1)
+print("wrote profiles/traffic_gather_vpl.json, profiles/traffic_splat.json")

@@ -29,7 +29,7 @@ fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_path
 c.primary((0, 0)); c.trace_light_paths(0); c.gather_vpl(fp); c.synchronize()
 st = c.pass_stats(ev.PASS_GATHER_VPL)
 raw = c.debug_counters(ev.PASS_GATHER_VPL)
-rays, nodes = int(raw[0]), int(raw[1])
+rays, nodes = int(st["rays"]), int(raw[1])
 hist = raw[4:4 + 32].astype(np.int64)
 walks, pairs, all_occ = int(raw[4 + 32]), int(raw[4 + 33]), int(raw[4 + 34])
 out = {
