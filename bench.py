@@ -276,6 +276,8 @@ def main():
             ctx.gather_vsl(fp)
         if wl != "ir":
             ctx.splat_photons(fp)
+            if os.environ.get("EVPLP_DUMP_SPLAT_HIST"):   # stats build: rectangle classes of the photons (tools/debug_splat_hist.py)
+                print("HIST", it, ctx.debug_counters(ev.PASS_SPLAT)[4:4 + 28].tolist(), flush=True)
         if use_dist:
             if wl != "ppm":
                 dist.all_gather_into_tensor(full, strip)
@@ -368,7 +370,7 @@ def main():
             nrec_bytes = nrec * 96 + (W * H * 64 + W * H * 24) / max(n_ranks, 1)          # SURVEY 8(d) algorithmic bytes per frame (per rank)
             sms = sum(splat_ms) / len(splat_ms)
             rs = {"bound": "hbm", "achieved": nrec_bytes / (sms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "frac": nrec_bytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "photon splat pass (prepare + scan + fill + tiles)", "pass_ms": sms,
+                  "frac": nrec_bytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "photon splat pass (tile boxes + bin + scatter + tiles)", "pass_ms": sms,
                   "tiles_kernel_ms": sum(splat_tiles_ms) / len(splat_tiles_ms), "pairs_per_frame": spairs / a.steps, "algorithmic_bytes": nrec_bytes}
             tpath = os.path.join(ROOT, "profiles", "traffic_splat.json")
             if os.path.exists(tpath):

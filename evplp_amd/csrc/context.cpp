@@ -113,10 +113,25 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
         while (k < 8 * mean && k < (1u << 20)) k <<= 1;
         c->bin_stride = (uint32_t)k;
         if (const char *env = std::getenv("EVPLP_BIN_STRIDE")) c->bin_stride = (uint32_t)std::max(1, atoi(env));   // tests: force the overflow / re-run path
+        // coarse buckets of 128 tiles (16 x 8) for the two-level binning (kernels.h)
+        c->bucket_w_log2 = 4; c->bucket_h_log2 = kBucketTilesLog2 - 4;
+        c->buckets_x = (c->tiles_x + (1 << c->bucket_w_log2) - 1) >> c->bucket_w_log2;
+        c->num_buckets = c->buckets_x * ((c->tiles_y + (1 << c->bucket_h_log2) - 1) >> c->bucket_h_log2);
+        if (c->num_buckets > kMaxBuckets) {
+            snprintf(g_create_error, sizeof(g_create_error), "evplp_create: more than %d x 128 image tiles in one context (use row strips)", kMaxBuckets);
+            evplp_destroy(c); return EVPLP_ERR_INVALID;
+        }
+        c->num_bin_groups = (int32_t)((nrec + kBinGroup - 1) / kBinGroup);
     }
     if ((e = hipMalloc((void **)&c->d_tile_box, sizeof(float4) * 2 * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_box)", e);
+    if ((e = hipMalloc((void **)&c->d_summary, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMalloc(summary)", e);
     if ((e = hipMalloc((void **)&c->d_tile_pairs, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_pairs)", e);
     if ((e = hipMalloc((void **)&c->d_tile_cursor, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_cursor)", e);
+    const size_t ngroups = std::max(c->num_bin_groups, 1);
+    if ((e = hipMalloc((void **)&c->d_seg, sizeof(uint32_t) * ngroups * kSegCap)) != hipSuccess) return fail("hipMalloc(seg)", e);
+    if ((e = hipMalloc((void **)&c->d_seg_off, sizeof(uint16_t) * ngroups * (c->num_buckets + 1))) != hipSuccess) return fail("hipMalloc(seg_off)", e);
+    if ((e = hipMalloc((void **)&c->d_big_list, sizeof(uint32_t) * ngroups * kBinGroup)) != hipSuccess) return fail("hipMalloc(big_list)", e);
+    if ((e = hipMalloc((void **)&c->d_big_count, sizeof(uint32_t) * ngroups)) != hipSuccess) return fail("hipMalloc(big_count)", e);
     if ((e = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * std::max<size_t>(ntiles * c->bin_stride, 1))) != hipSuccess) return fail("hipMalloc(bin_items)", e);
     if (cfg->deterministic && (e = hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * std::max<size_t>(ntiles * c->bin_stride, 1))) != hipSuccess) return fail("hipMalloc(bin_items_tmp)", e);
     if ((e = hipMalloc((void **)&c->d_compact, sizeof(float4) * kCompactF4 * nrec)) != hipSuccess) return fail("hipMalloc(compact)", e);
@@ -141,8 +156,8 @@ extern "C" void evplp_destroy(evplp_context *c) {
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
-    hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp);
-    hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs);
+    hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
+    hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if (c->ev_begin[i]) hipEventDestroy(c->ev_begin[i]);
         if (c->ev_end[i]) hipEventDestroy(c->ev_end[i]);
@@ -531,18 +546,15 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.out = (float4 *)c->buf[EVPLP_BUF_PHOTON_ACCUM];
     a.tile_box = c->d_tile_box; a.tile_pairs = c->d_tile_pairs; a.tile_cursor = c->d_tile_cursor;
     a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_stride = c->bin_stride;
-    a.compact = c->d_compact; a.overflow = &c->d_scalars[8]; a.summary = &c->d_scalars[10];
+    a.compact = c->d_compact; a.overflow = &c->d_scalars[8]; a.summary = c->d_summary;
+    a.seg = c->d_seg; a.seg_off = c->d_seg_off; a.big_list = c->d_big_list; a.big_count = c->d_big_count; a.num_bin_groups = c->num_bin_groups;
+    a.bucket_w_log2 = c->bucket_w_log2; a.bucket_h_log2 = c->bucket_h_log2; a.buckets_x = c->buckets_x; a.num_buckets = c->num_buckets;
     a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic;
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
     HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
     launch_splat_bin(a, c->stream);
-    // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
-    // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
-    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[0], &c->d_scalars[10], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[2], &c->d_scalars[8], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_summary, c->stream));
     // Tile kernel variant.  One wave per tile is cheapest while bins are short; when some bins are very full (tiles
     // that see a floor at grazing angle collect thousands of photons) those waves set the duration of the launch and
     // four waves per tile win.  Deterministic mode always uses one variant: the fold order is part of the result.
@@ -550,6 +562,11 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     // (config #4 shape): 0.12 / 0.22.  The fullest bin of the PREVIOUS pass decides (a heuristic either way).
     const bool split_tiles = c->cfg.deterministic ? true : c->last_bin_max >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
+    // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
+    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[0], &c->d_summary[kSummaryFinal], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[2], &c->d_scalars[8], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_summary, c->stream));
     c->splat_args = a; c->splat_pending = true;
     c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
     return pass_end(c, EVPLP_PASS_SPLAT);

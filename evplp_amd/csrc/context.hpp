@@ -45,12 +45,14 @@ struct evplp_context {
 
     // splat workspace
     int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_stride = 0, last_bin_entries = 0, last_bin_max = 0;   // bin_stride: slots per tile bin
+    int32_t num_bin_groups = 0, bucket_w_log2 = 0, bucket_h_log2 = 0, buckets_x = 0, num_buckets = 0;   // two-level binning (kernels.h)
+    uint32_t *d_seg = nullptr, *d_big_list = nullptr, *d_big_count = nullptr; uint16_t *d_seg_off = nullptr;
     uint32_t *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
-    float4 *d_compact = nullptr; float4 *d_tile_box = nullptr; uint32_t *d_tile_pairs = nullptr;
+    float4 *d_compact = nullptr; float4 *d_tile_box = nullptr; uint32_t *d_tile_pairs = nullptr; uint32_t *d_summary = nullptr;
     // The bin sizes of a splat are known only on the device.  The pass is enqueued completely (fill and tiles kernels do
     // nothing when the bins overflowed); the summary arrives in pinned host memory behind ev_summary and is looked at by the
     // NEXT call on the context (settle_splat): no host round trip, no GPU bubble inside the pass.
-    uint32_t *h_summary = nullptr;            // pinned: [0] bin entries, [1] fullest bin, [2] overflow (entries needed)
+    uint32_t *h_summary = nullptr;            // pinned: [0] bin entries, [1] fullest bin, [2] overflow (slots the fullest bin needed)
     hipEvent_t ev_summary = nullptr;
     bool splat_pending = false;
     evplp::SplatArgs splat_args{};            // the pending pass, for the re-run after the bins have grown

@@ -68,6 +68,28 @@ struct PathTraceArgs {
     PassCounters *counters;
 };
 
+constexpr int kSummaryShards = 1024, kSummaryStride = 32, kSummaryFinal = kSummaryShards * kSummaryStride;
+// Two-level binning of the photon splat, without contended atomics.  Returning atomics on scattered addresses retire at
+// ~20 G/s chip-wide (64-byte requests at the memory side) and adds to ONE address at 110-620 ns each: one atomic per (photon,
+// tile) entry on per-tile cursors cost 100 us for the 2 M entries of config #3 and 155 us on the cursor of its fullest bin; one
+// per (workgroup, coarse bucket) on 128 bucket cursors cost 1.2 ms.  So:
+//   splat_bin     : a workgroup (kBinChunks x 256 consecutive records) ranks its entries per BUCKET (a rectangle of
+//                   2^bucket_w_log2 x 2^bucket_h_log2 = 128 tiles) in LDS and writes them, sorted by bucket, into a segment of its
+//                   own + a table of bucket offsets -- no global atomic.
+//   splat_scatter : workgroup (slice, bucket): thread t takes the run of bucket entries of bin-workgroup slice * 256 + t, the
+//                   workgroup ranks them per tile in LDS and reserves the tiles' bin slots with ONE atomic per (workgroup,
+//                   tile): a tile cursor sees one add per slice.
+//   splat_big     : photons whose rectangle is larger than 2x2 tiles (huge radii) place their entries one atomic each.
+#ifndef EVPLP_BIN_CHUNKS
+#define EVPLP_BIN_CHUNKS 1
+#endif
+// 256-record chunks per workgroup of splat_bin_kernel.  Measured (bin + scatter + big kernels, us, configs #3 / #4):
+// 1 chunk 155 / 105, 2 chunks 186 / 134, 4 chunks 182 / 128: short workgroups, four per CU, hide latency best.
+constexpr int kBinChunks = EVPLP_BIN_CHUNKS;
+constexpr int kBinGroup = 256 * kBinChunks;   // records per workgroup
+constexpr int kSegCap = 4 * kBinGroup;        // entries of a workgroup's segment (a photon of the LDS path has at most 2x2)
+constexpr int kMaxBuckets = 1024;
+constexpr int kBucketTilesLog2 = 7;   // tiles per bucket
 struct SplatArgs {
     StripDev st; CamBasis cam;
     evplp_frame_params fp;
@@ -80,10 +102,16 @@ struct SplatArgs {
     uint32_t *tile_cursor;    // [ntiles] entries the photons wanted to put into the tile's bin (may exceed bin_stride: overflow)
     uint32_t *bin_items;      // [ntiles][bin_stride] compact photon ids
     uint32_t bin_stride;
+    uint32_t *seg;            // [num_bin_groups][kSegCap] entries: record - group base (10 bits) | tile within the bucket << 10, sorted by bucket
+    uint16_t *seg_off;        // [num_bin_groups][num_buckets + 1] first entry of every bucket in the group's segment
+    uint32_t *big_list;       // [num_bin_groups][kBinGroup] records whose rectangle is larger than 2x2 tiles
+    uint32_t *big_count;      // [num_bin_groups]
+    int32_t num_bin_groups, bucket_w_log2, bucket_h_log2, buckets_x, num_buckets;
     uint32_t *bin_items_tmp;  // [ntiles][bin_stride] (deterministic mode: unsorted fill target)
     float4 *compact;          // [num_records * kCompactF4] per-photon pre-shaded data
-    uint32_t *overflow;       // device flag: some bin wanted more than bin_stride entries (fill / tiles then do nothing; the host re-runs)
-    uint32_t *summary;        // device: [0] total bin entries, [1] entries of the fullest bin
+    uint32_t *overflow;       // device flag: the slots the fullest bin wanted, when that is more than bin_stride (tiles kernel then does nothing; the host re-runs) (fill / tiles then do nothing; the host re-runs)
+    uint32_t *summary;        // device: kSummaryShards x {entries, fullest bin} on separate 128-byte lines (scatter / big kernels, per workgroup),
+                              // folded into [kSummaryFinal + 0] total bin entries, [+1] entries of the fullest bin by the tile kernel
     int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
     PassCounters *counters;
 };

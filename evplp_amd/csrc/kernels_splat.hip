@@ -1,25 +1,25 @@
 // Image-space photon splat and the final composite.
 //   runPhotonSplat + shaders/photonsplatinstanced.{vert,geom,frag}
-//       (rt/rtcomphoton/rtcomphoton.h:789-837, frag:146-240)        -> prepare / scan / fill / tiles
+//       (rt/rtcomphoton/rtcomphoton.h:789-837, frag:146-240)        -> tile_box / bin / scatter / big / tiles
 //   shaders/final.frag:19-35, rtcomphoton.h:756-787                  -> resolve_kernel
 //
 // The reference rasterises one icosphere proxy per record and lets the ROP blend every fragment
 // (one RMW of HBM per fragment).  Here (ideal kernel of SURVEY A.4: photon i adds to pixel p iff
 // |X_p - P_i|^2 <= r^2):
-//   0. splat_tile_box : world-space bounding box of the G-buffer positions of every 8x8-pixel tile.
-//   1. splat_bin : one lane per record (records staged through LDS).  Everything of the fragment
-//      shader that does not depend on the pixel (w12, the MIS/clamp weight, 1/(pi r^2 N) scaling) is
-//      folded into a 64-byte compact photon; the photon id goes into the bin of every 8x8-pixel tile of the
-//      conservative screen rectangle of its radius-r sphere whose position box the sphere reaches.  Bins are
-//      fixed slabs of bin_stride slots per tile (slot = one returning atomic on the tile's cursor): no counting
-//      pass, no scan, one scattered atomic per entry instead of two.  A bin that wants more than its slab
-//      raises the overflow flag; the host doubles the slabs and runs the pass again (context.cpp settle_splat).
+//   0. splat_tile_box : world-space bounding box of the G-buffer positions of every 8x8-pixel tile (and clears the bin cursors).
+//   1. splat_bin : one lane per record (records staged through LDS).  Everything of the fragment shader that does not depend
+//      on the pixel (w12, the MIS/clamp weight, 1/(pi r^2 N) scaling) is folded into a 64-byte compact photon; the photon gets
+//      an entry for every 8x8-pixel tile of the conservative screen rectangle of its radius-r sphere whose position box the
+//      sphere reaches.  Entries are binned in two levels WITHOUT contended atomics (kernels.h "Two-level binning"):
+//      splat_bin sorts a workgroup's entries by coarse bucket into a segment of its own, splat_scatter ranks a bucket's
+//      entries per tile and reserves bin slots with one atomic per (workgroup, tile), splat_big handles photons with
+//      rectangles of more than 3x3 tiles.  Bins are fixed slabs of bin_stride slots per tile; a bin that wants more than its
+//      slab raises the overflow flag and the host doubles the slabs and runs the pass again (context.cpp settle_splat).
 //      (deterministic mode: + rank sort so every pixel accumulates in ascending record order, like the oracle.)
-//   2. splat_summary : total entries and fullest bin (sizes the slabs, picks the tile kernel variant).
-//   3. splat_tiles   : one wavefront per tile (four when bins are very full), lane = pixel with its G-buffer texel in registers;
-//      the bin streams through LDS 64 photons at a time (each lane fetches one compact photon,
-//      all lanes then read it back as an LDS broadcast); RGB accumulates in registers and is
-//      written once per pixel with coalesced 16-byte stores -- no atomics, no per-fragment RMW.
+//   2. splat_tiles   : one wavefront per tile (four when bins are very full), lane = pixel with its G-buffer texel in
+//      registers; the bin streams through LDS 64 photons at a time (each lane fetches one compact photon); every pixel first
+//      takes the radius test of the 64 photons (a 64-bit mask), then shades ITS photons in ascending order; RGB accumulates in
+//      registers and is written once per pixel with coalesced 16-byte stores -- no atomics, no per-fragment RMW.
 #include "device_common.hpp"
 #include "kernels.h"
 
@@ -53,9 +53,60 @@ EV_DEV Rec load_rec(const float4 *q) {
     return v;
 }
 
-// compact photon: [0] pos.xyz, cpn   [1] w12.xyz, d2   [2] wflux.xyz, alive   [3] brdf2.xyz, n1.w12 (unused)
-// Everything of one photon that does not depend on the pixel (compact record) + its conservative rectangle of 8x8-px
-// tiles, packed (x0 | x1 << 16, y0 | y1 << 16); x0 > x1 = nothing to splat.
+// Conservative rectangle of 8x8-px tiles (GLOBAL tile rows) of every visible point within r of `pos`, through the (jittered)
+// camera of this iteration (uMVP of runPhotonSplat is the jittered matrix, :982), packed (x0 | x1 << 16, y0 | y1 << 16);
+// x0 > x1 = nothing to splat.
+EV_DEV uint2 photon_rect(const SplatArgs &a, V3 pos) {
+    const uint2 none = make_uint2(1u, 0u);
+    const float r = a.fp.photon_radius;
+    V3 q = pos - v3(a.cam.eye);
+    float vx = dot(q, v3(a.cam.s)), vy = dot(q, v3(a.cam.u)), vz = dot(q, v3(a.cam.f));
+    // visible surface points have view depth in [near, far] = [0.1, 100] (rtcommon.h:586): clip the
+    // sphere's depth range to it -- a photon closer than r to the camera plane then needs no
+    // whole-screen fallback (those few photons used to produce most of the bin entries)
+    const float zlo = fmaxf(vz - r, 0.1f), zhi = fminf(vz + r, 100.0f);
+    if (zlo > zhi) return none;
+    float sx = 1.0f / (a.cam.aspect * a.cam.tan_half), sy = 1.0f / a.cam.tan_half;
+    float il = 1.0f / zlo, ih = 1.0f / zhi;
+    float nx0 = fminf((vx - r) * il, (vx - r) * ih) * sx + a.fp.jitter[0];
+    float nx1 = fmaxf((vx + r) * il, (vx + r) * ih) * sx + a.fp.jitter[0];
+    float ny0 = fminf((vy - r) * il, (vy - r) * ih) * sy + a.fp.jitter[1];
+    float ny1 = fmaxf((vy + r) * il, (vy + r) * ih) * sy + a.fp.jitter[1];
+    float fx0 = (nx0 * 0.5f + 0.5f) * (float)a.st.W - 0.5f, fx1 = (nx1 * 0.5f + 0.5f) * (float)a.st.W - 0.5f;
+    float fy0 = (ny0 * 0.5f + 0.5f) * (float)a.st.H - 0.5f, fy1 = (ny1 * 0.5f + 0.5f) * (float)a.st.H - 0.5f;
+    // guard against rounding in the projection (the G-buffer point of a pixel is seen exactly through the pixel centre of the
+    // jittered camera; the arithmetic above is good to ~1e-4 px at 4 k pixels).  A whole pixel of guard made one photon in
+    // five touch a third tile per axis.
+    const float guard = 1.0f / 32.0f;
+    fx0 = fminf(fmaxf(fx0 - guard, -1.0f), (float)a.st.W); fx1 = fminf(fmaxf(fx1 + guard, -1.0f), (float)a.st.W);
+    fy0 = fminf(fmaxf(fy0 - guard, -1.0f), (float)a.st.H); fy1 = fminf(fmaxf(fy1 + guard, -1.0f), (float)a.st.H);
+    int x0 = max((int)ceilf(fx0), 0), x1 = min((int)floorf(fx1), a.st.W - 1);
+    int y0 = max((int)ceilf(fy0), 0), y1 = min((int)floorf(fy1), a.st.H - 1);
+    if (x0 > x1 || y0 > y1) return none;
+    int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3;
+    return make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+}
+// squared reach of a photon at `pos`: the radius with a guard for the rounding of the distance computation (relative 1e-5 and
+// an absolute term scaled by the coordinates): a tile whose box is farther than that cannot hold a pixel within r of it
+EV_DEV float photon_reach2(const SplatArgs &a, V3 pos) {
+    const float pmag = fmaxf(fmaxf(fabsf(pos.x), fabsf(pos.y)), fmaxf(fabsf(pos.z), 1.0f));
+    const float reach = a.fp.photon_radius * (1.0f + 1.0e-5f) + 4.0e-6f * pmag;
+    return reach * reach;
+}
+EV_DEV bool box_within(float4 blo, float4 bhi, V3 c, float reach2) {
+    const float dx = fmaxf(fmaxf(blo.x - c.x, c.x - bhi.x), 0.0f), dy = fmaxf(fmaxf(blo.y - c.y, c.y - bhi.y), 0.0f),
+                dz = fmaxf(fmaxf(blo.z - c.z, c.z - bhi.z), 0.0f);
+    return !(dx * dx + dy * dy + dz * dz > reach2);
+}
+EV_DEV int local_tile_row(const SplatArgs &a, int ty) {                  // -1: row strip of another GPU
+    if (a.st.strip_count == 1) return ty;
+    const int tiles_per_block = a.st.strip_rows >> 3, blk = ty / tiles_per_block;
+    if (blk % a.st.strip_count != a.st.strip_rank) return -1;
+    return (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
+}
+
+// compact photon: [0] pos.xyz, cpn   [1] w12.xyz, d2   [2] wflux.xyz, alive   [3] brdf2.xyz (misMode 5 only)
+// Everything of one photon that does not depend on the pixel (compact record); returns its rectangle of tiles.
 EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_ph, const float4 *s_prev, V3 &photon_pos) {
     const uint2 none = make_uint2(1u, 0u);
     Rec ph = load_rec(s_ph);
@@ -85,36 +136,9 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     c[0] = make_float4(ph.pos.x, ph.pos.y, ph.pos.z, cpn);
     c[1] = make_float4(w12.x, w12.y, w12.z, d2);
     c[2] = make_float4(wflux.x, wflux.y, wflux.z, alive ? 1.0f : 0.0f);
-    c[3] = make_float4(brdf2.x, brdf2.y, brdf2.z, 0.f);
+    if (mode == 5u) c[3] = make_float4(brdf2.x, brdf2.y, brdf2.z, 0.f);       // read by misMode 5 only
 
-    // conservative screen rectangle of every visible point within r of the photon, through the
-    // (jittered) camera of this iteration: uMVP of runPhotonSplat is the jittered matrix (:982)
-    V3 q = ph.pos - v3(a.cam.eye);
-    float vx = dot(q, v3(a.cam.s)), vy = dot(q, v3(a.cam.u)), vz = dot(q, v3(a.cam.f));
-    // visible surface points have view depth in [near, far] = [0.1, 100] (rtcommon.h:586): clip the
-    // sphere's depth range to it -- a photon closer than r to the camera plane then needs no
-    // whole-screen fallback (those few photons used to produce most of the bin entries)
-    const float zlo = fmaxf(vz - r, 0.1f), zhi = fminf(vz + r, 100.0f);
-    int x0, x1, y0, y1;
-    if (zlo > zhi) return none;
-    {
-        float sx = 1.0f / (a.cam.aspect * a.cam.tan_half), sy = 1.0f / a.cam.tan_half;
-        float il = 1.0f / zlo, ih = 1.0f / zhi;
-        float nx0 = fminf((vx - r) * il, (vx - r) * ih) * sx + a.fp.jitter[0];
-        float nx1 = fmaxf((vx + r) * il, (vx + r) * ih) * sx + a.fp.jitter[0];
-        float ny0 = fminf((vy - r) * il, (vy - r) * ih) * sy + a.fp.jitter[1];
-        float ny1 = fmaxf((vy + r) * il, (vy + r) * ih) * sy + a.fp.jitter[1];
-        float fx0 = (nx0 * 0.5f + 0.5f) * (float)a.st.W - 0.5f, fx1 = (nx1 * 0.5f + 0.5f) * (float)a.st.W - 0.5f;
-        float fy0 = (ny0 * 0.5f + 0.5f) * (float)a.st.H - 0.5f, fy1 = (ny1 * 0.5f + 0.5f) * (float)a.st.H - 0.5f;
-        // +-1 pixel guard against rounding in the projection
-        fx0 = fminf(fmaxf(fx0 - 1.0f, -1.0f), (float)a.st.W); fx1 = fminf(fmaxf(fx1 + 1.0f, -1.0f), (float)a.st.W);
-        fy0 = fminf(fmaxf(fy0 - 1.0f, -1.0f), (float)a.st.H); fy1 = fminf(fmaxf(fy1 + 1.0f, -1.0f), (float)a.st.H);
-        x0 = max((int)ceilf(fx0), 0); x1 = min((int)floorf(fx1), a.st.W - 1);
-        y0 = max((int)ceilf(fy0), 0); y1 = min((int)floorf(fy1), a.st.H - 1);
-    }
-    if (x0 > x1 || y0 > y1) return none;
-    int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3;   // GLOBAL tile rows
-    return make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+    return photon_rect(a, ph.pos);
 }
 
 // World-space bounding box of every 8x8-px tile's G-buffer positions (one wave per tile).  A pixel can only receive a
@@ -123,82 +147,236 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
 // wall behind the chairs -- several times more than ever pass the radius test.  Every in-image pixel counts, background
 // included (its position is the clear colour, which is what the radius test of frag:152-154 sees too).
 __global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
+    // four tiles per wave, their texels fetched together; also clears the tile's bin cursor (and the pass summary)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
-    const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
-    const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
-    const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
-    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    if (in_image) {
-        float4 gp = a.g_pos[(size_t)ly * a.st.W + x];
-        lo[0] = hi[0] = gp.x; lo[1] = hi[1] = gp.y; lo[2] = hi[2] = gp.z;
+    const int tile0 = (blockIdx.x * 4 + wave) * 4;
+    if (blockIdx.x == 0) {
+        for (int k = tid; k < kSummaryShards; k += 256) { a.summary[k * kSummaryStride] = 0u; a.summary[k * kSummaryStride + 1] = 0u; }
     }
-    for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
-    if (lane == 0) { a.tile_box[2 * tile] = make_float4(lo[0], lo[1], lo[2], 0.f); a.tile_box[2 * tile + 1] = make_float4(hi[0], hi[1], hi[2], 0.f); }
-}
-
-// The 96-byte AoS records are read ONCE, as a coalesced 16 B/lane stream, into LDS (slot k = record base - 1 + k:
-// every photon also needs its predecessor on the light path, frag:163); a lane then picks its two records from LDS.
-// One lane per record reading its own 6 float4 at a 96-byte stride touched every line six times and every record
-// twice.
-__global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a, uint32_t *items) {
-    __shared__ float4 s_rec[257 * kRecF4];
-    const uint32_t base = blockIdx.x * 256u;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.records);
-        const uint32_t first = base == 0u ? 0u : base - 1u, last = min(base + 256u, a.num_records);   // records [first, last)
-        const uint32_t n4 = (last - first) * kRecF4, slot0 = (first + 1u - base) * kRecF4;
-        for (uint32_t k = threadIdx.x; k < n4; k += 256u) s_rec[slot0 + k] = src[(size_t)first * kRecF4 + k];
+    float4 gp[4]; bool in_image[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int tile = min(tile0 + q, ntiles - 1);
+        const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
+        const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
+        in_image[q] = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
+        gp[q] = a.g_pos[(size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1)];
     }
-    __syncthreads();
-    const uint32_t i = base + threadIdx.x;
-    uint2 rc = make_uint2(1u, 0u);
-    V3 c0 = v3(0.f, 0.f, 0.f);
-    if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(threadIdx.x + 1u) * kRecF4], &s_rec[threadIdx.x * kRecF4], c0);
-    const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
-    if (tx0 > tx1) return;
-    // squared radius with a guard for the rounding of the distance computation (relative 1e-5 and an absolute term scaled by
-    // the coordinates): a tile whose box is farther than that from the photon cannot hold a pixel within r of it
-    const float pmag = fmaxf(fmaxf(fabsf(c0.x), fabsf(c0.y)), fmaxf(fabsf(c0.z), 1.0f));
-    const float reach = a.fp.photon_radius * (1.0f + 1.0e-5f) + 4.0e-6f * pmag;
-    const float reach2 = reach * reach;
-    // bin entries of this photon on THIS rank's row strips; rectangles of more than 64 tiles (huge radii) are not depth-culled
-    const int tiles_per_block = a.st.strip_rows >> 3;
-    const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
-    const bool small = nx * ny <= 64;
-    for (int ty = ty0; ty <= ty1; ty++) {
-        int blk = ty / tiles_per_block;
-        if (blk % a.st.strip_count != a.st.strip_rank) continue;        // row strip of another GPU
-        int lty = (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
-        for (int tx = tx0; tx <= tx1; tx++) {
-            const int tile = lty * a.tiles_x + tx;
-            if (small) {
-                const float4 blo = a.tile_box[2 * tile], bhi = a.tile_box[2 * tile + 1];
-                const float dx = fmaxf(fmaxf(blo.x - c0.x, c0.x - bhi.x), 0.0f), dy = fmaxf(fmaxf(blo.y - c0.y, c0.y - bhi.y), 0.0f),
-                            dz = fmaxf(fmaxf(blo.z - c0.z, c0.z - bhi.z), 0.0f);
-                if (dx * dx + dy * dy + dz * dz > reach2) continue;
-            }
-            const uint32_t slot = atomicAdd(&a.tile_cursor[tile], 1u);
-            if (slot < a.bin_stride) items[(size_t)tile * a.bin_stride + slot] = i;
-            else atomicMax(a.overflow, slot + 1u);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int tile = tile0 + q;
+        if (tile >= ntiles) break;
+        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        if (in_image[q]) { lo[0] = hi[0] = gp[q].x; lo[1] = hi[1] = gp[q].y; lo[2] = hi[2] = gp[q].z; }
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+        if (lane == 0) {
+            a.tile_box[2 * tile] = make_float4(lo[0], lo[1], lo[2], 0.f); a.tile_box[2 * tile + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+            a.tile_cursor[tile] = 0u;
         }
     }
 }
 
-// total entries and fullest bin (one workgroup; the cursors of <= a few 100k tiles)
-__global__ __launch_bounds__(1024) void splat_summary_kernel(const uint32_t *cursor, uint32_t n, uint32_t *summary) {
-    __shared__ uint32_t s_sum, s_max;
-    if (threadIdx.x == 0) { s_sum = 0u; s_max = 0u; }
+// Bin kernel (kernels.h "Two-level binning").  The 96-byte AoS records are read ONCE, as a coalesced 16 B/lane stream, into LDS
+// (slot k = record base - 1 + k: every photon also needs its predecessor on the light path, frag:163) -- all seven loads of
+// a thread in flight together, the next chunk's issued before this chunk is worked on; a lane then picks its two records
+// from LDS (one lane per record reading its own 6 float4 at a 96-byte stride touched every line six times and every
+// record twice).
+// (plain variables: a struct or an array of these ends up in scratch memory)
+#define EV_BIN_FETCH(base_)                                                                                             \
+    {                                                                                                                   \
+        const float4 *src = reinterpret_cast<const float4 *>(a.records) + (size_t)(base_) * kRecF4;                      \
+        const uint32_t n4 = (min((base_) + 256u, a.num_records) - (base_)) * kRecF4, last = n4 - 1u;                      \
+        r0_ = src[min(tid, last)]; r1_ = src[min(tid + 256u, last)]; r2_ = src[min(tid + 512u, last)];                    \
+        r3_ = src[min(tid + 768u, last)]; r4_ = src[min(tid + 1024u, last)]; r5_ = src[min(tid + 1280u, last)];           \
+        pv = *(src + (((base_) != 0u && tid < (uint32_t)kRecF4) ? (int)tid - kRecF4 : 0));                                \
+    }
+#define EV_BIN_STAGE(base_)                                                                                             \
+    {                                                                                                                   \
+        const uint32_t n4 = (min((base_) + 256u, a.num_records) - (base_)) * kRecF4;                                      \
+        float4 *dst = s_rec + kRecF4;                                                                                   \
+        if (tid < n4) dst[tid] = r0_;                                                                                   \
+        if (tid + 256u < n4) dst[tid + 256u] = r1_;                                                                     \
+        if (tid + 512u < n4) dst[tid + 512u] = r2_;                                                                     \
+        if (tid + 768u < n4) dst[tid + 768u] = r3_;                                                                     \
+        if (tid + 1024u < n4) dst[tid + 1024u] = r4_;                                                                   \
+        if (tid + 1280u < n4) dst[tid + 1280u] = r5_;                                                                   \
+        if ((base_) != 0u && tid < (uint32_t)kRecF4) s_rec[tid] = pv;                                                   \
+    }
+// LDS entry: record - group base (10 bits; kBinGroup <= 1024) | tile within the bucket (7) << 10 | bucket (10) << 17
+__global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
+    __shared__ float4 s_rec[257 * kRecF4];
+    __shared__ uint32_t s_pair[kSegCap];
+    __shared__ uint32_t s_cnt[kMaxBuckets];
+    __shared__ uint32_t s_off[kMaxBuckets];
+    __shared__ uint32_t s_n, s_nbig, s_wsum[4];
+    const uint32_t tid = threadIdx.x, group = blockIdx.x, wg_base = group * (uint32_t)kBinGroup;
+    for (uint32_t b = tid; b < (uint32_t)kMaxBuckets; b += 256u) s_cnt[b] = 0u;
+    if (tid == 0u) { s_n = 0u; s_nbig = 0u; }
+    const uint32_t bw_mask = (1u << a.bucket_w_log2) - 1u, bh_mask = (1u << a.bucket_h_log2) - 1u;
+
+    float4 r0_, r1_, r2_, r3_, r4_, r5_, pv;
+    if (wg_base < a.num_records) EV_BIN_FETCH(wg_base)
+    for (int c = 0; c < kBinChunks; c++) {
+        const uint32_t base = wg_base + 256u * (uint32_t)c;
+        if (base >= a.num_records) break;
+        EV_BIN_STAGE(base)
+        __syncthreads();
+        if (c + 1 < kBinChunks && base + 256u < a.num_records) EV_BIN_FETCH(base + 256u)
+        const uint32_t i = base + tid;
+        uint2 rc = make_uint2(1u, 0u);
+        V3 c0 = v3(0.f, 0.f, 0.f);
+        if (i < a.num_records && i != 0u) rc = splat_prepare_one(a, i, &s_rec[(tid + 1u) * kRecF4], &s_rec[tid * kRecF4], c0);
+        const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
+        const float reach2 = photon_reach2(a, c0);
+#if EVPLP_TRAVERSAL_STATS
+        { const int nx_ = tx1 - tx0 + 1, ny_ = ty1 - ty0 + 1; int cls = tx0 > tx1 ? 0 : (nx_ <= 2 && ny_ <= 2) ? 1 : (nx_ <= 3 && ny_ <= 3) ? 2 : 3;
+          atomicAdd(&a.counters->hist[cls], 1ull); if (cls) { atomicAdd(&a.counters->hist[4], (unsigned long long)(nx_ * ny_)); atomicAdd(&a.counters->hist[8 + min(nx_ * ny_, 16)], 1ull); } }
+#endif
+        if (tx0 > tx1) {
+        } else if (tx1 - tx0 <= 2 && ty1 - ty0 <= 2) {
+            // the usual case at the radii of a converging run: up to 3x3 tiles, their boxes fetched together
+            int tx[9], lty[9]; float4 blo[9], bhi[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                tx[q] = tx0 + (q % 3);
+                const int ty = ty0 + (q / 3);
+                lty[q] = (tx[q] <= tx1 && ty <= ty1) ? local_tile_row(a, ty) : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) if (lty[q] >= 0) { const int t = lty[q] * a.tiles_x + tx[q]; blo[q] = a.tile_box[2 * t]; bhi[q] = a.tile_box[2 * t + 1]; }
+            uint32_t hit = 0u;
+#pragma unroll
+            for (int q = 0; q < 9; q++) if (lty[q] >= 0 && box_within(blo[q], bhi[q], c0, reach2)) hit |= 1u << q;
+            // the group's segment holds kSegCap entries (4 per photon on average; the depth cull leaves 1-2): a photon that
+            // does not fit any more goes the slow way
+            const uint32_t cnt = (uint32_t)__builtin_popcount(hit);
+            uint32_t at = cnt ? atomicAdd(&s_n, cnt) : 0u;
+            if (at + cnt > (uint32_t)kSegCap) {
+                for (uint32_t k = at; k < min(at + cnt, (uint32_t)kSegCap); k++) s_pair[k] = 0xffffffffu;
+                a.big_list[(size_t)group * kBinGroup + atomicAdd(&s_nbig, 1u)] = i;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; q++) if (hit & (1u << q)) {
+                    const uint32_t b = (uint32_t)(lty[q] >> a.bucket_h_log2) * (uint32_t)a.buckets_x + (uint32_t)(tx[q] >> a.bucket_w_log2);
+                    const uint32_t tib = (((uint32_t)lty[q] & bh_mask) << a.bucket_w_log2) | ((uint32_t)tx[q] & bw_mask);
+                    atomicAdd(&s_cnt[b], 1u);
+                    s_pair[at++] = (i - wg_base) | (tib << 10) | (b << 17);
+                }
+            }
+        } else {
+            a.big_list[(size_t)group * kBinGroup + atomicAdd(&s_nbig, 1u)] = i;      // -> splat_big_kernel
+        }
+        __syncthreads();
+    }
+    // counting sort of the entries by bucket: exclusive scan of the bucket counts (4 buckets per thread) ...
+    const uint32_t b0 = tid * 4u;
+    const uint32_t c0_ = s_cnt[b0], c1_ = s_cnt[b0 + 1u], c2_ = s_cnt[b0 + 2u], c3_ = s_cnt[b0 + 3u], tsum = c0_ + c1_ + c2_ + c3_;
+    uint32_t x = tsum;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if ((int)(tid & 63u) >= off) x += y; }
+    if ((tid & 63u) == 63u) s_wsum[tid >> 6] = x;
     __syncthreads();
-    uint32_t sum = 0u, mx = 0u;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) { const uint32_t v = cursor[i]; sum += v; mx = max(mx, v); }
-    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off); mx = max(mx, (uint32_t)__shfl_down((int)mx, off)); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_sum, sum); atomicMax(&s_max, mx); }
+    uint32_t excl = x - tsum;
+    for (uint32_t w = 0; w < (tid >> 6); w++) excl += s_wsum[w];
+    s_off[b0] = excl; s_off[b0 + 1u] = excl + c0_; s_off[b0 + 2u] = excl + c0_ + c1_; s_off[b0 + 3u] = excl + c0_ + c1_ + c2_;
+    s_cnt[b0] = 0u; s_cnt[b0 + 1u] = 0u; s_cnt[b0 + 2u] = 0u; s_cnt[b0 + 3u] = 0u;       // now: entries placed per bucket
     __syncthreads();
-    if (threadIdx.x == 0) { summary[0] = s_sum; summary[1] = s_max; }
+    const uint32_t n_raw = min(s_n, (uint32_t)kSegCap), n = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // slots used, entries
+    uint16_t *off_row = a.seg_off + (size_t)group * (a.num_buckets + 1);
+    for (uint32_t b = tid; b <= (uint32_t)a.num_buckets; b += 256u) off_row[b] = (uint16_t)(b < (uint32_t)a.num_buckets ? s_off[b] : n);
+    // ... and the entries leave for the group's segment in bucket order
+    uint32_t *seg = a.seg + (size_t)group * kSegCap;
+    for (uint32_t k = tid; k < n_raw; k += 256u) {
+        const uint32_t e = s_pair[k], b = e >> 17;
+        if (e != 0xffffffffu) seg[s_off[b] + atomicAdd(&s_cnt[b], 1u)] = e & 0x1ffffu;
+    }
+    if (tid == 0u) a.big_count[group] = s_nbig;
+}
+
+// Scatter kernel (kernels.h "Two-level binning"): workgroup (slice, bucket).  Also the pass summary: total entries and the
+// fullest bin, one atomic per workgroup on one of 1024 shard lines.
+__global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_t *items) {
+    constexpr int kTiles = 1 << kBucketTilesLog2;
+    __shared__ uint32_t s_cnt[kTiles], s_base[kTiles], s_max, s_total;
+    const uint32_t tid = threadIdx.x, b = blockIdx.y, group = blockIdx.x * 256u + tid;
+    uint32_t beg = 0u, end = 0u;
+    if (group < (uint32_t)a.num_bin_groups) {
+        const uint16_t *o = a.seg_off + (size_t)group * (a.num_buckets + 1) + b;
+        beg = o[0]; end = o[1];
+    }
+    if (tid < (uint32_t)kTiles) s_cnt[tid] = 0u;
+    if (tid == 0u) { s_max = 0u; s_total = 0u; }
+    __syncthreads();
+    const uint32_t *seg = a.seg + (size_t)group * kSegCap;
+    for (uint32_t k = beg; k < end; k++) atomicAdd(&s_cnt[seg[k] >> 10], 1u);
+    __syncthreads();
+    const uint32_t bx = b % (uint32_t)a.buckets_x, by = b / (uint32_t)a.buckets_x, bw_mask = (1u << a.bucket_w_log2) - 1u;
+    auto tile_of = [&](uint32_t t) -> uint32_t {
+        return ((by << a.bucket_h_log2) + (t >> a.bucket_w_log2)) * (uint32_t)a.tiles_x + (bx << a.bucket_w_log2) + (t & bw_mask);
+    };
+    if (tid < (uint32_t)kTiles) {
+        const uint32_t c = s_cnt[tid];
+        if (c != 0u) {
+            const uint32_t at = atomicAdd(&a.tile_cursor[tile_of(tid)], c);
+            s_base[tid] = at; s_cnt[tid] = 0u;                           // now: entries placed per tile
+            atomicMax(&s_max, at + c); atomicAdd(&s_total, c);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = beg; k < end; k++) {
+        const uint32_t e = seg[k], t = e >> 10, pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+        if (pos < a.bin_stride) items[(size_t)tile_of(t) * a.bin_stride + pos] = group * (uint32_t)kBinGroup + (e & 1023u);
+    }
+    if (tid == 0u && s_total != 0u) {
+        uint32_t *sh = a.summary + ((blockIdx.y * gridDim.x + blockIdx.x) & (uint32_t)(kSummaryShards - 1)) * kSummaryStride;
+        atomicAdd(&sh[0], s_total);
+        const uint32_t fullest = s_max;
+        if (fullest > __builtin_nontemporal_load(&sh[1])) atomicMax(&sh[1], fullest);
+        if (fullest > a.bin_stride) atomicMax(a.overflow, fullest);
+    }
+}
+
+// Photons whose rectangle is larger than 3x3 tiles (huge radii, or closer to the eye than a few radii) and those that did not
+// fit into their group's segment: workgroup g takes the list of bin-group g, one wave per photon, lanes over the tiles of the
+// rectangle, one atomic per entry.  Rectangles of more than 64 tiles are not depth-culled.
+__global__ __launch_bounds__(256) void splat_big_kernel(SplatArgs a, uint32_t *items) {
+    __shared__ uint32_t s_sum[4][2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, group = blockIdx.x;
+    const uint32_t nbig = a.big_count[group];
+    if (nbig == 0u) return;
+    uint32_t entries = 0u, fullest = 0u;
+    for (uint32_t k = wave; k < nbig; k += 4u) {
+        const uint32_t i = a.big_list[(size_t)group * kBinGroup + k];
+        const V3 c0 = v3(a.compact[(size_t)i * kCompactF4]);
+        const uint2 rc = photon_rect(a, c0);
+        const int tx0 = rc.x & 0xffff, tx1 = rc.x >> 16, ty0 = rc.y & 0xffff, ty1 = rc.y >> 16;
+        const float reach2 = photon_reach2(a, c0);
+        const uint32_t nx = (uint32_t)(tx1 - tx0 + 1), total = nx * (uint32_t)(ty1 - ty0 + 1);
+        const bool small = total <= 64u;
+        for (uint32_t q = lane; q < total; q += 64u) {
+            const int tx = tx0 + (int)(q % nx), ly = local_tile_row(a, ty0 + (int)(q / nx));
+            if (ly < 0) continue;
+            const int t = ly * a.tiles_x + tx;
+            if (small && !box_within(a.tile_box[2 * t], a.tile_box[2 * t + 1], c0, reach2)) continue;
+            const uint32_t slot = atomicAdd(&a.tile_cursor[t], 1u);
+            entries++; fullest = max(fullest, slot + 1u);
+            if (slot < a.bin_stride) items[(size_t)t * a.bin_stride + slot] = i;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { entries += __shfl_xor(entries, off); fullest = max(fullest, (uint32_t)__shfl_xor((int)fullest, off)); }
+    if (lane == 0u) { s_sum[wave][0] = entries; s_sum[wave][1] = fullest; }
+    __syncthreads();
+    if (tid == 0u) {
+        entries = s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0];
+        fullest = max(max(s_sum[0][1], s_sum[1][1]), max(s_sum[2][1], s_sum[3][1]));
+        if (entries != 0u) {
+            uint32_t *sh = a.summary + (group & (uint32_t)(kSummaryShards - 1)) * kSummaryStride;
+            atomicAdd(&sh[0], entries);
+            if (fullest > __builtin_nontemporal_load(&sh[1])) atomicMax(&sh[1], fullest);
+            if (fullest > a.bin_stride) atomicMax(a.overflow, fullest);
+        }
+    }
 }
 
 // deterministic mode: rank sort of every bin (ids are unique) so pixels accumulate in record order
@@ -214,7 +392,7 @@ __global__ __launch_bounds__(256) void splat_sort_kernel(const uint32_t *cursor,
 }
 
 template <int WAVES>   // waves per tile: 1 (four tiles per workgroup) or 4 (one tile per workgroup, for launches with very full bins)
-__global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
+__global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
     // One workgroup = one tile; its four waves share the bin (wave w takes the 64-photon batches w, w + 4, ...) and
     // their per-pixel sums are folded in wave order: the fullest bins (tiles that see a floor at grazing angle) set
     // the duration of the launch.
@@ -223,6 +401,12 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int part = WAVES == 4 ? wave : 0;                       // this wave's share of the bin
     const int tile = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (blockIdx.x == 0 && wave == 0) {                                   // fold the bin kernel's summary shards
+        uint32_t sum = 0u, mx = 0u;
+        for (int k = lane; k < kSummaryShards; k += 64) { sum += a.summary[k * kSummaryStride]; mx = max(mx, a.summary[k * kSummaryStride + 1]); }
+        for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); }
+        if (lane == 0) { a.summary[kSummaryFinal] = sum; a.summary[kSummaryFinal + 1] = mx; }
+    }
     if (tile >= a.tiles_x * a.tiles_y || *a.overflow != 0u) return;                    // (WAVES == 1 only: whole waves leave, no barrier below)
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
@@ -251,19 +435,29 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
         if ((uint32_t)lane < n) {
             uint32_t id = a.bin_items[base + lane];
             const float4 *c = a.compact + (size_t)id * kCompactF4;
-            float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-            stage[lane * kCompactF4 + 0] = c0; stage[lane * kCompactF4 + 1] = c1;
-            stage[lane * kCompactF4 + 2] = c2; stage[lane * kCompactF4 + 3] = c3;
+            float4 c0 = c[0], c1 = c[1], c2 = c[2];
+            stage[0 * 64 + lane] = c0; stage[1 * 64 + lane] = c1;         // [field][photon]: a lane-per-photon read is conflict-free
+            stage[2 * 64 + lane] = c2;
+            if (mode == 5u) stage[3 * 64 + lane] = c[3];
         }
         __builtin_amdgcn_wave_barrier();
+        // Pass 1: the radius test of every (pixel, photon) of the batch -> one 64-bit mask per pixel.  A photon reaches ~3 of a
+        // tile's 64 pixels at the radii of a converging run: running the shading under `if (inside)` for every photon that
+        // reaches ANY pixel kept 3 lanes of 64 busy.
+        uint64_t mask = 0ull;
         for (uint32_t j = 0; j < n; j++) {
-            float4 c0 = stage[j * kCompactF4 + 0];
-            V3 dv = v3(c0) - X;
-            bool inside = in_image && !(dot(dv, dv) > r2);                // frag:153-154
-            if (__ballot(inside) == 0ull) continue;
-            float4 c1 = stage[j * kCompactF4 + 1], c2 = stage[j * kCompactF4 + 2];
-            if (inside) {
-                pairs++;
+            V3 dv = v3(stage[j]) - X;
+            mask |= (uint64_t)(!(dot(dv, dv) > r2)) << j;                 // frag:153-154
+        }
+        if (!in_image) mask = 0ull;
+        pairs += (uint32_t)__builtin_popcountll(mask);
+        // Pass 2: every pixel walks ITS photons in ascending order (the accumulation order of the one-photon-at-a-time loop);
+        // the wave runs max-over-pixels iterations instead of one per photon.
+        while (__ballot(mask != 0ull) != 0ull) {
+            if (mask != 0ull) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                float4 c0 = stage[j], c1 = stage[64 + j], c2 = stage[128 + j];
                 V3 w12 = v3(c1);
                 V3 brdf1 = g_lambert_eval(w10, w12, sn, sd);                                       // frag:181
                 if (tile_glossy) brdf1 = brdf1 + g_phong_eval(w10, w12, sn, sps, se);
@@ -277,7 +471,7 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
                             float g = cc / c1.w;
                             if (mode == 4u) col = (brdf1 * v3(c2)) * fmaxf(g - clampv, 0.0f) / g;
                             else {
-                                V3 brdf2 = v3(stage[j * kCompactF4 + 3]);
+                                V3 brdf2 = v3(stage[192 + j]);
                                 V3 num = (brdf1 * brdf2) * g;
                                 num = v3(fmaxf(num.x - clampv, 0.f), fmaxf(num.y - clampv, 0.f), fmaxf(num.z - clampv, 0.f));
                                 V3 den = brdf2 * g;
@@ -309,14 +503,15 @@ __global__ __launch_bounds__(256) void splat_tiles_kernel(SplatArgs a) {
     }
 }
 
-// Phase A: tile depth ranges, compact photons + bins, summary.
+// Phase A: tile boxes (+ cleared cursors and summary), compact photons + bucket-sorted segments, segments -> tile bins
+// (+ summary), large photons.
 void launch_splat_bin(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-    hipMemsetAsync(a.tile_cursor, 0, sizeof(uint32_t) * ntiles, s);
-    hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
-    const uint32_t nb = (a.num_records + 255) / 256;
-    hipLaunchKernelGGL(splat_bin_kernel, dim3(nb), dim3(256), 0, s, a, a.deterministic ? a.bin_items_tmp : a.bin_items);
-    hipLaunchKernelGGL(splat_summary_kernel, dim3(1), dim3(1024), 0, s, a.tile_cursor, ntiles, a.summary);
+    hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);
+    uint32_t *items = a.deterministic ? a.bin_items_tmp : a.bin_items;
+    hipLaunchKernelGGL(splat_bin_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(splat_scatter_kernel, dim3(((uint32_t)a.num_bin_groups + 255u) / 256u, (uint32_t)a.num_buckets), dim3(256), 0, s, a, items);
+    hipLaunchKernelGGL(splat_big_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), 0, s, a, items);
 }
 // Phase B: (deterministic: sort the bins) and accumulate the tiles.  Both do nothing when a bin overflowed.
 void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {
