@@ -4,6 +4,7 @@
 //   LBVH : 63-bit Morton codes of triangle centroids, sorted, hierarchy split at the highest
 //          differing code bit (the Karras radix-tree topology, built top-down on the host).
 //   SAH  : top-down binned surface-area heuristic (16 bins).
+//   SBVH : the same with spatial splits (triangle references clipped at the split plane; a triangle may sit in several leaves).
 // Static scenes are built once per run like the reference's accel, so the host is acceptable.
 #include "evplp_types.h"
 
@@ -164,6 +165,171 @@ struct Builder {
         nodes[id].left = l; nodes[id].right = r;
         return finish_inner(id);
     }
+
+    // ---- SAH with spatial splits (SBVH) ---------------------------------------------------
+    // Stich, Friedrich, Dietrich 2009: besides the object split (partition of the references by centroid), every node
+    // tries a SPATIAL split -- a plane that cuts straddling triangles into two references with clipped boxes -- whenever the
+    // children of the best object split overlap.  Long or diagonal triangles (table tops, blinds, walls next to clutter)
+    // otherwise force large, overlapping boxes that every shadow segment in the neighbourhood has to enter.  A triangle
+    // may end up in several leaves; the walks do not mind (any-hit: the same answer; closest hit: ties keep the lowest
+    // original index).
+    struct Ref { int32_t tri; Box box; };
+    float root_area = 0.f;
+    size_t ref_budget = 0, refs_total = 0;       // duplication is capped
+    // bounds of triangle `tri` clipped to lo <= x[axis] <= hi (Sutherland-Hodgman against the two planes)
+    Box clip_tri(int32_t tri, int axis, float lo, float hi) const {
+        const float *v = verts + 9 * (size_t)tri;
+        float poly[8][3], tmp[8][3]; int n = 3;
+        for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) poly[i][k] = v[3 * i + k];
+        for (int side = 0; side < 2; side++) {
+            const float plane = side == 0 ? lo : hi, sign = side == 0 ? 1.f : -1.f;
+            int m = 0;
+            for (int i = 0; i < n; i++) {
+                const float *a = poly[i], *b = poly[(i + 1) % n];
+                const float da = sign * (a[axis] - plane), db = sign * (b[axis] - plane);
+                if (da >= 0.f) { for (int k = 0; k < 3; k++) tmp[m][k] = a[k]; m++; }
+                if ((da > 0.f && db < 0.f) || (da < 0.f && db > 0.f)) {
+                    const float t = da / (da - db);
+                    for (int k = 0; k < 3; k++) tmp[m][k] = a[k] + t * (b[k] - a[k]);
+                    tmp[m][axis] = plane; m++;
+                }
+            }
+            n = m;
+            for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) poly[i][k] = tmp[i][k];
+            if (n == 0) break;
+        }
+        Box b; b.reset();
+        for (int i = 0; i < n; i++) b.grow(poly[i]);
+        return b;
+    }
+    static Box intersect(const Box &a, const Box &b) {
+        Box r; for (int k = 0; k < 3; k++) { r.lo[k] = std::max(a.lo[k], b.lo[k]); r.hi[k] = std::min(a.hi[k], b.hi[k]); }
+        return r;
+    }
+    static bool valid(const Box &b) { return b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]; }
+    int32_t sbvh_leaf(const std::vector<Ref> &refs) {
+        TempNode n; n.first = (int32_t)ids.size(); n.count = (int32_t)refs.size(); n.box.reset();
+        for (const Ref &r : refs) { ids.push_back(r.tri); n.box.grow(r.box); }
+        nodes.push_back(n);
+        return (int32_t)nodes.size() - 1;
+    }
+    int32_t sbvh_rec(std::vector<Ref> &refs, int d) {
+        depth = std::max(depth, d);
+        const int32_t count = (int32_t)refs.size();
+        if (count <= 2) return sbvh_leaf(refs);
+        Box cb; cb.reset(); Box bb; bb.reset();
+        for (const Ref &r : refs) {
+            float c[3]; for (int k = 0; k < 3; k++) c[k] = 0.5f * (r.box.lo[k] + r.box.hi[k]);
+            cb.grow(c); bb.grow(r.box);
+        }
+        constexpr int NB = 16;
+        // object split
+        float obj_cost = 3.0e38f; int obj_axis = -1, obj_bin = -1; Box obj_l, obj_r;
+        for (int axis = 0; axis < 3; axis++) {
+            const float lo = cb.lo[axis], ext = cb.hi[axis] - lo;
+            if (!(ext > 0.f)) continue;
+            Box bins[NB]; int cnt[NB];
+            for (int b = 0; b < NB; b++) { bins[b].reset(); cnt[b] = 0; }
+            const float scale = NB / ext;
+            for (const Ref &r : refs) {
+                const int b = std::min(NB - 1, (int)((0.5f * (r.box.lo[axis] + r.box.hi[axis]) - lo) * scale));
+                bins[b].grow(r.box); cnt[b]++;
+            }
+            Box rb[NB]; int rc[NB]; Box acc; acc.reset(); int c = 0;
+            for (int b = NB - 1; b > 0; b--) { acc.grow(bins[b]); c += cnt[b]; rb[b] = acc; rc[b] = c; }
+            acc.reset(); c = 0;
+            for (int b = 0; b < NB - 1; b++) {
+                acc.grow(bins[b]); c += cnt[b];
+                if (c == 0 || rc[b + 1] == 0) continue;
+                const float cost = acc.area() * (float)c + rb[b + 1].area() * (float)rc[b + 1];
+                if (cost < obj_cost) { obj_cost = cost; obj_axis = axis; obj_bin = b; obj_l = acc; obj_r = rb[b + 1]; }
+            }
+        }
+        // spatial split: only where the object split leaves overlapping children, and while the duplication budget lasts
+        float sp_cost = 3.0e38f; int sp_axis = -1; float sp_pos = 0.f;
+        bool try_spatial = refs_total < ref_budget;
+        if (try_spatial && obj_axis >= 0) {
+            const Box ov = intersect(obj_l, obj_r);
+            try_spatial = valid(ov) && ov.area() > 1e-5f * root_area;
+        }
+        if (try_spatial) {
+            for (int axis = 0; axis < 3; axis++) {
+                const float lo = bb.lo[axis], ext = bb.hi[axis] - lo;
+                if (!(ext > 0.f)) continue;
+                Box bins[NB]; int enter[NB], leave[NB];
+                for (int b = 0; b < NB; b++) { bins[b].reset(); enter[b] = leave[b] = 0; }
+                const float scale = NB / ext, width = ext / NB;
+                for (const Ref &r : refs) {
+                    const int b0 = std::min(NB - 1, std::max(0, (int)((r.box.lo[axis] - lo) * scale)));
+                    const int b1 = std::min(NB - 1, std::max(b0, (int)((r.box.hi[axis] - lo) * scale)));
+                    enter[b0]++; leave[b1]++;
+                    if (b0 == b1) { bins[b0].grow(r.box); continue; }
+                    for (int b = b0; b <= b1; b++) {
+                        Box c = intersect(clip_tri(r.tri, axis, lo + width * (float)b, lo + width * (float)(b + 1)), r.box);
+                        if (valid(c)) bins[b].grow(c);
+                    }
+                }
+                Box rb[NB]; int rc[NB]; Box acc; acc.reset(); int c = 0;
+                for (int b = NB - 1; b > 0; b--) { acc.grow(bins[b]); c += leave[b]; rb[b] = acc; rc[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    acc.grow(bins[b]); c += enter[b];
+                    if (c == 0 || rc[b + 1] == 0 || c == count || rc[b + 1] == count) continue;   // a plane that separates nothing
+                    const float cost = acc.area() * (float)c + rb[b + 1].area() * (float)rc[b + 1];
+                    if (cost < sp_cost) { sp_cost = cost; sp_axis = axis; sp_pos = lo + width * (float)(b + 1); }
+                }
+            }
+        }
+        const float best_cost = std::min(obj_cost, sp_cost);
+        if (count <= kMaxLeafTris) {
+            const float leaf_cost = (float)count * bb.area();
+            if (best_cost >= 3.0e38f || best_cost + sah_ct * bb.area() >= leaf_cost) return sbvh_leaf(refs);
+        }
+        std::vector<Ref> left, right;
+        if (sp_cost < obj_cost) {
+            for (const Ref &r : refs) {
+                if (r.box.hi[sp_axis] <= sp_pos) left.push_back(r);
+                else if (r.box.lo[sp_axis] >= sp_pos) right.push_back(r);
+                else {
+                    Ref a = { r.tri, intersect(clip_tri(r.tri, sp_axis, -3.0e38f, sp_pos), r.box) };
+                    Ref b = { r.tri, intersect(clip_tri(r.tri, sp_axis, sp_pos, 3.0e38f), r.box) };
+                    const bool va = valid(a.box), vb = valid(b.box);
+                    if (va) left.push_back(a);
+                    if (vb) right.push_back(b);
+                    if (va && vb) refs_total++;
+                    if (!va && !vb) left.push_back(r);      // (numerically empty on both sides: keep it whole)
+                }
+            }
+            if (left.empty() || right.empty() || ((int32_t)left.size() == count && (int32_t)right.size() == count)) { left.clear(); right.clear(); }
+        }
+        if (left.empty() && obj_axis >= 0) {
+            const float lo = cb.lo[obj_axis], scale = NB / (cb.hi[obj_axis] - lo);
+            for (const Ref &r : refs) {
+                const int b = std::min(NB - 1, (int)((0.5f * (r.box.lo[obj_axis] + r.box.hi[obj_axis]) - lo) * scale));
+                (b <= obj_bin ? left : right).push_back(r);
+            }
+        }
+        if (left.empty() || right.empty()) {       // all centroids coincide: split the list in the middle
+            left.assign(refs.begin(), refs.begin() + count / 2); right.assign(refs.begin() + count / 2, refs.end());
+        }
+        std::vector<Ref>().swap(refs);
+        const int32_t id = (int32_t)nodes.size(); nodes.emplace_back();
+        const int32_t l = sbvh_rec(left, d + 1);
+        const int32_t r = sbvh_rec(right, d + 1);
+        nodes[id].left = l; nodes[id].right = r;
+        return finish_inner(id);
+    }
+    int32_t build_sbvh() {
+        std::vector<Ref> refs; refs.reserve(ids.size());
+        Box bb; bb.reset();
+        for (int32_t t : ids) { refs.push_back({ t, tbox[t] }); bb.grow(tbox[t]); }
+        root_area = bb.area();
+        float dup = 0.3f;
+        if (const char *e = std::getenv("EVPLP_SBVH_DUP")) dup = (float)atof(e);
+        refs_total = refs.size(); ref_budget = refs.size() + (size_t)(dup * (float)refs.size());
+        ids.clear();
+        return sbvh_rec(refs, 0);
+    }
 };
 
 inline void precompute_tri(const float *v, TriPair *tp, int half) {
@@ -192,10 +358,10 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
         if (area > 0.0f && !std::isinf(area)) { B.ids.push_back(i); scene.grow(tb); }
     }
     int32_t nvalid = (int32_t)B.ids.size();
-    B.nodes.reserve((size_t)2 * std::max(nvalid, 1) + 2);
+    B.nodes.reserve((size_t)3 * std::max(nvalid, 1) + 2);
     int32_t root = -1;
     if (const char *e = std::getenv("EVPLP_SAH_CT")) B.sah_ct = (float)atof(e);
-    if (nvalid > 0) root = (builder == EVPLP_BVH_SAH) ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
+    if (nvalid > 0) root = builder == EVPLP_BVH_SBVH ? B.build_sbvh() : builder == EVPLP_BVH_SAH ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
 
     // conservative padding: the device slab test is inexact, the triangle test is exact; a padded
     // box guarantees no triangle the exact test accepts is ever culled.  Error budget of the slab tests (coordinates bounded

@@ -292,7 +292,9 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     }
     if (light_count <= 0) { c->set_error("evplp_build_accel: the area-light mesh has no triangles"); return EVPLP_ERR_INVALID; }
     BvhBuild bb;
-    build_bvh(verts.data(), (int32_t)attrs.size(), c->cfg.bvh_builder, &bb);
+    int builder = c->cfg.bvh_builder;
+    if (const char *env = std::getenv("EVPLP_BVH_BUILDER")) builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : EVPLP_BVH_SAH;   // tests: every suite under every builder
+    build_bvh(verts.data(), (int32_t)attrs.size(), builder, &bb);
     c->accel_nodes = bb.nnodes; c->accel_leaves = bb.nleaves; c->accel_depth = bb.depth; c->accel_build_ms = bb.build_ms;
     if (bb.depth > kMaxDepth - 2) { free_bvh(&bb); c->set_error("BVH depth %d exceeds the traversal stack (%d)", bb.depth, kMaxDepth); return EVPLP_ERR_INVALID; }
     // area-light CDF, rt/rtcommon.h:501-531 (running float sum, then normalised); Triangle::ComputeArea

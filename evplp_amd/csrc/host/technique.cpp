@@ -25,6 +25,13 @@
 namespace evplp {
 
 namespace {
+// build-only key "bvhBuilder"
+int parse_bvh_builder(const std::string &v) {
+    if (v == "sah") return EVPLP_BVH_SAH;
+    if (v == "sbvh") return EVPLP_BVH_SBVH;
+    if (v == "lbvh") return EVPLP_BVH_LBVH;
+    throw std::runtime_error("bvhBuilder: expected \"sah\", \"sbvh\" or \"lbvh\", got \"" + v + "\"");
+}
 const std::map<std::string, int> kFrameModes = { { "accumulate", 1 }, { "cleareveryframe", 2 } };   // rtcomphoton.h:1194-1197
 const std::map<std::string, int> kMisModes = { { "one", 0 }, { "balance", 1 }, { "max", 2 }, { "power2", 3 },
                                                { "geometryClamp", 4 }, { "geometryBrdfClamp", 5 } }; // :1199-1206
@@ -130,7 +137,7 @@ public:
         num_max_bounce = (int)json.at("numMaxBounces").as_int("numMaxBounces");
         write_every_frame = json.has("writeEveryFrame") ? json.at("writeEveryFrame").as_bool("writeEveryFrame") : false;
         int bvh_builder = EVPLP_BVH_SAH;
-        if (json.has("bvhBuilder")) bvh_builder = json.at("bvhBuilder").as_string("bvhBuilder") == "sah" ? EVPLP_BVH_SAH : EVPLP_BVH_LBVH;
+        if (json.has("bvhBuilder")) bvh_builder = parse_bvh_builder(json.at("bvhBuilder").as_string("bvhBuilder"));
 
         evplp_config cfg; std::memset(&cfg, 0, sizeof(cfg));
         cfg.abi_version = EVPLP_ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y;
@@ -245,7 +252,7 @@ public:
         }
         if (num_vpl_light_paths == 0) { std::printf("WARN: 0 VPL light paths. Disable mDoVplSplat\n"); do_vpl_splat = false; }   // :200-203
         if (!lvc && json.has("forceVsl")) force_vsl = json.at("forceVsl").as_bool("forceVsl");
-        if (json.has("bvhBuilder")) bvh_builder = json.at("bvhBuilder").as_string("bvhBuilder") == "sah" ? EVPLP_BVH_SAH : EVPLP_BVH_LBVH;   // build-only key
+        if (json.has("bvhBuilder")) bvh_builder = parse_bvh_builder(json.at("bvhBuilder").as_string("bvhBuilder"));   // build-only key
 
         // ---- setup(): context + scene upload (replaces GL/OptiX setup :646-708)
         evplp_config cfg; std::memset(&cfg, 0, sizeof(cfg));
