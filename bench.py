@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--workload", default="ir", choices=sorted(WORKLOADS))
     ap.add_argument("--scene", default="hard", choices=["hard", "easy"])
     ap.add_argument("--mis", default="", help="override misMode")
-    ap.add_argument("--bvh", default="sah", choices=["sah", "sbvh", "lbvh"], help="acceleration-structure builder (same flattened node format)")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "sbvh", "lbvh", "gpu"], help="acceleration-structure builder (same flattened node format)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other scene, 16384-slot variant, GPU path tracer)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="path-tracer iterations of the CPU baseline sample (0 = auto, ~12 s)")
@@ -217,7 +217,7 @@ def main():
         dist.barrier()
 
     strip_rows = 8      # finest interleave (tiles are 8 rows)
-    builder = {"sah": ev.BVH_SAH, "sbvh": ev.BVH_SBVH, "lbvh": ev.BVH_LBVH}[a.bvh]
+    builder = {"sah": ev.BVH_SAH, "sbvh": ev.BVH_SBVH, "lbvh": ev.BVH_LBVH, "gpu": ev.BVH_LBVH_GPU}[a.bvh]
 
     def make_ctx(path, nl, nv):
         c = ev.Context(W, H, nl, nv, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows, bvh_builder=builder)
@@ -374,8 +374,8 @@ def main():
                   "tiles_kernel_ms": sum(splat_tiles_ms) / len(splat_tiles_ms), "pairs_per_frame": spairs / a.steps, "algorithmic_bytes": nrec_bytes}
             tpath = os.path.join(ROOT, "profiles", "traffic_splat.json")
             if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("config") == f"{wl}:{a.scene}:{W}x{H}:{n_ranks}":
+                tj = json.load(open(tpath)).get("configs", {}).get(f"{wl}:{a.scene}:{W}x{H}:{n_ranks}")
+                if tj:
                     rs["traffic"] = tj.get("hbm_bytes_per_pass"); rs["traffic_source"] = "profiles/traffic_splat.json (committed PMC summary; not measured inside this run)"
             if wl == "ppm":
                 out["roofline"] = rs

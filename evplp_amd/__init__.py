@@ -27,7 +27,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_OOM = 0, -1, -2,
 USABLE_VPL, USABLE_PHOTON, LAMBERT_ONLY, PHONG_ONLY = 1, 2, 4, 8
 # EMis (rtcomphoton.h:64-72, string map :1199-1206)
 MIS_MODES = {"one": 0, "balance": 1, "max": 2, "power2": 3, "geometryClamp": 4, "geometryBrdfClamp": 5}
-BVH_LBVH, BVH_SAH, BVH_SBVH = 0, 1, 2
+BVH_LBVH, BVH_SAH, BVH_SBVH, BVH_LBVH_GPU = 0, 1, 2, 3
 (BUF_RECORDS, BUF_GBUF_POSITION, BUF_GBUF_NORMAL, BUF_GBUF_DIFFUSE, BUF_GBUF_PHONG, BUF_LIGHT,
  BUF_VPL_ACCUM, BUF_PHOTON_ACCUM, BUF_COUNT) = range(9)
 (PASS_PRIMARY, PASS_LIGHT_TRACE, PASS_GATHER_VPL, PASS_GATHER_VSL, PASS_SPLAT, PASS_RESOLVE, PASS_PATH_TRACE,

@@ -370,8 +370,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     // 1e-4 of its length short of the surface it ends on (lighttracing.cu:292), and only while pad < 1e-4 |d_perp| does it stay
     // out of the leaf boxes of that surface -- with the former 2e-5 D every segment shorter than 6 units entered the leaf under
     // its end point, and a beam shaft every leaf under its tile's footprint.
-    float pad_scale = 4e-6f;
-    if (const char *e = std::getenv("EVPLP_BVH_PAD")) pad_scale = (float)atof(e);
+    const float pad_scale = bvh_pad_scale();
     float diag = 0.f;
     if (nvalid > 0) { float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2]; diag = std::sqrt(dx * dx + dy * dy + dz * dz); }
     const float pad = pad_scale * diag + 1e-30f;
@@ -446,6 +445,12 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     out->nleaves = nleaves; out->depth = B.depth + 1;
     out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
+}
+
+float bvh_pad_scale() {
+    float pad_scale = 4e-6f;
+    if (const char *e = std::getenv("EVPLP_BVH_PAD")) pad_scale = (float)atof(e);
+    return pad_scale;
 }
 
 void free_bvh(BvhBuild *b) {

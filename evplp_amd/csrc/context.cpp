@@ -293,10 +293,17 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     if (light_count <= 0) { c->set_error("evplp_build_accel: the area-light mesh has no triangles"); return EVPLP_ERR_INVALID; }
     BvhBuild bb;
     int builder = c->cfg.bvh_builder;
-    if (const char *env = std::getenv("EVPLP_BVH_BUILDER")) builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : EVPLP_BVH_SAH;   // tests: every suite under every builder
-    build_bvh(verts.data(), (int32_t)attrs.size(), builder, &bb);
+    if (const char *env = std::getenv("EVPLP_BVH_BUILDER"))   // tests: every suite under every builder
+        builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : !std::strcmp(env, "gpu") ? EVPLP_BVH_LBVH_GPU : EVPLP_BVH_SAH;
+    if (builder == EVPLP_BVH_LBVH_GPU) {
+        BvhDeviceBuild gb;
+        const int e = build_bvh_gpu(verts.data(), (int32_t)attrs.size(), bvh_pad_scale(), c->stream, &gb);
+        if (e != 0) { c->set_error("evplp_build_accel: device LBVH build: %s", hipGetErrorString((hipError_t)e)); return EVPLP_ERR_HIP; }
+        c->sc.nodes = gb.nodes; c->sc.leaves = gb.leaves; c->sc.tri_flat = gb.tri_flat; c->sc.tri_index = gb.tri_index;
+        bb.nnodes = gb.nnodes; bb.nleaves = gb.nleaves; bb.depth = gb.depth; bb.build_ms = gb.build_ms; bb.ntris = gb.ntris;
+    } else build_bvh(verts.data(), (int32_t)attrs.size(), builder, &bb);
     c->accel_nodes = bb.nnodes; c->accel_leaves = bb.nleaves; c->accel_depth = bb.depth; c->accel_build_ms = bb.build_ms;
-    if (bb.depth > kMaxDepth - 2) { free_bvh(&bb); c->set_error("BVH depth %d exceeds the traversal stack (%d)", bb.depth, kMaxDepth); return EVPLP_ERR_INVALID; }
+    if (bb.depth > kMaxDepth - 2) { free_bvh(&bb); free_scene_device(c); c->set_error("BVH depth %d exceeds the traversal stack (%d)", bb.depth, kMaxDepth); return EVPLP_ERR_INVALID; }
     // area-light CDF, rt/rtcommon.h:501-531 (running float sum, then normalised); Triangle::ComputeArea
     auto tri_area = [](const float *v) {
         float a[3] = { v[3] - v[0], v[4] - v[1], v[5] - v[2] }, b[3] = { v[6] - v[0], v[7] - v[1], v[8] - v[2] };
@@ -328,10 +335,12 @@ extern "C" int evplp_build_accel(evplp_context *c) {
         tdesc.push_back(d);
     }
     int rc;
-    if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
-    if ((rc = upload_array(c, bb.leaves, (size_t)std::max(bb.nleaves, 1), &c->sc.leaves))) { free_bvh(&bb); return rc; }
-    if ((rc = upload_array(c, bb.tri_index, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
-    if ((rc = upload_array(c, bb.tri_flat, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_flat))) { free_bvh(&bb); return rc; }
+    if (builder != EVPLP_BVH_LBVH_GPU) {
+        if ((rc = upload_array(c, bb.nodes, (size_t)bb.nnodes, &c->sc.nodes))) { free_bvh(&bb); return rc; }
+        if ((rc = upload_array(c, bb.leaves, (size_t)std::max(bb.nleaves, 1), &c->sc.leaves))) { free_bvh(&bb); return rc; }
+        if ((rc = upload_array(c, bb.tri_index, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_index))) { free_bvh(&bb); return rc; }
+        if ((rc = upload_array(c, bb.tri_flat, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_flat))) { free_bvh(&bb); return rc; }
+    }
     c->sc.ntris = bb.ntris; c->sc.bvh_depth = bb.depth;
     free_bvh(&bb);
     if ((rc = upload_array(c, attrs.data(), attrs.size(), &c->sc.attrs))) return rc;

@@ -105,9 +105,17 @@ struct BvhBuild {
     int32_t nleaves = 0, depth = 0;
     float build_ms = 0.f;
 };
+// Device-side build (bvh_gpu.hip): the four arrays are device allocations handed to the caller.
+struct BvhDeviceBuild {
+    BvhNode *nodes = nullptr; LeafBlock *leaves = nullptr; TriFlat *tri_flat = nullptr; int32_t *tri_index = nullptr;
+    int32_t nnodes = 0, nleaves = 0, ntris = 0, depth = 0;
+    float build_ms = 0.f;
+};
 // verts: 9 floats per original triangle.  Degenerate triangles (rt/triangleintersect.cu:62-81
 // meshBound invalidates them) are dropped.  Returns 0 on success.
 int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out);
+// box padding of both builders, as a fraction of the scene diagonal (bvh_build.cpp explains the value)
+float bvh_pad_scale();
 void free_bvh(BvhBuild *b);
 
 } // namespace evplp

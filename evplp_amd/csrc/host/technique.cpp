@@ -30,7 +30,8 @@ int parse_bvh_builder(const std::string &v) {
     if (v == "sah") return EVPLP_BVH_SAH;
     if (v == "sbvh") return EVPLP_BVH_SBVH;
     if (v == "lbvh") return EVPLP_BVH_LBVH;
-    throw std::runtime_error("bvhBuilder: expected \"sah\", \"sbvh\" or \"lbvh\", got \"" + v + "\"");
+    if (v == "gpu") return EVPLP_BVH_LBVH_GPU;
+    throw std::runtime_error("bvhBuilder: expected \"sah\", \"sbvh\", \"lbvh\" or \"gpu\", got \"" + v + "\"");
 }
 const std::map<std::string, int> kFrameModes = { { "accumulate", 1 }, { "cleareveryframe", 2 } };   // rtcomphoton.h:1194-1197
 const std::map<std::string, int> kMisModes = { { "one", 0 }, { "balance", 1 }, { "max", 2 }, { "power2", 3 },

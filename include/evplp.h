@@ -63,7 +63,8 @@ typedef enum evplp_mis_mode {
 typedef enum evplp_bvh_builder {
     EVPLP_BVH_LBVH = 0,   /* Morton-code LBVH (Karras topology) */
     EVPLP_BVH_SAH = 1,    /* binned-SAH top-down build into the same flattened node format (default of the host side) */
-    EVPLP_BVH_SBVH = 2    /* binned SAH with spatial splits (triangle references clipped at split planes; ~30 % more leaf slots) */
+    EVPLP_BVH_SBVH = 2,   /* binned SAH with spatial splits (triangle references clipped at split planes; ~20 % more leaf slots) */
+    EVPLP_BVH_LBVH_GPU = 3 /* the LBVH built on the device (Morton sort, Karras hierarchy, bottom-up refit): for scenes that change */
 } evplp_bvh_builder;
 
 /* Creation-time configuration: what RtComPhoton::render fixes before setup()

@@ -12,7 +12,7 @@ for wl in ir evplp ppm; do
   find $O/kt_$wl -name "*kernel_trace.csv" -delete; find $O/kt_$wl -name "*_agent_info.csv" -delete
 done
 pmc() { wl=$1; name=$2; shift 2; rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_${wl}_$name -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_${wl}_$name.log 2>&1; }
-for wl in ir evplp; do
+for wl in ir evplp ppm; do
   pmc $wl a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU
   pmc $wl b SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_REQ SQ_INST_LEVEL_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_WAIT_INST_ANY
   pmc $wl c GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_LEVEL_WAVES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS_F32
@@ -23,6 +23,7 @@ done
 cd $ROOT
 python3 tools/pmc_summary.py $O ir > $O/${tag}_bench_ir_pmc.txt 2>&1
 python3 tools/pmc_summary.py $O evplp > $O/${tag}_bench_evplp_pmc.txt 2>&1
+python3 tools/pmc_summary.py $O ppm > $O/${tag}_bench_ppm_pmc.txt 2>&1
 find $O -name "*_agent_info.csv" -delete
 cat $O/${tag}_bench_ir_pmc.txt $O/${tag}_bench_evplp_pmc.txt | head -60
 for wl in ir evplp ppm; do head -12 $O/${tag}_bench_${wl}_kernel_stats.csv | cut -c1-200; done
