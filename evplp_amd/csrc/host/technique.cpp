@@ -392,6 +392,41 @@ extern "C" int evplp_jitter_sequence(uint32_t rng_offset, int32_t count, int32_t
     return EVPLP_OK;
 }
 
+// The product's JSON reader as the technique blocks use it (pinned against the reference's nlohmann::json 2.1.1 by
+// tests/test_oracle_pins.py): `path` = keys separated by '/', decimal indices into arrays.  want: 0 int, 1 float, 2 bool,
+// 3 string, 4 size, 5 kind (0 null, 1 bool, 2 number, 3 string, 4 array, 5 object).
+// Returns 0 ok, 1 parse error, 2 key missing / index out of range, 3 conversion error.
+extern "C" int evplp_json_query(const char *text, const char *path, int32_t want, double *num, char *str, int32_t cap) {
+    using namespace evplp;
+    if (!text || !path || !num) return EVPLP_ERR_INVALID;
+    Json root;
+    try { root = Json::parse(text); } catch (const std::exception &) { return 1; }
+    const Json *j = &root;
+    const std::string p(path);
+    size_t at = 0;
+    try {
+        while (at < p.size()) {
+            size_t e = p.find('/', at); if (e == std::string::npos) e = p.size();
+            const std::string key = p.substr(at, e - at);
+            at = e + 1;
+            if (j->is_array()) { const size_t i = (size_t)std::stoul(key); if (i >= j->size()) return 2; j = &j->at(i); }
+            else if (j->is_object()) { if (!j->has(key)) return 2; j = &j->at(key); }
+            else return 2;
+        }
+    } catch (const std::exception &) { return 2; }
+    try {
+        switch (want) {
+        case 0: *num = (double)(int)j->as_int(); break;
+        case 1: *num = (double)j->as_float(); break;
+        case 2: *num = j->as_bool() ? 1.0 : 0.0; break;
+        case 3: { const std::string v = j->as_string(); if (!str || (int32_t)v.size() + 1 > cap) return 3; std::memcpy(str, v.data(), v.size()); str[v.size()] = 0; *num = (double)v.size(); break; }
+        case 4: *num = (double)j->size(); break;
+        default: *num = (double)j->kind(); break;
+        }
+    } catch (const std::exception &) { return 3; }
+    return 0;
+}
+
 extern "C" int evplp_load_scene_json(evplp_context *ctx, const char *json_path) {
     using namespace evplp;
     if (!ctx || !json_path) return EVPLP_ERR_INVALID;

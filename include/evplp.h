@@ -271,6 +271,11 @@ int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, flo
  * (2 u - 1) / resolution with u = IndependentSampler(rngOffset).nextVec2() (rtcomphoton.h:887, 946-952) -- the reference's own
  * sampler headers as they behave under g++ / libstdc++ (tests/golden/jitter.npz); out_ndc_xy: 2 * count floats. */
 int evplp_jitter_sequence(uint32_t rng_offset, int32_t count, int32_t res_x, int32_t res_y, float *out_ndc_xy);
+/* The library's JSON reader as the technique blocks use it, for checking it against the reference's (vendored nlohmann::json
+ * 2.1.1; main.cpp:105-121, rtcomphoton.h:107-223 -- tests/golden/json_pins.json): `path` = keys separated by '/', decimal indices
+ * into arrays.  want: 0 `int v = json[..]`, 1 float, 2 bool, 3 std::string (into str, cap bytes), 4 size(), 5 kind (0 null, 1 bool,
+ * 2 number, 3 string, 4 array, 5 object).  Returns 0 ok, 1 not JSON, 2 key missing / index out of range, 3 conversion error. */
+int evplp_json_query(const char *text, const char *path, int32_t want, double *num, char *str, int32_t cap);
 /* Progressive schedule, rtcomphoton.h:1033-1063; call after numIterations++ */
 void evplp_progressive_step(int32_t num_iterations_done, float alpha, float clamp_start,
                             uint32_t n_vpl_paths, uint32_t n_light_paths,
@@ -308,7 +313,7 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
 /* main() + LoadScene + RtComPhoton::render (main.cpp:87-121, rtcomphoton.h:107-223): parse the
  * scene JSON, load OBJ/MTL, run the `photonfam` technique, write the three images + stat file.
  * json_overrides: optional JSON object text merged over the technique block (may be NULL).
- * Build-only keys of a technique block: "bvhBuilder": "sah" | "lbvh"; "deterministic": bool (photon bins accumulated in record
+ * Build-only keys of a technique block: "bvhBuilder": "sah" | "sbvh" | "lbvh" | "gpu" (evplp_bvh_builder); "deterministic": bool (photon bins accumulated in record
  * order); "device": {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool} -- run on an evplp_group of N row-strip ranks
  * (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a single rank goes through RCCL too). */
 int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap);

@@ -89,4 +89,5 @@ float ref_triangle_area(const float a[3], const float b[3], const float c[3]) {
     glm::vec3 A(a[0], a[1], a[2]), B(b[0], b[1], b[2]), Cc(c[0], c[1], c[2]);
     return glm::length(glm::cross(B - A, Cc - A)) / 2.0f;
 }
+
 }

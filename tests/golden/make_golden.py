@@ -163,6 +163,9 @@ def make_textures(ref):
     print("textures.npz:", len(files), "files,", sum(len(v) for v in files.values()), "bytes of image files")
 
 
+sys.path.insert(0, HERE)
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/libref_pin.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -238,6 +241,24 @@ def main():
     tris[:20, 3:6] = tris[:20, 0:3] + (tris[:20, 6:9] - tris[:20, 0:3]) * np.float32(0.5) + np.float32(1e-4) * rng.randn(20, 3).astype(np.float32)   # skinny
     areas = np.array([ref.ref_triangle_area(P(t[0:3].copy()), P(t[3:6].copy()), P(t[6:9].copy())) for t in tris], np.float32)
     np.savez(os.path.join(HERE, "areas.npz"), tris=tris, areas=areas)
+
+    # the reference's JSON reader (vendored nlohmann::json 2.1.1) on the texts of json_cases.py (written for this repository):
+    # conversions (`int v = json["k"]`, float, bool, std::string), size(), kind, missing keys, and what is not JSON at all
+    import json as pyjson
+    from json_cases import CASES
+    ref.ref_json_query.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    pins = []
+    for ci, (text, paths) in enumerate(CASES):
+        for path in paths:
+            for want in range(6):
+                if path.endswith("huge") and want == 0:
+                    continue                                   # double -> int out of range: undefined in C++, nothing to pin
+                num = C.c_double(0); buf = C.create_string_buffer(4096)
+                rc = ref.ref_json_query(text.encode("utf-8"), path.encode(), want, C.byref(num), buf, 4096)
+                pins.append([ci, path, want, rc, repr(num.value) if rc == 0 else None, buf.value.hex() if rc == 0 and want == 3 else None])
+    with open(os.path.join(HERE, "json_pins.json"), "w") as f:
+        pyjson.dump({"source": "oracle/_ref ref_json_query = nlohmann::json 2.1.1 as vendored by the reference (reflectcuts/json/json.hpp)",
+                     "columns": ["case index in json_cases.CASES", "path", "want", "rc", "repr(number)", "hex(string)"], "pins": pins}, f, indent=0)
     print("wrote", os.listdir(HERE))
 
 

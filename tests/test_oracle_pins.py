@@ -259,3 +259,28 @@ def test_triangle_area_matches_the_reference_expression(oracle):
     (rtcommon.h:501-531), the light area and totalArea (default clamping value, :759-768)."""
     for t, ref in zip(AREAS["tris"], AREAS["areas"]):
         assert oracle.evo_tri_area(oa.ptr(np.ascontiguousarray(t))) == ref
+
+
+# ---- round 2 pin: the JSON reader against the reference's vendored nlohmann::json 2.1.1 (tests/golden/json_pins.json)
+def test_json_reader_matches_the_reference_reader(evplp):
+    """The technique blocks are read with `int v = json["k"]`-style conversions of nlohmann::json 2.1.1 (rtcomphoton.h:114-222,
+    main.cpp:105-121).  The product has its own reader: same values, same conversions (a boolean converts to a number, nothing
+    converts to a boolean or a string), same size(), a repeated key keeps its last value, \\u escapes become UTF-8, and what is
+    not RFC 7159 JSON (NaN, +1, .5, 01, trailing commas, comments, control characters in strings) is rejected."""
+    import ctypes as C, json, sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from json_cases import CASES
+    pins = json.load(open(os.path.join(HERE, "golden", "json_pins.json")))["pins"]
+    assert len(pins) > 700
+    q = evplp.lib().evplp_json_query
+    q.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]
+    for ci, path, want, rc, num, hexstr in pins:
+        text = CASES[ci][0]
+        got_num = C.c_double(0); buf = C.create_string_buffer(4096)
+        got = q(text.encode("utf-8"), path.encode(), want, C.byref(got_num), buf, 4096)
+        what = f"case {ci} {text[:40]!r} path {path!r} want {want}"
+        assert got == rc, f"{what}: status {got}, the reference's reader says {rc}"
+        if rc == 0:
+            assert repr(got_num.value) == num, f"{what}: {got_num.value!r} vs {num}"
+            if want == 3:
+                assert buf.value.hex() == hexstr, what
