@@ -130,6 +130,7 @@ _SIGNATURES = {
     "evplp_group_synchronize": (C.c_int, [_P]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_jitter_sequence": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "evplp_json_query": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "evplp_save_image": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P]),

@@ -273,7 +273,6 @@ def test_json_reader_matches_the_reference_reader(evplp):
     pins = json.load(open(os.path.join(HERE, "golden", "json_pins.json")))["pins"]
     assert len(pins) > 700
     q = evplp.lib().evplp_json_query
-    q.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]
     for ci, path, want, rc, num, hexstr in pins:
         text = CASES[ci][0]
         got_num = C.c_double(0); buf = C.create_string_buffer(4096)
