@@ -113,12 +113,20 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
         while (k < 8 * mean && k < (1u << 20)) k <<= 1;
         c->bin_stride = (uint32_t)k;
         if (const char *env = std::getenv("EVPLP_BIN_STRIDE")) c->bin_stride = (uint32_t)std::max(1, atoi(env));   // tests: force the overflow / re-run path
-        // coarse buckets of 128 tiles (16 x 8) for the two-level binning (kernels.h)
+        // coarse buckets of 128 tiles (16 x 8) for the two-level binning (kernels.h); larger ones (up to 32 x 16) for images
+        // that would need more than kMaxBuckets of them
         c->bucket_w_log2 = 4; c->bucket_h_log2 = kBucketTilesLog2 - 4;
-        c->buckets_x = (c->tiles_x + (1 << c->bucket_w_log2) - 1) >> c->bucket_w_log2;
-        c->num_buckets = c->buckets_x * ((c->tiles_y + (1 << c->bucket_h_log2) - 1) >> c->bucket_h_log2);
+        auto count_buckets = [&]() {
+            c->buckets_x = (c->tiles_x + (1 << c->bucket_w_log2) - 1) >> c->bucket_w_log2;
+            c->num_buckets = c->buckets_x * ((c->tiles_y + (1 << c->bucket_h_log2) - 1) >> c->bucket_h_log2);
+        };
+        count_buckets();
+        while (c->num_buckets > kMaxBuckets && c->bucket_w_log2 + c->bucket_h_log2 < kMaxBucketTilesLog2) {
+            if (c->bucket_h_log2 < c->bucket_w_log2) c->bucket_h_log2++; else c->bucket_w_log2++;
+            count_buckets();
+        }
         if (c->num_buckets > kMaxBuckets) {
-            snprintf(g_create_error, sizeof(g_create_error), "evplp_create: more than %d x 128 image tiles in one context (use row strips)", kMaxBuckets);
+            snprintf(g_create_error, sizeof(g_create_error), "evplp_create: more than %d x %d image tiles in one context (use row strips)", kMaxBuckets, 1 << kMaxBucketTilesLog2);
             evplp_destroy(c); return EVPLP_ERR_INVALID;
         }
         c->num_bin_groups = (int32_t)((nrec + kBinGroup - 1) / kBinGroup);

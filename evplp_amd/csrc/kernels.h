@@ -89,7 +89,8 @@ constexpr int kBinChunks = EVPLP_BIN_CHUNKS;
 constexpr int kBinGroup = 256 * kBinChunks;   // records per workgroup
 constexpr int kSegCap = 4 * kBinGroup;        // entries of a workgroup's segment (a photon of the LDS path has at most 2x2)
 constexpr int kMaxBuckets = 1024;
-constexpr int kBucketTilesLog2 = 7;   // tiles per bucket
+constexpr int kBucketTilesLog2 = 7;   // tiles per bucket: 16 x 8 ...
+constexpr int kMaxBucketTilesLog2 = 9; // ... up to 32 x 16 for images of more than 131 072 tiles (kMaxBuckets buckets at most)
 struct SplatArgs {
     StripDev st; CamBasis cam;
     evplp_frame_params fp;
@@ -102,7 +103,7 @@ struct SplatArgs {
     uint32_t *tile_cursor;    // [ntiles] entries the photons wanted to put into the tile's bin (may exceed bin_stride: overflow)
     uint32_t *bin_items;      // [ntiles][bin_stride] compact photon ids
     uint32_t bin_stride;
-    uint32_t *seg;            // [num_bin_groups][kSegCap] entries: record - group base (10 bits) | tile within the bucket << 10, sorted by bucket
+    uint32_t *seg;            // [num_bin_groups][kSegCap] entries: record - group base (10 bits) | tile within the bucket (<= 9 bits) << 10, sorted by bucket
     uint16_t *seg_off;        // [num_bin_groups][num_buckets + 1] first entry of every bucket in the group's segment
     uint32_t *big_list;       // [num_bin_groups][kBinGroup] records whose rectangle is larger than 2x2 tiles
     uint32_t *big_count;      // [num_bin_groups]

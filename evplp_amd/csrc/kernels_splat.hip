@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
         if (tid + 1280u < n4) dst[tid + 1280u] = r5_;                                                                   \
         if ((base_) != 0u && tid < (uint32_t)kRecF4) s_rec[tid] = pv;                                                   \
     }
-// LDS entry: record - group base (10 bits; kBinGroup <= 1024) | tile within the bucket (7) << 10 | bucket (10) << 17
+// LDS entry: record - group base (10 bits; kBinGroup <= 1024) | tile within the bucket (<= 9 bits) << 10 | bucket (10) << 19
 __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
     __shared__ float4 s_rec[257 * kRecF4];
     __shared__ uint32_t s_pair[kSegCap];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
                     const uint32_t b = (uint32_t)(lty[q] >> a.bucket_h_log2) * (uint32_t)a.buckets_x + (uint32_t)(tx[q] >> a.bucket_w_log2);
                     const uint32_t tib = (((uint32_t)lty[q] & bh_mask) << a.bucket_w_log2) | ((uint32_t)tx[q] & bw_mask);
                     atomicAdd(&s_cnt[b], 1u);
-                    s_pair[at++] = (i - wg_base) | (tib << 10) | (b << 17);
+                    s_pair[at++] = (i - wg_base) | (tib << 10) | (b << 19);
                 }
             }
         } else {
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
     // ... and the entries leave for the group's segment in bucket order
     uint32_t *seg = a.seg + (size_t)group * kSegCap;
     for (uint32_t k = tid; k < n_raw; k += 256u) {
-        const uint32_t e = s_pair[k], b = e >> 17;
-        if (e != 0xffffffffu) seg[s_off[b] + atomicAdd(&s_cnt[b], 1u)] = e & 0x1ffffu;
+        const uint32_t e = s_pair[k], b = e >> 19;
+        if (e != 0xffffffffu) seg[s_off[b] + atomicAdd(&s_cnt[b], 1u)] = e & 0x7ffffu;
     }
     if (tid == 0u) a.big_count[group] = s_nbig;
 }
@@ -297,15 +297,16 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
 // Scatter kernel (kernels.h "Two-level binning"): workgroup (slice, bucket).  Also the pass summary: total entries and the
 // fullest bin, one atomic per workgroup on one of 1024 shard lines.
 __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_t *items) {
-    constexpr int kTiles = 1 << kBucketTilesLog2;
-    __shared__ uint32_t s_cnt[kTiles], s_base[kTiles], s_max, s_total;
+    constexpr int kTilesMax = 1 << kMaxBucketTilesLog2;
+    __shared__ uint32_t s_cnt[kTilesMax], s_base[kTilesMax], s_max, s_total;
+    const uint32_t ntile = 1u << (a.bucket_w_log2 + a.bucket_h_log2);   // tiles of a bucket
     const uint32_t tid = threadIdx.x, b = blockIdx.y, group = blockIdx.x * 256u + tid;
     uint32_t beg = 0u, end = 0u;
     if (group < (uint32_t)a.num_bin_groups) {
         const uint16_t *o = a.seg_off + (size_t)group * (a.num_buckets + 1) + b;
         beg = o[0]; end = o[1];
     }
-    if (tid < (uint32_t)kTiles) s_cnt[tid] = 0u;
+    for (uint32_t t = tid; t < ntile; t += 256u) s_cnt[t] = 0u;
     if (tid == 0u) { s_max = 0u; s_total = 0u; }
     __syncthreads();
     const uint32_t *seg = a.seg + (size_t)group * kSegCap;
@@ -315,11 +316,11 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
     auto tile_of = [&](uint32_t t) -> uint32_t {
         return ((by << a.bucket_h_log2) + (t >> a.bucket_w_log2)) * (uint32_t)a.tiles_x + (bx << a.bucket_w_log2) + (t & bw_mask);
     };
-    if (tid < (uint32_t)kTiles) {
-        const uint32_t c = s_cnt[tid];
+    for (uint32_t t = tid; t < ntile; t += 256u) {
+        const uint32_t c = s_cnt[t];
         if (c != 0u) {
-            const uint32_t at = atomicAdd(&a.tile_cursor[tile_of(tid)], c);
-            s_base[tid] = at; s_cnt[tid] = 0u;                           // now: entries placed per tile
+            const uint32_t at = atomicAdd(&a.tile_cursor[tile_of(t)], c);
+            s_base[t] = at; s_cnt[t] = 0u;                               // now: entries placed per tile
             atomicMax(&s_max, at + c); atomicAdd(&s_total, c);
         }
     }

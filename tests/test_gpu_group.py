@@ -96,3 +96,25 @@ def test_group_errors_are_reported(evplp):
     assert "distinct device" in str(e.value)
     with pytest.raises(evplp.EvplpError):
         evplp.Group(16, 16, 4, 4, 2, 0)
+
+
+def test_large_frames_use_larger_bins_buckets_and_give_the_same_splat(evplp, tmp_path):
+    """A 4096 x 2176 frame has 139 264 tiles: more than 1024 buckets of 16 x 8 tiles, so the single context bins with 16 x 16
+    buckets; two strip ranks (69 632 tiles each) still use 16 x 8.  Deterministic mode: the photon image must not depend on it."""
+    BW, BH, NL = 4096, 2176, 20000
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, BW, BH, style="hard")
+    sd, _ = scenes.load_obj_scene(jp)
+    imgs = {}
+    for n in (1, 2):
+        with evplp.Group(BW, BH, NL, 0, P, n, devices=[0] * n, deterministic=True) as g:
+            g.load_scene_json(jp)
+            import ctypes as C
+            r_, t_, l_ = C.c_float(), C.c_float(), C.c_float()
+            evplp.lib().evplp_scene_metrics(evplp.lib().evplp_group_context(g._h, 0), C.byref(r_), C.byref(t_), C.byref(l_))
+            r = 0.01 * r_.value
+            fp = evplp.frame_params(camera_pos=sd.cam_origin, mis_mode="one", photon_radius=r, num_light_paths=NL, num_vpl_light_paths=0, photons_per_path=P)
+            g.clear_accumulators()
+            g.primary((0.0, 0.0)); g.trace_light_paths(3); g.splat_photons(fp, clear=True)
+            imgs[n] = g.resolve(0.0, 1.0, 0.0)
+    assert imgs[1].max() > 0 and imgs[1].shape == (BH, BW, 3)
+    assert imgs[1].tobytes() == imgs[2].tobytes()
