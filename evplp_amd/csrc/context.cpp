@@ -398,8 +398,7 @@ static int settle_splat(evplp_context *c) {
     c->bin_stride = (uint32_t)want;
     SplatArgs &a = c->splat_args;
     a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_stride = c->bin_stride;
-    HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
-    launch_splat_bin(a, c->stream);
+    launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
     const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     HIP_TRY(c, hipEventRecord(c->ev_end[EVPLP_PASS_SPLAT], c->stream));
@@ -572,8 +571,7 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
-    HIP_TRY(c, hipMemsetAsync(&c->d_scalars[8], 0, sizeof(uint32_t), c->stream));
-    launch_splat_bin(a, c->stream);
+    launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
     // Tile kernel variant.  One wave per tile is cheapest while bins are short; when some bins are very full (tiles
     // that see a floor at grazing angle collect thousands of photons) those waves set the duration of the launch and
     // four waves per tile win.  Deterministic mode always uses one variant: the fold order is part of the result.

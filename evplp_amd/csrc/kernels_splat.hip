@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
     const int tile0 = (blockIdx.x * 4 + wave) * 4;
     if (blockIdx.x == 0) {
         for (int k = tid; k < kSummaryShards; k += 256) { a.summary[k * kSummaryStride] = 0u; a.summary[k * kSummaryStride + 1] = 0u; }
+        if (tid == 0) *a.overflow = 0u;
     }
     float4 gp[4]; bool in_image[4];
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
                 }
             }
         } else {
-            a.big_list[(size_t)group * kBinGroup + atomicAdd(&s_nbig, 1u)] = i;      // -> splat_big_kernel
+            a.big_list[(size_t)group * kBinGroup + atomicAdd(&s_nbig, 1u)] = i;      // -> splat_big_group
         }
         __syncthreads();
     }
@@ -296,7 +297,12 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
 
 // Scatter kernel (kernels.h "Two-level binning"): workgroup (slice, bucket).  Also the pass summary: total entries and the
 // fullest bin, one atomic per workgroup on one of 1024 shard lines.
+EV_DEV void splat_big_group(const SplatArgs &a, uint32_t *items, uint32_t group);
 __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_t *items) {
+    if (blockIdx.y >= (uint32_t)a.num_buckets) {                           // the rows beyond the buckets: photons with large rectangles
+        splat_big_group(a, items, (blockIdx.y - (uint32_t)a.num_buckets) * gridDim.x + blockIdx.x);
+        return;
+    }
     constexpr int kTilesMax = 1 << kMaxBucketTilesLog2;
     __shared__ uint32_t s_cnt[kTilesMax], s_base[kTilesMax], s_max, s_total;
     const uint32_t ntile = 1u << (a.bucket_w_log2 + a.bucket_h_log2);   // tiles of a bucket
@@ -340,10 +346,12 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
 
 // Photons whose rectangle is larger than 3x3 tiles (huge radii, or closer to the eye than a few radii) and those that did not
 // fit into their group's segment: workgroup g takes the list of bin-group g, one wave per photon, lanes over the tiles of the
-// rectangle, one atomic per entry.  Rectangles of more than 64 tiles are not depth-culled.
-__global__ __launch_bounds__(256) void splat_big_kernel(SplatArgs a, uint32_t *items) {
+// rectangle, one atomic per entry.  Rectangles of more than 64 tiles are not depth-culled.  (Rows of the scatter launch beyond
+// the buckets: one launch less.)
+EV_DEV void splat_big_group(const SplatArgs &a, uint32_t *items, uint32_t group) {
     __shared__ uint32_t s_sum[4][2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, group = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (group >= (uint32_t)a.num_bin_groups) return;
     const uint32_t nbig = a.big_count[group];
     if (nbig == 0u) return;
     uint32_t entries = 0u, fullest = 0u;
@@ -511,8 +519,8 @@ void launch_splat_bin(const SplatArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);
     uint32_t *items = a.deterministic ? a.bin_items_tmp : a.bin_items;
     hipLaunchKernelGGL(splat_bin_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(splat_scatter_kernel, dim3(((uint32_t)a.num_bin_groups + 255u) / 256u, (uint32_t)a.num_buckets), dim3(256), 0, s, a, items);
-    hipLaunchKernelGGL(splat_big_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), 0, s, a, items);
+    const uint32_t slices = ((uint32_t)a.num_bin_groups + 255u) / 256u, big_rows = ((uint32_t)a.num_bin_groups + slices - 1u) / slices;
+    hipLaunchKernelGGL(splat_scatter_kernel, dim3(slices, (uint32_t)a.num_buckets + big_rows), dim3(256), 0, s, a, items);
 }
 // Phase B: (deterministic: sort the bins) and accumulate the tiles.  Both do nothing when a bin overflowed.
 void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dom_begin, hipEvent_t dom_end) {

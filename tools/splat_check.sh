@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out/splat_ab; rm -rf $O; mkdir -p $O
 cd $ROOT
-timeout 1200 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_end_to_end.py -q -x -k "splat or photon or bins or evplp or progressive or ppm or determin" 2>/dev/null | tail -3 > $O/tests.txt
+timeout 1200 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_end_to_end.py -q -x -k "splat or photon or bins or evplp or progressive or ppm or determin" > $O/tests_full.txt 2>&1; grep -E "passed|failed|error" $O/tests_full.txt | tail -3 > $O/tests.txt
 cat $O/tests.txt
 cd /tmp
 for wl in evplp ppm; do
