@@ -357,6 +357,15 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     if ((rc = upload_array(c, pool.data(), pool.size(), &c->sc.tex_pool))) return rc;
     if ((rc = upload_array(c, cdf.data(), cdf.size(), &c->sc.light_cdf))) return rc;
     c->sc.light_first = light_first; c->sc.light_count = light_count; c->sc.light_area = sum;
+    {   // bounds of the light mesh, padded by far more than the rounding of a slab test
+        float llo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, lhi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (int32_t i = 0; i < light_count; i++) for (int k = 0; k < 9; k++) {
+            const float v = attrs[(size_t)light_first + i].v[k];
+            llo[k % 3] = std::min(llo[k % 3], v); lhi[k % 3] = std::max(lhi[k % 3], v);
+        }
+        const float pad = 1e-4f * (2.0f * c->bounding_radius) + 1e-30f;
+        for (int k = 0; k < 3; k++) { c->sc.light_lo[k] = llo[k] - pad; c->sc.light_hi[k] = lhi[k] + pad; }
+    }
     std::memcpy(c->sc.light_intensity, c->light_scaled, 16); std::memcpy(c->sc.light_unscaled, c->light_unscaled, 16);
     c->accel_built = true;
     return EVPLP_OK;

@@ -84,6 +84,7 @@ struct SceneDev {
     float light_area;
     float light_intensity[4];    // (I*pi, w)
     float light_unscaled[4];     // (I, w)
+    float light_lo[3], light_hi[3];   // bounds of the light mesh, padded (primary_kernel skips its walk for tiles that cannot see it)
 };
 
 // Strip geometry shared by all per-pixel kernels.

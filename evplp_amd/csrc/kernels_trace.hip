@@ -43,7 +43,24 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     // both directions have camera-space z = -1, so t is the view depth on either ray
     const bool light_unoccluded = (a.clear_light & EVPLP_LIGHT_UNOCCLUDED) != 0;      // wave-uniform
     const float light_far = (tri >= 0 && !light_unoccluded) ? fminf(t * 1.000001f + 1.0e-30f, 100.0f) : 100.0f;
-    int32_t ltri = a.sc.light_count > 0 ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl) : -1;
+    // ... and only tiles with a ray through the (padded) bounds of the light mesh walk at all: the emitters cover a small
+    // part of most views and this second walk otherwise costs as much as the first
+    bool light_maybe = in_image;
+    {
+        float t0 = 0.1f, t1 = light_far;
+        const float o[3] = { eye.x, eye.y, eye.z }, d[3] = { d0.x, d0.y, d0.z };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (d[k] == 0.0f) { if (o[k] < a.sc.light_lo[k] || o[k] > a.sc.light_hi[k]) light_maybe = false; }
+            else {
+                const float inv = 1.0f / d[k], ta = (a.sc.light_lo[k] - o[k]) * inv, tb = (a.sc.light_hi[k] - o[k]) * inv;
+                t0 = fmaxf(t0, fminf(ta, tb) * 0.99999f - 1.0e-6f); t1 = fminf(t1, fmaxf(ta, tb) * 1.00001f + 1.0e-6f);
+            }
+        }
+        if (t0 > t1) light_maybe = false;
+    }
+    const bool walk_light = a.sc.light_count > 0 && __ballot(light_maybe) != 0ull;        // wave-uniform
+    int32_t ltri = walk_light ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl) : -1;
     if (!in_image) return;
     bool use_light = ltri >= 0 && (tri < 0 || tl <= t);  // depth LEQUAL, light mesh drawn last
     const bool light_visible = light_unoccluded ? ltri >= 0 : use_light;              // the emitter IMAGE (rtcomphoton.h:985-995)
