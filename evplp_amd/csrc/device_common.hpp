@@ -590,8 +590,11 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
     int32_t best = -1; float bt = tmax, bb = 0.f, bg = 0.f;
     int sp = 0;
     int32_t cur = 0;
-    for (;;) {
-        if (cur >= 0) {
+    bool done = false;
+    // "while-while" (Aila & Laine 2009): every lane first descends to its next leaf, then the wave tests leaves together; with one
+    // node-or-leaf step per iteration a wave of incoherent rays runs both branches, half empty, every time
+    while (!done) {
+        while (cur >= 0) {
             const BvhNode &n = sc.nodes[cur];
             bool h0, h1;
             const float lo0[3] = { n.ctr[0][0] - n.hal[0][0], n.ctr[1][0] - n.hal[1][0], n.ctr[2][0] - n.hal[2][0] };
@@ -604,10 +607,13 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
                 bool first0 = n0 <= n1;
                 stack[sp * STACK_STRIDE] = first0 ? n.c1 : n.c0; sp++;
                 cur = first0 ? n.c0 : n.c1;
-                continue;
-            } else if (h0) { cur = n.c0; continue; }
-            else if (h1) { cur = n.c1; continue; }
-        } else if (cur != kNoChild) {
+            } else if (h0) cur = n.c0;
+            else if (h1) cur = n.c1;
+            else if (sp == 0) { done = true; break; }
+            else { --sp; cur = stack[sp * STACK_STRIDE]; }
+        }
+        if (done) break;
+        if (cur != kNoChild) {
             int32_t id = ~cur;
             int32_t block = id >> 2, cnt = (id & 3) + 1;
             for (int32_t k = 0; k < cnt; k++) {
@@ -635,18 +641,23 @@ EV_DEV bool occluded_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int sp = 0;
     int32_t cur = 0;
-    for (;;) {
-        if (cur >= 0) {
+    bool done = false;
+    while (!done) {                                                      // while-while, as closest_lane
+        while (cur >= 0) {
             const BvhNode &n = sc.nodes[cur];
             const float lo0[3] = { n.ctr[0][0] - n.hal[0][0], n.ctr[1][0] - n.hal[1][0], n.ctr[2][0] - n.hal[2][0] };
             const float hi0[3] = { n.ctr[0][0] + n.hal[0][0], n.ctr[1][0] + n.hal[1][0], n.ctr[2][0] + n.hal[2][0] };
             const float lo1[3] = { n.ctr[0][1] - n.hal[0][1], n.ctr[1][1] - n.hal[1][1], n.ctr[2][1] - n.hal[2][1] };
             const float hi1[3] = { n.ctr[0][1] + n.hal[0][1], n.ctr[1][1] + n.hal[1][1], n.ctr[2][1] + n.hal[2][1] };
             bool h0 = slab_hit(lo0, hi0, inv, noi, tmin, tmax), h1 = slab_hit(lo1, hi1, inv, noi, tmin, tmax);
-            if (h0 && h1) { stack[sp * STACK_STRIDE] = n.c1; sp++; cur = n.c0; continue; }
-            else if (h0) { cur = n.c0; continue; }
-            else if (h1) { cur = n.c1; continue; }
-        } else if (cur != kNoChild) {
+            if (h0 && h1) { stack[sp * STACK_STRIDE] = n.c1; sp++; cur = n.c0; }
+            else if (h0) cur = n.c0;
+            else if (h1) cur = n.c1;
+            else if (sp == 0) { done = true; break; }
+            else { --sp; cur = stack[sp * STACK_STRIDE]; }
+        }
+        if (done) break;
+        if (cur != kNoChild) {
             int32_t id = ~cur;
             int32_t block = id >> 2, cnt = (id & 3) + 1;
             for (int32_t k = 0; k < cnt; k++) {
