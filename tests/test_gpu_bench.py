@@ -39,6 +39,18 @@ def test_bench_collective_path_on_one_rank():
     assert a["config"]["usable_vpl_records"] == b["config"]["usable_vpl_records"]
 
 
+@pytest.mark.parametrize("wl", ["evplp", "ppm"])
+def test_bench_photon_workloads_through_the_collective_path(wl):
+    """The photon workloads with EVPLP_BENCH_FORCE_DIST=1: light paths traced by path range + in-place record all-gather, both
+    framebuffers all-gathered -- the same photon-pixel pairs as without collectives."""
+    args = ["--workload", wl, "--steps", "2", "--warmup", "1", "--tris", "20000", "--no-cpu-baseline", "--no-extras"] + (["--res", "256"] if wl == "evplp" else [])
+    a = run_bench(args, {"EVPLP_BENCH_FORCE_DIST": "1"})
+    b = run_bench(args)
+    ra, rb = (a.get("roofline_splat") or a["roofline"]), (b.get("roofline_splat") or b["roofline"])
+    assert a["n_gpus"] == 1 and ra["pairs_per_frame"] > 0 and ra["pairs_per_frame"] == rb["pairs_per_frame"]
+    assert ra["bound"] == "hbm" and 0 < ra["frac"] < 1
+
+
 def test_bench_refuses_a_rank_count_it_cannot_start():
     """--gpus 2 on a one-GPU box: bench.py starts two ranks itself; the second has no device and the parent reports failure
     instead of silently measuring one GPU."""
