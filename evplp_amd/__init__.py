@@ -343,8 +343,13 @@ class Context:
     def bind_buffer(self, which: int, device_ptr: int, nbytes: int):
         self._check(self._lib.evplp_bind_buffer(self._h, which, C.c_void_p(device_ptr), nbytes))
 
+    def buffer_bytes(self, which: int) -> int:
+        n = C.c_size_t()
+        self._check(self._lib.evplp_buffer_info(self._h, which, None, C.byref(n)))   # (no pointer taken: see evplp_buffer_info)
+        return n.value
+
     def download(self, which: int) -> np.ndarray:
-        _, n = self.buffer_info(which)
+        n = self.buffer_bytes(which)
         if which == BUF_RECORDS:
             out = np.empty(n // 96, dtype=RECORD_DTYPE)
         else:

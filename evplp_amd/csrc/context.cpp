@@ -442,8 +442,10 @@ extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t cl
     a.g_pos = (float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
     a.g_dif = (float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
     a.g_light = (float4 *)c->buf[EVPLP_BUF_LIGHT];
+    a.tile_box = c->d_tile_box;
     if ((rc = pass_begin(c, EVPLP_PASS_PRIMARY))) return rc;
     launch_primary(a, c->stream);
+    c->tile_box_valid = !c->gbuf_pos_exposed;
     c->stats_host[EVPLP_PASS_PRIMARY].rays = 2ull * (uint64_t)c->st.W * c->rows_in_image;
     return pass_end(c, EVPLP_PASS_PRIMARY);
 }
@@ -576,7 +578,7 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.compact = c->d_compact; a.overflow = &c->d_scalars[8]; a.summary = c->d_summary;
     a.seg = c->d_seg; a.seg_off = c->d_seg_off; a.big_list = c->d_big_list; a.big_count = c->d_big_count; a.num_bin_groups = c->num_bin_groups;
     a.bucket_w_log2 = c->bucket_w_log2; a.bucket_h_log2 = c->bucket_h_log2; a.buckets_x = c->buckets_x; a.num_buckets = c->num_buckets;
-    a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic;
+    a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic; a.boxes_valid = c->tile_box_valid ? 1 : 0;
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
@@ -590,8 +592,7 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
     // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
-    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[0], &c->d_summary[kSummaryFinal], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[2], &c->d_scalars[8], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[0], &c->d_summary[kSummaryFinal], 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));   // entries, fullest bin, overflow
     HIP_TRY(c, hipEventRecord(c->ev_summary, c->stream));
     c->splat_args = a; c->splat_pending = true;
     c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
@@ -638,7 +639,8 @@ extern "C" int evplp_local_rows(const evplp_context *c) { return c ? c->st.local
 extern "C" int evplp_buffer_info(evplp_context *c, int32_t which, void **ptr, size_t *bytes) {
     CTX_CHECK(c);
     if (which < 0 || which >= EVPLP_BUF_COUNT) { c->set_error("evplp_buffer_info: bad buffer id %d", which); return EVPLP_ERR_INVALID; }
-    if (ptr) *ptr = c->buf[which]; if (bytes) *bytes = buffer_bytes(c, which);
+    if (ptr) { *ptr = c->buf[which]; if (which == EVPLP_BUF_GBUF_POSITION) { c->gbuf_pos_exposed = true; c->tile_box_valid = false; } }
+    if (bytes) *bytes = buffer_bytes(c, which);
     return EVPLP_OK;
 }
 extern "C" int evplp_bind_buffer(evplp_context *c, int32_t which, void *ptr, size_t bytes) {
@@ -651,6 +653,7 @@ extern "C" int evplp_bind_buffer(evplp_context *c, int32_t which, void *ptr, siz
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->buf_owned[which]) hipFree(c->buf[which]);
     c->buf[which] = ptr; c->buf_owned[which] = false;
+    if (which == EVPLP_BUF_GBUF_POSITION) { c->gbuf_pos_exposed = true; c->tile_box_valid = false; }
     return EVPLP_OK;
 }
 extern "C" int evplp_download(evplp_context *c, int32_t which, void *dst, size_t bytes) {
@@ -669,6 +672,7 @@ extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, si
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipMemcpyAsync(c->buf[which], src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (which == EVPLP_BUF_GBUF_POSITION) c->tile_box_valid = false;
     return EVPLP_OK;
 }
 

@@ -47,6 +47,8 @@ struct evplp_context {
 
     // splat workspace
     int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_stride = 0, last_bin_entries = 0, last_bin_max = 0;   // bin_stride: slots per tile bin
+    bool gbuf_pos_exposed = false;             // the caller holds a device pointer to the position plane (buffer_info / bind_buffer): it may write it unseen
+    bool tile_box_valid = false;               // d_tile_box describes the current G-buffer (written by evplp_primary; any other way in clears it)
     int32_t num_bin_groups = 0, bucket_w_log2 = 0, bucket_h_log2 = 0, buckets_x = 0, num_buckets = 0;   // two-level binning (kernels.h)
     uint32_t *d_seg = nullptr, *d_big_list = nullptr, *d_big_count = nullptr; uint16_t *d_seg_off = nullptr;
     uint32_t *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;

@@ -8,6 +8,7 @@ struct PrimaryArgs {
     SceneDev sc; StripDev st; CamBasis cam;
     float jitter[2]; int32_t clear_light; int32_t pad;
     float4 *g_pos, *g_nrm, *g_dif, *g_phg, *g_light;
+    float4 *tile_box;         // [tiles][2] world-space box of every 8x8-px tile's positions (the photon splat's bin cull), or null
 };
 
 struct LightTraceArgs {
@@ -88,6 +89,10 @@ constexpr int kSummaryShards = 1024, kSummaryStride = 32, kSummaryFinal = kSumma
 constexpr int kBinChunks = EVPLP_BIN_CHUNKS;
 constexpr int kBinGroup = 256 * kBinChunks;   // records per workgroup
 constexpr int kSegCap = 4 * kBinGroup;        // entries of a workgroup's segment (a photon of the LDS path has at most 2x2)
+#ifndef EVPLP_SCATTER_G
+#define EVPLP_SCATTER_G 2
+#endif
+constexpr int kScatterG = EVPLP_SCATTER_G;    // bin-groups per thread of splat_scatter_kernel (a slice = 256 * kScatterG groups)
 constexpr int kMaxBuckets = 1024;
 constexpr int kBucketTilesLog2 = 7;   // tiles per bucket: 16 x 8 ...
 constexpr int kMaxBucketTilesLog2 = 9; // ... up to 32 x 16 for images of more than 131 072 tiles (kMaxBuckets buckets at most)
@@ -113,7 +118,7 @@ struct SplatArgs {
     uint32_t *overflow;       // device flag: the slots the fullest bin wanted, when that is more than bin_stride (tiles kernel then does nothing; the host re-runs) (fill / tiles then do nothing; the host re-runs)
     uint32_t *summary;        // device: kSummaryShards x {entries, fullest bin} on separate 128-byte lines (scatter / big kernels, per workgroup),
                               // folded into [kSummaryFinal + 0] total bin entries, [+1] entries of the fullest bin by the tile kernel
-    int32_t tiles_x, tiles_y; int32_t deterministic; int32_t pad;
+    int32_t tiles_x, tiles_y; int32_t deterministic; int32_t boxes_valid;   // boxes_valid: tile_box was written by the primary pass
     PassCounters *counters;
 };
 constexpr int kSplatTile = 8;        // pixels per tile edge (one wave per tile)

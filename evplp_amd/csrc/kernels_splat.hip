@@ -6,7 +6,8 @@
 // The reference rasterises one icosphere proxy per record and lets the ROP blend every fragment
 // (one RMW of HBM per fragment).  Here (ideal kernel of SURVEY A.4: photon i adds to pixel p iff
 // |X_p - P_i|^2 <= r^2):
-//   0. splat_tile_box : world-space bounding box of the G-buffer positions of every 8x8-pixel tile (and clears the bin cursors).
+//   0. splat_tile_box : world-space bounding box of the G-buffer positions of every 8x8-pixel tile -- only for G-buffers that
+//      were uploaded: evplp_primary writes the boxes as it writes the G-buffer.
 //   1. splat_bin : one lane per record (records staged through LDS).  Everything of the fragment shader that does not depend
 //      on the pixel (w12, the MIS/clamp weight, 1/(pi r^2 N) scaling) is folded into a 64-byte compact photon; the photon gets
 //      an entry for every 8x8-pixel tile of the conservative screen rectangle of its radius-r sphere whose position box the
@@ -147,14 +148,10 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
 // wall behind the chairs -- several times more than ever pass the radius test.  Every in-image pixel counts, background
 // included (its position is the clear colour, which is what the radius test of frag:152-154 sees too).
 __global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
-    // four tiles per wave, their texels fetched together; also clears the tile's bin cursor (and the pass summary)
+    // four tiles per wave, their texels fetched together
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tile0 = (blockIdx.x * 4 + wave) * 4;
-    if (blockIdx.x == 0) {
-        for (int k = tid; k < kSummaryShards; k += 256) { a.summary[k * kSummaryStride] = 0u; a.summary[k * kSummaryStride + 1] = 0u; }
-        if (tid == 0) *a.overflow = 0u;
-    }
     float4 gp[4]; bool in_image[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -174,7 +171,6 @@ __global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
             for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
         if (lane == 0) {
             a.tile_box[2 * tile] = make_float4(lo[0], lo[1], lo[2], 0.f); a.tile_box[2 * tile + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-            a.tile_cursor[tile] = 0u;
         }
     }
 }
@@ -215,6 +211,12 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
     const uint32_t tid = threadIdx.x, group = blockIdx.x, wg_base = group * (uint32_t)kBinGroup;
     for (uint32_t b = tid; b < (uint32_t)kMaxBuckets; b += 256u) s_cnt[b] = 0u;
     if (tid == 0u) { s_n = 0u; s_nbig = 0u; }
+    // this launch also clears what the NEXT two use: the tiles' bin cursors, the pass summary, the overflow flag
+    for (uint32_t k = blockIdx.x * 256u + tid; k < (uint32_t)(a.tiles_x * a.tiles_y); k += gridDim.x * 256u) a.tile_cursor[k] = 0u;
+    if (blockIdx.x == 0u) {
+        for (uint32_t k = tid; k < (uint32_t)kSummaryShards; k += 256u) { a.summary[k * kSummaryStride] = 0u; a.summary[k * kSummaryStride + 1] = 0u; }
+        if (tid == 0u) *a.overflow = 0u;
+    }
     const uint32_t bw_mask = (1u << a.bucket_w_log2) - 1u, bh_mask = (1u << a.bucket_h_log2) - 1u;
 
     float4 r0_, r1_, r2_, r3_, r4_, r5_, pv;
@@ -306,17 +308,25 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
     constexpr int kTilesMax = 1 << kMaxBucketTilesLog2;
     __shared__ uint32_t s_cnt[kTilesMax], s_base[kTilesMax], s_max, s_total;
     const uint32_t ntile = 1u << (a.bucket_w_log2 + a.bucket_h_log2);   // tiles of a bucket
-    const uint32_t tid = threadIdx.x, b = blockIdx.y, group = blockIdx.x * 256u + tid;
-    uint32_t beg = 0u, end = 0u;
-    if (group < (uint32_t)a.num_bin_groups) {
-        const uint16_t *o = a.seg_off + (size_t)group * (a.num_buckets + 1) + b;
-        beg = o[0]; end = o[1];
+    const uint32_t tid = threadIdx.x, b = blockIdx.y, group0 = blockIdx.x * (256u * kScatterG) + tid;
+    uint32_t beg[kScatterG], end[kScatterG];
+#pragma unroll
+    for (int g = 0; g < kScatterG; g++) {
+        const uint32_t group = group0 + 256u * (uint32_t)g;
+        beg[g] = end[g] = 0u;
+        if (group < (uint32_t)a.num_bin_groups) {
+            const uint16_t *o = a.seg_off + (size_t)group * (a.num_buckets + 1) + b;
+            beg[g] = o[0]; end[g] = o[1];
+        }
     }
     for (uint32_t t = tid; t < ntile; t += 256u) s_cnt[t] = 0u;
     if (tid == 0u) { s_max = 0u; s_total = 0u; }
     __syncthreads();
-    const uint32_t *seg = a.seg + (size_t)group * kSegCap;
-    for (uint32_t k = beg; k < end; k++) atomicAdd(&s_cnt[seg[k] >> 10], 1u);
+#pragma unroll
+    for (int g = 0; g < kScatterG; g++) {
+        const uint32_t *seg = a.seg + (size_t)(group0 + 256u * (uint32_t)g) * kSegCap;
+        for (uint32_t k = beg[g]; k < end[g]; k++) atomicAdd(&s_cnt[seg[k] >> 10], 1u);
+    }
     __syncthreads();
     const uint32_t bx = b % (uint32_t)a.buckets_x, by = b / (uint32_t)a.buckets_x, bw_mask = (1u << a.bucket_w_log2) - 1u;
     auto tile_of = [&](uint32_t t) -> uint32_t {
@@ -331,9 +341,14 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
         }
     }
     __syncthreads();
-    for (uint32_t k = beg; k < end; k++) {
-        const uint32_t e = seg[k], t = e >> 10, pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-        if (pos < a.bin_stride) items[(size_t)tile_of(t) * a.bin_stride + pos] = group * (uint32_t)kBinGroup + (e & 1023u);
+#pragma unroll
+    for (int g = 0; g < kScatterG; g++) {
+        const uint32_t group = group0 + 256u * (uint32_t)g;
+        const uint32_t *seg = a.seg + (size_t)group * kSegCap;
+        for (uint32_t k = beg[g]; k < end[g]; k++) {
+            const uint32_t e = seg[k], t = e >> 10, pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+            if (pos < a.bin_stride) items[(size_t)tile_of(t) * a.bin_stride + pos] = group * (uint32_t)kBinGroup + (e & 1023u);
+        }
     }
     if (tid == 0u && s_total != 0u) {
         uint32_t *sh = a.summary + ((blockIdx.y * gridDim.x + blockIdx.x) & (uint32_t)(kSummaryShards - 1)) * kSummaryStride;
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
         uint32_t sum = 0u, mx = 0u;
         for (int k = lane; k < kSummaryShards; k += 64) { sum += a.summary[k * kSummaryStride]; mx = max(mx, a.summary[k * kSummaryStride + 1]); }
         for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); }
-        if (lane == 0) { a.summary[kSummaryFinal] = sum; a.summary[kSummaryFinal + 1] = mx; }
+        if (lane == 0) { a.summary[kSummaryFinal] = sum; a.summary[kSummaryFinal + 1] = mx; a.summary[kSummaryFinal + 2] = *a.overflow; }   // one read-back for the host
     }
     if (tile >= a.tiles_x * a.tiles_y || *a.overflow != 0u) return;                    // (WAVES == 1 only: whole waves leave, no barrier below)
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
@@ -516,10 +531,10 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
 // (+ summary), large photons.
 void launch_splat_bin(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-    hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);
+    if (!a.boxes_valid) hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);   // (else: written by primary_kernel)
     uint32_t *items = a.deterministic ? a.bin_items_tmp : a.bin_items;
     hipLaunchKernelGGL(splat_bin_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), 0, s, a);
-    const uint32_t slices = ((uint32_t)a.num_bin_groups + 255u) / 256u, big_rows = ((uint32_t)a.num_bin_groups + slices - 1u) / slices;
+    const uint32_t per = 256u * kScatterG, slices = ((uint32_t)a.num_bin_groups + per - 1u) / per, big_rows = ((uint32_t)a.num_bin_groups + slices - 1u) / slices;
     hipLaunchKernelGGL(splat_scatter_kernel, dim3(slices, (uint32_t)a.num_buckets + big_rows), dim3(256), 0, s, a, items);
 }
 // Phase B: (deterministic: sort the bins) and accumulate the tiles.  Both do nothing when a bin overflowed.

@@ -61,7 +61,6 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     }
     const bool walk_light = a.sc.light_count > 0 && __ballot(light_maybe) != 0ull;        // wave-uniform
     int32_t ltri = walk_light ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl) : -1;
-    if (!in_image) return;
     bool use_light = ltri >= 0 && (tri < 0 || tl <= t);  // depth LEQUAL, light mesh drawn last
     const bool light_visible = light_unoccluded ? ltri >= 0 : use_light;              // the emitter IMAGE (rtcomphoton.h:985-995)
     if (use_light) { tri = ltri; b = bl; g = gl; }
@@ -82,6 +81,17 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
         dif = make_float4(kd.x, kd.y, kd.z, 0.f);
         phg = make_float4(ks.x, ks.y, ks.z, ns);
     }
+    if (a.tile_box) {
+        // world-space box of the tile's G-buffer positions, background pixels (the clear colour) included: the photon splat
+        // bins a photon only into tiles whose box its sphere reaches (kernels_splat.hip; splat_tile_box_kernel computes the
+        // same for G-buffers that did not come from this pass)
+        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        if (in_image) { lo[0] = hi[0] = pos.x; lo[1] = hi[1] = pos.y; lo[2] = hi[2] = pos.z; }
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+        if (lane == 0) { a.tile_box[2 * tile] = make_float4(lo[0], lo[1], lo[2], 0.f); a.tile_box[2 * tile + 1] = make_float4(hi[0], hi[1], hi[2], 0.f); }
+    }
+    if (!in_image) return;
     a.g_pos[p] = pos; a.g_nrm[p] = nrm; a.g_dif[p] = dif; a.g_phg[p] = phg;
     if (!(a.clear_light & EVPLP_LIGHT_SKIP)) {
         if (light_visible) a.g_light[p] = make_float4(a.sc.light_unscaled[0], a.sc.light_unscaled[1], a.sc.light_unscaled[2], 0.f);

@@ -221,6 +221,9 @@ int evplp_clear_accumulators(evplp_context *ctx);
 
 /* ---- buffers / statistics ---- */
 int evplp_local_rows(const evplp_context *ctx);
+/* device_ptr and bytes may each be null.  Taking the device pointer of EVPLP_BUF_GBUF_POSITION (or binding memory to it)
+ * tells the library that the caller may write that plane unseen: the photon splat then rebuilds its per-tile position boxes
+ * in every pass instead of taking them from evplp_primary. */
 int evplp_buffer_info(evplp_context *ctx, int32_t which, void **device_ptr, size_t *bytes);
 /* Use caller-owned device memory (e.g. a torch tensor passed to an RCCL collective). */
 int evplp_bind_buffer(evplp_context *ctx, int32_t which, void *device_ptr, size_t bytes);
