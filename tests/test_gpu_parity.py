@@ -361,3 +361,22 @@ def test_resolve_composite(ctx, evplp, oracle):
         ref = np.zeros((ctx.local_rows, W, 3), np.float32)
         oracle.evo_resolve(W, ctx.local_rows, oa.ptr(planes[0]), oa.ptr(planes[1]), oa.ptr(planes[2]), 0.5, 0.25, 1.0, mask, gamma, oa.ptr(ref))
         assert np.allclose(got, ref, rtol=4e-6, atol=1e-7), (mask, gamma)
+
+
+def test_tile_boxes_from_the_primary_pass_equal_the_fallback_kernel(room, evplp):
+    """evplp_primary writes the per-tile position boxes the photon splat culls with; a G-buffer that came in another way
+    (evplp_upload, a bound buffer, a pointer handed out by evplp_buffer_info) has them rebuilt by splat_tile_box_kernel.
+    Same bins, same image."""
+    kw = dict(camera_pos=room.cam_origin, mis_mode=1, pdf_mc=0.35, photon_radius=0.3, num_light_paths=NPATHS, num_vpl_light_paths=NPATHS, photons_per_path=P)
+    outs = []
+    for reupload in (False, True):
+        with evplp.Context(W, H, NPATHS, NPATHS, P, deterministic=True) as c:
+            room.upload(c)
+            c.primary((0.001, 0.002), clear_light=True)
+            c.trace_light_paths(3)
+            if reupload:
+                c.upload(evplp.BUF_GBUF_POSITION, c.download(evplp.BUF_GBUF_POSITION))
+            c.splat_photons(evplp.frame_params(**kw), clear=True)
+            st = c.pass_stats(evplp.PASS_SPLAT)
+            outs.append((c.download(evplp.BUF_PHOTON_ACCUM)[:H].tobytes(), st["pairs"]))
+    assert outs[0][1] > 500 and outs[0] == outs[1]
