@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTr
     int32_t *stack = lds_stack + lane;
 
     const V3 zero = v3(0.f, 0.f, 0.f);
-    for (uint32_t i = 1; i < P; i++) store_record(&rec[i], zero, 0u, zero, 0.f, zero, zero, zero, zero, 0.f);  // :197-200
+    uint32_t filled = 1;     // slots written so far; the rest are cleared at the end (:197-200 clears them all first: same final state)
 
     Rng rng; rng_init(rng, id, a.rng_seed, 0u);
     V3 position, normal; float pdf;
@@ -175,9 +175,11 @@ __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTr
             }
         }
         store_record(&rec[i], hit_pos, flag, ffn, psel, stored_flux, -next_dir, kd, ks, ns);
+        filled = i + 1;
         if (done) break;
         next_pos = hit_pos; next_dir = dir;
     }
+    for (uint32_t i = filled; i < P; i++) store_record(&rec[i], zero, 0u, zero, 0.f, zero, zero, zero, zero, 0.f);
 }
 
 // Stable compaction of the usable VPL records (flags & IsUsableVpl, rt/lighttracing.cu:372) of
