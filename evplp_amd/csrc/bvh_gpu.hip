@@ -249,9 +249,46 @@ __global__ __launch_bounds__(256) void emit_leaves_kernel(const float *verts, co
     }
 }
 
+// node4[i] from binary node i: child s of i, if it is an inner node, is replaced by ITS two children (their boxes are stored in
+// that child's own record); a leaf or absent child stays.  lo / hi are computed exactly as the binary per-lane walk computes them.
+__global__ __launch_bounds__(256) void node4_kernel(const BvhNode *nodes, int n, BvhNode4 *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const BvhNode b = nodes[i];
+    BvhNode4 r;
+    for (int q = 0; q < 4; q++) { r.child[q] = kNoChild; r.pad[q] = 0; for (int k = 0; k < 3; k++) { r.lo[k][q] = 3.0e38f; r.hi[k][q] = -3.0e38f; } }
+    const int32_t ch[2] = { b.c0, b.c1 };
+    for (int s = 0; s < 2; s++) {
+        if (ch[s] >= 0) {
+            const BvhNode c = nodes[ch[s]];
+            const int32_t gc[2] = { c.c0, c.c1 };
+            for (int q = 0; q < 2; q++) {
+                r.child[2 * s + q] = gc[q];
+                for (int k = 0; k < 3; k++) { r.lo[k][2 * s + q] = c.ctr[k][q] - c.hal[k][q]; r.hi[k][2 * s + q] = c.ctr[k][q] + c.hal[k][q]; }
+            }
+        } else if (ch[s] != kNoChild) {
+            r.child[2 * s] = ch[s];
+            for (int k = 0; k < 3; k++) { r.lo[k][2 * s] = b.ctr[k][s] - b.hal[k][s]; r.hi[k][2 * s] = b.ctr[k][s] + b.hal[k][s]; }
+        }
+    }
+    out[i] = r;
+}
+
 #define GB_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
 
 } // namespace
+
+// The four-wide nodes of a flattened binary tree that is already on the device (all builders); *out is a device allocation.
+int build_nodes4(const BvhNode *d_nodes, int32_t nnodes, hipStream_t stream, BvhNode4 **out) {
+    BvhNode4 *p = nullptr;
+    hipError_t e = hipMalloc((void **)&p, sizeof(BvhNode4) * (size_t)std::max(nnodes, 1));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(node4_kernel, dim3((unsigned)((nnodes + 255) / 256)), dim3(256), 0, stream, d_nodes, nnodes, p);
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { hipFree(p); return (int)e; }
+    *out = p;
+    return 0;
+}
 
 // Builds on `stream` from the host triangle list; the four output arrays are device allocations owned by the caller
 // (hipFree).  Returns hipSuccess or the failing HIP status.

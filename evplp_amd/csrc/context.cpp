@@ -151,7 +151,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
 }
 
 static void free_scene_device(evplp_context *c) {
-    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.leaves); hipFree((void *)c->sc.tri_flat); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
+    hipFree((void *)c->sc.nodes); hipFree((void *)c->sc.nodes4); hipFree((void *)c->sc.leaves); hipFree((void *)c->sc.tri_flat); hipFree((void *)c->sc.tri_index); hipFree((void *)c->sc.attrs);
     hipFree((void *)c->sc.materials); hipFree((void *)c->sc.textures); hipFree((void *)c->sc.tex_pool); hipFree((void *)c->sc.light_cdf);
     std::memset(&c->sc, 0, sizeof(c->sc));
 }
@@ -350,6 +350,9 @@ extern "C" int evplp_build_accel(evplp_context *c) {
         if ((rc = upload_array(c, bb.tri_flat, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_flat))) { free_bvh(&bb); return rc; }
     }
     c->sc.ntris = bb.ntris; c->sc.bvh_depth = bb.depth;
+    { BvhNode4 *n4 = nullptr; const int e4 = build_nodes4(c->sc.nodes, bb.nnodes, c->stream, &n4);
+      if (e4 != 0) { free_bvh(&bb); c->set_error("evplp_build_accel: four-wide nodes: %s", hipGetErrorString((hipError_t)e4)); return EVPLP_ERR_HIP; }
+      c->sc.nodes4 = n4; }
     free_bvh(&bb);
     if ((rc = upload_array(c, attrs.data(), attrs.size(), &c->sc.attrs))) return rc;
     if ((rc = upload_array(c, c->materials.data(), c->materials.size(), &c->sc.materials))) return rc;

@@ -8,6 +8,7 @@
 namespace evplp {
 // bvh_gpu.hip: LBVH built on the device (arrays are device allocations owned by the caller)
 int build_bvh_gpu(const float *verts_host, int32_t ntri, float pad_scale, hipStream_t stream, BvhDeviceBuild *out);
+int build_nodes4(const BvhNode *d_nodes, int32_t nnodes, hipStream_t stream, BvhNode4 **out);
 struct HostMesh { std::vector<float> verts, uvs; std::vector<int32_t> idx; int32_t material = 0; };
 struct HostTexture { int32_t w = 0, h = 0; std::vector<float> rgba; };
 struct HostStats { uint64_t rays = 0; };

@@ -582,6 +582,101 @@ EV_DEV int32_t closest_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
 // light sub-paths).  Replaces rtTrace(..., ray type 0) + meshFineIntersect.  The closest hit is
 // order-independent: ties in t keep the lowest ORIGINAL triangle index (same rule as the oracle).
 // filter: 0 all, 1 skip light mesh, 2 light mesh only.  Returns original triangle index or -1.
+// Four-wide variants (BvhNode4, evplp_types.h): the same boxes, the same leaves, half the dependent node fetches per ray.  A ray of
+// an incoherent wave spends its time waiting for the next node (300 k light paths are 4.6 waves per SIMD, nothing to switch to).
+EV_DEV void node4_slabs(const BvhNode4 &n, V3 inv, V3 noi, float tmin, float tmax, float tn[4], bool h[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float lo[3] = { n.lo[0][q], n.lo[1][q], n.lo[2][q] }, hi[3] = { n.hi[0][q], n.hi[1][q], n.hi[2][q] };
+        tn[q] = slab_near(lo, hi, inv, noi, tmin, tmax, h[q]);
+    }
+}
+template <int STACK_STRIDE>
+EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
+                             float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */) {
+    V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+    int32_t best = -1; float bt = tmax, bb = 0.f, bg = 0.f;
+    int sp = 0;
+    int32_t cur = 0;
+    bool done = false;
+    while (!done) {
+        while (cur >= 0) {
+            const BvhNode4 &n = sc.nodes4[cur];
+            float tn[4]; bool h[4];
+            node4_slabs(n, inv, noi, tmin, bt, tn, h);
+            int32_t c[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (!h[q] || c[q] == kNoChild) { tn[q] = 3.0e38f; c[q] = kNoChild; }
+            // nearest first: sorting network on (entry distance, child)
+#define EV_CSWAP(i_, j_) { const bool sw = tn[j_] < tn[i_]; const float tt = sw ? tn[j_] : tn[i_]; tn[j_] = sw ? tn[i_] : tn[j_]; tn[i_] = tt; \
+                           const int32_t cc = sw ? c[j_] : c[i_]; c[j_] = sw ? c[i_] : c[j_]; c[i_] = cc; }
+            EV_CSWAP(0, 1) EV_CSWAP(2, 3) EV_CSWAP(0, 2) EV_CSWAP(1, 3) EV_CSWAP(1, 2)
+#undef EV_CSWAP
+            if (c[3] != kNoChild) { stack[sp * STACK_STRIDE] = c[3]; sp++; }
+            if (c[2] != kNoChild) { stack[sp * STACK_STRIDE] = c[2]; sp++; }
+            if (c[1] != kNoChild) { stack[sp * STACK_STRIDE] = c[1]; sp++; }
+            if (c[0] != kNoChild) cur = c[0];
+            else if (sp == 0) { done = true; break; }
+            else { --sp; cur = stack[sp * STACK_STRIDE]; }
+        }
+        if (done) break;
+        if (cur != kNoChild) {
+            int32_t id = ~cur;
+            int32_t block = id >> 2, cnt = (id & 3) + 1;
+            for (int32_t k = 0; k < cnt; k++) {
+                int32_t orig = sc.tri_index[block * 4 + k];
+                bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
+                if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
+                float t, b, g;
+                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, 3.0e38f, t, b, g)) {
+                    if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stack[sp * STACK_STRIDE];
+    }
+    if (best >= 0) { t_out = bt; beta_out = bb; gamma_out = bg; }
+    return best;
+}
+template <int STACK_STRIDE>
+EV_DEV bool occluded_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int32_t *stack) {
+    V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+    int sp = 0;
+    int32_t cur = 0;
+    bool done = false;
+    while (!done) {
+        while (cur >= 0) {
+            const BvhNode4 &n = sc.nodes4[cur];
+            float tn[4]; bool h[4];
+            node4_slabs(n, inv, noi, tmin, tmax, tn, h);
+            int32_t next = kNoChild;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int32_t c = n.child[q];
+                if (h[q] && c != kNoChild) { if (next != kNoChild) { stack[sp * STACK_STRIDE] = next; sp++; } next = c; }
+            }
+            if (next != kNoChild) cur = next;
+            else if (sp == 0) { done = true; break; }
+            else { --sp; cur = stack[sp * STACK_STRIDE]; }
+        }
+        if (done) break;
+        if (cur != kNoChild) {
+            int32_t id = ~cur;
+            int32_t block = id >> 2, cnt = (id & 3) + 1;
+            for (int32_t k = 0; k < cnt; k++) {
+                float t, b, g;
+                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, tmax, t, b, g)) return true;
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stack[sp * STACK_STRIDE];
+    }
+    return false;
+}
+
 template <int STACK_STRIDE>
 EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
                             float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */) {

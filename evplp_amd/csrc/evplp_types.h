@@ -21,6 +21,15 @@ struct BvhNode {
     int32_t pad[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+// Four-wide node for the per-lane walks (incoherent rays: light tracing, path tracer, light-path windows): the two children of
+// a binary node replaced by its (up to four) grandchildren -- half the dependent fetches per ray.  node4[i] is derived from
+// binary node i on the device (bvh_gpu.hip build_nodes4); the walks only ever visit every second level of it.
+struct BvhNode4 {
+    float lo[3][4], hi[3][4];   // [axis][child]; an absent child has lo > hi
+    int32_t child[4];           // binary node index (>= 0), ~leaf reference, or kNoChild
+    int32_t pad[4];
+};
+static_assert(sizeof(BvhNode4) == 128, "BvhNode4 must be 128 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr int kMaxLeafTris = 4;
 constexpr int kMaxDepth = 64;
@@ -70,6 +79,7 @@ struct CamBasis {
 // wave-uniform => scalar loads).
 struct SceneDev {
     const BvhNode *nodes;
+    const BvhNode4 *nodes4;      // per-lane walks
     const LeafBlock *leaves;     // one block per leaf
     const TriFlat *tri_flat;     // 4 slots per leaf (per-lane walks)
     const int32_t *tri_index;    // 4 slots per leaf: original triangle index or -1

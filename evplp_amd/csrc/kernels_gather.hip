@@ -239,6 +239,14 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 // consecutive light paths starting at its own random path.  Neighbouring pixels see different records, so
 // there is no shared origin to build a packet on: one shadow ray per lane, per-lane LDS stack (the authors
 // note the variant is experimental and slower than the plain gather for the same reason).
+#ifndef EVPLP_LVC_WIDE
+#define EVPLP_LVC_WIDE 0
+#endif
+#if EVPLP_LVC_WIDE
+#define LVC_OCCLUDED occluded_lane4
+#else
+#define LVC_OCCLUDED occluded_lane
+#endif
 #ifndef EVPLP_LVC_WAVES
 #define EVPLP_LVC_WAVES 6   // 5 = 56.7 ms, 6 = 53.5, 7 = 54.4, 8 = 55.9 (1024^2, 64-path windows)
 #endif
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(64, EVPLP_LVC_WAVES) void gather_lvc_kernel(GatherA
             float c1c2 = c1 * c2;
             if (c1c2 <= 0.0f) continue;
             rays++;
-            if (occluded_lane<64>(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, stack)) continue;
+            if (LVC_OCCLUDED<64>(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, stack)) continue;
             result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2);
         }
     }

@@ -8,6 +8,20 @@
 #include "device_common.hpp"
 #include "kernels.h"
 
+// per-lane walks: binary nodes (EVPLP_PT_WIDE 0) or four-wide nodes (1).  1024^2, furnished scene: binary at 6 waves per SIMD 365 M
+// camera paths/s, four-wide at 4 waves (no spills) 363, at 6 waves (220 B of spills) 343: no gain here, the path tracer has waves
+// to switch to while a node is in flight; the four-wide nodes pay off in light tracing (kernels_trace.hip)
+#ifndef EVPLP_PT_WIDE
+#define EVPLP_PT_WIDE 0
+#endif
+#if EVPLP_PT_WIDE
+#define PT_OCCLUDED occluded_lane4
+#define PT_CLOSEST closest_lane4
+#else
+#define PT_OCCLUDED occluded_lane
+#define PT_CLOSEST closest_lane
+#endif
+
 namespace evplp {
 
 // pathtracing.cu:53-56
@@ -36,7 +50,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
         V3 lval = light_sample(a.sc, lp, ln, lpdf, rng);
         V3 to_light = lp - first_pos;
         V3 tln = normalize(to_light);
-        bool hit = occluded_lane<64>(a.sc, lp, -to_light, 0.0001f, 1.0f - 0.0001f, stack); rays++;
+        bool hit = PT_OCCLUDED<64>(a.sc, lp, -to_light, 0.0001f, 1.0f - 0.0001f, stack); rays++;
         float ml = max_color(rd1), mp = max_color(rs1);
         float psel = ml / (mp + ml);
         if (ml + mp <= 0.000001f) alive = false;
@@ -66,7 +80,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
     for (uint32_t i = 0; alive && i < a.max_bounces; i++) {
         const bool done = (i == a.max_bounces - 1);
         float t, b, g;
-        int32_t tri = closest_lane<64>(a.sc, prd_pos, dir, 0.00001f, 3.0e38f, 0, t, b, g, stack); rays++;
+        int32_t tri = PT_CLOSEST<64>(a.sc, prd_pos, dir, 0.00001f, 3.0e38f, 0, t, b, g, stack); rays++;
         if (tri < 0) break;                                               // no miss program: the path ends
         const TriAttr &ta = a.sc.attrs[tri];
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
@@ -89,7 +103,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
         V3 lval = light_sample(a.sc, lp, ln, lpdf, rng);
         V3 to_light = lp - npos;
         V3 tln = normalize(to_light);
-        bool hit = occluded_lane<64>(a.sc, lp, -to_light, 0.00001f, 0.99999f, stack); rays++;
+        bool hit = PT_OCCLUDED<64>(a.sc, lp, -to_light, 0.00001f, 0.99999f, stack); rays++;
         V3 kd, ks; float ns;
         material_at(a.sc, ta, b, g, kd, ks, ns);
         float ml = max_color(kd), mp = max_color(ks);

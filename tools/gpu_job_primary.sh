@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out/prim; rm -rf $O; mkdir -p $O
 cd $ROOT
-timeout 1200 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_end_to_end.py tests/test_gpu_bvh.py tests/test_gpu_baseline_configs.py -q -x > $O/tests_full.txt 2>&1; grep -E "passed|failed|error" $O/tests_full.txt | tail -3
+timeout 1500 python3 -m pytest tests -m gpu -q -x > $O/tests_full.txt 2>&1; grep -E "passed|failed|error" $O/tests_full.txt | tail -3
 cd /tmp
 for wl in ir ppm; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_${wl} -- python3 $ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/kt_${wl}.log 2>&1
