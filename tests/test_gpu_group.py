@@ -118,3 +118,30 @@ def test_large_frames_use_larger_bins_buckets_and_give_the_same_splat(evplp, tmp
             imgs[n] = g.resolve(0.0, 1.0, 0.0)
     assert imgs[1].max() > 0 and imgs[1].shape == (BH, BW, 3)
     assert imgs[1].tobytes() == imgs[2].tobytes()
+
+
+@pytest.mark.parametrize("kind", ["vsl", "lvc", "pt"])
+def test_the_other_gathers_and_the_path_tracer_on_virtual_ranks(evplp, tmp_path, kind):
+    """VSL gather, light-path-window gather and the path tracer on 1 / 3 strip ranks: per-pixel RNG streams are keyed by the global
+    pixel, so the partition cannot change a bit."""
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H, style="hard")
+    sd, _ = scenes.load_obj_scene(jp)
+    NL, NV = 64, 16
+    images = {}
+    for n in (1, 3):
+        with evplp.Group(W, H, NL, NV, P, n, devices=[0] * n, deterministic=True) as g:
+            g.load_scene_json(jp)
+            import ctypes as C
+            r_, t_, l_ = C.c_float(), C.c_float(), C.c_float()
+            evplp.lib().evplp_scene_metrics(evplp.lib().evplp_group_context(g._h, 0), C.byref(r_), C.byref(t_), C.byref(l_))
+            fp = frame(evplp, g, sd, r_.value, t_.value, NL, NV)
+            g.clear_accumulators()
+            g.primary((0.002, -0.001)); g.trace_light_paths(4)
+            if kind == "pt":
+                cp = (C.c_float * 3)(*[float(v) for v in sd.cam_origin])
+                assert evplp.lib().evplp_group_path_trace(g._h, C.byref(cp), 5, 3, 0) == 0
+            else:
+                g.gather(fp, 1 if kind == "vsl" else 2)
+            images[n] = g.resolve(1.0, 0.0, 1.0)
+    assert images[1].max() > 0 and np.isfinite(images[1]).all()
+    assert images[1].tobytes() == images[3].tobytes()
