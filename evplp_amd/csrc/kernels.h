@@ -125,8 +125,9 @@ constexpr int kSplatTile = 8;        // pixels per tile edge (one wave per tile)
 constexpr int kCompactF4 = 4;        // float4 per compact photon
 
 // dynamic LDS of the kernels that walk the BVH one ray per lane: an [entry][lane] stack as deep as the tree
+inline size_t lane_stack_bytes(const SceneDev &sc) { return (size_t)(sc.bvh_depth + 2) * 64 * sizeof(int32_t); }
 // (four-wide walk: every second level of the binary tree, up to three pushes per level)
-inline size_t lane_stack_bytes(const SceneDev &sc) { return (size_t)(3 * ((sc.bvh_depth + 1) / 2) + 4) * 64 * sizeof(int32_t); }
+inline size_t lane_stack_bytes4(const SceneDev &sc) { return (size_t)(3 * ((sc.bvh_depth + 1) / 2) + 4) * 64 * sizeof(int32_t); }
 
 void launch_primary(const PrimaryArgs &a, hipStream_t s);
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s);

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64, EVPLP_LVC_WAVES) void gather_lvc_kernel(GatherA
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
     if (tiles_x * tiles_y == 0) return;
-    hipLaunchKernelGGL(gather_lvc_kernel, dim3(tiles_x * tiles_y), dim3(64), lane_stack_bytes(a.sc), s, a, records);
+    hipLaunchKernelGGL(gather_lvc_kernel, dim3(tiles_x * tiles_y), dim3(64), EVPLP_LVC_WIDE ? lane_stack_bytes4(a.sc) : lane_stack_bytes(a.sc), s, a, records);
 }
 
 // ------------------------------------------------------------------------------------ VSL

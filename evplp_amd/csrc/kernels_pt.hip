@@ -8,9 +8,9 @@
 #include "device_common.hpp"
 #include "kernels.h"
 
-// per-lane walks: binary nodes (EVPLP_PT_WIDE 0) or four-wide nodes (1).  1024^2, furnished scene: binary at 6 waves per SIMD 365 M
-// camera paths/s, four-wide at 4 waves (no spills) 363, at 6 waves (220 B of spills) 343: no gain here, the path tracer has waves
-// to switch to while a node is in flight; the four-wide nodes pay off in light tracing (kernels_trace.hip)
+// per-lane walks: binary nodes (EVPLP_PT_WIDE 0) or four-wide nodes (1).  1024^2, furnished scene: binary at 6 waves per SIMD 361 M
+// camera paths/s, four-wide at 4 waves (no spills, 1.5x the LDS stack) 362: no gain here, the path tracer has waves to switch to
+// while a node is in flight; the four-wide nodes pay off in light tracing (kernels_trace.hip)
 #ifndef EVPLP_PT_WIDE
 #define EVPLP_PT_WIDE 0
 #endif
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64, EVPLP_PT_WAVES) void path_trace_kernel(PathTrac
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
     if (tiles_x * tiles_y == 0) return;
-    hipLaunchKernelGGL(path_trace_kernel, dim3(tiles_x * tiles_y), dim3(64), lane_stack_bytes(a.sc), s, a);
+    hipLaunchKernelGGL(path_trace_kernel, dim3(tiles_x * tiles_y), dim3(64), EVPLP_PT_WIDE ? lane_stack_bytes4(a.sc) : lane_stack_bytes(a.sc), s, a);
 }
 
 } // namespace evplp

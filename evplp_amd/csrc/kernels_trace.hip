@@ -223,7 +223,7 @@ void launch_primary(const PrimaryArgs &a, hipStream_t s) {
 }
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s) {
     if (a.path_count == 0) return;
-    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), lane_stack_bytes(a.sc), s, a);
+    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), lane_stack_bytes4(a.sc), s, a);
 }
 void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
                         uint32_t *count_out, hipStream_t s) {
