@@ -364,16 +364,20 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     if (nvalid > 0) root = builder == EVPLP_BVH_SBVH ? B.build_sbvh() : builder == EVPLP_BVH_SAH ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
 
     // conservative padding: the device slab test is inexact, the triangle test is exact; a padded
-    // box guarantees no triangle the exact test accepts is ever culled.  Error budget of the slab tests (coordinates bounded
-    // by the scene diagonal D): ~6 roundings of terms of size <= D (6e-8 D each) + the 1-ulp reciprocal applied to a
-    // difference <= D: < 7e-7 D in position.  The pad is 6x that.  It is kept this small on purpose: a shadow segment stops
+    // box guarantees no triangle the exact test accepts is ever culled.  Error budget of the slab tests, with S = the larger of
+    // the scene diagonal and the largest coordinate magnitude (the slab form plane * inv - o * inv cancels terms of the size of
+    // the coordinates): ~6 roundings of terms of size <= S (6e-8 S each) + the 1-ulp reciprocal applied to a difference <= S:
+    // < 7e-7 S in position.  The pad is 3x that (2e-6 S; 4e-6: +2 % / +8 % gather time on the furnished / box scene, 1e-6:
+    // -1 % / -4 % but only 1.4x the budget).  It is kept this small on purpose: a shadow segment stops
     // 1e-4 of its length short of the surface it ends on (lighttracing.cu:292), and only while pad < 1e-4 |d_perp| does it stay
     // out of the leaf boxes of that surface -- with the former 2e-5 D every segment shorter than 6 units entered the leaf under
     // its end point, and a beam shaft every leaf under its tile's footprint.
     const float pad_scale = bvh_pad_scale();
     float diag = 0.f;
     if (nvalid > 0) { float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2]; diag = std::sqrt(dx * dx + dy * dy + dz * dz); }
-    const float pad = pad_scale * diag + 1e-30f;
+    float coord = 0.f;
+    if (nvalid > 0) for (int k = 0; k < 3; k++) coord = std::max(coord, std::max(std::abs(scene.lo[k]), std::abs(scene.hi[k])));
+    const float pad = pad_scale * std::max(diag, coord) + 1e-30f;
 
     // flatten: inner nodes in DFS pre-order; each inner node carries both child boxes
     std::vector<BvhNode> flat; std::vector<int32_t> order; order.reserve((size_t)nvalid);   // 4 slots per leaf, -1 = empty
@@ -448,7 +452,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
 }
 
 float bvh_pad_scale() {
-    float pad_scale = 4e-6f;
+    float pad_scale = 2e-6f;
     if (const char *e = std::getenv("EVPLP_BVH_PAD")) pad_scale = (float)atof(e);
     return pad_scale;
 }

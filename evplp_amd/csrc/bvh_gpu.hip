@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(const Topo *topo, int n
                                                          const Bx *lbox, const Bx *ibox, const uint32_t *bounds, float pad_scale, BvhNode *nodes) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float dx = o2f(bounds[9]) - o2f(bounds[6]), dy = o2f(bounds[10]) - o2f(bounds[7]), dz = o2f(bounds[11]) - o2f(bounds[8]);
-    const float pad = pad_scale * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-30f;
+    float coord = 0.f;
+    for (int k = 0; k < 3; k++) coord = fmaxf(coord, fmaxf(fabsf(o2f(bounds[6 + k])), fabsf(o2f(bounds[9 + k]))));
+    const float pad = pad_scale * fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), coord) + 1e-30f;
     if (n - 1 < 1 || !kept[0]) {
         // at most 4 triangles: a root with the block as its only child
         if (i == 0) {
