@@ -3,6 +3,7 @@
 tag=${1:-r02}
 export TMPDIR=/tmp
 O=gpurun_out/final_$tag; mkdir -p $O
+make -j16 stats > $O/make_stats.log 2>&1   # the counters build that tools/traversal_stats.py loads must match the tree
 python3 bench.py > $O/${tag}_bench_ir.jsonl 2> $O/bench_ir.err
 python3 bench.py --workload evplp --steps 30 --warmup 3 --no-cpu-baseline > $O/${tag}_bench_evplp.jsonl 2> $O/bench_evplp.err
 python3 bench.py --workload ppm --steps 100 --warmup 5 --no-cpu-baseline > $O/${tag}_bench_ppm.jsonl 2> $O/bench_ppm.err
