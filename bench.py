@@ -220,7 +220,7 @@ def main():
     builder = {"sah": ev.BVH_SAH, "sbvh": ev.BVH_SBVH, "lbvh": ev.BVH_LBVH, "gpu": ev.BVH_LBVH_GPU}[a.bvh]
 
     def make_ctx(path, nl, nv):
-        c = ev.Context(W, H, nl, nv, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows, bvh_builder=builder)
+        c = ev.Context(W, H, nl, nv, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows, bvh_builder=builder, overlap_light_tracing=True)
         c.load_scene_json(path)
         return c
     ctx = make_ctx(json_path, n_light, n_vpl)

@@ -49,7 +49,7 @@ class Config(C.Structure):
                 ("strip_rank", C.c_int32), ("strip_count", C.c_int32), ("strip_rows", C.c_int32),
                 ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
                 ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("gather_splits_per_wave", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("overlap_light_tracing", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Material(C.Structure):
@@ -200,7 +200,7 @@ class Context:
 
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
-                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0):
+                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0, overlap_light_tracing: bool = False):
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y
@@ -208,6 +208,7 @@ class Context:
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths
         cfg.photons_per_path = photons_per_path; cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
         cfg.gather_splits_per_wave = gather_splits_per_wave
+        cfg.overlap_light_tracing = int(overlap_light_tracing)
         self.cfg = cfg
         h = C.c_void_p()
         rc = self._lib.evplp_create(C.byref(cfg), C.byref(h))

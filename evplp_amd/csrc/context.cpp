@@ -82,6 +82,11 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     };
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     c->stream = c->own_stream;
+    if (cfg->overlap_light_tracing) {
+        if ((e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->ev_records_read, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->ev_light_done, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    }
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if ((e = hipEventCreate(&c->ev_begin[i])) != hipSuccess) return fail("hipEventCreate", e);
         if ((e = hipEventCreate(&c->ev_end[i])) != hipSuccess) return fail("hipEventCreate", e);
@@ -160,6 +165,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);
     c->splat_pending = false;
+    if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
@@ -174,12 +180,16 @@ extern "C" void evplp_destroy(evplp_context *c) {
     }
     if (c->ev_summary) hipEventDestroy(c->ev_summary);
     if (c->h_summary) hipHostFree(c->h_summary);
+    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
+    if (c->ev_records_read) hipEventDestroy(c->ev_records_read);
+    if (c->ev_light_done) hipEventDestroy(c->ev_light_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
 
 extern "C" int evplp_set_stream(evplp_context *c, void *s) {
     CTX_CHECK(c);
+    if (c->aux_stream) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));    // (its pending wait was enqueued on the old stream)
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return EVPLP_OK;
 }
@@ -414,6 +424,7 @@ static int settle_splat(evplp_context *c) {
     const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     HIP_TRY(c, hipEventRecord(c->ev_end[EVPLP_PASS_SPLAT], c->stream));
+    if (c->aux_stream) HIP_TRY(c, hipEventRecord(c->ev_records_read, c->stream));
     HIP_TRY(c, hipGetLastError());
     return EVPLP_OK;
 }
@@ -432,6 +443,8 @@ static int pass_begin(evplp_context *c, int pass) {
 }
 static int pass_end(evplp_context *c, int pass) {
     HIP_TRY(c, hipEventRecord(c->ev_end[pass], c->stream));
+    if (c->aux_stream && (pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL || pass == EVPLP_PASS_GATHER_LVC || pass == EVPLP_PASS_SPLAT))
+        HIP_TRY(c, hipEventRecord(c->ev_records_read, c->stream));
     HIP_TRY(c, hipGetLastError());
     return EVPLP_OK;
 }
@@ -460,9 +473,23 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
     LightTraceArgs a; std::memset(&a, 0, sizeof(a));
     a.sc = c->sc; a.rng_seed = rng_seed; a.path_begin = path_begin; a.path_count = path_count; a.photons_per_path = c->cfg.photons_per_path;
     a.records = (evplp_record *)c->buf[EVPLP_BUF_RECORDS];
-    if ((rc = pass_begin(c, EVPLP_PASS_LIGHT_TRACE))) return rc;
-    launch_light_trace(a, c->stream);
-    return pass_end(c, EVPLP_PASS_LIGHT_TRACE);
+    if (!c->aux_stream) {
+        if ((rc = pass_begin(c, EVPLP_PASS_LIGHT_TRACE))) return rc;
+        launch_light_trace(a, c->stream);
+        return pass_end(c, EVPLP_PASS_LIGHT_TRACE);
+    }
+    // overlapped: behind the last reader of the records, beside whatever the main stream is doing now (the G-buffer pass of
+    // this iteration), in front of everything the main stream is given from here on
+    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_records_read, 0));
+    HIP_TRY(c, hipMemsetAsync(&c->d_counters[EVPLP_PASS_LIGHT_TRACE], 0, sizeof(PassCounters), c->aux_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_begin[EVPLP_PASS_LIGHT_TRACE], c->aux_stream));
+    c->pass_ran[EVPLP_PASS_LIGHT_TRACE] = true; c->pass_has_dom[EVPLP_PASS_LIGHT_TRACE] = false;
+    launch_light_trace(a, c->aux_stream);
+    HIP_TRY(c, hipEventRecord(c->ev_end[EVPLP_PASS_LIGHT_TRACE], c->aux_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_light_done, c->aux_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_light_done, 0));
+    HIP_TRY(c, hipGetLastError());
+    return EVPLP_OK;
 }
 
 static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, GatherArgs &a, int pass) {

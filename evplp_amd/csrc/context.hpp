@@ -48,6 +48,9 @@ struct evplp_context {
 
     // splat workspace
     int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_stride = 0, last_bin_entries = 0, last_bin_max = 0;   // bin_stride: slots per tile bin
+    // overlap_light_tracing (evplp_config): light tracing on aux_stream, behind ev_records_read (recorded after every pass that reads
+    // the record buffer), in front of whatever the main stream is given next (it waits for ev_light_done)
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_records_read = nullptr, ev_light_done = nullptr; bool light_in_flight = false;
     bool gbuf_pos_exposed = false;             // the caller holds a device pointer to the position plane (buffer_info / bind_buffer): it may write it unseen
     bool tile_box_valid = false;               // d_tile_box describes the current G-buffer (written by evplp_primary; any other way in clears it)
     int32_t num_bin_groups = 0, bucket_w_log2 = 0, bucket_h_log2 = 0, buckets_x = 0, num_buckets = 0;   // two-level binning (kernels.h)

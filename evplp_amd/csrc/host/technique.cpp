@@ -262,6 +262,7 @@ public:
         cfg.num_light_paths = (uint32_t)num_light_paths; cfg.num_vpl_light_paths = (uint32_t)num_vpl_light_paths;
         cfg.photons_per_path = (uint32_t)photons_per_path; cfg.bvh_builder = bvh_builder;
         if (json.has("deterministic")) cfg.deterministic = json.at("deterministic").as_bool("deterministic") ? 1 : 0;   // build-only key
+        cfg.overlap_light_tracing = 1;      // the loop below calls primary, then light tracing: they overlap
         Grp grp; create_group(grp, cfg, json, device);
         upload_scene_group(grp.g, scene);
         float bsr = 0.f, total_area = 0.f, light_area = 0.f;

@@ -83,7 +83,13 @@ typedef struct evplp_config {
     int32_t deterministic;       /* 1: photon bins are accumulated in record order (bitwise reproducible) */
     int32_t gather_splits_per_wave; /* VPL gather work-item size: consecutive VPL splits (of 128) one wavefront sums; a power of two
                                   * 1..32, 0 = the library's default.  Results do not depend on it (fixed summation tree). */
-    int32_t reserved[3];
+    int32_t overlap_light_tracing;  /* 1: evplp_trace_light_paths runs on a second HIP stream of the context, ordered only behind the last
+                                  * pass that READ the record buffer (gathers, photon splat) and in front of everything enqueued on the
+                                  * context's stream after it -- so a preceding evplp_primary overlaps with it (light paths are
+                                  * latency-bound, 4.6 waves per SIMD).  Off by default: a caller with kernels of its own on the
+                                  * context's stream that read the records between the last such pass and the next light tracing
+                                  * needs them ordered.  The technique loops of evplp_render_json and bench.py switch it on. */
+    int32_t reserved[2];
 } evplp_config;
 
 /* rt/rtcommon.h:278-308 RtMaterial: three RGBA32F textures (a constant is a 1x1 texture,

@@ -380,3 +380,27 @@ def test_tile_boxes_from_the_primary_pass_equal_the_fallback_kernel(room, evplp)
             st = c.pass_stats(evplp.PASS_SPLAT)
             outs.append((c.download(evplp.BUF_PHOTON_ACCUM)[:H].tobytes(), st["pairs"]))
     assert outs[0][1] > 500 and outs[0] == outs[1]
+
+
+def test_overlapped_light_tracing_changes_no_bit(room, evplp):
+    """evplp_config.overlap_light_tracing: light tracing on a second stream beside the G-buffer pass, ordered behind the last
+    reader of the records and in front of the next one.  Several iterations of the technique loop, with and without."""
+    outs = []
+    for overlap in (False, True):
+        with evplp.Context(W, H, NPATHS, NPATHS, P, deterministic=True, overlap_light_tracing=overlap) as c:
+            room.upload(c)
+            c.clear_accumulators()
+            recs = []
+            for it in range(4):
+                kw = dict(camera_pos=room.cam_origin, mis_mode=1, pdf_mc=0.35, photon_radius=0.3, num_light_paths=NPATHS, num_vpl_light_paths=NPATHS,
+                          photons_per_path=P, do_accumulate=1, rng_seed=it)
+                c.primary((0.001 * it, -0.002), clear_light=True)
+                c.trace_light_paths(10 + it)
+                c.gather_vpl(evplp.frame_params(**kw))
+                c.splat_photons(evplp.frame_params(**kw))
+                if it == 2:
+                    recs.append(c.download(evplp.BUF_RECORDS).tobytes())
+            st = c.pass_stats(evplp.PASS_LIGHT_TRACE)
+            assert st["ms"] > 0
+            outs.append((c.download(evplp.BUF_VPL_ACCUM)[:H].tobytes(), c.download(evplp.BUF_PHOTON_ACCUM)[:H].tobytes(), recs[0]))
+    assert outs[0] == outs[1]
