@@ -384,12 +384,12 @@ class Group:
     """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
 
     def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=8,
-                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH):
+                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False):
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths; cfg.photons_per_path = photons_per_path
-        cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
+        cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic); cfg.overlap_light_tracing = int(overlap_light_tracing)
         gc = GroupConfig(); gc.n_ranks = n_ranks; gc.strip_rows = strip_rows; gc.use_rccl = int(use_rccl)
         self._devs = (C.c_int32 * n_ranks)(*devices) if devices is not None else None
         gc.devices = C.cast(self._devs, C.POINTER(C.c_int32)) if self._devs is not None else None

@@ -32,7 +32,8 @@ def test_virtual_ranks_equal_the_single_context(evplp, tmp_path, NL):
     NV = 32
     images = {}
     for n in (1, 2, 4):
-        with evplp.Group(W, H, NL, NV, P, n, devices=[0] * n, deterministic=True) as g:
+        # (the 4-rank group also runs light tracing on its second stream, beside the G-buffer pass)
+        with evplp.Group(W, H, NL, NV, P, n, devices=[0] * n, deterministic=True, overlap_light_tracing=(n == 4)) as g:
             g.load_scene_json(jp)
             c0 = evplp.lib().evplp_group_context(g._h, 0)
             import ctypes as C
