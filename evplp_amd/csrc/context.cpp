@@ -435,8 +435,15 @@ static int pass_ready(evplp_context *c, const char *name, bool need_camera) {
     if (e != hipSuccess) { c->set_error("hipSetDevice: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
     return settle_splat(c);
 }
+// device counters are written by the gathers and the path tracer (and by the counters build of the splat)
+#ifndef EVPLP_TRAVERSAL_STATS
+#define EVPLP_TRAVERSAL_STATS 0
+#endif
+static bool pass_uses_counters(int pass) {
+    return pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL || pass == EVPLP_PASS_GATHER_LVC || pass == EVPLP_PASS_PATH_TRACE || EVPLP_TRAVERSAL_STATS;
+}
 static int pass_begin(evplp_context *c, int pass) {
-    HIP_TRY(c, hipMemsetAsync(&c->d_counters[pass], 0, sizeof(PassCounters), c->stream));
+    if (pass_uses_counters(pass)) HIP_TRY(c, hipMemsetAsync(&c->d_counters[pass], 0, sizeof(PassCounters), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_begin[pass], c->stream));
     c->pass_ran[pass] = true; c->pass_has_dom[pass] = false;
     return EVPLP_OK;
@@ -481,7 +488,6 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
     // overlapped: behind the last reader of the records, beside whatever the main stream is doing now (the G-buffer pass of
     // this iteration), in front of everything the main stream is given from here on
     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_records_read, 0));
-    HIP_TRY(c, hipMemsetAsync(&c->d_counters[EVPLP_PASS_LIGHT_TRACE], 0, sizeof(PassCounters), c->aux_stream));
     HIP_TRY(c, hipEventRecord(c->ev_begin[EVPLP_PASS_LIGHT_TRACE], c->aux_stream));
     c->pass_ran[EVPLP_PASS_LIGHT_TRACE] = true; c->pass_has_dom[EVPLP_PASS_LIGHT_TRACE] = false;
     launch_light_trace(a, c->aux_stream);
