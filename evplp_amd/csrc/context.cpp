@@ -138,6 +138,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     }
     if ((e = hipMalloc((void **)&c->d_tile_box, sizeof(float4) * 2 * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_box)", e);
     if ((e = hipMalloc((void **)&c->d_summary, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMalloc(summary)", e);
+    if ((e = hipMemset(c->d_summary, 0, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMemset(summary)", e);
     if ((e = hipMalloc((void **)&c->d_tile_pairs, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_pairs)", e);
     if ((e = hipMalloc((void **)&c->d_tile_cursor, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_cursor)", e);
     const size_t ngroups = std::max(c->num_bin_groups, 1);
@@ -753,6 +754,12 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
         HIP_TRY(c, hipMemcpy(tp.data(), c->d_tile_pairs, tp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint64_t sum = 0; for (uint32_t v : tp) sum += v;
         out->pairs = sum; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries; out->reserved[1] = c->last_bin_max;
+        // `shaded`: (photon, pixel) pairs of ALL splat passes of this context so far (device-side running total)
+        std::vector<uint32_t> sh((size_t)kSummaryFinal);
+        HIP_TRY(c, hipMemcpy(sh.data(), c->d_summary, sh.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (int k = 0; k < kSummaryShards; k++) total += (uint64_t)sh[(size_t)k * kSummaryStride + 4] | ((uint64_t)sh[(size_t)k * kSummaryStride + 5] << 32);
+        out->shaded = total;
     } else if (pass == EVPLP_PASS_PATH_TRACE) { out->pairs = pc.pairs; out->rays = pc.rays; }
     else if (pass == EVPLP_PASS_GATHER_LVC) { out->pairs = pc.pairs; out->rays = pc.rays; }
     else if (pass == EVPLP_PASS_PRIMARY) out->rays = c->stats_host[pass].rays;

@@ -523,7 +523,12 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
             float4 o = a.out[p];
             a.out[p] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w);   // additive blend ONE, ONE (:793)
         }
-        if (lane == 0) a.tile_pairs[tile] = pairs;
+        if (lane == 0) {
+            a.tile_pairs[tile] = pairs;
+            // running total of the context (never cleared; words 4-5 of the 1024 summary lines): lets a caller count pairs over many
+            // passes without reading anything back in between
+            if (pairs) atomicAdd(reinterpret_cast<unsigned long long *>(&a.summary[((uint32_t)tile & (uint32_t)(kSummaryShards - 1)) * kSummaryStride + 4]), (unsigned long long)pairs);
+        }
     }
 }
 

@@ -145,7 +145,8 @@ typedef struct evplp_pass_stats {
     uint64_t usable;         /* usable VPL / photon records consumed */
     float dominant_kernel_ms;/* device time of the pass's dominant kernel alone (summed over its launches) */
     uint32_t reserved[3];
-    uint64_t shaded;         /* gather: pairs that passed the cosine test AND the visibility test (contributions evaluated) */
+    uint64_t shaded;         /* gather: pairs that passed the cosine test AND the visibility test (contributions evaluated);
+                              * photon splat: (photon, pixel) pairs of ALL splat passes of the context so far (running total) */
     uint32_t launches;       /* launches of the dominant kernel in the pass */
     uint32_t pad;
 } evplp_pass_stats;
