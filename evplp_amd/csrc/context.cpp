@@ -86,6 +86,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
         if ((e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
         if ((e = hipEventCreateWithFlags(&c->ev_records_read, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&c->ev_light_done, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->ev_back_read, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     }
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if ((e = hipEventCreate(&c->ev_begin[i])) != hipSuccess) return fail("hipEventCreate", e);
@@ -184,6 +185,8 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->ev_records_read) hipEventDestroy(c->ev_records_read);
     if (c->ev_light_done) hipEventDestroy(c->ev_light_done);
+    if (c->ev_back_read) hipEventDestroy(c->ev_back_read);
+    hipFree(c->records_back);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -425,16 +428,17 @@ static int settle_splat(evplp_context *c) {
     const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     HIP_TRY(c, hipEventRecord(c->ev_end[EVPLP_PASS_SPLAT], c->stream));
-    if (c->aux_stream) HIP_TRY(c, hipEventRecord(c->ev_records_read, c->stream));
+    // (the records this pass read may meanwhile be the BACK buffer of the overlapped light tracing: its readers' event then)
+    if (c->aux_stream) HIP_TRY(c, hipEventRecord((const void *)a.records == c->buf[EVPLP_BUF_RECORDS] ? c->ev_records_read : c->ev_back_read, c->stream));
     HIP_TRY(c, hipGetLastError());
     return EVPLP_OK;
 }
-static int pass_ready(evplp_context *c, const char *name, bool need_camera) {
+static int pass_ready(evplp_context *c, const char *name, bool need_camera, bool settle = true) {
     if (!c->accel_built) { c->set_error("%s: scene not built (evplp_build_accel)", name); return EVPLP_ERR_INVALID; }
     if (need_camera && !c->camera_set) { c->set_error("%s: camera not set", name); return EVPLP_ERR_INVALID; }
     hipError_t e = hipSetDevice(c->cfg.device);
     if (e != hipSuccess) { c->set_error("hipSetDevice: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
-    return settle_splat(c);
+    return settle ? settle_splat(c) : EVPLP_OK;
 }
 // device counters are written by the gathers and the path tracer (and by the counters build of the splat)
 #ifndef EVPLP_TRAVERSAL_STATS
@@ -476,7 +480,12 @@ extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t cl
 
 extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint32_t path_begin, uint32_t path_count) {
     CTX_CHECK(c);
-    int rc = pass_ready(c, "evplp_trace_light_paths", false); if (rc) return rc;
+    // A photon splat that is still in flight may have to run again (bins too small: settle_splat), from the records and the G-buffer
+    // it was given.  Waiting for its verdict here stalls the host once per iteration -- unless these light paths go to the OTHER
+    // record buffer (double buffering below): then the pending splat keeps its inputs and the next evplp_primary settles it.
+    const bool to_back_buffer = c->aux_stream && path_begin == 0 && path_count == c->cfg.num_light_paths && c->buf_owned[EVPLP_BUF_RECORDS] && !c->records_exposed;
+    const bool splat_keeps_its_records = to_back_buffer && c->splat_pending && c->records_back && (const void *)c->splat_args.records != c->records_back;
+    int rc = pass_ready(c, "evplp_trace_light_paths", false, !splat_keeps_its_records); if (rc) return rc;
     if ((uint64_t)path_begin + path_count > c->cfg.num_light_paths) { c->set_error("evplp_trace_light_paths: path range exceeds num_light_paths"); return EVPLP_ERR_INVALID; }
     LightTraceArgs a; std::memset(&a, 0, sizeof(a));
     a.sc = c->sc; a.rng_seed = rng_seed; a.path_begin = path_begin; a.path_count = path_count; a.photons_per_path = c->cfg.photons_per_path;
@@ -488,7 +497,20 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
     }
     // overlapped: behind the last reader of the records, beside whatever the main stream is doing now (the G-buffer pass of
     // this iteration), in front of everything the main stream is given from here on
+    if (to_back_buffer) {
+        // double buffer: write the records nobody reads any more, and make them EVPLP_BUF_RECORDS for every later call
+        if (!c->records_back) {
+            hipError_t me = hipMalloc(&c->records_back, buffer_bytes(c, EVPLP_BUF_RECORDS));
+            if (me != hipSuccess) { c->set_error("evplp_trace_light_paths: second record buffer: %s", hipGetErrorString(me)); return EVPLP_ERR_OOM; }
+        }
+        std::swap(c->buf[EVPLP_BUF_RECORDS], c->records_back);
+        std::swap(c->ev_records_read, c->ev_back_read);                  // (the event of the readers of the buffer that is now in front)
+        a.records = (evplp_record *)c->buf[EVPLP_BUF_RECORDS];
+    }
     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_records_read, 0));
+    // ... and not before the G-buffer pass most recently given to the main stream starts: a caller that calls evplp_primary first wants
+    // the light paths beside IT, not beside the long gather that may still be running in front of it (they would share its CUs)
+    if (c->pass_ran[EVPLP_PASS_PRIMARY]) HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_begin[EVPLP_PASS_PRIMARY], 0));
     HIP_TRY(c, hipEventRecord(c->ev_begin[EVPLP_PASS_LIGHT_TRACE], c->aux_stream));
     c->pass_ran[EVPLP_PASS_LIGHT_TRACE] = true; c->pass_has_dom[EVPLP_PASS_LIGHT_TRACE] = false;
     launch_light_trace(a, c->aux_stream);
@@ -676,7 +698,11 @@ extern "C" int evplp_local_rows(const evplp_context *c) { return c ? c->st.local
 extern "C" int evplp_buffer_info(evplp_context *c, int32_t which, void **ptr, size_t *bytes) {
     CTX_CHECK(c);
     if (which < 0 || which >= EVPLP_BUF_COUNT) { c->set_error("evplp_buffer_info: bad buffer id %d", which); return EVPLP_ERR_INVALID; }
-    if (ptr) { *ptr = c->buf[which]; if (which == EVPLP_BUF_GBUF_POSITION) { c->gbuf_pos_exposed = true; c->tile_box_valid = false; } }
+    if (ptr) {
+        *ptr = c->buf[which];
+        if (which == EVPLP_BUF_GBUF_POSITION) { c->gbuf_pos_exposed = true; c->tile_box_valid = false; }
+        if (which == EVPLP_BUF_RECORDS) c->records_exposed = true;       // the pointer must stay the record buffer: no double buffering
+    }
     if (bytes) *bytes = buffer_bytes(c, which);
     return EVPLP_OK;
 }

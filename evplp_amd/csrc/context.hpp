@@ -51,6 +51,10 @@ struct evplp_context {
     // overlap_light_tracing (evplp_config): light tracing on aux_stream, behind ev_records_read (recorded after every pass that reads
     // the record buffer), in front of whatever the main stream is given next (it waits for ev_light_done)
     hipStream_t aux_stream = nullptr; hipEvent_t ev_records_read = nullptr, ev_light_done = nullptr; bool light_in_flight = false;
+    // ... and into a SECOND record buffer when the whole path set is traced and the library owns the records (nobody holds a pointer
+    // to them): the call flips EVPLP_BUF_RECORDS to the buffer being written, so the light paths of iteration i + 1 do not wait for
+    // the passes of iteration i that still read the other one (config #4: light tracing is the long pole and becomes a pipeline)
+    void *records_back = nullptr; hipEvent_t ev_back_read = nullptr; bool records_exposed = false;
     bool gbuf_pos_exposed = false;             // the caller holds a device pointer to the position plane (buffer_info / bind_buffer): it may write it unseen
     bool tile_box_valid = false;               // d_tile_box describes the current G-buffer (written by evplp_primary; any other way in clears it)
     int32_t num_bin_groups = 0, bucket_w_log2 = 0, bucket_h_log2 = 0, buckets_x = 0, num_buckets = 0;   // two-level binning (kernels.h)

@@ -312,8 +312,14 @@ private:
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :946-952
             evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
             const int light_flags = !do_light_render ? EVPLP_LIGHT_SKIP : frame_mode == 2 ? (EVPLP_LIGHT_CLEAR | EVPLP_LIGHT_UNOCCLUDED) : 0;   // :985-995
+            // The reference draws the G-buffer first; the two passes are independent.  Pure photon mapping (no gather): light paths
+            // first -- they start on the context's second stream, into the record buffer nobody reads, before the host has waited for
+            // the previous iteration's photon bins.  With a gather in the frame they run beside the G-buffer pass instead of beside the
+            // gather, whose CUs they would share.
+            const bool light_first = !do_vpl_splat;
+            if (light_first && do_light_tracing) check(h, evplp_group_trace_light_paths(h, (uint32_t)num_iterations + rng_offset), "light tracing");  // :962-966
             if (do_deferred) check(h, evplp_group_primary(h, jitter, light_flags), "primary");   // :954-960
-            if (do_light_tracing) check(h, evplp_group_trace_light_paths(h, (uint32_t)num_iterations + rng_offset), "light tracing");  // :962-966
+            if (!light_first && do_light_tracing) check(h, evplp_group_trace_light_paths(h, (uint32_t)num_iterations + rng_offset), "light tracing");
             if (do_vpl_splat) check(h, evplp_group_gather(h, &fp, lvc ? 2 : force_vsl ? 1 : 0), "gather");  // :968-972
             // radius 0 (radiusPercentage 0 of the VPL-only configs): the proxy spheres are degenerate, nothing is drawn
             if (do_photon_splat && photon_radius > 0.0f) check(h, evplp_group_splat_photons(h, &fp, frame_mode == 2 ? 1 : 0), "photon splat");    // :974-983
