@@ -187,6 +187,8 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->ev_light_done) hipEventDestroy(c->ev_light_done);
     if (c->ev_back_read) hipEventDestroy(c->ev_back_read);
     hipFree(c->records_back);
+    for (int k = 0; k < 4; k++) hipFree(c->gbuf_back[k]);
+    hipFree(c->d_tile_box_back);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -463,7 +465,26 @@ static int pass_end(evplp_context *c, int pass) {
 
 extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t clear_light) {
     CTX_CHECK(c);
-    int rc = pass_ready(c, "evplp_primary", true); if (rc) return rc;
+    // A pending photon splat may have to run again from the G-buffer it was given (settle_splat).  With overlap_light_tracing the
+    // G-buffer is double-buffered like the records: this pass writes the set that splat does not read and the host does not wait here
+    // (every reader of that set is in front of this pass on the same stream).
+    static const int kPlanes[4] = { EVPLP_BUF_GBUF_POSITION, EVPLP_BUF_GBUF_NORMAL, EVPLP_BUF_GBUF_DIFFUSE, EVPLP_BUF_GBUF_PHONG };
+    bool flip = c->aux_stream && c->splat_pending && !c->gbuf_exposed && !c->gbuf_pos_exposed;
+    for (int k = 0; k < 4 && flip; k++) flip = c->buf_owned[kPlanes[k]];
+    if (flip && c->gbuf_back[0] && (const void *)c->splat_args.g_pos == c->gbuf_back[0]) flip = false;   // (it reads the set we would write: settle first)
+    int rc = pass_ready(c, "evplp_primary", true, !flip); if (rc) return rc;
+    if (flip) {
+        for (int k = 0; k < 4; k++) if (!c->gbuf_back[k]) {
+            hipError_t me = hipMalloc(&c->gbuf_back[k], buffer_bytes(c, kPlanes[k]));
+            if (me != hipSuccess) { c->set_error("evplp_primary: second G-buffer: %s", hipGetErrorString(me)); return EVPLP_ERR_OOM; }
+        }
+        if (!c->d_tile_box_back) {
+            hipError_t me = hipMalloc((void **)&c->d_tile_box_back, sizeof(float4) * 2 * std::max<size_t>((size_t)c->tiles_x * c->tiles_y, 1));
+            if (me != hipSuccess) { c->set_error("evplp_primary: second tile-box table: %s", hipGetErrorString(me)); return EVPLP_ERR_OOM; }
+        }
+        for (int k = 0; k < 4; k++) std::swap(c->buf[kPlanes[k]], c->gbuf_back[k]);
+        std::swap(c->d_tile_box, c->d_tile_box_back);
+    }
     PrimaryArgs a; std::memset(&a, 0, sizeof(a));
     a.sc = c->sc; a.st = c->st; a.cam = c->cam;
     a.jitter[0] = jitter ? jitter[0] : 0.f; a.jitter[1] = jitter ? jitter[1] : 0.f; a.clear_light = clear_light;
@@ -701,6 +722,7 @@ extern "C" int evplp_buffer_info(evplp_context *c, int32_t which, void **ptr, si
     if (ptr) {
         *ptr = c->buf[which];
         if (which == EVPLP_BUF_GBUF_POSITION) { c->gbuf_pos_exposed = true; c->tile_box_valid = false; }
+        if (which >= EVPLP_BUF_GBUF_POSITION && which <= EVPLP_BUF_GBUF_PHONG) c->gbuf_exposed = true;
         if (which == EVPLP_BUF_RECORDS) c->records_exposed = true;       // the pointer must stay the record buffer: no double buffering
     }
     if (bytes) *bytes = buffer_bytes(c, which);
@@ -717,6 +739,7 @@ extern "C" int evplp_bind_buffer(evplp_context *c, int32_t which, void *ptr, siz
     if (c->buf_owned[which]) hipFree(c->buf[which]);
     c->buf[which] = ptr; c->buf_owned[which] = false;
     if (which == EVPLP_BUF_GBUF_POSITION) { c->gbuf_pos_exposed = true; c->tile_box_valid = false; }
+    if (which >= EVPLP_BUF_GBUF_POSITION && which <= EVPLP_BUF_GBUF_PHONG) c->gbuf_exposed = true;
     return EVPLP_OK;
 }
 extern "C" int evplp_download(evplp_context *c, int32_t which, void *dst, size_t bytes) {

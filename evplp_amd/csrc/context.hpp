@@ -55,6 +55,9 @@ struct evplp_context {
     // to them): the call flips EVPLP_BUF_RECORDS to the buffer being written, so the light paths of iteration i + 1 do not wait for
     // the passes of iteration i that still read the other one (config #4: light tracing is the long pole and becomes a pipeline)
     void *records_back = nullptr; hipEvent_t ev_back_read = nullptr; bool records_exposed = false;
+    // ... and the four G-buffer planes + the tile boxes likewise: evplp_primary writes the set the pending splat does not read, and it
+    // is the next evplp_splat_photons call (by then that splat has long finished) that waits for its verdict
+    void *gbuf_back[4] = { nullptr, nullptr, nullptr, nullptr }; float4 *d_tile_box_back = nullptr; bool gbuf_exposed = false;
     bool gbuf_pos_exposed = false;             // the caller holds a device pointer to the position plane (buffer_info / bind_buffer): it may write it unseen
     bool tile_box_valid = false;               // d_tile_box describes the current G-buffer (written by evplp_primary; any other way in clears it)
     int32_t num_bin_groups = 0, bucket_w_log2 = 0, bucket_h_log2 = 0, buckets_x = 0, num_buckets = 0;   // two-level binning (kernels.h)
