@@ -150,9 +150,12 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if ((e = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * std::max<size_t>(ntiles * c->bin_stride, 1))) != hipSuccess) return fail("hipMalloc(bin_items)", e);
     if (cfg->deterministic && (e = hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * std::max<size_t>(ntiles * c->bin_stride, 1))) != hipSuccess) return fail("hipMalloc(bin_items_tmp)", e);
     if ((e = hipMalloc((void **)&c->d_compact, sizeof(float4) * kCompactF4 * nrec)) != hipSuccess) return fail("hipMalloc(compact)", e);
-    if ((e = hipHostMalloc((void **)&c->h_summary, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc(summary)", e);
-    std::memset(c->h_summary, 0, 4 * sizeof(uint32_t));
-    if ((e = hipEventCreate(&c->ev_summary)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void **)&c->h_summary, 8 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc(summary)", e);
+    std::memset(c->h_summary, 0, 8 * sizeof(uint32_t));
+    for (int i = 0; i < 2; i++) {
+        if ((e = hipEventCreate(&c->pend[i].ev)) != hipSuccess) return fail("hipEventCreate", e);
+        c->pend[i].h = c->h_summary + 4 * i;
+    }
     *out = c;
     return EVPLP_OK;
 }
@@ -166,7 +169,7 @@ static void free_scene_device(evplp_context *c) {
 extern "C" void evplp_destroy(evplp_context *c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);
-    c->splat_pending = false;
+    c->npend = 0;
     if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
@@ -180,7 +183,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
         if (c->ev_dom_begin[i]) hipEventDestroy(c->ev_dom_begin[i]);
         if (c->ev_dom_end[i]) hipEventDestroy(c->ev_dom_end[i]);
     }
-    if (c->ev_summary) hipEventDestroy(c->ev_summary);
+    for (int i = 0; i < 2; i++) if (c->pend[i].ev) hipEventDestroy(c->pend[i].ev);
     if (c->h_summary) hipHostFree(c->h_summary);
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->ev_records_read) hipEventDestroy(c->ev_records_read);
@@ -406,26 +409,31 @@ extern "C" int evplp_accel_info(evplp_context *c, int32_t *nodes, int32_t *leave
 // Look at the bin summary of the last photon splat (see context.hpp).  Called at the start of every entry point that
 // enqueues work, reads results or changes buffers.  Overflow is rare (the bins carry 25 % slack over the last pass and the
 // radius only shrinks in a progressive run): then the bins grow and fill + tiles of that pass run again -- they wrote nothing.
-static int settle_splat(evplp_context *c) {
-    if (!c->splat_pending) return EVPLP_OK;
-    c->splat_pending = false;
+static int settle_one(evplp_context *c) {                                // the oldest pending pass
+    if (c->npend == 0) return EVPLP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipEventSynchronize(c->ev_summary));
-    const uint32_t total = c->h_summary[0], biggest = c->h_summary[1], overflow = c->h_summary[2];
+    HIP_TRY(c, hipEventSynchronize(c->pend[0].ev));
+    const uint32_t total = c->pend[0].h[0], biggest = c->pend[0].h[1], overflow = c->pend[0].h[2];
+    SplatArgs a = c->pend[0].args;
+    std::swap(c->pend[0], c->pend[1]); c->npend--;                       // (the slot keeps its event and its pinned words)
     c->last_bin_entries = total; c->last_bin_max = biggest;
     if (!overflow) return EVPLP_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint64_t want = 64; while (want < (uint64_t)overflow + overflow / 4) want <<= 1;     // overflow = slots the fullest bin wanted
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     if (want * ntiles > 0xfffffff0ull) { c->set_error("photon bins: %llu slots per tile needed", (unsigned long long)overflow); return EVPLP_ERR_OOM; }
-    hipFree(c->d_bin_items); c->d_bin_items = nullptr;
-    if (c->d_bin_items_tmp) { hipFree(c->d_bin_items_tmp); c->d_bin_items_tmp = nullptr; }
-    hipError_t e1 = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * ntiles * want);
-    hipError_t e2 = c->cfg.deterministic ? hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * ntiles * want) : hipSuccess;
-    if (e1 != hipSuccess || e2 != hipSuccess) { c->set_error("photon bins: cannot allocate %zu x %llu slots", ntiles, (unsigned long long)want); return EVPLP_ERR_OOM; }
-    c->bin_stride = (uint32_t)want;
-    SplatArgs &a = c->splat_args;
+    if (want > c->bin_stride) {                                          // (a younger pending pass may have grown them already)
+        hipFree(c->d_bin_items); c->d_bin_items = nullptr;
+        if (c->d_bin_items_tmp) { hipFree(c->d_bin_items_tmp); c->d_bin_items_tmp = nullptr; }
+        hipError_t e1 = hipMalloc((void **)&c->d_bin_items, sizeof(uint32_t) * ntiles * want);
+        hipError_t e2 = c->cfg.deterministic ? hipMalloc((void **)&c->d_bin_items_tmp, sizeof(uint32_t) * ntiles * want) : hipSuccess;
+        if (e1 != hipSuccess || e2 != hipSuccess) { c->set_error("photon bins: cannot allocate %zu x %llu slots", ntiles, (unsigned long long)want); return EVPLP_ERR_OOM; }
+        c->bin_stride = (uint32_t)want;
+    }
     a.bin_items = c->d_bin_items; a.bin_items_tmp = c->d_bin_items_tmp; a.bin_stride = c->bin_stride;
+    for (int i = 0; i < c->npend; i++) {                                 // a younger pass ran with the old slabs: if IT has to run again, then with these
+        c->pend[i].args.bin_items = c->d_bin_items; c->pend[i].args.bin_items_tmp = c->d_bin_items_tmp; c->pend[i].args.bin_stride = c->bin_stride;
+    }
     launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
     const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
@@ -433,6 +441,19 @@ static int settle_splat(evplp_context *c) {
     // (the records this pass read may meanwhile be the BACK buffer of the overlapped light tracing: its readers' event then)
     if (c->aux_stream) HIP_TRY(c, hipEventRecord((const void *)a.records == c->buf[EVPLP_BUF_RECORDS] ? c->ev_records_read : c->ev_back_read, c->stream));
     HIP_TRY(c, hipGetLastError());
+    return EVPLP_OK;
+}
+static int settle_splat(evplp_context *c) {
+    while (c->npend > 0) { int rc = settle_one(c); if (rc) return rc; }
+    return EVPLP_OK;
+}
+// the pending passes that read `records` or the G-buffer whose position plane is `g_pos` (and every older one) must be settled
+// before those are overwritten
+static int settle_readers_of(evplp_context *c, const void *records, const void *g_pos) {
+    int upto = 0;
+    for (int i = 0; i < c->npend; i++)
+        if ((records && (const void *)c->pend[i].args.records == records) || (g_pos && (const void *)c->pend[i].args.g_pos == g_pos)) upto = i + 1;
+    for (int i = 0; i < upto; i++) { int rc = settle_one(c); if (rc) return rc; }
     return EVPLP_OK;
 }
 static int pass_ready(evplp_context *c, const char *name, bool need_camera, bool settle = true) {
@@ -469,10 +490,10 @@ extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t cl
     // G-buffer is double-buffered like the records: this pass writes the set that splat does not read and the host does not wait here
     // (every reader of that set is in front of this pass on the same stream).
     static const int kPlanes[4] = { EVPLP_BUF_GBUF_POSITION, EVPLP_BUF_GBUF_NORMAL, EVPLP_BUF_GBUF_DIFFUSE, EVPLP_BUF_GBUF_PHONG };
-    bool flip = c->aux_stream && c->splat_pending && !c->gbuf_exposed && !c->gbuf_pos_exposed;
+    bool flip = c->aux_stream && c->npend > 0 && !c->gbuf_exposed && !c->gbuf_pos_exposed;
     for (int k = 0; k < 4 && flip; k++) flip = c->buf_owned[kPlanes[k]];
-    if (flip && c->gbuf_back[0] && (const void *)c->splat_args.g_pos == c->gbuf_back[0]) flip = false;   // (it reads the set we would write: settle first)
     int rc = pass_ready(c, "evplp_primary", true, !flip); if (rc) return rc;
+    if (flip && c->gbuf_back[0] && (rc = settle_readers_of(c, nullptr, c->gbuf_back[0]))) return rc;      // (a splat two passes old: long finished)
     if (flip) {
         for (int k = 0; k < 4; k++) if (!c->gbuf_back[k]) {
             hipError_t me = hipMalloc(&c->gbuf_back[k], buffer_bytes(c, kPlanes[k]));
@@ -505,8 +526,8 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
     // it was given.  Waiting for its verdict here stalls the host once per iteration -- unless these light paths go to the OTHER
     // record buffer (double buffering below): then the pending splat keeps its inputs and the next evplp_primary settles it.
     const bool to_back_buffer = c->aux_stream && path_begin == 0 && path_count == c->cfg.num_light_paths && c->buf_owned[EVPLP_BUF_RECORDS] && !c->records_exposed;
-    const bool splat_keeps_its_records = to_back_buffer && c->splat_pending && c->records_back && (const void *)c->splat_args.records != c->records_back;
-    int rc = pass_ready(c, "evplp_trace_light_paths", false, !splat_keeps_its_records); if (rc) return rc;
+    int rc = pass_ready(c, "evplp_trace_light_paths", false, !to_back_buffer); if (rc) return rc;
+    if (to_back_buffer && c->records_back && (rc = settle_readers_of(c, c->records_back, nullptr))) return rc;   // (a splat two passes old)
     if ((uint64_t)path_begin + path_count > c->cfg.num_light_paths) { c->set_error("evplp_trace_light_paths: path range exceeds num_light_paths"); return EVPLP_ERR_INVALID; }
     LightTraceArgs a; std::memset(&a, 0, sizeof(a));
     a.sc = c->sc; a.rng_seed = rng_seed; a.path_begin = path_begin; a.path_count = path_count; a.photons_per_path = c->cfg.photons_per_path;
@@ -643,7 +664,14 @@ extern "C" int evplp_path_trace(evplp_context *c, const float camera_pos[3], uin
 
 extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *fp, int32_t clear) {
     CTX_CHECK(c);
-    int rc = pass_ready(c, "evplp_splat_photons", true); if (rc) return rc;
+    // (overlapped mode, accumulating: the previous pass may stay pending -- only look whether its verdict has arrived; a clearing pass
+    // settles it first, its re-run would otherwise land in the cleared buffer)
+    const bool relaxed = c->aux_stream && !clear;
+    int rc = pass_ready(c, "evplp_splat_photons", true, !relaxed); if (rc) return rc;
+    if (relaxed) {
+        while (c->npend >= 2) if ((rc = settle_one(c))) return rc;
+        while (c->npend > 0 && hipEventQuery(c->pend[0].ev) == hipSuccess) if ((rc = settle_one(c))) return rc;
+    }
     if ((rc = check_fp(c, fp, "evplp_splat_photons"))) return rc;
     if (!(fp->photon_radius > 0.0f)) { c->set_error("evplp_splat_photons: photon_radius must be > 0"); return EVPLP_ERR_INVALID; }
     SplatArgs a; std::memset(&a, 0, sizeof(a));
@@ -672,9 +700,10 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
     // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
-    HIP_TRY(c, hipMemcpyAsync(&c->h_summary[0], &c->d_summary[kSummaryFinal], 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));   // entries, fullest bin, overflow
-    HIP_TRY(c, hipEventRecord(c->ev_summary, c->stream));
-    c->splat_args = a; c->splat_pending = true;
+    evplp_context::PendingSplat &slot = c->pend[c->npend];
+    HIP_TRY(c, hipMemcpyAsync(slot.h, &c->d_summary[kSummaryFinal], 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));   // entries, fullest bin, overflow
+    HIP_TRY(c, hipEventRecord(slot.ev, c->stream));
+    slot.args = a; c->npend++;
     c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
     return pass_end(c, EVPLP_PASS_SPLAT);
 }

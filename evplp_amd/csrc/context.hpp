@@ -67,10 +67,14 @@ struct evplp_context {
     // The bin sizes of a splat are known only on the device.  The pass is enqueued completely (fill and tiles kernels do
     // nothing when the bins overflowed); the summary arrives in pinned host memory behind ev_summary and is looked at by the
     // NEXT call on the context (settle_splat): no host round trip, no GPU bubble inside the pass.
-    uint32_t *h_summary = nullptr;            // pinned: [0] bin entries, [1] fullest bin, [2] overflow (slots the fullest bin needed)
-    hipEvent_t ev_summary = nullptr;
-    bool splat_pending = false;
-    evplp::SplatArgs splat_args{};            // the pending pass, for the re-run after the bins have grown
+    uint32_t *h_summary = nullptr;            // pinned, 4 words per pending pass: [0] bin entries, [1] fullest bin, [2] overflow (slots the fullest bin needed)
+    // Up to two passes wait for their verdict (oldest first).  One is the rule: every entry point settles it.  With
+    // overlap_light_tracing a second may be in flight: evplp_splat_photons only LOOKS whether the previous one is known yet, and
+    // evplp_primary / evplp_trace_light_paths wait for a pending splat only if they are about to overwrite what it read (by then
+    // it is two passes old and long finished) -- the host then runs a whole iteration ahead of the GPU.
+    struct PendingSplat { evplp::SplatArgs args; hipEvent_t ev = nullptr; uint32_t *h = nullptr; };
+    PendingSplat pend[2];
+    int npend = 0;
 
     char error[512] = "";
     void set_error(const char *fmt, ...);

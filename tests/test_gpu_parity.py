@@ -404,3 +404,26 @@ def test_overlapped_light_tracing_changes_no_bit(room, evplp):
             assert st["ms"] > 0
             outs.append((c.download(evplp.BUF_VPL_ACCUM)[:H].tobytes(), c.download(evplp.BUF_PHOTON_ACCUM)[:H].tobytes(), recs[0]))
     assert outs[0] == outs[1]
+
+
+def test_bins_grow_with_two_passes_in_flight(room, evplp, monkeypatch):
+    """overlap_light_tracing keeps up to two photon splats pending.  With two-slot bins every pass overflows and runs again -- the
+    older one after the younger one was enqueued -- and the technique loop must still add up to the same image (the order of the
+    additions may differ: fp32 round-off only)."""
+    imgs = []
+    for cap, overlap in ((None, False), ("2", True)):
+        if cap:
+            monkeypatch.setenv("EVPLP_BIN_STRIDE", cap)
+        with evplp.Context(W, H, NPATHS, NPATHS, P, deterministic=True, overlap_light_tracing=overlap) as c:
+            room.upload(c)
+            c.clear_accumulators()
+            for it in range(5):
+                kw = dict(camera_pos=room.cam_origin, mis_mode=1, pdf_mc=0.35, photon_radius=0.3 - 0.02 * it, num_light_paths=NPATHS,
+                          num_vpl_light_paths=NPATHS, photons_per_path=P, do_accumulate=1, rng_seed=it)
+                c.trace_light_paths(20 + it)
+                c.primary((0.001 * it, 0.0), clear_light=True)
+                c.splat_photons(evplp.frame_params(**kw))
+            imgs.append(c.download(evplp.BUF_PHOTON_ACCUM)[:H].astype(np.float64))
+        monkeypatch.delenv("EVPLP_BIN_STRIDE", raising=False)
+    assert imgs[0].max() > 0
+    assert np.abs(imgs[0] - imgs[1]).max() <= 1e-5 * imgs[0].max()
