@@ -70,10 +70,11 @@ struct PathTraceArgs {
 };
 
 constexpr int kSummaryShards = 1024, kSummaryStride = 32, kSummaryFinal = kSummaryShards * kSummaryStride;
-// Two-level binning of the photon splat, without contended atomics.  Returning atomics on scattered addresses retire at
-// ~20 G/s chip-wide (64-byte requests at the memory side) and adds to ONE address at 110-620 ns each: one atomic per (photon,
-// tile) entry on per-tile cursors cost 100 us for the 2 M entries of config #3 and 155 us on the cursor of its fullest bin; one
-// per (workgroup, coarse bucket) on 128 bucket cursors cost 1.2 ms.  So:
+// Two-level binning of the photon splat, without contended atomics.  Measured (tools/ub/atomics.hip): returning atomics on
+// scattered addresses retire at 27 G/s chip-wide (64-byte requests at the memory side), atomics on ONE 128-byte line at 88 M/s
+// (11 ns each, whichever words of the line), lines in parallel.  One atomic per (photon, tile) entry on per-tile cursors cost
+// 100 us for the 2 M entries of config #3; one per (workgroup, coarse bucket) cost 1.2 ms on 128 bucket cursors packed into four
+// lines and 115 us on cursors with a line each (8 k adds per line: a 90 us chain).  So:
 //   splat_bin     : a workgroup (kBinChunks x 256 consecutive records) ranks its entries per BUCKET (a rectangle of
 //                   2^bucket_w_log2 x 2^bucket_h_log2 = 128 tiles) in LDS and writes them, sorted by bucket, into a segment of its
 //                   own + a table of bucket offsets -- no global atomic.
