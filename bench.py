@@ -365,7 +365,7 @@ def main():
             achieved = rays_per_launch * flop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             out["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/prof_pmc.sh); not measured inside this run",
+                "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/prof_all.sh); not measured inside this run",
                 "kernel": kname, "kernel_ms": kms, "flop_per_pair": flop,
                 "frac_nominal_pairs": (nominal_local / a.steps) * flop / (kms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if kms > 0 else 0.0,
                 "note": "fp32 VECTOR-ALU bound (BVH packet traversal + shading; not GEMM-shaped). achieved = algorithmic flop per evaluated pair "
