@@ -111,11 +111,43 @@ struct Builder {
 
     // ---- binned SAH ---------------------------------------------------------------------
     float sah_ct = 1.0f;
+    int32_t peel_min = 16, peel_min_flat = 8; float peel_eps = 1e-4f, peel_frac = 0.2f, peel_cov = 0.7f, peel_big = 0.05f, root_area_sah = 0.f;
+    std::vector<float> tarea;
     int32_t sah_rec(int32_t first, int32_t count, int d) {
         depth = std::max(depth, d);
         if (count <= kMaxLeafTris && count <= 2) return make_leaf(first, count);
         Box cb; cb.reset(); Box bb; bb.reset();
         for (int32_t i = 0; i < count; i++) { cb.grow(&centroid[3 * (size_t)ids[first + i]]); bb.grow(tbox[ids[first + i]]); }
+        if (peel_min > 0 && count >= peel_min) {
+            // face peel: triangles that lie flat on one face of this node's box go into a child of their own
+            int best_face = -1; int32_t best_n = 0; float best_cov = 0.f;
+            const bool big = bb.area() >= peel_big * root_area_sah;
+            for (int face = 0; face < 6; face++) {
+                const int axis = face >> 1; const bool hi_side = face & 1;
+                const float plane = hi_side ? bb.hi[axis] : bb.lo[axis];
+                const float eps = peel_eps * (bb.hi[axis] - bb.lo[axis]);
+                if (!(bb.hi[axis] - bb.lo[axis] > 0.f)) continue;
+                int32_t n = 0; double area = 0.0;
+                for (int32_t i = 0; i < count; i++) { const int32_t id = ids[first + i]; const Box &t = tbox[id]; if (std::fabs(t.lo[axis] - plane) <= eps && std::fabs(t.hi[axis] - plane) <= eps) { n++; area += tarea[id]; } }
+                if (n == 0 || n == count) continue;
+                const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+                const float face_area = (bb.hi[a1] - bb.lo[a1]) * (bb.hi[a2] - bb.lo[a2]);
+                const float cov = face_area > 0.f ? (float)(area / face_area) : 0.f;
+                const bool ok = cov >= peel_cov && n >= peel_min_flat && (big || (float)n >= peel_frac * (float)count);
+                if (ok && n > best_n) { best_n = n; best_face = face; best_cov = cov; }
+            }
+            if (best_face >= 0) {
+                const int axis = best_face >> 1; const float plane = (best_face & 1) ? bb.hi[axis] : bb.lo[axis];
+                const float eps = peel_eps * (bb.hi[axis] - bb.lo[axis]);
+                auto it = std::partition(ids.begin() + first, ids.begin() + first + count, [&](int32_t id) { const Box &t = tbox[id]; return std::fabs(t.lo[axis] - plane) <= eps && std::fabs(t.hi[axis] - plane) <= eps; });
+                const int32_t mid = (int32_t)(it - ids.begin());
+                const int32_t id = (int32_t)nodes.size(); nodes.emplace_back();
+                const int32_t l = sah_rec(first, mid - first, d + 1);
+                const int32_t r = sah_rec(mid, first + count - mid, d + 1);
+                nodes[id].left = l; nodes[id].right = r;
+                return finish_inner(id);
+            }
+        }
         constexpr int NB = 16;
         float best_cost = 3.0e38f; int best_axis = -1, best_bin = -1;
         for (int axis = 0; axis < 3; axis++) {
@@ -345,7 +377,7 @@ inline void precompute_tri(const float *v, TriPair *tp, int half) {
 int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     auto t0 = std::chrono::steady_clock::now();
     Builder B; B.verts = verts;
-    B.tbox.resize((size_t)std::max(ntri, 1)); B.centroid.resize(3 * (size_t)std::max(ntri, 1));
+    B.tbox.resize((size_t)std::max(ntri, 1)); B.centroid.resize(3 * (size_t)std::max(ntri, 1)); B.tarea.resize((size_t)std::max(ntri, 1));
     Box scene; scene.reset();
     for (int32_t i = 0; i < ntri; i++) {
         const float *v = verts + 9 * (size_t)i;
@@ -355,12 +387,20 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
         float area = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
         Box &tb = B.tbox[i]; tb.reset(); tb.grow(v); tb.grow(v + 3); tb.grow(v + 6);
         for (int k = 0; k < 3; k++) B.centroid[3 * (size_t)i + k] = 0.5f * (tb.lo[k] + tb.hi[k]);
+        B.tarea[i] = 0.5f * area;
         if (area > 0.0f && !std::isinf(area)) { B.ids.push_back(i); scene.grow(tb); }
     }
     int32_t nvalid = (int32_t)B.ids.size();
     B.nodes.reserve((size_t)3 * std::max(nvalid, 1) + 2);
     int32_t root = -1;
     if (const char *e = std::getenv("EVPLP_SAH_CT")) B.sah_ct = (float)atof(e);
+    if (const char *e = std::getenv("EVPLP_PEEL_MIN")) B.peel_min = atoi(e);
+    if (const char *e = std::getenv("EVPLP_PEEL_FLAT")) B.peel_min_flat = atoi(e);
+    if (const char *e = std::getenv("EVPLP_PEEL_FRAC")) B.peel_frac = (float)atof(e);
+    if (const char *e = std::getenv("EVPLP_PEEL_EPS")) B.peel_eps = (float)atof(e);
+    if (const char *e = std::getenv("EVPLP_PEEL_COV")) B.peel_cov = (float)atof(e);
+    if (const char *e = std::getenv("EVPLP_PEEL_BIG")) B.peel_big = (float)atof(e);
+    B.root_area_sah = scene.area();
     if (nvalid > 0) root = builder == EVPLP_BVH_SBVH ? B.build_sbvh() : builder == EVPLP_BVH_SAH ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
 
     // conservative padding: the device slab test is inexact, the triangle test is exact; a padded

@@ -387,7 +387,7 @@ EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 #ifndef EVPLP_TRAVERSAL_STATS
 #define EVPLP_TRAVERSAL_STATS 0    // 1: count node visits / leaf blocks / triangle pairs per walk (diagnostic build, tools/traversal_stats.py)
 #endif
-struct WalkStats { uint32_t nodes, leaves, pairs, exact; };
+struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
 
 EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
@@ -468,6 +468,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, ex);
             const unsigned long long hm = ballot64(any) & alive;
             if (hm != 0ull) {
+#if EVPLP_TRAVERSAL_STATS
+                if (ws) ws->hit_leaf = cur;
+#endif
                 hitm |= hm;
                 alive &= ~hm;
                 if (alive == 0ull) break;

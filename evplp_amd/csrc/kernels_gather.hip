@@ -143,6 +143,9 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     const int k = a.splits_per_wave;
     V3 total = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, shaded = 0;
+#if EVPLP_TRAVERSAL_STATS
+    int32_t cache_leaf = kNoChild; bool prev_all_occ = false;
+#endif
     for (int jj = 0; jj < k; jj++) {
         const uint32_t split = (uint32_t)(t.group * k + jj);
         V3 result = v3(0.f, 0.f, 0.f);
@@ -159,15 +162,37 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
             bool occ;
             {
 #if EVPLP_TRAVERSAL_STATS
-                WalkStats ws = { 0u, 0u, 0u, 0u };
+                // cache simulation: would the leaf block that last occluded a lane of this item occlude this VPL's lanes too?
+                unsigned long long cache_kill = 0ull;
+                const unsigned long long act_m = ballot64(active);
+                if (cache_leaf != kNoChild) {
+                    const LeafOps L = fetch_leaf(reinterpret_cast<const char *>(a.sc.leaves), (uint32_t)cache_leaf);
+                    const V3 dd = -v12;
+                    bool any = tri_pair_any(L.A, v.pos, dd, 0.0001f, 1.0f - 0.0001f);
+                    if (L.cnt > 2u) any = any | tri_pair_any(L.B, v.pos, dd, 0.0001f, 1.0f - 0.0001f);
+                    cache_kill = ballot64(any) & act_m;
+                }
+                WalkStats ws = { 0u, 0u, 0u, 0u, kNoChild };
                 occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
+                const bool all_occ = ballot64(active && !occ) == 0ull;
                 if (lane == 0) {
                     atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
                     atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
                     atomicAdd(&a.counters->hist[32], 1ull);
                     atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
-                    if (ballot64(active && !occ) == 0ull) atomicAdd(&a.counters->hist[34], 1ull);
+                    if (all_occ) { atomicAdd(&a.counters->hist[34], 1ull); atomicAdd(&a.counters->hist[36], (unsigned long long)ws.nodes); atomicAdd(&a.counters->hist[37], (unsigned long long)ws.leaves); }
+                    if (ws.leaves == 0u) atomicAdd(&a.counters->hist[35], (unsigned long long)ws.nodes);
+                    if (cache_leaf != kNoChild) {
+                        atomicAdd(&a.counters->hist[42], 1ull);
+                        atomicAdd(&a.counters->hist[40], (unsigned long long)__builtin_popcountll(cache_kill));
+                        if (cache_kill == act_m) { atomicAdd(&a.counters->hist[38], 1ull); atomicAdd(&a.counters->hist[39], (unsigned long long)ws.nodes); }
+                        if (prev_all_occ) { atomicAdd(&a.counters->hist[44], 1ull); if (cache_kill == act_m) atomicAdd(&a.counters->hist[43], 1ull); }
+                    }
+                    atomicAdd(&a.counters->hist[41], (unsigned long long)__builtin_popcountll(ballot64(active && occ)));
+                    atomicAdd(&a.counters->hist[45 + min(ws.nodes / 16u, 18u)], 1ull);
                 }
+                if (ws.hit_leaf != kNoChild) cache_leaf = ws.hit_leaf;
+                prev_all_occ = all_occ;
 #else
                 occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
 #endif
