@@ -148,12 +148,12 @@ struct Builder {
                 return finish_inner(id);
             }
         }
-        constexpr int NB = 16;
+        constexpr int NB = 16, NBMAX = NB;
         float best_cost = 3.0e38f; int best_axis = -1, best_bin = -1;
         for (int axis = 0; axis < 3; axis++) {
             float lo = cb.lo[axis], ext = cb.hi[axis] - lo;
             if (!(ext > 0.f)) continue;
-            Box bins[NB]; int cnt[NB];
+            Box bins[NBMAX]; int cnt[NBMAX];
             for (int b = 0; b < NB; b++) { bins[b].reset(); cnt[b] = 0; }
             float scale = NB / ext;
             for (int32_t i = 0; i < count; i++) {
@@ -161,7 +161,7 @@ struct Builder {
                 int b = std::min(NB - 1, (int)((centroid[3 * (size_t)id + axis] - lo) * scale));
                 bins[b].grow(tbox[id]); cnt[b]++;
             }
-            float ra[NB]; int rc[NB]; Box acc; acc.reset(); int c = 0;
+            float ra[NBMAX]; int rc[NBMAX]; Box acc; acc.reset(); int c = 0;
             for (int b = NB - 1; b > 0; b--) { acc.grow(bins[b]); c += cnt[b]; ra[b] = acc.area(); rc[b] = c; }
             acc.reset(); c = 0;
             for (int b = 0; b < NB - 1; b++) {

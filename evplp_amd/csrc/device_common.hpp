@@ -308,6 +308,34 @@ EV_DEV float safe_rcp(float d) {
 // One wide scalar fetch of a wave-uniform 64-byte block (s_load_dwordx16): the whole BVH node (or a
 // third of a leaf block) arrives with ONE exposed latency instead of one per field.
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+// Scalar loads spelled out.  Left to the compiler a wave-uniform load becomes s_load only while it can prove the memory is not
+// written -- which it gives up as soon as the pointer has been anywhere it cannot see through; and pointers it CAN see through
+// (kernel arguments) it re-loads from the argument block inside the traversal loop when SGPRs are short: a dependent scalar
+// load in front of every node fetch.  So the hot wave-uniform fetches are inline s_load_dwordx16 / x8 (the wait is part of the
+// statement: nothing is in flight when it ends), and their base pointers go through `pinned` once per kernel.
+EV_DEV v16i sload16(const void *base, uint32_t byte_offset) {
+    v16i r;
+    asm("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(byte_offset));
+    return r;
+}
+EV_DEV v8i sload8(const void *base, uint32_t byte_offset) {
+    v8i r;
+    asm("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(base), "s"(byte_offset));
+    return r;
+}
+// two / three consecutive 64-byte blocks with one wait
+EV_DEV void sload16x2(const void *base, uint32_t byte_offset, v16i &a, v16i &b) {
+    asm("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %3 offset:0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(base), "s"(byte_offset));
+}
+EV_DEV void sload16x3(const void *base, uint32_t byte_offset, v16i &a, v16i &b, v16i &c) {
+    asm("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %4 offset:0x40\n\ts_load_dwordx16 %2, %3, %4 offset:0x80\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(base), "s"(byte_offset));
+}
+template <class T> EV_DEV const T *pinned(const T *p) { asm("" : "+s"(p)); return p; }
+// (Measured and removed: prefetching both children's nodes into the scalar cache with one-dword s_loads into SGPRs kept outside
+// the allocatable set -- cfg2 85.9 ms with, 78.5 ms without on the furnished scene, 36.5 / 32.2 on the box scene.  The scalar
+// pipe of a CU is as busy as its vector pipe in this walk; two more SMEM instructions per visit cost more than they hide.)
 EV_DEV float f_of(int x) { return __int_as_float(x); }
 EV_DEV v2f pk(int a, int b) { v2f r; r.x = __int_as_float(a); r.y = __int_as_float(b); return r; }
 EV_DEV v2f bc(float a) { v2f r; r.x = a; r.y = a; return r; }
@@ -355,15 +383,16 @@ struct LeafOps { PairOps A, B; uint32_t cnt; };
 EV_DEV LeafOps fetch_leaf(const char *leaf_base, uint32_t leafref) {
     const uint32_t id = ~leafref;
     LeafOps L; L.cnt = (id & 3u) + 1u;
-    const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + (id >> 2) * 192u);
-    const v16i a = tp[0], b = tp[1];
-    L.A.p0x = pk(a[0], a[1]); L.A.p0y = pk(a[2], a[3]); L.A.p0z = pk(a[4], a[5]); L.A.e0x = pk(a[6], a[7]); L.A.e0y = pk(a[8], a[9]); L.A.e0z = pk(a[10], a[11]);
-    L.A.e1x = pk(a[12], a[13]); L.A.e1y = pk(a[14], a[15]); L.A.e1z = pk(b[0], b[1]); L.A.nx = pk(b[2], b[3]); L.A.ny = pk(b[4], b[5]); L.A.nz = pk(b[6], b[7]);
+    const uint32_t off = (id >> 2) * 192u;
+    v16i a, b;
     if (L.cnt > 2u) {
-        const v16i c = tp[2];
+        v16i c;
+        sload16x3(leaf_base, off, a, b, c);
         L.B.p0x = pk(b[8], b[9]); L.B.p0y = pk(b[10], b[11]); L.B.p0z = pk(b[12], b[13]); L.B.e0x = pk(b[14], b[15]); L.B.e0y = pk(c[0], c[1]); L.B.e0z = pk(c[2], c[3]);
         L.B.e1x = pk(c[4], c[5]); L.B.e1y = pk(c[6], c[7]); L.B.e1z = pk(c[8], c[9]); L.B.nx = pk(c[10], c[11]); L.B.ny = pk(c[12], c[13]); L.B.nz = pk(c[14], c[15]);
-    }      // (else: pair B is never read, the callers test it only when cnt > 2)
+    } else sload16x2(leaf_base, off, a, b);     // (pair B is never read, the callers test it only when cnt > 2)
+    L.A.p0x = pk(a[0], a[1]); L.A.p0y = pk(a[2], a[3]); L.A.p0z = pk(a[4], a[5]); L.A.e0x = pk(a[6], a[7]); L.A.e0y = pk(a[8], a[9]); L.A.e0z = pk(a[10], a[11]);
+    L.A.e1x = pk(a[12], a[13]); L.A.e1y = pk(a[14], a[15]); L.A.e1z = pk(b[0], b[1]); L.A.nx = pk(b[2], b[3]); L.A.ny = pk(b[4], b[5]); L.A.nz = pk(b[6], b[7]);
     return L;
 }
 
@@ -389,7 +418,7 @@ EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 #endif
 struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
 
-EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
+EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
     // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
     // far bound `tfar`: a lane that is inactive or already occluded carries tfar = -1, so its slab tests
@@ -413,11 +442,9 @@ EV_DEV bool occluded_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
     int sp = 0;
     int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
-    const char *node_base = reinterpret_cast<const char *>(sc.nodes);
-    const char *leaf_base = reinterpret_cast<const char *>(sc.leaves);
     for (;;) {
         while (cur >= 0) {
-            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
+            const v16i n = sload16(node_base, (uint32_t)cur << 6);
 #if EVPLP_TRAVERSAL_STATS
             if (ws) ws->nodes++;
 #endif

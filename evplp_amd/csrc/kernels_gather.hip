@@ -112,7 +112,6 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
 #ifndef EVPLP_GATHER_WAVES
 #define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene: 5 = 106.0 / 54.3 ms, 6 = 94.3 / 48.7, 7 = 91.0 / 47.6, 8 = 94.6 / 50.0
 #endif
-typedef int v8i __attribute__((ext_vector_type(8)));
 
 // wave-uniform scalar fetch of one 96-byte record (s_load_dwordx16 + s_load_dwordx8)
 EV_DEV Vpl fetch_vpl(const evplp_record *r) {
@@ -123,6 +122,18 @@ EV_DEV Vpl fetch_vpl(const evplp_record *r) {
     v.flux = v3(f_of(ra[8]), f_of(ra[9]), f_of(ra[10])); v.fdir = v3(f_of(ra[12]), f_of(ra[13]), f_of(ra[14]));
     v.rd = v3(f_of(rb[0]), f_of(rb[1]), f_of(rb[2])); v.rs = v3(f_of(rb[4]), f_of(rb[5]), f_of(rb[6])); v.e = f_of(rb[7]);
     return v;
+}
+// ... in two parts around the walk (gather_vpl_kernel): position + normal first (all the cosine test and the walk need), the
+// shading fields afterwards.  Held across the walk the 24 dwords cost the walk its SGPRs: eight were spilled to VGPR lanes for
+// every VPL and the node base pointer was re-loaded from the kernel arguments at every node visit.
+EV_DEV void fetch_vpl_head(const evplp_record *vpls, uint32_t i, V3 &pos, V3 &n, float &psel) {
+    const v8i ra = sload8(vpls, i * (uint32_t)sizeof(evplp_record));
+    pos = v3(f_of(ra[0]), f_of(ra[1]), f_of(ra[2])); n = v3(f_of(ra[4]), f_of(ra[5]), f_of(ra[6])); psel = f_of(ra[7]);
+}
+EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
+    const v16i rb = sload16(vpls, i * (uint32_t)sizeof(evplp_record) + 32u);
+    v.flux = v3(f_of(rb[0]), f_of(rb[1]), f_of(rb[2])); v.fdir = v3(f_of(rb[4]), f_of(rb[5]), f_of(rb[6]));
+    v.rd = v3(f_of(rb[8]), f_of(rb[9]), f_of(rb[10])); v.rs = v3(f_of(rb[12]), f_of(rb[13]), f_of(rb[14])); v.e = f_of(rb[15]);
 }
 
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
@@ -141,6 +152,8 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
 
     const uint32_t nvpl = *a.nvpl;
     const int k = a.splits_per_wave;
+    const char *node_base = pinned(reinterpret_cast<const char *>(a.sc.nodes)), *leaf_base = pinned(reinterpret_cast<const char *>(a.sc.leaves));
+    const evplp_record *vpls = pinned(a.vpls);
     V3 total = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, shaded = 0;
 #if EVPLP_TRAVERSAL_STATS
@@ -150,10 +163,10 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         const uint32_t split = (uint32_t)(t.group * k + jj);
         V3 result = v3(0.f, 0.f, 0.f);
         for (uint32_t i = split; i < nvpl; i += kVplSplit) {
-            const Vpl v = fetch_vpl(a.vpls + i);
-            V3 v12 = v.pos - px.p1;                                         // :282
+            V3 vpos, vn; float vpsel; fetch_vpl_head(vpls, i, vpos, vn, vpsel);
+            V3 v12 = vpos - px.p1;                                         // :282
             float c1 = fmaxf(dot_exact(px.n1, v12), 0.0f);
-            float c2 = fmaxf(-dot_exact(v.n, v12), 0.0f);
+            float c2 = fmaxf(-dot_exact(vn, v12), 0.0f);
             float c1c2 = c1 * c2;
             bool active = valid && !(c1c2 <= 0.0f);                         // :288
             if (ballot64(active) == 0ull) continue;
@@ -166,14 +179,14 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 unsigned long long cache_kill = 0ull;
                 const unsigned long long act_m = ballot64(active);
                 if (cache_leaf != kNoChild) {
-                    const LeafOps L = fetch_leaf(reinterpret_cast<const char *>(a.sc.leaves), (uint32_t)cache_leaf);
+                    const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cache_leaf);
                     const V3 dd = -v12;
-                    bool any = tri_pair_any(L.A, v.pos, dd, 0.0001f, 1.0f - 0.0001f);
-                    if (L.cnt > 2u) any = any | tri_pair_any(L.B, v.pos, dd, 0.0001f, 1.0f - 0.0001f);
+                    bool any = tri_pair_any(L.A, vpos, dd, 0.0001f, 1.0f - 0.0001f);
+                    if (L.cnt > 2u) any = any | tri_pair_any(L.B, vpos, dd, 0.0001f, 1.0f - 0.0001f);
                     cache_kill = ballot64(any) & act_m;
                 }
                 WalkStats ws = { 0u, 0u, 0u, 0u, kNoChild };
-                occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
+                occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
                 const bool all_occ = ballot64(active && !occ) == 0ull;
                 if (lane == 0) {
                     atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
@@ -194,10 +207,13 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 if (ws.hit_leaf != kNoChild) cache_leaf = ws.hit_leaf;
                 prev_all_occ = all_occ;
 #else
-                occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+                occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active);
 #endif
             }
-            if (active && !occ) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2); shaded++; }
+            const bool lit = active && !occ;
+            if (ballot64(lit) == 0ull) continue;
+            Vpl v; v.pos = vpos; v.n = vn; v.psel = vpsel; fetch_vpl_tail(vpls, i, v);
+            if (lit) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2); shaded++; }
         }
         // fold the split sums in the fixed balanced-tree order: a binary counter whose level j holds the sum of 2^j splits.
         // The levels live in LDS ([level][component][lane], touched once per split): registers are what limits occupancy here.
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
         float dist2 = dot(v12, v12);
         float dist = sqrtf(dist2);
         rays += valid ? 1u : 0u;
-        bool occ = occluded_wave(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid);  // :612-614
+        bool occ = occluded_wave(reinterpret_cast<const char *>(a.sc.nodes), reinterpret_cast<const char *>(a.sc.leaves), v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid);  // :612-614
         V3 nv12 = v12 / dist;
         float c1c2 = fmaxf(dot(px.n1, nv12), 0.0f) * fmaxf(-dot(v.n, nv12), 0.0f);
         bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
