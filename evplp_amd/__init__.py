@@ -366,7 +366,9 @@ class Context:
         s = PassStats()
         self._check(self._lib.evplp_pass_stats_get(self._h, which, C.byref(s)))
         return {"ms": s.ms, "pairs": s.pairs, "rays": s.rays, "usable": s.usable, "dominant_kernel_ms": s.dominant_kernel_ms,
-                "nodes": s.reserved[0] | (s.reserved[1] << 32), "shaded": s.shaded, "launches": s.launches}
+                "nodes": s.reserved[0] | (s.reserved[1] << 32), "shaded": s.shaded, "launches": s.launches,
+                # VSL gather: the same two words carry the sample-iterations of the estimators (lighttracing.cu:632-640)
+                "samples": (s.reserved[0] | (s.reserved[1] << 32)) if which == PASS_GATHER_VSL else 0}
 
     def debug_counters(self, which: int) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint64)

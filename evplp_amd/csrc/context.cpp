@@ -611,7 +611,7 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     // work-item size: k consecutive splits per wavefront (fixed summation tree: the result does not depend on k).  The per-item
     // statistics need (VPLs per split) * k < 65536.
     int k = 1;
-    if (!vsl) {
+    {
         k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : kDefaultSplitsPerWave;
         if (const char *e = std::getenv("EVPLP_GATHER_K")) { int v = atoi(e); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k = v; }
         const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
@@ -825,6 +825,10 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
         for (int k = 0; k < kCounterShards; k++) { rays += pc.shard_rays[k]; shaded += pc.shard_shaded[k]; }
         out->usable = scal[0]; out->pairs = px * scal[0]; out->rays = rays; out->shaded = shaded; out->reserved[0] = (uint32_t)std::min<unsigned long long>(pc.nodes, 0xffffffffull);
         out->reserved[1] = (uint32_t)(pc.nodes >> 32);
+        if (pass == EVPLP_PASS_GATHER_VSL && !EVPLP_TRAVERSAL_STATS) {     // VSL: sample-iterations of the estimators (64 shards), in the same two words
+            unsigned long long samples = 0; for (int k = 0; k < 64; k++) samples += pc.hist[k];
+            out->reserved[0] = (uint32_t)samples; out->reserved[1] = (uint32_t)(samples >> 32);
+        }
     } else if (pass == EVPLP_PASS_SPLAT) {
         // per-tile pair counts (a single counter word would take one device-scope atomic per tile: measured 0.28 ms of
         // a 0.41 ms launch at 1920x1080), summed here

@@ -38,7 +38,9 @@ EV_DEV Vpl load_vpl(const float4 *r) {
 }
 
 // vplSplat after the visibility test (rt/lighttracing.cu:296-345)
-EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px, const Vpl &v, V3 v12, float c1c2) {
+// wi10_lds: where the caller parked the pixel's view direction ([component][lane], LDS) instead of holding it in three VGPRs
+// across the walks -- it is only read for tiles with a glossy pixel
+EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px, const Vpl &v, V3 v12, float c1c2, const float *wi10_lds = nullptr) {
     // Radiance is toleranced arithmetic (stated bars: rel. L2 1e-5, 2e-4 per pixel; powf already differs between
     // glibc and ocml): 1-ulp hardware rsq / rcp instead of the IEEE-correct sqrt + 4 divisions (~50 instructions).
     float dist2 = dot(v12, v12);
@@ -52,7 +54,8 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
         else ph2 = phong_eval_f(-wi12, v.fdir, v.n, v.e);
     }
     float ph1 = 0.0f;
-    if (ballot64(px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f) != 0ull) ph1 = phong_eval_f(px.wi10, wi12, px.n1, px.e);
+    if (ballot64(px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f) != 0ull)
+        ph1 = phong_eval_f(wi10_lds ? v3(wi10_lds[0], wi10_lds[64], wi10_lds[128]) : px.wi10, wi12, px.n1, px.e);
     V3 brdf2 = v.rd * EV_INV_PI + v.rs * ph2;
     V3 brdf1 = px.rd * EV_INV_PI + px.rs * ph1;
     float g21 = c1c2 * __builtin_amdgcn_rcpf(dist2 * dist2);
@@ -109,6 +112,20 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
     return t;
 }
 
+// the texel index of item_setup alone (no row-strip division): what a kernel re-derives late instead of carrying it in registers
+EV_DEV uint32_t item_texel(const GatherArgs &a, int lane) {
+    const StripDev &st = a.st;
+    const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
+    const int groups = kVplSplit / a.splits_per_wave;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int tile = (j / groups) * 8 + xcd;
+    const int shl = a.block_h_log2, per_block = 8 << shl, nbx = (tiles_x + 7) >> 3;
+    const int blk = tile / per_block, l = tile - blk * per_block;
+    const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * (1 << shl) + (l >> 3);
+    const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+    return (uint32_t)max(min(ly, st.local_rows - 1), 0) * (uint32_t)st.W + (uint32_t)min(x, st.W - 1);
+}
+
 #ifndef EVPLP_GATHER_WAVES
 #define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene: 5 = 106.0 / 54.3 ms, 6 = 94.3 / 48.7, 7 = 91.0 / 47.6, 8 = 94.6 / 50.0
 #endif
@@ -139,6 +156,7 @@ EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
     __shared__ float s_lvl[6 * 192];
+    __shared__ float s_wi10[192];
     const int lane = threadIdx.x;
     const Item t = item_setup(a, lane);
     if (!t.has_tile) return;   // padding of the block grid
@@ -147,7 +165,14 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     Pixel px;
     float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
     px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
-    px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);  // lighttracing.cu:363
+#ifndef EVPLP_WI10_LDS
+#define EVPLP_WI10_LDS 1
+#endif
+    {   // lighttracing.cu:363; parked in LDS (single-wavefront workgroup: in order, no barrier)
+        const V3 w = normalize(v3(a.fp.camera_pos) - px.p1);
+        s_wi10[lane] = w.x; s_wi10[64 + lane] = w.y; s_wi10[128 + lane] = w.z;
+        px.wi10 = EVPLP_WI10_LDS ? v3(0.f, 0.f, 0.f) : w;
+    }
     const bool valid = t.in_image && gp.w != 0.0f;      // stencil test, lighttracing.cu:354
 
     const uint32_t nvpl = *a.nvpl;
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
             const bool lit = active && !occ;
             if (ballot64(lit) == 0ull) continue;
             Vpl v; v.pos = vpos; v.n = vn; v.psel = vpsel; fetch_vpl_tail(vpls, i, v);
-            if (lit) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2); shaded++; }
+            if (lit) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2, EVPLP_WI10_LDS ? s_wi10 + lane : nullptr); shaded++; }
         }
         // fold the split sums in the fixed balanced-tree order: a binary counter whose level j holds the sum of 2^j splits.
         // The levels live in LDS ([level][component][lane], touched once per split): registers are what limits occupancy here.
@@ -230,7 +255,9 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         total = result;     // after the last jj (k - 1 = all ones) this is the sum of all k splits
     }
     // per-lane statistics ride in the unused fourth component: shadow rays | unoccluded pairs << 16 (both < 65536 per item)
-    if (t.in_image) a.partial[(size_t)t.group * a.partial_stride + p] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (shaded << 16)));
+    int lane_out = lane;
+    asm volatile("" : "+v"(lane_out));              // (the store address is formed here, not carried through the walks)
+    if (t.in_image) a.partial[(size_t)t.group * a.partial_stride + item_texel(a, lane_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (shaded << 16)));
 }
 
 // out = (balanced-tree sum of the per-group partials) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378);
@@ -426,8 +453,8 @@ struct VslCtx {
 // lobe with rho_s = 0 is skipped altogether (exact: its terms are multiplied by 0 / PhongPdfW returns 0 for
 // rho_s.x <= 1e-6).  The reference normalises already-unit vectors again inside its pdfs; that is dropped
 // here (last-ulp differences, far below the VSL tolerance).
-struct VslPixel { V3 R1; float psel, inv_psel, inv_1mpsel; bool dead, glossy, pdf_glossy; };
-struct VslLight { V3 R2; float psel, inv_psel, inv_1mpsel; bool dead, glossy, pdf_glossy; };
+struct VslPixel { V3 R1; float psel; bool dead, glossy, pdf_glossy; };
+struct VslLight { V3 R2; float psel; bool dead, glossy, pdf_glossy; };
 EV_DEV float lobe_pow(float c, float e) { return c <= 0.000001f ? 0.0f : vslm::fpow(c, e); }
 // brdf1, brdf2 and the shared MIS denominators (:433-443, 508-518, 581-591; reference quirk of SURVEY A.6: pdf2 uses the
 // PIXEL's lobe-selection probability for its Lambert term and no (1 - psel) on its Phong term) for direction w = wi12
@@ -465,8 +492,8 @@ EV_DEV V3 vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, con
     if (P.dead) return zero;
     float choose = fminf(rng_uniform(rng), 0.999999f);
     V3 wi12, brdf1; float pdfw;
-    if (choose < P.psel) brdf1 = vslm::lambert_sample(wi12, pdfw, px.n1, px.rd, rng) * P.inv_psel;
-    else brdf1 = vslm::phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) * P.inv_1mpsel;
+    if (choose < P.psel) brdf1 = vslm::lambert_sample(wi12, pdfw, px.n1, px.rd, rng) * vslm::rcp(P.psel);
+    else brdf1 = vslm::phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) * vslm::rcp(1.0f - P.psel);
     if (dot(wi12, c.nd12) <= c.cos_half_cone) return zero;
     float cos1 = fmaxf(dot(px.n1, wi12), 0.0f);
     if (cos1 <= 0.000000001f) return zero;
@@ -482,8 +509,8 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, con
     if (L.dead) return zero;
     V3 wi21, brdf2; float pdfw;
     float choose = fminf(rng_uniform(rng), 0.999999f);
-    if (choose < L.psel) brdf2 = vslm::lambert_sample(wi21, pdfw, v.n, v.rd, rng) * L.inv_psel;
-    else brdf2 = vslm::phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) * L.inv_1mpsel;
+    if (choose < L.psel) brdf2 = vslm::lambert_sample(wi21, pdfw, v.n, v.rd, rng) * vslm::rcp(L.psel);
+    else brdf2 = vslm::phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) * vslm::rcp(1.0f - L.psel);
     if (-dot(wi21, c.nd12) <= c.cos_half_cone) return zero;
     float cos2 = fmaxf(dot(v.n, wi21), 0.0f);
     if (cos2 <= 0.00000001f) return zero;
@@ -497,77 +524,135 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, con
 }
 
 #ifndef EVPLP_VSL_WAVES
-#define EVPLP_VSL_WAVES 8   // 5: 56.4 ms, 6: 51.0, 7: 48.0, 8: 46.0 (512^2, 760 VSLs): occupancy beats the spills it costs
+#define EVPLP_VSL_WAVES 4   // 128 VGPRs: the estimators need ~125; zero scratch (cfg5-shaped 1024^2 launch: 3 waves 200 ms, 4 waves 176 ms, 6 waves with 40 spills 172 ms)
 #endif
+constexpr int kVslChunk = 128;     // VSLs of one split whose lit masks wait in LDS between the two phases (1 KB per wavefront)
+// Two phases per chunk of a split's VSLs, because the walk and the estimators have disjoint register sets and together they
+// do not fit (round 2: one loop, 65 VGPR + 72 SGPR spills at 64 registers, 2-3 TB/s of scratch traffic):
+//   phase 1  the packet walk of every VSL of the chunk; all it keeps per lane is the pixel's position and normal; the 64-bit mask
+//            of lit lanes goes to LDS.  Lanes whose pair has a zero geometry term (c1 c2 <= 1e-9, lighttracing.cu:619) do not
+//            enter the walk: the reference traces their shadow ray and then discards the pair -- same radiance, fewer rays
+//            (the `rays` statistic counts the rays actually traced);
+//   phase 2  the estimators of the lit pairs, with the walk's registers dead, the rest of the G-buffer texel loaded only now
+//            and the VSL record in SGPRs.
+// k consecutive splits per wavefront, folded in the fixed tree of gather_vpl_kernel (the partial sums shrink by k).
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
+    __shared__ float s_lvl[6 * 192];
+    __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
     const int W = a.st.W;
-    const Item t = item_setup(a, lane);      // splits_per_wave = 1: group = split
+    const Item t = item_setup(a, lane);
     if (!t.has_tile) return;
-    const uint32_t p = t.p;
-    const bool in_image = t.in_image;
-
-    Pixel px;
-    float4 gp = a.g_pos[p], gn = a.g_nrm[p], gd = a.g_dif[p], gs = a.g_phg[p];
-    px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w;
-    px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);   // :704
-    const bool valid = in_image;                        // no stencil test in splatSplotch (:694-695)
+    const bool valid = t.in_image;                      // no stencil test in splatSplotch (:694-695)
     const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
-
-    VslPixel P;
-    {
-        float ml = max_color(px.rd), mp = max_color(px.rs);
-        P.dead = ml + mp <= 0.000001f; P.psel = ml / (mp + ml); P.inv_psel = 1.0f / P.psel; P.inv_1mpsel = 1.0f / (1.0f - P.psel);
-        P.glossy = px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f; P.pdf_glossy = !(px.rs.x <= 0.000001f);
-        P.R1 = reflect(-px.wi10, px.n1);
-    }
     const uint32_t nvpl = *a.nvpl;
-    V3 result = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0, nlit = 0;
-    for (uint32_t i = (uint32_t)t.group; i < nvpl; i += kVplSplit) {
-        const Vpl v = fetch_vpl(a.vpls + i);
-        V3 v12 = v.pos - px.p1;                                       // :605
-        float dist2 = dot(v12, v12);
-        float dist = sqrtf(dist2);
-        rays += valid ? 1u : 0u;
-        bool occ = occluded_wave(reinterpret_cast<const char *>(a.sc.nodes), reinterpret_cast<const char *>(a.sc.leaves), v.pos, -v12, 0.0001f, 1.0f - 0.0001f, valid);  // :612-614
-        V3 nv12 = v12 / dist;
-        float c1c2 = fmaxf(dot(px.n1, nv12), 0.0f) * fmaxf(-dot(v.n, nv12), 0.0f);
-        bool lit = valid && !occ && !(c1c2 <= 0.000000001f);        // :619
-        if (ballot64(lit) == 0ull) continue;
-        if (lit) {
-            nlit++;
-            VslCtx c;
-            float rdratio = a.fp.vsl_radius / dist;
-            c.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
-            c.cos_half_cone = (rdratio >= 1.0f) ? cosf(EV_PI / 2.0f) : vslm::fsqrt(1.0f - rdratio * rdratio);   // cos(asin x)
-            c.solid_angle = EV_PI * 2.0f * (1.0f - c.cos_half_cone);
-            c.inv_solid_angle = vslm::rcp(c.solid_angle);
-            c.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; c.nd12 = nv12;
-            int num_samples = (int)(c.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
-            // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
-            Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
-            VslLight L;
+    const int k = a.splits_per_wave;
+    const char *node_base = pinned(reinterpret_cast<const char *>(a.sc.nodes)), *leaf_base = pinned(reinterpret_cast<const char *>(a.sc.leaves));
+    const evplp_record *vpls = pinned(a.vpls);
+    V3 p1, n1;
+    { const float4 gp = a.g_pos[t.p], gn = a.g_nrm[t.p]; p1 = v3(gp); n1 = v3(gn); }
+    V3 total = v3(0.f, 0.f, 0.f);
+    uint32_t rays = 0, nlit = 0, nsamp = 0;
+    for (int jj = 0; jj < k; jj++) {
+        const uint32_t split = (uint32_t)(t.group * k + jj);
+        V3 result = v3(0.f, 0.f, 0.f);
+        for (uint32_t first = split; first < nvpl; first += (uint32_t)(kVplSplit * kVslChunk)) {
+            const uint32_t n = min((uint32_t)kVslChunk, (nvpl - first + (uint32_t)kVplSplit - 1u) / (uint32_t)kVplSplit);
+            // ---- phase 1: visibility
+            for (uint32_t c = 0; c < n; c++) {
+                const uint32_t i = first + c * (uint32_t)kVplSplit;
+                V3 vpos, vn; float vpsel; fetch_vpl_head(vpls, i, vpos, vn, vpsel);
+                const V3 v12 = vpos - p1;                                     // :605
+                const float dist = sqrtf(dot(v12, v12));
+                const V3 nv12 = v12 / dist;
+                const float c1c2 = fmaxf(dot(n1, nv12), 0.0f) * fmaxf(-dot(vn, nv12), 0.0f);
+                const bool pre = valid && !(c1c2 <= 0.000000001f);           // :619, taken before the shadow ray instead of after it
+                unsigned long long lit = 0ull;
+                if (ballot64(pre) != 0ull) {
+                    rays += pre ? 1u : 0u;
+                    const bool occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, pre);   // :612-614
+                    lit = ballot64(pre && !occ);
+                }
+                if (lane == 0) s_lit[c] = lit;          // (single-wavefront workgroup: LDS is in order, no barrier)
+            }
+            // ---- phase 2: the estimators of the lit pairs
+            int lane2 = lane;
+            asm volatile("" : "+v"(lane2));             // the texel index is formed again and the texel fetched HERE, not above the walks
+            const uint32_t pidx = item_texel(a, lane2);
+            Pixel px; px.p1 = p1; px.n1 = n1;
+            { const float4 gd = a.g_dif[pidx], gs = a.g_phg[pidx]; px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w; }
+            px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);   // :704
+            VslPixel P;
             {
-                float ml = max_color(v.rd), mp = max_color(v.rs);
-                L.dead = ml + mp <= 0.000001f; L.psel = ml / (mp + ml); L.inv_psel = 1.0f / L.psel; L.inv_1mpsel = 1.0f / (1.0f - L.psel);
-                L.glossy = v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f; L.pdf_glossy = !(v.rs.x <= 0.000001f);
-                L.R2 = reflect(-v.fdir, v.n);
+                const float ml = max_color(px.rd), mp = max_color(px.rs);
+                P.dead = ml + mp <= 0.000001f; P.psel = ml / (mp + ml);
+                P.glossy = px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f; P.pdf_glossy = !(px.rs.x <= 0.000001f);
+                P.R1 = reflect(-px.wi10, px.n1);
             }
-            V3 acc = v3(0.f, 0.f, 0.f);
-            for (int s = 0; s < num_samples; s++) {
-                float wc = 0.f, w1 = 0.f, w2 = 0.f;
-                V3 rc = vsl_sample_cone(px, v, P, L, c, wc, rng);
-                V3 r1 = vsl_sample_brdf1(px, v, P, L, c, w1, rng);
-                V3 r2 = vsl_sample_brdf2(px, v, P, L, c, w2, rng);
-                acc = acc + rc * wc;
-                acc = acc + r1 * w1;
-                acc = acc + r2 * w2;
+            for (uint32_t c = 0; c < n; c++) {
+                const unsigned long long lit = s_lit[c];
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)lit), hi = __builtin_amdgcn_readfirstlane((uint32_t)(lit >> 32));
+                if ((lo | hi) == 0u) continue;
+                const uint32_t i = first + c * (uint32_t)kVplSplit;
+                Vpl v; fetch_vpl_head(vpls, i, v.pos, v.n, v.psel); fetch_vpl_tail(vpls, i, v);
+                const bool lit_lane = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
+                if (lit_lane) {
+                    nlit++;
+                    const V3 v12 = v.pos - px.p1;
+                    const float dist = sqrtf(dot(v12, v12));
+                    const V3 nv12 = v12 / dist;
+                    VslCtx cx;
+                    const float rdratio = a.fp.vsl_radius / dist;
+                    cx.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
+                    cx.cos_half_cone = (rdratio >= 1.0f) ? cosf(EV_PI / 2.0f) : vslm::fsqrt(1.0f - rdratio * rdratio);   // cos(asin x)
+                    cx.solid_angle = EV_PI * 2.0f * (1.0f - cx.cos_half_cone);
+                    cx.inv_solid_angle = vslm::rcp(cx.solid_angle);
+                    cx.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; cx.nd12 = nv12;
+                    const int num_samples = (int)(cx.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
+                    nsamp += (uint32_t)num_samples;
+                    // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
+                    uint32_t pid = pixel_id;
+                    asm volatile("" : "+v"(pid));      // (keeps the seed arithmetic here: hoisted above the loops its 64-bit partial result was the one spill left)
+                    Rng rng; rng_init(rng, pid, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
+                    VslLight L;
+                    {
+                        const float ml = max_color(v.rd), mp = max_color(v.rs);
+                        L.dead = ml + mp <= 0.000001f; L.psel = ml / (mp + ml);
+                        L.glossy = v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f; L.pdf_glossy = !(v.rs.x <= 0.000001f);
+                        L.R2 = reflect(-v.fdir, v.n);
+                    }
+                    V3 acc = v3(0.f, 0.f, 0.f);
+                    for (int sidx = 0; sidx < num_samples; sidx++) {
+                        float wc = 0.f, w1 = 0.f, w2 = 0.f;
+                        const V3 rc = vsl_sample_cone(px, v, P, L, cx, wc, rng);
+                        const V3 r1 = vsl_sample_brdf1(px, v, P, L, cx, w1, rng);
+                        const V3 r2 = vsl_sample_brdf2(px, v, P, L, cx, w2, rng);
+                        acc = acc + rc * wc;
+                        acc = acc + r1 * w1;
+                        acc = acc + r2 * w2;
+                    }
+                    result = result + acc * vslm::rcp((float)num_samples);
+                }
             }
-            result = result + acc * vslm::rcp((float)num_samples);
         }
+        {   // fold the split sums in the fixed balanced-tree order (as gather_vpl_kernel)
+            int lev = 0;
+            while ((jj >> lev) & 1) {
+                float *q = s_lvl + lev * 192 + lane;
+                result = v3(q[0], q[64], q[128]) + result;
+                lev++;
+            }
+            float *q = s_lvl + lev * 192 + lane;
+            q[0] = result.x; q[64] = result.y; q[128] = result.z;
+        }
+        total = result;
     }
-    if (in_image) a.partial[(size_t)t.group * a.partial_stride + p] = make_float4(result.x, result.y, result.z, __uint_as_float(rays | (nlit << 16)));
+    // sample-iterations of the item (the unit the estimators' work is priced in): one add per wavefront into 64 counter shards
+    for (int off = 32; off > 0; off >>= 1) nsamp += __shfl_down(nsamp, off);
+    if (lane == 0) atomicAdd(&a.counters->hist[blockIdx.x & 63u], (unsigned long long)nsamp);
+    int lane3 = lane;
+    asm volatile("" : "+v"(lane3));                 // (the store address is formed here, not carried through both phases)
+    if (valid) a.partial[(size_t)t.group * a.partial_stride + item_texel(a, lane3)] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (nlit << 16)));
 }
 
 static dim3 gather_grid(const GatherArgs &a) {

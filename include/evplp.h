@@ -144,7 +144,7 @@ typedef struct evplp_pass_stats {
     uint64_t rays;           /* rays traced by the pass */
     uint64_t usable;         /* usable VPL / photon records consumed */
     float dominant_kernel_ms;/* device time of the pass's dominant kernel alone (summed over its launches) */
-    uint32_t reserved[3];
+    uint32_t reserved[3];    /* [0], [1]: a 64-bit count -- VSL gather: sample-iterations of the estimators; diagnostic builds: node visits; splat: bin entries, fullest bin */
     uint64_t shaded;         /* gather: pairs that passed the cosine test AND the visibility test (contributions evaluated);
                               * photon splat: (photon, pixel) pairs of ALL splat passes of the context so far (running total) */
     uint32_t launches;       /* launches of the dominant kernel in the pass */
