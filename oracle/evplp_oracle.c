@@ -907,15 +907,15 @@ static v3 vsl_sample_brdf2(const vsl_ctx *c, float *w, evo_rng *rng) {
     *w = pdf2 / (pdf1 + pdf2 + c->inv_solid_angle);
     return mulv(mulv(muls(muls(c->pflux, c->vsl_inv_pi_r2), cos1), brdf1), brdf2);
 }
-/* :596-686 vslSplat */
-static v3 vsl_splat(const evo_scene *s, const evo_frame_params *fp, v3 wi10, v3 p1, v3 n1, v3 rd1, v3 rs1, float e1,
-                    const evo_record *rec, evo_rng *rng) {
+/* :596-686 vslSplat, after the shadow ray (:612-614).  `only` and `samples_override` exist for tests/test_oracle_selfcheck.py alone
+ * (evo_vsl_splat_pair): only = 0 is the reference's MIS-combined sum; only = 1 / 2 / 3 keeps the cone / pixel-BRDF / VSL-BRDF estimator
+ * ALONE with weight 1 -- each is then by itself an estimator of the same integral; samples_override > 0 replaces numSamples (:632). */
+static v3 vsl_splat_lit(const evo_frame_params *fp, v3 wi10, v3 p1, v3 n1, v3 rd1, v3 rs1, float e1,
+                        const evo_record *rec, evo_rng *rng, int only, int samples_override) {
     v3 pv = ld3(rec->pos);
     v3 v12 = sub(pv, p1);
     float dist2 = dot(v12, v12);
     float dist = sqrtf(dist2);
-    float o[3], d[3]; st3(o, pv); st3(d, neg(v12));
-    if (evo_occluded(s, o, d, 0.0001f, 1.0f - 0.0001f)) return V3(0, 0, 0);
     v3 nv12 = divs(v12, dist);
     vsl_ctx c;
     c.pn = ld3(rec->normal);
@@ -930,17 +930,37 @@ static v3 vsl_splat(const evo_scene *s, const evo_frame_params *fp, v3 wi10, v3 
     c.pfd = ld3(rec->flux_dir); c.pflux = ld3(rec->flux); c.prd = ld3(rec->rho_d); c.prs = ld3(rec->rho_s); c.pe = rec->phong_exp;
     c.nd12 = nv12; c.vsl_inv_pi_r2 = fp->vsl_inv_pi_radius2;
     int num_samples = (int)(c.half_cone / EVO_PI * 2.0f * 100.0f) + 1;
+    if (samples_override > 0) num_samples = samples_override;
     v3 result = V3(0, 0, 0);
     for (int i = 0; i < num_samples; i++) {
         float wc = 0.0f, w1 = 0.0f, w2 = 0.0f;
         v3 rc = vsl_sample_cone(&c, &wc, rng);
         v3 r1 = vsl_sample_brdf1(&c, &w1, rng);
         v3 r2 = vsl_sample_brdf2(&c, &w2, rng);
+        if (only) { wc = only == 1 ? 1.0f : 0.0f; w1 = only == 2 ? 1.0f : 0.0f; w2 = only == 3 ? 1.0f : 0.0f; }
         result = add(result, muls(rc, wc));
         result = add(result, muls(r1, w1));
         result = add(result, muls(r2, w2));
     }
     return divs(result, (float)num_samples);
+}
+static v3 vsl_splat(const evo_scene *s, const evo_frame_params *fp, v3 wi10, v3 p1, v3 n1, v3 rd1, v3 rs1, float e1,
+                    const evo_record *rec, evo_rng *rng) {
+    v3 pv = ld3(rec->pos);
+    v3 v12 = sub(pv, p1);
+    float o[3], d[3]; st3(o, pv); st3(d, neg(v12));
+    if (evo_occluded(s, o, d, 0.0001f, 1.0f - 0.0001f)) return V3(0, 0, 0);
+    return vsl_splat_lit(fp, wi10, p1, n1, rd1, rs1, e1, rec, rng, 0, 0);
+}
+void evo_vsl_splat_pair(const evo_frame_params *fp, const float wi10[3], const float p1[3], const float n1[3],
+                        const float rd[3], const float rs[3], float e, const evo_record *rec, int visible,
+                        uint32_t rng_index, uint32_t rng_sequence, uint32_t rng_substream, int only, int samples_override, float out[3]) {
+    v3 r = V3(0, 0, 0);
+    if (visible) {
+        evo_rng rng; evo_rng_init(&rng, rng_index, rng_sequence, rng_substream);
+        r = vsl_splat_lit(fp, ld3(wi10), ld3(p1), ld3(n1), ld3(rd), ld3(rs), e, rec, &rng, only, samples_override);
+    }
+    st3(out, r);
 }
 /* :689-722 splatSplotch.  RNG: one substream per (pixel, record) instead of one cuRAND
  * stream per pixel, so any decomposition of the record loop reproduces the same numbers. */

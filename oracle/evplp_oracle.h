@@ -145,6 +145,12 @@ void evo_trace_light_paths(const evo_scene *s, uint32_t rng_seed, uint32_t path_
 void evo_vpl_splat_pair(const evo_frame_params *fp, const float wi10[3], const float p1[3], const float n1[3],
                         const float rho_d[3], const float rho_s[3], float e,
                         const evo_record *rec, int visible, float out[3]);
+/* lighttracing.cu:596-686 vslSplat for one pair, visibility supplied by the caller, RNG stream (index, sequence, substream).
+ * TEST HOOK (tests/test_oracle_selfcheck.py): only = 0 the reference's MIS-combined estimator; 1 / 2 / 3 the cone / pixel-BRDF /
+ * VSL-BRDF estimator alone with weight 1; samples_override > 0 replaces numSamples (:632). */
+void evo_vsl_splat_pair(const evo_frame_params *fp, const float wi10[3], const float p1[3], const float n1[3],
+                        const float rho_d[3], const float rho_s[3], float e, const evo_record *rec, int visible,
+                        uint32_t rng_index, uint32_t rng_sequence, uint32_t rng_substream, int only, int samples_override, float out[3]);
 /* lvclighttracing.cu:348-384: splatColor with a per-pixel random light-path window */
 void evo_gather_lvc(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H,
                     int32_t row_begin, int32_t row_end,

@@ -89,6 +89,7 @@ def load():
     l.evo_primary.argtypes = [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32]
     l.evo_trace_light_paths.argtypes = [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]
     l.evo_vpl_splat_pair.argtypes = [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, _P]
+    l.evo_vsl_splat_pair.argtypes = [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _P]
     l.evo_gather_vpl.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]
     l.evo_gather_vpl_counts.argtypes = [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]
     l.evo_gather_vsl.argtypes = l.evo_gather_vpl.argtypes

@@ -277,3 +277,151 @@ def test_shared_direction_sampling_math_against_libm(oracle):
     assert worst <= 0.51, worst
     assert oracle.evo_math_pow(0.0, 2.0) == 0.0 and oracle.evo_math_pow(0.3, 0.0) == 1.0 and oracle.evo_math_pow(1.0, 77.0) == 1.0
     assert oracle.evo_math_pow(0.25, 0.5) == 0.5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Vouching for the oracle's VSL estimators (vslSplat, rt/lighttracing.cu:395-686) -- the most intricate function on the path.
+# The reference cannot be run here, so the restatement is checked against (a) the limit it must have,
+# (b) the integral every one of its three estimators -- and their MIS combination -- must converge to, computed by quadrature,
+# (c) a single-sample answer derived by hand from a known RNG draw.
+
+def _vsl_setup(glossy=True):
+    n = lambda v: (np.array(v, np.float64) / np.linalg.norm(v)).astype(np.float32)
+    rec = np.zeros(1, oa.RECORD_DTYPE)
+    rec[0]["pos"] = (0.4, 0.3, 1.5); rec[0]["normal"] = n((-0.2, -0.1, -1.0)); rec[0]["flux"] = (1.0, 0.8, 0.6)
+    rec[0]["flux_dir"] = n((0.1, -0.3, -0.9)); rec[0]["rho_d"] = (0.4, 0.4, 0.4)
+    rec[0]["rho_s"] = (0.2, 0.2, 0.2) if glossy else (0, 0, 0); rec[0]["phong_exp"] = 5.0 if glossy else 0.0
+    rec[0]["p_select_lambert"] = 0.4 / 0.6 if glossy else 1.0; rec[0]["flags"] = 1
+    px = dict(wi10=n((0.3, -0.2, 0.9)), p1=np.zeros(3, np.float32), n1=np.array([0, 0, 1], np.float32),
+              rd=np.full(3, 0.5, np.float32), rs=np.full(3, 0.3 if glossy else 0.0, np.float32), e=8.0 if glossy else 0.0)
+    return rec, px
+
+
+def _vsl_pair(oracle, rec, px, radius, only, samples, stream=(5, 7, 11), visible=1):
+    fp = oa.frame_params(camera_pos=(0, 0, 0), vsl_radius=radius, vsl_inv_pi_radius2=1.0 / (math.pi * radius * radius),
+                         num_light_paths=1, num_vpl_light_paths=1, photons_per_path=1)
+    out = np.zeros(3, np.float32)
+    oracle.evo_vsl_splat_pair(C.byref(fp), oa.ptr(px["wi10"]), oa.ptr(px["p1"]), oa.ptr(px["n1"]), oa.ptr(px["rd"]), oa.ptr(px["rs"]), px["e"],
+                              oa.ptr(rec), visible, stream[0], stream[1], stream[2], only, samples, oa.ptr(out))
+    return out.astype(np.float64)
+
+
+def _vsl_integral_by_quadrature(rec, px, radius, nz=600, nphi=720):
+    """flux / (pi r^2) * integral over the cone (axis = direction to the VSL, half angle asin(r / d)) of
+    cos1 cos2 brdf1 brdf2 d_omega  -- the quantity vslSampleCone / vslSampleBrdf1 / vslSampleBrdf2 each estimate (:395-594)."""
+    f64 = lambda a: np.asarray(a, np.float64)
+    p2, n2, fdir = f64(rec[0]["pos"]), f64(rec[0]["normal"]), f64(rec[0]["flux_dir"])
+    n1, wi10 = f64(px["n1"]), f64(px["wi10"])
+    v12 = p2 - f64(px["p1"]); d = np.linalg.norm(v12); axis = v12 / d
+    cos_max = math.cos(math.asin(min(radius / d, 1.0)))
+    t = np.cross(axis, [1.0, 0, 0]); t /= np.linalg.norm(t); b = np.cross(axis, t)
+    z = 1.0 - (np.arange(nz) + 0.5) / nz * (1.0 - cos_max); phi = (np.arange(nphi) + 0.5) / nphi * 2 * math.pi
+    Z, PH = np.meshgrid(z, phi, indexing="ij"); S = np.sqrt(np.maximum(1 - Z * Z, 0))
+    w = Z[..., None] * axis + (S * np.cos(PH))[..., None] * t + (S * np.sin(PH))[..., None] * b
+    c1 = np.maximum(w @ n1, 0); c2 = np.maximum(-(w @ n2), 0)
+    def phong(out, inn, nrm, e):                                  # PhongEvalF, rtmaterial.cuh:112-118
+        r = -inn + 2.0 * nrm * (inn @ nrm)[..., None] if inn.ndim > 1 else -inn + 2.0 * nrm * float(inn @ nrm)
+        dd = np.maximum(np.sum(out * r, axis=-1), 0)
+        return np.where(dd <= 1e-6, 0.0, (e + 2) * np.power(np.maximum(dd, 1e-300), e) / (2 * math.pi))
+    ph1 = phong(np.broadcast_to(wi10, w.shape), w, n1, px["e"])
+    ph2 = phong(-w, np.broadcast_to(fdir, w.shape), n2, float(rec[0]["phong_exp"]))
+    dom = (1.0 - cos_max) / nz * (2 * math.pi / nphi)
+    out = []
+    for ch in range(3):
+        f1 = float(px["rd"][ch]) / math.pi + float(px["rs"][ch]) * ph1
+        f2 = float(rec[0]["rho_d"][ch]) / math.pi + float(rec[0]["rho_s"][ch]) * ph2
+        out.append(float(rec[0]["flux"][ch]) / (math.pi * radius * radius) * float(np.sum(c1 * c2 * f1 * f2)) * dom)
+    return np.array(out)
+
+
+@pytest.mark.parametrize("glossy", [False, True])
+def test_vsl_estimators_each_converge_to_the_cone_integral(oracle, glossy):
+    """(b) the cone estimator alone, the pixel-BRDF estimator alone, the VSL-BRDF estimator alone (MIS weight forced to 1 by the
+    test hook) and the reference's MIS combination all estimate flux / (pi r^2) * int_cone cos1 cos2 f1 f2: each is compared
+    with a 600 x 720-point quadrature of that integral."""
+    rec, px = _vsl_setup(glossy)
+    radius = 0.9                                         # r / d = 0.57: a wide cone, so the BRDF estimators land in it often
+    want = _vsl_integral_by_quadrature(rec, px, radius)
+    assert (want > 0).all()
+    n = 300000
+    for only, tol in ((1, 0.01), (2, 0.03), (3, 0.03), (0, 0.01)):
+        got = np.mean([_vsl_pair(oracle, rec, px, radius, only, n, stream=(3, 1, k)) for k in range(4)], axis=0)
+        assert np.all(np.abs(got - want) <= tol * want), (only, got, want)
+
+
+def test_vsl_small_radius_limit_is_the_vpl(oracle, room_scene):
+    """(a) r -> 0: the cone shrinks onto the connection, the integrand is constant over it and
+    flux / (pi r^2) * cos1 cos2 f1 f2 * Omega  ->  flux f1 f2 cos1 cos2 / d^2 = vplSplat with misMode one (:309-312)."""
+    # (fp32 note: Omega = 2 pi (1 - cos t) cancels catastrophically for r / d below ~1e-3 -- the reference floors the radius at 0.008,
+    # rtcomphoton.h:1050-1054 -- so the limit is taken at r / d = 0.02 and the first-order variation of the integrand over the cone
+    # is averaged out with many samples: what is left is O((r/d)^2))
+    for glossy, tol in ((False, 2e-3), (True, 1e-2)):
+        rec, px = _vsl_setup(glossy)
+        fp = oa.frame_params(camera_pos=(0, 0, 0), mis_mode=0, num_light_paths=1, num_vpl_light_paths=1, photons_per_path=1)
+        vpl = np.zeros(3, np.float32)
+        oracle.evo_vpl_splat_pair(C.byref(fp), oa.ptr(px["wi10"]), oa.ptr(px["p1"]), oa.ptr(px["n1"]), oa.ptr(px["rd"]), oa.ptr(px["rs"]), px["e"], oa.ptr(rec), 1, oa.ptr(vpl))
+        d = float(np.linalg.norm(rec[0]["pos"]))
+        vsl = _vsl_pair(oracle, rec, px, 0.02 * d, 0, 40000)
+        assert (vpl > 0).all() and np.all(np.abs(vsl - vpl) <= tol * vpl), (glossy, vsl, vpl)
+        assert (_vsl_pair(oracle, rec, px, 0.02 * d, 0, 0, visible=0) == 0).all()      # occluded centre ray: nothing (:612-616)
+    # ... and as whole gathers over a room (visibility, record loop, normalisation included)
+    room, s = room_scene
+    W, H = 24, 16
+    room.aspect = W / H
+    g = s.primary(W, H)
+    rec = s.trace_light_paths(3, 64, 4)
+    kw = dict(camera_pos=room.cam_origin, num_light_paths=64, num_vpl_light_paths=64, photons_per_path=4, rng_seed=2)
+    r = 0.02
+    vsl, pairs_v = s.gather(oa.frame_params(vsl_radius=r, vsl_inv_pi_radius2=1.0 / (math.pi * r * r), **kw), W, H, g, rec, vsl=True)
+    vpl, pairs_p = s.gather(oa.frame_params(mis_mode=0, **kw), W, H, g, rec)
+    assert pairs_v == pairs_p and vpl[..., :3].max() > 0
+    a, b = vsl[..., :3].astype(np.float64), vpl[..., :3].astype(np.float64)
+    assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b)
+
+
+def test_vsl_cone_sample_known_answer(oracle):
+    """(c) one cone sample, by hand.  Pixel at the origin facing +z, VSL two units above it facing down, both Lambertian:
+    every direction w of the cone has cos1 = cos2 = w.z, so the cone estimator (:395-446) returns
+        flux / (pi r^2) * z^2 * (rho1 / pi) (rho2 / pi) * Omega,   Omega = 2 pi (1 - cos t),  cos t = sqrt(1 - (r/d)^2),
+        z = 1 - u_b (1 - cos t)   (SquareToSolidAngle, :382-390; the rotation about the cone axis +z keeps z),
+    with u_b the THIRD draw of the stream (the first is the unused chooseMaterial of :414, the second the azimuth)."""
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+
+    def uniforms(index, seq, sub, n):                       # the build's generator (test_rng_known_answers), (0, 1] like curand_uniform
+        s0 = sm((((seq << 32) | index) + sub * 0xD1B54A32D192ED03) & M)
+        inc = sm(s0) | 1
+        state = (s0 + inc) & M
+        out = []
+        for k in range(n + 1):
+            old = state
+            state = (old * 6364136223846793005 + inc) & M
+            xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+            rot = old >> 59
+            out.append(((((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF) >> 8) + 1)
+        return [v / 16777216.0 for v in out[1:]]
+    rec = np.zeros(1, oa.RECORD_DTYPE)
+    rec[0]["pos"] = (0, 0, 2); rec[0]["normal"] = (0, 0, -1); rec[0]["flux"] = (1.0, 0.5, 0.25); rec[0]["flux_dir"] = (0, 0, -1)
+    rec[0]["rho_d"] = (0.4, 0.4, 0.4); rec[0]["p_select_lambert"] = 1.0; rec[0]["flags"] = 1
+    px = dict(wi10=np.array([0, 0.6, 0.8], np.float32), p1=np.zeros(3, np.float32), n1=np.array([0, 0, 1], np.float32),
+              rd=np.full(3, 0.5, np.float32), rs=np.zeros(3, np.float32), e=0.0)
+    radius, d = 0.5, 2.0
+    cos_t = math.sqrt(1 - (radius / d) ** 2); omega = 2 * math.pi * (1 - cos_t)
+    for stream in ((5, 7, 11), (0, 0, 1), (123, 4, 9)):
+        u = uniforms(*stream, 3)
+        z = 1 - u[2] * (1 - cos_t)
+        want = np.array([1.0, 0.5, 0.25]) / (math.pi * radius ** 2) * z * z * (0.5 / math.pi) * (0.4 / math.pi) * omega
+        got = _vsl_pair(oracle, rec, px, radius, 1, 1, stream=stream)
+        assert np.allclose(got, want, rtol=2e-5, atol=0), (stream, got, want)
+        # the MIS weight of that sample (:433-445): pdfCone / (pdf1 + pdf2 + pdfCone), pdf1 = pdf2 = z (LambertPdfW has no 1/pi in
+        # the CUDA source, rtmaterial.cuh:40-44; p_select = 1) -- read off a run whose two BRDF samples cannot land in the cone
+    # numSamples (:632) = (int)(halfCone / pi * 2 * 100) + 1
+    half = math.asin(radius / d)
+    n_ref = int(half / math.pi * 2 * 100) + 1
+    a = _vsl_pair(oracle, rec, px, radius, 1, 0, stream=(1, 1, 1)); b = _vsl_pair(oracle, rec, px, radius, 1, n_ref, stream=(1, 1, 1))
+    assert (a == b).all() and n_ref == 17
