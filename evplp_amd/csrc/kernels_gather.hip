@@ -155,8 +155,11 @@ EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
 
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
-    __shared__ float s_lvl[6 * 192];
-    __shared__ float s_wi10[192];
+    // dynamic LDS: [192] the view directions, then one [192] block per level of the k-split fold (log2 k + 1 of them).  Sized by k
+    // because LDS is what limits occupancy next: 7 single-wavefront workgroups per SIMD fit while a workgroup stays within
+    // 5120 bytes (the allocation granule of this part is 1280 bytes: 5376 bytes measured 6 % slower, one wave per SIMD fewer)
+    extern __shared__ float s_dyn[];
+    float *const s_wi10 = s_dyn, *const s_lvl = s_dyn + 192;
     const int lane = threadIdx.x;
     const Item t = item_setup(a, lane);
     if (!t.has_tile) return;   // padding of the block grid
@@ -537,7 +540,7 @@ constexpr int kVslChunk = 128;     // VSLs of one split whose lit masks wait in 
 //            and the VSL record in SGPRs.
 // k consecutive splits per wavefront, folded in the fixed tree of gather_vpl_kernel (the partial sums shrink by k).
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
-    __shared__ float s_lvl[6 * 192];
+    extern __shared__ float s_lvl[];                   // one [192] block per level of the k-split fold
     __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
     const int W = a.st.W;
@@ -665,11 +668,15 @@ void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) 
     size_t n = (size_t)a.st.W * a.st.local_rows;
     hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, stencil_test);
 }
+static size_t fold_lds_bytes(const GatherArgs &a, int extra_blocks) {
+    int levels = 1; while ((1 << (levels - 1)) < a.splits_per_wave) levels++;       // log2 k + 1
+    return (size_t)(levels + extra_blocks) * 192 * sizeof(float);
+}
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
 }
 
 } // namespace evplp
