@@ -115,6 +115,7 @@ _SIGNATURES = {
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "evplp_accel_builder": (C.c_int, [_P]),
     "evplp_group_create": (C.c_int, [C.POINTER(Config), _P, C.POINTER(_P)]),
     "evplp_group_destroy": (None, [_P]),
     "evplp_group_last_error": (C.c_char_p, [_P]),
@@ -291,7 +292,9 @@ class Context:
     def accel_info(self):
         n, l, d, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
         self._check(self._lib.evplp_accel_info(self._h, C.byref(n), C.byref(l), C.byref(d), C.byref(ms)))
-        return {"nodes": n.value, "leaves": l.value, "depth": d.value, "build_ms": ms.value}
+        b = self._lib.evplp_accel_builder(self._h)
+        return {"nodes": n.value, "leaves": l.value, "depth": d.value, "build_ms": ms.value,
+                "builder": {0: "lbvh", 1: "sah", 2: "sbvh", 3: "gpu"}.get(b, "none")}
 
     # -- passes
     def set_stream(self, stream_ptr: int):

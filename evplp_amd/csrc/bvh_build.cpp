@@ -357,7 +357,9 @@ struct Builder {
         for (int32_t t : ids) { refs.push_back({ t, tbox[t] }); bb.grow(tbox[t]); }
         root_area = bb.area();
         float dup = 0.3f;
+#ifdef EVPLP_DEV_KNOBS
         if (const char *e = std::getenv("EVPLP_SBVH_DUP")) dup = (float)atof(e);
+#endif
         refs_total = refs.size(); ref_budget = refs.size() + (size_t)(dup * (float)refs.size());
         ids.clear();
         return sbvh_rec(refs, 0);
@@ -393,6 +395,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     int32_t nvalid = (int32_t)B.ids.size();
     B.nodes.reserve((size_t)3 * std::max(nvalid, 1) + 2);
     int32_t root = -1;
+#ifdef EVPLP_DEV_KNOBS   // builder tuning (tools/bvh_eval is compiled with it; the product library is not)
     if (const char *e = std::getenv("EVPLP_SAH_CT")) B.sah_ct = (float)atof(e);
     if (const char *e = std::getenv("EVPLP_PEEL_MIN")) B.peel_min = atoi(e);
     if (const char *e = std::getenv("EVPLP_PEEL_FLAT")) B.peel_min_flat = atoi(e);
@@ -400,6 +403,7 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
     if (const char *e = std::getenv("EVPLP_PEEL_EPS")) B.peel_eps = (float)atof(e);
     if (const char *e = std::getenv("EVPLP_PEEL_COV")) B.peel_cov = (float)atof(e);
     if (const char *e = std::getenv("EVPLP_PEEL_BIG")) B.peel_big = (float)atof(e);
+#endif
     B.root_area_sah = scene.area();
     if (nvalid > 0) root = builder == EVPLP_BVH_SBVH ? B.build_sbvh() : builder == EVPLP_BVH_SAH ? B.sah_rec(0, nvalid, 0) : B.build_lbvh();
 
@@ -493,7 +497,9 @@ int build_bvh(const float *verts, int32_t ntri, int builder, BvhBuild *out) {
 
 float bvh_pad_scale() {
     float pad_scale = 2e-6f;
+#ifdef EVPLP_DEV_KNOBS
     if (const char *e = std::getenv("EVPLP_BVH_PAD")) pad_scale = (float)atof(e);
+#endif
     return pad_scale;
 }
 

@@ -67,6 +67,10 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
 
     evplp_context *c = new evplp_context();
     c->cfg = *cfg; c->cfg.strip_count = strip_count; c->cfg.strip_rows = strip_rows;
+    if (const char *env = std::getenv("EVPLP_BVH_BUILDER"))
+        c->env_bvh_builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : !std::strcmp(env, "gpu") ? EVPLP_BVH_LBVH_GPU : EVPLP_BVH_SAH;
+    if (const char *env = std::getenv("EVPLP_GATHER_K")) { int v = atoi(env); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) c->env_gather_k = v; }
+    if (const char *env = std::getenv("EVPLP_TILE_BLOCK_LOG2")) c->env_tile_block_log2 = std::max(0, atoi(env));
     c->st.W = cfg->res_x; c->st.H = cfg->res_y;
     c->st.strip_rank = cfg->strip_rank; c->st.strip_count = strip_count; c->st.strip_rows = strip_rows;
     int nblocks = (cfg->res_y + strip_rows - 1) / strip_rows;
@@ -319,9 +323,7 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     }
     if (light_count <= 0) { c->set_error("evplp_build_accel: the area-light mesh has no triangles"); return EVPLP_ERR_INVALID; }
     BvhBuild bb;
-    int builder = c->cfg.bvh_builder;
-    if (const char *env = std::getenv("EVPLP_BVH_BUILDER"))   // tests: every suite under every builder
-        builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : !std::strcmp(env, "gpu") ? EVPLP_BVH_LBVH_GPU : EVPLP_BVH_SAH;
+    const int builder = c->env_bvh_builder >= 0 ? c->env_bvh_builder : c->cfg.bvh_builder;   // (override read by evplp_create)
     if (builder == EVPLP_BVH_LBVH_GPU) {
         BvhDeviceBuild gb;
         const int e = build_bvh_gpu(verts.data(), (int32_t)attrs.size(), bvh_pad_scale(), c->stream, &gb);
@@ -405,6 +407,11 @@ extern "C" int evplp_accel_info(evplp_context *c, int32_t *nodes, int32_t *leave
     return EVPLP_OK;
 }
 
+extern "C" int evplp_accel_builder(const evplp_context *c) {
+    if (!c || !c->accel_built) return -1;
+    return c->env_bvh_builder >= 0 ? c->env_bvh_builder : c->cfg.bvh_builder;
+}
+
 // ---------------------------------------------------------------------------------- passes
 // Look at the bin summary of the last photon splat (see context.hpp).  Called at the start of every entry point that
 // enqueues work, reads results or changes buffers.  Overflow is rare (the bins carry 25 % slack over the last pass and the
@@ -434,6 +441,7 @@ static int settle_one(evplp_context *c) {                                // the 
     for (int i = 0; i < c->npend; i++) {                                 // a younger pass ran with the old slabs: if IT has to run again, then with these
         c->pend[i].args.bin_items = c->d_bin_items; c->pend[i].args.bin_items_tmp = c->d_bin_items_tmp; c->pend[i].args.bin_stride = c->bin_stride;
     }
+    HIP_TRY(c, hipEventRecord(c->ev_begin[EVPLP_PASS_SPLAT], c->stream));  // (the pass statistics then describe this re-run as a whole, not a mix of two passes)
     launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
     const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
@@ -577,7 +585,7 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     int sh = 8;
     if (c->st.strip_count > 1) { sh = 1; while (sh * 2 <= std::min(8, c->st.strip_rows / 8) && (c->st.strip_rows / 8) % (sh * 2) == 0) sh *= 2; }
     a.block_h_log2 = sh == 8 ? 3 : sh == 4 ? 2 : sh == 2 ? 1 : 0;
-    if (const char *e = std::getenv("EVPLP_TILE_BLOCK_LOG2")) a.block_h_log2 = std::max(0, std::min(atoi(e), a.block_h_log2));   // developer knob: 0 = rows of 8 tiles
+    if (c->env_tile_block_log2 >= 0) a.block_h_log2 = std::min(c->env_tile_block_log2, a.block_h_log2);   // developer knob: 0 = rows of 8 tiles
     return EVPLP_OK;
 }
 // gather workspace (lazy: path-tracing / photon-only contexts never pay for it): per-item partial sums for `groups` groups
@@ -613,7 +621,7 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     int k = 1;
     {
         k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : kDefaultSplitsPerWave;
-        if (const char *e = std::getenv("EVPLP_GATHER_K")) { int v = atoi(e); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) k = v; }
+        if (c->env_gather_k > 0) k = c->env_gather_k;
         const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
         while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
     }
@@ -666,7 +674,10 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     CTX_CHECK(c);
     // (overlapped mode, accumulating: the previous pass may stay pending -- only look whether its verdict has arrived; a clearing pass
     // settles it first, its re-run would otherwise land in the cleared buffer)
-    const bool relaxed = c->aux_stream && !clear;
+    // Deterministic mode never leaves a pass pending behind a younger one: the re-run of an overflowed pass would otherwise be
+    // enqueued before or after the younger pass depending on when its verdict arrives, and the float sums into the photon
+    // accumulator would differ between runs.
+    const bool relaxed = c->aux_stream && !clear && !c->cfg.deterministic;
     int rc = pass_ready(c, "evplp_splat_photons", true, !relaxed); if (rc) return rc;
     if (relaxed) {
         while (c->npend >= 2) if ((rc = settle_one(c))) return rc;

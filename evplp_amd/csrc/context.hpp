@@ -76,6 +76,10 @@ struct evplp_context {
     PendingSplat pend[2];
     int npend = 0;
 
+    // Test / developer overrides, read ONCE by evplp_create (never in a pass): EVPLP_BVH_BUILDER (every suite under every builder),
+    // EVPLP_BIN_STRIDE (forces the photon-bin overflow path), EVPLP_GATHER_K, EVPLP_TILE_BLOCK_LOG2.  -1 / 0 = not set.
+    int32_t env_bvh_builder = -1, env_gather_k = 0, env_tile_block_log2 = -1;
+
     char error[512] = "";
     void set_error(const char *fmt, ...);
 };

@@ -20,7 +20,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define EVM_FN __host__ __device__ static inline
 #else
 #define EVM_FN static inline

@@ -242,6 +242,9 @@ int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out
 int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_t capacity);
 /* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
 int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
+/* The builder evplp_build_accel actually used (an evplp_bvh_builder value): cfg.bvh_builder unless the test override
+ * EVPLP_BVH_BUILDER was set when the context was created.  < 0 before the first build. */
+int evplp_accel_builder(const evplp_context *ctx);
 
 /* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread drives
  * n_ranks contexts, one per GPU of the node, that own interleaved row strips of the image (see the top of this file); scene and

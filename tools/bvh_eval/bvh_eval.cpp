@@ -3,7 +3,7 @@
 // points (area weighted; a "tile" is 64 points on a small disc around a surface point) and replays occluded_wave's control
 // flow in plain C++.  A proxy for tools/traversal_stats.py that needs no GPU: use it to compare builder heuristics, then
 // confirm on the device.
-//   g++ -O2 -std=c++17 -I evplp_amd/csrc -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bvh_eval/bvh_eval.cpp evplp_amd/csrc/bvh_build.cpp -o build/bvh_eval
+//   g++ -O2 -std=c++17 -DEVPLP_DEV_KNOBS -I evplp_amd/csrc -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bvh_eval/bvh_eval.cpp evplp_amd/csrc/bvh_build.cpp -o build/bvh_eval
 //   build/bvh_eval scene.obj [builder 0..2] [walks]
 #include "evplp_types.h"
 #include <cmath>
