@@ -2,7 +2,7 @@
 """bench.py -- the reference's headline metric on MI355X:
 "Mpaths/s + ms/frame, conference 1024^2, 4096 VPLs, 1/2/4/8 GPU" (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload ir|evplp|ppm|vsl] [--scene hard|easy]
+    python bench.py --gpus N --steps K --warmup W [--workload ir|evplp|ppm|vsl] [--scene hard|easy] [--front-end ranks|group]
 
 A step = one iteration of the technique loop (rt/rtcomphoton/rtcomphoton.h:936-1068):
   ir    BASELINE config #2 (default, the headline): Instant Radiosity, 1024 light paths x 4 vertices = 4096 VPL record
@@ -15,13 +15,24 @@ A step = one iteration of the technique loop (rt/rtcomphoton/rtcomphoton.h:936-1
 The scene is a procedural conference stand-in (the reference's meshes are Git-LFS stubs): "data": "synthetic";
 --scene hard (default) is furnished with curved and thin parts, --scene easy is the room of tessellated boxes.
 
-N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL).  Launched by the driver as
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; when no launcher set WORLD_SIZE,
-`python bench.py --gpus N` starts the N rank processes itself (before anything touches a GPU) and relays rank 0's
-JSON line.  The image is cut into interleaved 8-row strips (rank r owns row blocks b with b % N == r); the scene and
-the BVH are replicated; large light-path sets are traced 1/N per rank and shared by an all-gather of the record
-buffer, small ones are traced redundantly; each rank gathers / splats its own pixels; the framebuffer strips are
-all-gathered every frame.  Total work is fixed ("scaling": "strong").
+The default run (no flags: config #2 on one GPU) also carries, as extra objects of the same JSON line, short runs of the other
+configurations -- `evplp` (config #3, roofline of the photon splat), `ppm` (config #4: iteration time, splat roofline, the
+light-tracing and G-buffer kernels), `vsl` (config #5) -- the other scene style, the 16 384-slot reading of "4096 VPLs", the GPU
+path tracer, and `render_json`: the same configuration run through evplp_render_json, the entry a maintainer of the reference
+binds (its per-iteration time must agree with ms_per_step).
+
+N GPUs, two front ends:
+  ranks (default)  one process per GPU (torch.distributed, backend nccl = RCCL).  Launched by the driver as
+        `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; when no launcher set WORLD_SIZE,
+        `python bench.py --gpus N` starts the N rank processes itself (before anything touches a GPU) and relays rank 0's JSON
+        line.  EVPLP_BENCH_BACKEND=gloo stages the collectives through the host and lets the ranks share GPUs (rank r uses
+        device r mod #devices): the N > 1 logic with the real kernels on a one-GPU box.
+  group  one process, `evplp_group` -- the native multi-GPU entry of the C ABI (one host thread, N contexts, RCCL opened by the
+        library; ranks on one device exchange by device copies).
+Either way the image is cut into interleaved 8-row strips (rank r owns row blocks b with b % N == r); the scene and the BVH are
+replicated; large light-path sets are traced 1/N per rank and shared by an all-gather of the record buffer, small ones are traced
+redundantly; each rank gathers / splats its own pixels; the framebuffer strips are all-gathered every frame.  Total work is
+fixed ("scaling": "strong").
 
 Path = one evaluated light-transport sample: gather -> one (pixel, usable VPL record) pair
 that passes the cosine test and traces its shadow ray; splat -> one (photon, covered pixel) pair.
@@ -41,6 +52,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 125.0          # vplSplat, misMode one (lighttracing.cu:282-312)
 FLOP_PER_PAIR_MIS = 195.0      # balance / max / power2
+FLOP_PER_VSL_SAMPLE = 540.0    # 3 estimators x ~180 flop per sample-iteration (+ 11 RNG draws, not counted)
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: FP32 vector peak
 PEAK_HBM_GBS = 8000.0
 
@@ -50,6 +62,8 @@ WORKLOADS = {
     "ppm": "Progressive photon mapping, 1920x1080, 300k light paths x 4 = 1.2M photon record slots, no VPLs, alpha 0.7 (BASELINE config #4)",
     "vsl": "Progressive VSL gather (forceVsl, 4096 VPL paths = 16384 record slots, radius 5 %) + 300k-path photon splat, 2048x2048 (BASELINE config #5)",
 }
+P = 4                                   # numMaxBounces 3 -> 4 record slots per path
+STRIP_ROWS = 8                          # finest interleave (tiles are 8 rows)
 
 
 def parse():
@@ -64,9 +78,11 @@ def parse():
     ap.add_argument("--scene", default="hard", choices=["hard", "easy"])
     ap.add_argument("--mis", default="", help="override misMode")
     ap.add_argument("--bvh", default="sah", choices=["sah", "sbvh", "lbvh", "gpu"], help="acceleration-structure builder (same flattened node format)")
+    ap.add_argument("--front-end", default="ranks", choices=["ranks", "group"], help="N > 1: one process per GPU over torch.distributed, or one process driving evplp_group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other scene, 16384-slot variant, GPU path tracer)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (configs #3-#5, other scene, 16384-slot variant, GPU path tracer, render_json)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="path-tracer iterations of the CPU baseline sample (0 = auto, ~12 s)")
+    ap.add_argument("--dump-frame", default="", help="rank 0 writes the assembled VPL + photon accumulators of the last frame to this .npy file (tests)")
     a = ap.parse_args()
     heavy = a.workload == "vsl"
     if a.steps is None:
@@ -161,225 +177,349 @@ def cpu_baseline(json_path, res, iters_hint):
     return base, like
 
 
-def main():
-    a = parse()
-    world_env = os.environ.get("WORLD_SIZE")
-    if a.gpus > 1 and world_env is None:
-        spawn_ranks(a)
-        return
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import evplp_amd as ev
+class Env:
+    """What every measurement of one process shares: the modules, the process group, this rank's device and stream."""
 
-    world = int(world_env or "1")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # EVPLP_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (1-GPU smoke of the N>1 path)
-    force_dist = os.environ.get("EVPLP_BENCH_FORCE_DIST") == "1"
-    use_dist = world > 1 or force_dist
-    if use_dist:
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
-        if dist.get_world_size() != a.gpus:
-            raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
+    def __init__(self, a):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        import evplp_amd as ev
+        self.a, self.np, self.torch, self.dist, self.ev = a, np, torch, dist, ev
+        world_env = os.environ.get("WORLD_SIZE")
+        self.world = int(world_env or "1")
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.group_front_end = a.front_end == "group" and a.gpus > 1
+        if not self.group_front_end and self.world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+        ndev = torch.cuda.device_count()
+        self.backend = os.environ.get("EVPLP_BENCH_BACKEND", "nccl")
+        if self.backend not in ("nccl", "gloo"):
+            raise SystemExit("EVPLP_BENCH_BACKEND must be nccl or gloo")
+        # RCCL refuses two ranks on one device; the host-staged gloo backend lets the ranks share GPUs
+        self.device_index = local_rank % ndev if self.backend == "gloo" else local_rank
+        torch.cuda.set_device(self.device_index)
+        self.dev = torch.device("cuda", self.device_index)
+        self.ndev = ndev
+        # EVPLP_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (1-GPU smoke of the N>1 path)
+        self.force_dist = os.environ.get("EVPLP_BENCH_FORCE_DIST") == "1"
+        self.use_dist = (self.world > 1 or self.force_dist) and not self.group_front_end
+        if self.use_dist:
+            if "MASTER_ADDR" not in os.environ:
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+            if dist.get_world_size() != a.gpus:
+                raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
+        # one explicit (non-null) HIP stream carries the kernels AND orders the collectives: torch.distributed
+        # synchronises its RCCL work with the current stream, so kernels must be launched on that stream
+        self.stream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.stream)
 
-    wl = a.workload
+    # ---- collectives (nccl: on the device, in stream order; gloo: staged through the host)
+    def all_gather(self, full, part):
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(full, part)
+            return
+        self.torch.cuda.synchronize(self.dev)
+        h = part.cpu()
+        parts = [self.torch.empty_like(h) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, h)
+        full.copy_(self.torch.cat(parts))
+
+    def all_reduce(self, t, op):
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        self.dist.all_reduce(h, op=op)
+        return h.to(t.device)
+
+    def sync_all(self):
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def scene_json(self, style, W, H):
+        d = os.path.join("/tmp", f"evplp_bench_{os.getuid()}_{style}_{self.a.tris}_{W}x{H}")
+        if self.rank == 0 or not self.use_dist:
+            self.ev.synth_scene(d, "conference_synth", self.a.tris, 1234, W, H, style=style)
+        if self.use_dist:
+            self.dist.barrier()
+        return os.path.join(d, "conference_synth.json")
+
+
+def workload_shape(a, wl, primary):
     if wl == "ppm":
         W, H = 1920, 1080
     elif wl == "vsl":
-        W = H = a.res or 2048
+        W = H = (a.res if primary and a.res else 2048)
     else:
-        W = H = a.res or 1024
-    P = 4                                   # numMaxBounces 3 -> 4 record slots per path
+        W = H = (a.res if primary and a.res else 1024)
     n_vpl = {"ir": 1024, "evplp": 1024, "ppm": 0, "vsl": 4096}[wl]
-    if a.paths and wl != "ppm":
+    if primary and a.paths and wl != "ppm":
         n_vpl = a.paths
     n_light = {"ir": n_vpl, "evplp": 500000, "ppm": 300000, "vsl": 300000}[wl]
-    mis = a.mis or {"ir": "one", "evplp": "balance", "ppm": "one", "vsl": "one"}[wl]
+    mis = (a.mis if primary and a.mis else {"ir": "one", "evplp": "balance", "ppm": "one", "vsl": "one"}[wl])
+    return W, H, n_vpl, n_light, mis
+
+
+def run_workload(env, wl, steps, warmup, scene, primary=True):
+    """`steps` timed iterations of one configuration on this process's rank (or on an evplp_group); rank 0 returns the result object."""
+    a, np, torch, dist, ev = env.a, env.np, env.torch, env.dist, env.ev
+    W, H, n_vpl, n_light, mis = workload_shape(a, wl, primary)
     progressive = wl in ("ppm", "vsl")
-
-    # ---- inputs: procedural conference stand-in, written once per node
-    def scene_json(style):
-        d = os.path.join("/tmp", f"evplp_bench_{os.getuid()}_{style}_{a.tris}_{W}x{H}")
-        if local_rank == 0:
-            ev.synth_scene(d, "conference_synth", a.tris, 1234, W, H, style=style)
-        return os.path.join(d, "conference_synth.json")
-    json_path = scene_json(a.scene)
-    if use_dist:
-        dist.barrier()
-
-    strip_rows = 8      # finest interleave (tiles are 8 rows)
+    use_dist, world, rank, dev = env.use_dist, (env.world if env.use_dist else 1), (env.rank if env.use_dist else 0), env.dev
+    json_path = env.scene_json(scene, W, H)
     builder = {"sah": ev.BVH_SAH, "sbvh": ev.BVH_SBVH, "lbvh": ev.BVH_LBVH, "gpu": ev.BVH_LBVH_GPU}[a.bvh]
-
-    def make_ctx(path, nl, nv):
-        c = ev.Context(W, H, nl, nv, P, device=local_rank, strip_rank=rank, strip_count=world, strip_rows=strip_rows, bvh_builder=builder, overlap_light_tracing=True)
-        c.load_scene_json(path)
-        return c
-    ctx = make_ctx(json_path, n_light, n_vpl)
+    nrec = n_light * P
+    group = None
+    if env.group_front_end:
+        # one process, the native multi-GPU entry: a.gpus ranks on distinct devices (RCCL) or, when the box has fewer, all on device 0
+        devices = list(range(a.gpus)) if env.ndev >= a.gpus else [0] * a.gpus
+        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=STRIP_ROWS, bvh_builder=builder, overlap_light_tracing=True)
+        group.load_scene_json(json_path)
+        ranks = [group.rank(r) for r in range(a.gpus)]
+        ctx = ranks[0]
+        n_ranks = a.gpus
+    else:
+        ctx = ev.Context(W, H, n_light, n_vpl, P, device=env.device_index, strip_rank=rank, strip_count=world, strip_rows=STRIP_ROWS,
+                         bvh_builder=builder, overlap_light_tracing=True)
+        ctx.load_scene_json(json_path)
+        ctx.set_stream(env.stream.cuda_stream)
+        ranks = [ctx]
+        n_ranks = world
     cam = ctx.camera()
     bsr, total_area, _ = ctx.scene_metrics()
     radius0 = 0.003 * bsr if wl != "ir" else 0.0
     vsl_radius0 = max(0.05 * bsr, 0.008) if wl == "vsl" else 0.0
-    # one explicit (non-null) HIP stream carries the kernels AND orders the collectives: torch.distributed
-    # synchronises its RCCL work with the current stream, so kernels must be launched on that stream
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
 
-    # torch owns the buffers that take part in collectives
-    nrec = n_light * P
-    records = torch.zeros(nrec * 96 // 4, dtype=torch.float32, device=dev)
-    strip = torch.zeros(ctx.local_rows * W * 4, dtype=torch.float32, device=dev)
-    pstrip = torch.zeros(ctx.local_rows * W * 4, dtype=torch.float32, device=dev)
-    if use_dist:     # (one GPU: the library keeps the records and double-buffers them behind the overlapped light tracing)
-        ctx.bind_buffer(ev.BUF_RECORDS, records.data_ptr(), records.numel() * 4)
-    ctx.bind_buffer(ev.BUF_VPL_ACCUM, strip.data_ptr(), strip.numel() * 4)
-    ctx.bind_buffer(ev.BUF_PHOTON_ACCUM, pstrip.data_ptr(), pstrip.numel() * 4)
-    full = torch.zeros(world * strip.numel(), dtype=torch.float32, device=dev) if use_dist else strip
-    pfull = torch.zeros(world * pstrip.numel(), dtype=torch.float32, device=dev) if (use_dist and wl != "ir") else pstrip
-    # a light-tracing launch is latency-bound (0.26 ms for 1024 paths, 0.25 ms for 128): small path counts are traced
-    # redundantly by every rank (identical records, no exchange); large ones are split and all-gathered
-    split_paths = use_dist and n_light % world == 0 and (n_light >= 16384 or force_dist)
-    per_rank = n_light // world if split_paths else n_light
-    send = torch.empty(records.numel() // world, dtype=torch.float32, device=dev) if split_paths else None   # reused out-of-place send slice
+    if group is None:
+        # torch owns the buffers that take part in collectives
+        records = torch.zeros(nrec * 96 // 4, dtype=torch.float32, device=dev)
+        strip = torch.zeros(ctx.local_rows * W * 4, dtype=torch.float32, device=dev)
+        pstrip = torch.zeros(ctx.local_rows * W * 4, dtype=torch.float32, device=dev)
+        if use_dist:     # (one GPU: the library keeps the records and double-buffers them behind the overlapped light tracing)
+            ctx.bind_buffer(ev.BUF_RECORDS, records.data_ptr(), records.numel() * 4)
+        ctx.bind_buffer(ev.BUF_VPL_ACCUM, strip.data_ptr(), strip.numel() * 4)
+        ctx.bind_buffer(ev.BUF_PHOTON_ACCUM, pstrip.data_ptr(), pstrip.numel() * 4)
+        full = torch.zeros(world * strip.numel(), dtype=torch.float32, device=dev) if use_dist else strip
+        pfull = torch.zeros(world * pstrip.numel(), dtype=torch.float32, device=dev) if (use_dist and wl != "ir") else pstrip
+        # a light-tracing launch is latency-bound (0.26 ms for 1024 paths, 0.25 ms for 128): small path counts are traced
+        # redundantly by every rank (identical records, no exchange); large ones are split and all-gathered
+        split_paths = use_dist and n_light % world == 0 and (n_light >= 16384 or env.force_dist)
+        per_rank = n_light // world if split_paths else n_light
+        chunk = records.numel() // world
+        # in place, as evplp_group does it: rank r traced its paths into slice r of its own record buffer
+        send = records[rank * chunk:(rank + 1) * chunk] if split_paths else None
 
-    jrng = np.random.RandomState(0)
+    # the jitter of rtcomphoton.h:887,946-952: IndependentSampler(rngOffset = 0), pinned to the reference's sampler (tests/golden/jitter.npz)
+    jitters = ev.jitter_sequence(0, warmup + steps + 1, W, H)
     sched = {"radius": radius0, "clamp": 1.0 / total_area, "pdf_mc": (n_vpl / n_light) / math.pi / (radius0 * radius0) if radius0 > 0 else 0.0,
              "vsl_radius": vsl_radius0, "vsl_inv": (1.0 / (math.pi * vsl_radius0 * vsl_radius0)) if vsl_radius0 > 0 else 0.0}
     clamp_start = sched["clamp"]
 
     def frame(it):
-        u = jrng.rand(2)
-        jitter = ((2 * u[0] - 1) / W, (2 * u[1] - 1) / H)
+        jitter = (float(jitters[it][0]), float(jitters[it][1]))
         fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode=mis, pdf_mc=sched["pdf_mc"], clamping_value=sched["clamp"],
                              photon_radius=sched["radius"], vsl_radius=sched["vsl_radius"], vsl_inv_pi_radius2=sched["vsl_inv"],
                              num_light_paths=n_light, num_vpl_light_paths=n_vpl, photons_per_path=P,
                              do_accumulate=1, rng_seed=it, jitter=jitter)
-        def light_paths():
-            if split_paths:
-                ctx.trace_light_paths(it, rank * per_rank, per_rank)
-                chunk = records.numel() // world
-                send.copy_(records[rank * chunk:(rank + 1) * chunk])
-                dist.all_gather_into_tensor(records, send)
+        if group is not None:
+            # the technique loop of host/technique.cpp on the group, + the per-frame exchange of the strips
+            if wl == "ppm":
+                group.trace_light_paths(it); group.primary(jitter)
             else:
-                ctx.trace_light_paths(it)
-        # Light tracing runs on the context's second stream.  Pure photon mapping: light paths first -- they go to the record buffer
-        # nobody reads (double-buffered), start while the previous iteration's splat still runs, and the G-buffer pass (whose call
-        # waits for the verdict of the previous photon bins) follows.  With a gather in the frame the order of the reference is
-        # better: light paths beside the G-buffer pass, not beside the 90 ms gather whose CUs they would share (+0.5 ms measured).
-        if wl == "ppm":
-            light_paths(); ctx.primary(jitter)
-        else:
-            ctx.primary(jitter); light_paths()
-        if wl in ("ir", "evplp"):
-            ctx.gather_vpl(fp)
-        elif wl == "vsl":
-            ctx.gather_vsl(fp)
-        if wl != "ir":
-            ctx.splat_photons(fp)
-            if os.environ.get("EVPLP_DUMP_SPLAT_HIST"):   # stats build: rectangle classes of the photons (tools/debug_splat_hist.py)
-                print("HIST", it, ctx.debug_counters(ev.PASS_SPLAT)[4:4 + 28].tolist(), flush=True)
-        if use_dist:
-            if wl != "ppm":
-                dist.all_gather_into_tensor(full, strip)
+                group.primary(jitter); group.trace_light_paths(it)
+            if wl in ("ir", "evplp"):
+                group.gather(fp, 0)
+            elif wl == "vsl":
+                group.gather(fp, 1)
             if wl != "ir":
-                dist.all_gather_into_tensor(pfull, pstrip)
+                group.splat_photons(fp)
+            group.present(1.0, 1.0, 1.0)
+        else:
+            def light_paths():
+                if split_paths:
+                    ctx.trace_light_paths(it, rank * per_rank, per_rank)
+                    env.all_gather(records, send)
+                else:
+                    ctx.trace_light_paths(it)
+            # Light tracing runs on the context's second stream.  Pure photon mapping: light paths first -- they go to the record buffer
+            # nobody reads (double-buffered), start while the previous iteration's splat still runs, and the G-buffer pass (whose call
+            # waits for the verdict of the previous photon bins) follows.  With a gather in the frame the order of the reference is
+            # better: light paths beside the G-buffer pass, not beside the 90 ms gather whose CUs they would share (+0.5 ms measured).
+            if wl == "ppm":
+                light_paths(); ctx.primary(jitter)
+            else:
+                ctx.primary(jitter); light_paths()
+            if wl in ("ir", "evplp"):
+                ctx.gather_vpl(fp)
+            elif wl == "vsl":
+                ctx.gather_vsl(fp)
+            if wl != "ir":
+                ctx.splat_photons(fp)
+                if os.environ.get("EVPLP_DUMP_SPLAT_HIST"):   # stats build: rectangle classes of the photons (tools/debug_splat_hist.py)
+                    print("HIST", it, ctx.debug_counters(ev.PASS_SPLAT)[4:4 + 28].tolist(), flush=True)
+            if use_dist:
+                if wl != "ppm":
+                    env.all_gather(full, strip)
+                if wl != "ir":
+                    env.all_gather(pfull, pstrip)
         if progressive:   # rtcomphoton.h:1033-1063 after numIterations++
             r, c, p, vr, vi = ev.progressive_step(it + 1, 0.7, clamp_start, n_vpl, n_light, sched["radius"], sched["clamp"], sched["pdf_mc"],
                                                   wl == "vsl", sched["vsl_radius"], sched["vsl_inv"])
             sched.update(radius=r, clamp=c, pdf_mc=p, vsl_radius=vr, vsl_inv=vi)
 
     def sync_all():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        if group is not None:
+            group.synchronize()
+        else:
+            env.sync_all()
 
     gather_pass = ev.PASS_GATHER_VSL if wl == "vsl" else ev.PASS_GATHER_VPL
-    for i in range(a.warmup):
+    for i in range(warmup):
         frame(i)
     sync_all()
-    kernel_ms, nominal_local, rays_local, shaded_local, splat_ms, splat_tiles_ms, splat_pairs, usable = [], 0, 0, 0, [], [], 0, 0
-    # Pass statistics synchronise the stream.  The gather workloads (>= 90 ms per step) read them every step; config #4's 0.9 ms
-    # iterations read the splat's HIP events on ten steps spread over the timed region and count pairs with the library's device-side
-    # running total, read before and after (a read-back per step cost 15 % of the iteration).
-    sample_every = max(1, a.steps // 10) if wl == "ppm" else 1
-    pairs_before = ctx.pass_stats(ev.PASS_SPLAT)["shaded"] if wl != "ir" else 0
+    kernel_ms, nominal_local, rays_local, shaded_local, samples_local, splat_ms, splat_tiles_ms, usable = [], 0, 0, 0, 0, [], [], 0
+    feeder_ms = {"light_trace": [], "primary": []}
+    # Pass statistics synchronise the stream.  The gather workloads (>= 80 ms per step) read them every step; config #4's 0.7 ms
+    # iterations read the HIP events of their passes on ten steps spread over the timed region and count pairs with the library's
+    # device-side running total, read before and after (a read-back per step cost 15 % of the iteration).
+    sample_every = max(1, steps // 10) if wl == "ppm" else 1
+    pairs_before = sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) if wl != "ir" else 0
     sync_all()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        frame(a.warmup + i)
+    for i in range(steps):
+        frame(warmup + i)
         if wl != "ppm":
-            st = ctx.pass_stats(gather_pass)      # HIP events on the launch stream; syncs this rank's stream
-            kernel_ms.append(st["dominant_kernel_ms"]); nominal_local += st["pairs"]; rays_local += st["rays"]; shaded_local += st.get("shaded", 0)
-            usable = st["usable"]
+            for c in ranks:
+                st = c.pass_stats(gather_pass)      # HIP events on the launch stream; syncs that rank's stream
+                if c is ranks[0]:
+                    kernel_ms.append(st["dominant_kernel_ms"]); usable = st["usable"]
+                nominal_local += st["pairs"]; rays_local += st["rays"]; shaded_local += st.get("shaded", 0); samples_local += st.get("samples", 0)
         if wl != "ir" and i % sample_every == 0:
             ss = ctx.pass_stats(ev.PASS_SPLAT)
             splat_ms.append(ss["ms"]); splat_tiles_ms.append(ss["dominant_kernel_ms"])
+        if i % sample_every == 0 and (wl == "ppm" or i < 10):
+            feeder_ms["light_trace"].append(ctx.pass_stats(ev.PASS_LIGHT_TRACE)["ms"]); feeder_ms["primary"].append(ctx.pass_stats(ev.PASS_PRIMARY)["ms"])
     sync_all()
     dt = time.perf_counter() - t0
-    if wl != "ir":
-        splat_pairs = ctx.pass_stats(ev.PASS_SPLAT)["shaded"] - pairs_before
+    splat_pairs = (sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) - pairs_before) if wl != "ir" else 0
     kms_local = sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0
-    stats = torch.tensor([dt, float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt, float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local), float(samples_local)], dtype=torch.float64, device=dev)
     if use_dist:
-        mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt = float(mx[0]); nominal = float(sm[1]); rays = float(sm[2]); spairs = float(sm[3]); kms = float(mx[4]); shaded = float(sm[5])
+        mx = env.all_reduce(stats.clone(), dist.ReduceOp.MAX)
+        sm = env.all_reduce(stats.clone(), dist.ReduceOp.SUM)
+        dt = float(mx[0]); nominal = float(sm[1]); rays = float(sm[2]); spairs = float(sm[3]); kms = float(mx[4]); shaded = float(sm[5]); samples = float(sm[6])
         n_ranks = dist.get_world_size()
     else:
-        nominal, rays, spairs, kms, shaded = float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local)
-        n_ranks = 1
+        nominal, rays, spairs, kms, shaded, samples = float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local), float(samples_local)
+
+    if a.dump_frame and primary:
+        # the assembled accumulators of the last frame (tests: N ranks == 1 rank, bit for bit)
+        if group is not None:
+            rows = [c.global_rows() for c in ranks]
+            vp = np.zeros((H, W, 4), np.float32); pp = np.zeros((H, W, 4), np.float32)
+            for c, gr in zip(ranks, rows):
+                ok = gr < H
+                vp[gr[ok]] = c.download(ev.BUF_VPL_ACCUM)[ok]; pp[gr[ok]] = c.download(ev.BUF_PHOTON_ACCUM)[ok]
+        else:
+            def assemble(t):
+                t = t.cpu().numpy().reshape(n_ranks if use_dist else 1, ctx.local_rows, W, 4)
+                img = np.zeros((H, W, 4), np.float32)
+                for r in range(t.shape[0]):
+                    l = np.arange(ctx.local_rows); blk = l // STRIP_ROWS
+                    gr = (blk * t.shape[0] + r) * STRIP_ROWS + (l - blk * STRIP_ROWS)
+                    ok = gr < H
+                    img[gr[ok]] = t[r][ok]
+                return img
+            if use_dist and wl == "ppm":
+                env.all_gather(full, strip)
+            if use_dist and wl == "ir":
+                pfull = torch.zeros(world * pstrip.numel(), dtype=torch.float32, device=dev); env.all_gather(pfull, pstrip)
+            torch.cuda.synchronize(dev)
+            vp, pp = assemble(full), assemble(pfull)
+        if rank == 0:
+            np.save(a.dump_frame, np.stack([vp, pp]))
 
     out = None
     if rank == 0:
-        ms_per_step = dt / a.steps * 1e3
+        ms_per_step = dt / steps * 1e3
         total_paths = rays + spairs
         value = total_paths / dt / 1e6
         acc = ctx.accel_info()
+        physical = len(set(devices)) if group is not None else (min(n_ranks, env.ndev) if env.backend == "gloo" else n_ranks)
         out = {
-            "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup,
+            "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": n_ranks, "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[wl],
-                       "scene": f"procedural conference stand-in, style {a.scene} ({'curved / thin furniture, rotated clutter, ~2400 small occluders' if a.scene == 'hard' else 'tessellated boxes'}), "
+                       "scene": f"procedural conference stand-in, style {scene} ({'curved / thin furniture, rotated clutter, ~2400 small occluders' if scene == 'hard' else 'tessellated boxes'}), "
                                 f"{a.tris} target triangles, seed 1234 (reference meshes are LFS stubs)",
                        "resolution": [W, H], "num_light_paths": n_light, "num_vpl_light_paths": n_vpl, "photons_per_path": P, "mis_mode": mis,
-                       "usable_vpl_records": int(usable), "partition": f"{n_ranks} x interleaved {strip_rows}-row strips",
+                       "usable_vpl_records": int(usable), "partition": f"{n_ranks} x interleaved {STRIP_ROWS}-row strips",
+                       "front_end": "evplp_group (one process, C ABI)" if group is not None else ("one process per rank, torch.distributed " + env.backend if use_dist else "one context"),
+                       "physical_gpus": physical,
                        "path_definition": "gather: (pixel, usable VPL record) pair that passes the cosine test = 1 shadow ray; splat: (photon, covered pixel) pair",
-                       "pairs_nominal_per_frame": nominal / a.steps, "mpairs_nominal_per_s": nominal / dt / 1e6,
-                       "shadow_rays_per_frame": rays / a.steps, "unoccluded_pairs_per_frame": shaded / a.steps,
-                       "mrays_per_s": rays / dt / 1e6, "bvh_builder": a.bvh, "bvh": acc},
+                       "pairs_nominal_per_frame": nominal / steps, "mpairs_nominal_per_s": nominal / dt / 1e6,
+                       "shadow_rays_per_frame": rays / steps, "unoccluded_pairs_per_frame": shaded / steps,
+                       "mrays_per_s": rays / dt / 1e6, "bvh_builder": acc.get("builder", a.bvh), "bvh": acc},
+        }
+        if physical < n_ranks:
+            out["config"]["note"] = f"{n_ranks} ranks share {physical} physical GPU(s): the N > 1 logic with the real kernels, not a scaling measurement"
+        feeders = {k: (sum(v) / len(v) if v else None) for k, v in feeder_ms.items()}
+        rays_lt = n_light * 1.0       # at least the first segment of every light path; (<= numMaxBounces per path)
+        out["feeders"] = {
+            "primary": {"ms": feeders["primary"], "grays_per_s": (2.0 * W * H / max(n_ranks, 1)) / (feeders["primary"] * 1e-3) / 1e9 if feeders["primary"] else None,
+                        "note": "primary_kernel: jittered scene ray + un-jittered light-mesh ray per pixel of this rank's strip; HIP events of the pass "
+                                "(with overlap_light_tracing it may share the GPU with light tracing: the figure is then an upper bound of its cost)"},
+            "light_trace": {"ms": feeders["light_trace"], "paths": n_light, "waves_per_simd": (n_light / max(n_ranks if (group is not None or (use_dist and split_paths)) else 1, 1) / 64.0) / 1024.0,
+                            "mpaths_per_s": (n_light / 1e6) / (feeders["light_trace"] * 1e-3) if feeders["light_trace"] else None,
+                            "note": "light_trace_kernel (tracePhotons + closest hit, lighttracing.cu:192-250): one light path per lane, <= 3 rays per path; "
+                                    "waves_per_simd = wavefronts of the launch / 1024 SIMDs -- far below the ~8 a latency-bound walk wants"},
         }
         if wl != "ppm":
-            flop = FLOP_PER_PAIR if mis in ("one", "geometryClamp", "geometryBrdfClamp") else FLOP_PER_PAIR_MIS
-            rays_per_launch = rays_local / a.steps              # this rank's kernel
+            if wl == "vsl":
+                flop_total = samples / steps / max(n_ranks, 1) * FLOP_PER_VSL_SAMPLE      # this rank's launch
+                flop = None
+            else:
+                flop = FLOP_PER_PAIR if mis in ("one", "geometryClamp", "geometryBrdfClamp") else FLOP_PER_PAIR_MIS
+                flop_total = (rays_local / len(ranks)) / steps * flop
             kname = "gather_vsl_kernel" if wl == "vsl" else "gather_vpl_kernel"
-            achieved = rays_per_launch * flop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+            achieved = flop_total / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             out["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/prof_all.sh); not measured inside this run",
-                "kernel": kname, "kernel_ms": kms, "flop_per_pair": flop,
-                "frac_nominal_pairs": (nominal_local / a.steps) * flop / (kms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if kms > 0 else 0.0,
-                "note": "fp32 VECTOR-ALU bound (BVH packet traversal + shading; not GEMM-shaped). achieved = algorithmic flop per evaluated pair "
-                        "(SURVEY 8d) x pairs that trace a shadow ray per launch / HIP-event kernel time; traversal flops are overhead and not counted. "
-                        "frac_nominal_pairs prices every (pixel, usable VPL) loop iteration instead (round-1 definition)."
-                        + (" VSL: 125 flop counts one vplSplat-equivalent per pair; the estimator's per-sample flops are not counted." if wl == "vsl" else "")}
+                "kernel": kname, "kernel_ms": kms}
+            if wl == "vsl":
+                out["roofline"].update({
+                    "flop_per_sample_iteration": FLOP_PER_VSL_SAMPLE, "sample_iterations_per_frame": samples / steps, "lit_pairs_per_frame": shaded / steps,
+                    "note": "fp32 VECTOR-ALU bound.  achieved = sample-iterations of the three MIS-combined estimators counted ON THE DEVICE "
+                            "(lighttracing.cu:632-640) x 540 flop (SURVEY 8d: 3 x ~180; the 11 RNG draws per iteration and the BVH walks are "
+                            "overhead, not counted) / HIP-event kernel time."})
+            else:
+                out["roofline"].update({
+                    "flop_per_pair": flop,
+                    "frac_nominal_pairs": (nominal_local / len(ranks) / steps) * flop / (kms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if kms > 0 else 0.0,
+                    "note": "fp32 VECTOR-ALU bound (BVH packet traversal + shading; not GEMM-shaped). achieved = algorithmic flop per evaluated pair "
+                            "(SURVEY 8d) x pairs that trace a shadow ray per launch / HIP-event kernel time; traversal flops are overhead and not counted. "
+                            "frac_nominal_pairs prices every (pixel, usable VPL) loop iteration instead (round-1 definition)."})
+            n_usable = usable
+            alg_bytes = (W * H * (64 + 16 + 16)) / max(n_ranks, 1) + n_usable * 96
             tpath = os.path.join(ROOT, "profiles", "traffic_gather_vpl.json")
             if os.path.exists(tpath) and wl == "ir":
                 tj = json.load(open(tpath))
-                if tj.get("config") == f"{a.scene}:{W}x{H}:{n_vpl}:{n_ranks}":
+                if tj.get("config") == f"{scene}:{W}x{H}:{n_vpl}:{n_ranks}":
                     out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = "profiles/traffic_gather_vpl.json (committed PMC summary of this configuration; not measured inside this run)"
-            n_usable = usable
-            alg_bytes = (W * H * (64 + 16 + 16)) / max(n_ranks, 1) + n_usable * 96
+                    out["roofline"]["traffic_ratio"] = tj.get("hbm_bytes_per_launch") / alg_bytes if tj.get("hbm_bytes_per_launch") else None
+                    out["roofline"]["traffic_source"] = f"profiles/traffic_gather_vpl.json ({tj.get('round', 'committed')} PMC summary of this configuration; not measured inside this run)"
+            out["roofline"]["algorithmic_bytes"] = alg_bytes
             out["roofline_hbm"] = {"bound": "hbm", "achieved": alg_bytes / (kms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, "kernel": kname,
                                    "note": "the gather priced against HBM (north star: fraction of HBM roofline): tiny by construction, the kernel is issue-bound"}
@@ -387,31 +527,121 @@ def main():
             nrec_bytes = nrec * 96 + (W * H * 64 + W * H * 24) / max(n_ranks, 1)          # SURVEY 8(d) algorithmic bytes per frame (per rank)
             sms = sum(splat_ms) / len(splat_ms)
             rs = {"bound": "hbm", "achieved": nrec_bytes / (sms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "frac": nrec_bytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "photon splat pass (tile boxes + bin + scatter + tiles)", "pass_ms": sms,
-                  "tiles_kernel_ms": sum(splat_tiles_ms) / len(splat_tiles_ms), "pairs_per_frame": spairs / a.steps, "algorithmic_bytes": nrec_bytes}
+                  "frac": nrec_bytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "photon splat pass (bin + scatter + tiles)", "pass_ms": sms,
+                  "tiles_kernel_ms": sum(splat_tiles_ms) / len(splat_tiles_ms), "pairs_per_frame": spairs / steps, "algorithmic_bytes": nrec_bytes}
             tpath = os.path.join(ROOT, "profiles", "traffic_splat.json")
             if os.path.exists(tpath):
-                tj = json.load(open(tpath)).get("configs", {}).get(f"{wl}:{a.scene}:{W}x{H}:{n_ranks}")
+                tj = json.load(open(tpath)).get("configs", {}).get(f"{wl}:{scene}:{W}x{H}:{n_ranks}")
                 if tj:
-                    rs["traffic"] = tj.get("hbm_bytes_per_pass"); rs["traffic_source"] = "profiles/traffic_splat.json (committed PMC summary; not measured inside this run)"
+                    rs["traffic"] = tj.get("hbm_bytes_per_pass"); rs["traffic_ratio"] = tj.get("hbm_bytes_per_pass") / nrec_bytes if tj.get("hbm_bytes_per_pass") else None
+                    rs["traffic_source"] = "profiles/traffic_splat.json (committed PMC summary; not measured inside this run)"
             if wl == "ppm":
                 out["roofline"] = rs
             else:
                 out["roofline_splat"] = rs
-    ctx.close()
+    if group is not None:
+        group.close()
+    else:
+        ctx.close()
+    return out, json_path, (W, H, n_vpl, n_light, mis)
 
-    # ---- secondary measurements (rank 0, one GPU): the other scene style, the 16 384-slot reading of "4096 VPLs", the GPU path tracer
-    if rank == 0 and world == 1 and wl == "ir" and not a.no_extras and not force_dist:
+
+def technique_block(wl, n_vpl, n_light, mis, iterations, tag):
+    """The `photonfam` block of the scene file for this configuration (keys of rtcomphoton.h:107-223)."""
+    block = {"rngOffset": 0, "numMaxIteration": iterations, "timeLimitMs": 1000000000, "frameMode": "accumulate", "renderMode": "vpl", "misMode": mis,
+             "combinedFilename": f"{tag}_combined.pfm", "weightedPhotonFilename": f"{tag}_weightedpm.pfm", "weightedVplFilename": f"{tag}_weightedvpl.pfm",
+             "statFilename": f"{tag}_stat.json", "useJitter": True, "useStat": True,
+             "numLightPaths": n_light, "numVplLightPaths": n_vpl, "numMaxBounces": 3, "radiusPercentage": 0.0 if wl == "ir" else 0.003}
+    if wl == "ir":
+        block["run"] = {"photonSplat": False}
+    if wl in ("ppm", "vsl"):
+        block.update(DoProgressive=True, AlphaProgressive=0.7)
+    if wl == "vsl":
+        block.update(forceVsl=True, vslRadiusPercentage=0.05)
+    return block
+
+
+def render_json_time(env, wl, json_path, shape, iterations):
+    """The same configuration through evplp_render_json -- what a maintainer of the reference binds in place of
+    RtComPhoton::render (host/technique.cpp: the technique loop on an evplp_group of one rank).  Time per iteration from the
+    stat file the loop writes ({time, numIterations}, rtcomphoton.h:1109-1119)."""
+    W, H, n_vpl, n_light, mis = shape
+    root = json.load(open(json_path))
+    tag = f"bench_{wl}_{os.getpid()}"
+    root["photonfam"] = technique_block(wl, n_vpl, n_light, mis, iterations, tag)
+    for k in ("pt", "lvcphotonfam"):
+        root.pop(k, None)
+    d = os.path.dirname(json_path)
+    jp = os.path.join(d, tag + ".json")
+    json.dump(root, open(jp, "w"))
+    t0 = time.perf_counter()
+    env.ev.render_json(jp, None, env.device_index)
+    wall = time.perf_counter() - t0
+    stat = json.load(open(os.path.join(d, f"{tag}_stat.json")))
+    for f in (jp, os.path.join(d, f"{tag}_stat.json"), os.path.join(d, f"{tag}_combined.pfm"), os.path.join(d, f"{tag}_weightedpm.pfm"), os.path.join(d, f"{tag}_weightedvpl.pfm")):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    res = {"ms_per_iteration": stat["time"] / max(stat.get("numIterations", iterations), 1), "iterations": stat.get("numIterations", iterations),
+           "loop_ms": stat["time"], "call_wall_ms": wall * 1e3,
+           "note": "evplp_render_json on the same scene file with this configuration's photonfam block: time of the technique loop (first iteration's "
+                   "allocations included) / numIterations, from the stat file; call_wall_ms adds scene load, BVH build and the three PFM outputs"}
+    res["last_pass_ms"] = {k[:-2]: v for k, v in stat.items() if k.endswith("Ms")}     # HIP-event time of each pass of the LAST iteration
+    return res
+
+
+def main():
+    a = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and world_env is None and a.front_end == "ranks":
+        spawn_ranks(a)
+        return
+    env = Env(a)
+    wl = a.workload
+    out, json_path, shape = run_workload(env, wl, a.steps, a.warmup, a.scene)
+    rank0 = env.rank == 0 or not env.use_dist
+    single = rank0 and not env.use_dist and not env.group_front_end
+
+    # ---- secondary measurements (one GPU): the path a maintainer binds, configs #3 / #4 / #5, the other scene style, the
+    # 16 384-slot reading of "4096 VPLs", the GPU path tracer
+    if single and not a.no_extras and not env.force_dist:
+        ev, torch = env.ev, env.torch
+        it = {"ir": 20, "evplp": 10, "ppm": 400, "vsl": 2}[wl]
+        rj = render_json_time(env, wl, json_path, shape, it)
+        rj["ratio_to_ms_per_step"] = rj["ms_per_iteration"] / out["ms_per_step"]
+        out["render_json"] = rj
+    if single and wl == "ir" and not a.no_extras and not env.force_dist:
+        def brief(o, keys=("ms_per_step", "value", "steps", "roofline", "roofline_splat", "feeders")):
+            r = {k: o[k] for k in keys if k in o}
+            r["config"] = {k: o["config"][k] for k in ("workload", "resolution", "num_light_paths", "num_vpl_light_paths", "mis_mode", "usable_vpl_records")}
+            return r
+        o3, jp3, sh3 = run_workload(env, "evplp", 20, 2, a.scene, primary=False)
+        out["evplp"] = brief(o3)
+        o4, jp4, sh4 = run_workload(env, "ppm", 100, 5, a.scene, primary=False)
+        out["ppm"] = brief(o4)
+        out["ppm"]["ms_per_iteration"] = o4["ms_per_step"]
+        rj4 = render_json_time(env, "ppm", jp4, sh4, 400)
+        rj4["ratio_to_ms_per_step"] = rj4["ms_per_iteration"] / o4["ms_per_step"]
+        out["ppm"]["render_json"] = rj4
+        o5, _, _ = run_workload(env, "vsl", 2, 1, a.scene, primary=False)
+        out["vsl"] = brief(o5)
+        out["vsl"]["ms_per_iteration"] = o5["ms_per_step"]
+
+        W, H, n_vpl, n_light, mis = shape
+        builder = {"sah": ev.BVH_SAH, "sbvh": ev.BVH_SBVH, "lbvh": ev.BVH_LBVH, "gpu": ev.BVH_LBVH_GPU}[a.bvh]
+
         def quick_ir(path, nv, steps=5):
-            c = make_ctx(path, nv, nv)
-            c.set_stream(stream.cuda_stream)
+            c = ev.Context(W, H, nv, nv, P, device=env.device_index, strip_rows=STRIP_ROWS, bvh_builder=builder, overlap_light_tracing=True)
+            c.load_scene_json(path)
+            c.set_stream(env.stream.cuda_stream)
             cm = c.camera()
             _, ta, _ = c.scene_metrics()
             ms, rr, nom, us = [], 0, 0, 0
             for it in range(steps + 1):
                 fp = ev.frame_params(camera_pos=list(cm.origin), mis_mode=mis, clamping_value=1.0 / ta, num_light_paths=nv, num_vpl_light_paths=nv,
                                      photons_per_path=P, do_accumulate=1, rng_seed=it)
-                torch.cuda.synchronize(dev); t = time.perf_counter()
+                torch.cuda.synchronize(env.dev); t = time.perf_counter()
                 c.primary((0.0, 0.0)); c.trace_light_paths(it); c.gather_vpl(fp); c.synchronize()
                 if it:
                     ms.append((time.perf_counter() - t) * 1e3)
@@ -419,12 +649,13 @@ def main():
             res = {"ms_per_frame": sum(ms) / len(ms), "mpaths_per_s": rr / (sum(ms) * 1e-3) / 1e6, "mpairs_nominal_per_s": nom / (sum(ms) * 1e-3) / 1e6, "usable_vpl_records": int(us)}
             return c, res
         other = "easy" if a.scene == "hard" else "hard"
-        c2, r2 = quick_ir(scene_json(other), n_vpl)
+        c2, r2 = quick_ir(env.scene_json(other, W, H), n_vpl)
         out["scene_" + other] = r2
         c2.close()
         c3, r3 = quick_ir(json_path, 4 * n_vpl, steps=3)
         out["slots_16384_variant"] = dict(r3, note="'4096 VPLs' read as 4096 light PATHS (16384 record slots), SURVEY 8d")
         # GPU path tracer on the same context (same unit as cpu_baseline)
+        cam = c3.camera()
         pt_ms, pt_paths = [], 0
         for it in range(6):
             c3.primary((0.0, 0.0)); c3.path_trace(list(cam.origin), it, 3, accumulate=True); c3.synchronize()
@@ -433,8 +664,8 @@ def main():
                 pt_ms.append(s["ms"]); pt_paths += s["pairs"]
         out["gpu_path_tracer_mpaths_s"] = pt_paths / (sum(pt_ms) * 1e-3) / 1e6
         c3.close()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        base, like = cpu_baseline(json_path, min(W, H), a.cpu_iters)
+    if single and not a.no_cpu_baseline:
+        base, like = cpu_baseline(json_path, min(shape[0], shape[1]), a.cpu_iters)
         out["cpu_baseline"] = base
         out["cpu_baseline_like_for_like"] = like
 
@@ -444,12 +675,12 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if env.use_dist:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
-    if rank == 0:
-        if world > 1:
+    if rank0:
+        if env.use_dist and env.world > 1:
             time.sleep(1.0)       # let the other ranks' processes drain whatever they still print while exiting
         print(json.dumps(out), flush=True)
 

@@ -130,6 +130,7 @@ _SIGNATURES = {
     "evplp_group_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_group_synchronize": (C.c_int, [_P]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
+    "evplp_group_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_jitter_sequence": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "evplp_json_query": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
@@ -220,6 +221,16 @@ class Context:
         self.local_rows = self._lib.evplp_local_rows(h)
         self.num_records = num_light_paths * photons_per_path
 
+    @classmethod
+    def borrowed(cls, handle, res_x: int, res_y: int, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 8):
+        """A view of a context somebody else owns (a rank of an evplp_group): statistics and buffers; close() does not destroy it."""
+        self = cls.__new__(cls)
+        self._lib = lib(); self._h = C.c_void_p(handle); self._borrowed = True
+        self.cfg = Config(); self.cfg.strip_rank = strip_rank; self.cfg.strip_count = strip_count; self.cfg.strip_rows = strip_rows
+        self.W, self.H = res_x, res_y
+        self.local_rows = self._lib.evplp_local_rows(self._h)
+        return self
+
     # -- plumbing
     def _check(self, rc: int) -> int:
         if rc < 0:
@@ -228,7 +239,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.evplp_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.evplp_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -403,6 +415,7 @@ class Group:
         if rc != OK:
             raise EvplpError(rc, self._lib.evplp_group_last_error(None).decode())
         self._h = h; self.W, self.H, self.n = res_x, res_y, n_ranks
+        self.strip_rows = strip_rows
 
     def _check(self, rc):
         if rc < 0:
@@ -440,6 +453,18 @@ class Group:
 
     def synchronize(self):
         self._check(self._lib.evplp_group_synchronize(self._h))
+
+    def present(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
+        """composite + all-gather of the strips on the devices (the per-frame exchange); nothing comes to the host"""
+        self._check(self._lib.evplp_group_present(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma)))
+
+    def rank(self, r: int) -> "Context":
+        """rank r's context (borrowed): pass statistics, buffers"""
+        self._lib.evplp_group_context.restype = C.c_void_p
+        h = self._lib.evplp_group_context(self._h, r)
+        if not h:
+            raise EvplpError(ERR_INVALID, "evplp_group_context: bad rank")
+        return Context.borrowed(h, self.W, self.H, strip_rank=r, strip_count=self.n, strip_rows=self.strip_rows)
 
     def resolve(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
         out = np.empty((self.H, self.W, 3), dtype=np.float32)

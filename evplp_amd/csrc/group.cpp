@@ -49,6 +49,7 @@ struct evplp_group {
     bool virtual_ranks = false;             // all ranks on one device: exchange by copies
     Rccl rccl; std::vector<ncclComm_t> comms;
     std::vector<float *> d_frame;           // per rank: [n][local_rows * W * 3] the all-gathered composite
+    float *d_assembled = nullptr;           // rank 0's device: [H][W][3] the frame in image order (evplp_group_resolve)
     size_t strip_floats = 0;                // local_rows * W * 3
     bool split_paths = false; uint32_t per_rank_paths = 0;
     char error[512] = "";
@@ -67,6 +68,7 @@ extern "C" evplp_context *evplp_group_context(evplp_group *g, int32_t rank) { re
 extern "C" void evplp_group_destroy(evplp_group *g) {
     if (!g) return;
     for (int r = 0; r < (int)g->d_frame.size(); r++) if (g->d_frame[r]) { hipSetDevice(g->device[r]); hipFree(g->d_frame[r]); }
+    if (g->d_assembled) { hipSetDevice(g->device[0]); hipFree(g->d_assembled); }
     for (ncclComm_t c : g->comms) if (c && g->rccl.CommDestroy) g->rccl.CommDestroy(c);
     for (evplp_context *c : g->ctx) evplp_destroy(c);
     delete g;
@@ -151,7 +153,10 @@ extern "C" int evplp_group_trace_light_paths(evplp_group *g, uint32_t rng_seed) 
         int rc = evplp_trace_light_paths(g->ctx[r], rng_seed, (uint32_t)r * g->per_rank_paths, g->per_rank_paths);
         if (rc < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[r])); return rc; }
     }
-    // in place: rank r's own slice already sits at offset r * chunk of its record buffer
+    // in place: rank r's own slice already sits at offset r * chunk of its record buffer.  (A partial path range never goes to the
+    // second record buffer of overlap_light_tracing -- context.cpp only double-buffers whole path sets -- so EVPLP_BUF_RECORDS is the
+    // buffer the call above wrote; checked, because the exchange below would otherwise gather the wrong buffer.)
+    for (int r = 0; r < g->n; r++) if (g->ctx[r]->records_back && g->per_rank_paths == g->ctx[r]->cfg.num_light_paths) { g->set_error("evplp_group_trace_light_paths: split light paths with a flipped record buffer"); return EVPLP_ERR_INVALID; }
     const size_t chunk = (size_t)g->per_rank_paths * g->ctx[0]->cfg.photons_per_path * (sizeof(evplp_record) / sizeof(float));
     std::vector<const float *> send((size_t)g->n); std::vector<float *> recv((size_t)g->n);
     for (int r = 0; r < g->n; r++) { recv[r] = (float *)g->ctx[r]->buf[EVPLP_BUF_RECORDS]; send[r] = recv[r] + (size_t)r * chunk; }
@@ -169,28 +174,34 @@ extern "C" int evplp_group_path_trace(evplp_group *g, const float camera_pos[3],
     GRP_CHECK(g); GRP_EACH(g, evplp_path_trace(c, camera_pos, rng_seed, max_bounces, do_accumulate)); return EVPLP_OK;
 }
 
-// Composite every strip on its GPU, all-gather the strips (every GPU then holds the frame), assemble on the host from rank 0.
-extern "C" int evplp_group_resolve(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
+// Composite every strip on its GPU and all-gather the strips: every GPU then holds the frame, strip by strip.  This is
+// the per-frame exchange of a run that presents every frame; nothing comes to the host.
+extern "C" int evplp_group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
     GRP_CHECK(g);
-    if (!out_rgb) { g->set_error("evplp_group_resolve: null output"); return EVPLP_ERR_INVALID; }
     GRP_EACH(g, evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma));
     std::vector<const float *> send((size_t)g->n); std::vector<float *> recv((size_t)g->n);
     for (int r = 0; r < g->n; r++) { send[r] = g->ctx[r]->d_rgb; recv[r] = g->d_frame[r]; }
-    int rc = group_all_gather(g, send, recv, g->strip_floats);
+    return group_all_gather(g, send, recv, g->strip_floats);
+}
+
+// evplp_group_present, then the frame in image order on rank 0's device and one copy to the caller.
+extern "C" int evplp_group_resolve(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
+    GRP_CHECK(g);
+    if (!out_rgb) { g->set_error("evplp_group_resolve: null output"); return EVPLP_ERR_INVALID; }
+    int rc = evplp_group_present(g, vs, ps, ls, mask_emitter, gamma);
     if (rc < 0) return rc;
+    // rank 0 puts the strips into image order on the device; one copy lands the frame in the caller's buffer (no host-side assembly:
+    // a run that writes every frame resolves every iteration)
     evplp_context *c0 = g->ctx[0];
-    std::vector<float> host(g->strip_floats * (size_t)g->n);
     hipSetDevice(g->device[0]);
-    hipError_t e = hipMemcpyAsync(host.data(), g->d_frame[0], host.size() * sizeof(float), hipMemcpyDeviceToHost, c0->stream);
+    const size_t frame_floats = (size_t)c0->st.W * c0->st.H * 3;
+    if (!g->d_assembled) {
+        hipError_t me = hipMalloc((void **)&g->d_assembled, sizeof(float) * frame_floats);
+        if (me != hipSuccess) { g->set_error("evplp_group_resolve: hipMalloc(frame): %s", hipGetErrorString(me)); return EVPLP_ERR_OOM; }
+    }
+    evplp::launch_assemble_strips(c0->st, g->n, g->d_frame[0], g->d_assembled, c0->stream);
+    hipError_t e = hipMemcpyAsync(out_rgb, g->d_assembled, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c0->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
     if (e != hipSuccess) { g->set_error("frame download: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
-    const int W = c0->st.W, H = c0->st.H, local_rows = c0->st.local_rows;
-    for (int r = 0; r < g->n; r++) {
-        const evplp::StripDev &st = g->ctx[r]->st;
-        for (int l = 0; l < local_rows; l++) {
-            const int y = st.global_row(l);
-            if (y < H) std::memcpy(out_rgb + (size_t)y * W * 3, host.data() + ((size_t)r * local_rows + l) * W * 3, sizeof(float) * 3 * (size_t)W);
-        }
-    }
     return EVPLP_OK;
 }

@@ -572,6 +572,20 @@ void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, con
     size_t n = (size_t)st.W * st.local_rows;
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, vpl, pm, light, vs, ps, ls, mask_emitter, gamma, out_rgb);
 }
+// De-interleave of the all-gathered row strips (evplp_group_resolve): gathered = [n ranks][local_rows][W][3], rank r's local row l
+// is image row StripDev{rank r}.global_row(l); frame = [H][W][3].  One thread per float of the frame.
+__global__ __launch_bounds__(256) void assemble_strips_kernel(StripDev st, int nranks, const float *gathered, float *frame) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row_floats = (size_t)st.W * 3, n = row_floats * (size_t)st.H;
+    if (i >= n) return;
+    const int y = (int)(i / row_floats); const size_t x = i - (size_t)y * row_floats;
+    const int blk = y / st.strip_rows, r = blk % nranks, l = (blk / nranks) * st.strip_rows + (y - blk * st.strip_rows);
+    frame[i] = gathered[((size_t)r * st.local_rows + l) * row_floats + x];
+}
+void launch_assemble_strips(const StripDev &st, int nranks, const float *gathered, float *frame, hipStream_t s) {
+    const size_t n = (size_t)st.W * 3 * st.H;
+    hipLaunchKernelGGL(assemble_strips_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, nranks, gathered, frame);
+}
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s) { hipMemsetAsync(p, 0, bytes, s); }
 
 } // namespace evplp

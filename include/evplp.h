@@ -276,6 +276,10 @@ int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int3
 int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
 int evplp_group_synchronize(evplp_group *g);
 /* evplp_resolve for the whole frame: out_rgb = HOST pointer, res_y * res_x * 3 floats, y = 0 bottom */
+/* The per-frame exchange alone: composite every rank's strip on its GPU (final.frag:19-35) and all-gather the strips, so that every
+ * GPU holds the frame; nothing is copied to the host.  evplp_group_resolve = this + the strips put into image order on rank 0's device
+ * (no host-side assembly) + one copy of the W x H x 3 frame to the caller. */
+int evplp_group_present(evplp_group *g, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma);
 int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, float light_scale,
                         int32_t mask_emitter, int32_t gamma, float *out_rgb);
 

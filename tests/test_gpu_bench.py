@@ -77,3 +77,51 @@ def test_two_strip_contexts_assemble_to_the_single_frame(evplp, tmp_path):
     full = strips.assemble(gathered, H, 2, 8)
     ref = render(0, 1)[:H]
     assert ref[..., :3].max() > 0 and full.tobytes() == ref.tobytes()
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--res", "256", "--tris", "20000", "--no-cpu-baseline", "--no-extras"]
+
+
+@pytest.mark.parametrize("wl", ["ir", "evplp"])
+def test_bench_two_ranks_share_one_gpu_over_gloo(wl, tmp_path):
+    """EVPLP_BENCH_BACKEND=gloo: `bench.py --gpus 2` starts its two ranks, both on the one GPU of the box, with the collectives staged
+    through the host (RCCL refuses two ranks on one device).  Everything else is the N > 1 code: strip contexts, split light
+    tracing + record all-gather (evplp), framebuffer all-gathers, max / sum over ranks.  Same shadow rays and photon-pixel pairs as
+    one rank; the assembled VPL frame is bit-identical, the photon frame to fp32 round-off (bin order)."""
+    args = ["--workload", wl] + SMALL
+    two = run_bench(args + ["--gpus", "2", "--dump-frame", str(tmp_path / "two.npy")], {"EVPLP_BENCH_BACKEND": "gloo"})
+    one = run_bench(args + ["--dump-frame", str(tmp_path / "one.npy")])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["config"]["physical_gpus"] == 1
+    assert two["config"]["shadow_rays_per_frame"] == one["config"]["shadow_rays_per_frame"] > 0
+    assert two["config"]["usable_vpl_records"] == one["config"]["usable_vpl_records"]
+    a, b = np.load(tmp_path / "two.npy"), np.load(tmp_path / "one.npy")
+    assert b[0][..., :3].max() > 0 and a[0].tobytes() == b[0].tobytes()
+    if wl == "evplp":
+        assert two["roofline_splat"]["pairs_per_frame"] == one["roofline_splat"]["pairs_per_frame"] > 0
+        assert b[1][..., :3].max() > 0 and np.abs(a[1] - b[1]).max() <= 1e-5 * b[1].max()
+
+
+def test_bench_group_front_end(tmp_path):
+    """--front-end group: one process drives evplp_group (the native multi-GPU entry of the C ABI); on a one-GPU box its two ranks
+    share the device.  Same rays, bit-identical VPL frame."""
+    two = run_bench(SMALL + ["--gpus", "2", "--front-end", "group", "--dump-frame", str(tmp_path / "two.npy")])
+    one = run_bench(SMALL + ["--dump-frame", str(tmp_path / "one.npy")])
+    assert two["n_gpus"] == 2 and "evplp_group" in two["config"]["front_end"]
+    assert two["config"]["shadow_rays_per_frame"] == one["config"]["shadow_rays_per_frame"] > 0
+    a, b = np.load(tmp_path / "two.npy"), np.load(tmp_path / "one.npy")
+    assert a[0].tobytes() == b[0].tobytes()
+
+
+def test_bench_default_extras_small():
+    """The default line's extra objects (here at a small size): the path through evplp_render_json agrees with the timed loop, and
+    configs #3 / #4 / #5 ride along with their rooflines."""
+    d = run_bench(["--steps", "3", "--warmup", "1", "--tris", "20000", "--no-cpu-baseline"])
+    rj = d["render_json"]
+    assert rj["iterations"] == 20 and rj["ms_per_iteration"] > 0
+    assert 0.8 <= rj["ratio_to_ms_per_step"] <= 1.25, rj
+    assert d["evplp"]["roofline_splat"]["bound"] == "hbm" and 0 < d["evplp"]["roofline_splat"]["frac"] < 1
+    p = d["ppm"]
+    assert p["roofline"]["bound"] == "hbm" and p["ms_per_iteration"] > 0 and p["feeders"]["light_trace"]["ms"] > 0 and p["feeders"]["primary"]["ms"] > 0
+    assert 0.7 <= p["render_json"]["ratio_to_ms_per_step"] <= 1.4, p["render_json"]
+    v = d["vsl"]["roofline"]
+    assert v["kernel"] == "gather_vsl_kernel" and v["sample_iterations_per_frame"] > v["lit_pairs_per_frame"] > 0
