@@ -319,7 +319,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
         send = records[rank * chunk:(rank + 1) * chunk] if split_paths else None
 
     # the jitter of rtcomphoton.h:887,946-952: IndependentSampler(rngOffset = 0), pinned to the reference's sampler (tests/golden/jitter.npz)
-    jitters = ev.jitter_sequence(0, warmup + steps + 1, W, H)
+    jitters = ev.jitter_sequence(0, warmup + steps + 11, W, H)
     sched = {"radius": radius0, "clamp": 1.0 / total_area, "pdf_mc": (n_vpl / n_light) / math.pi / (radius0 * radius0) if radius0 > 0 else 0.0,
              "vsl_radius": vsl_radius0, "vsl_inv": (1.0 / (math.pi * vsl_radius0 * vsl_radius0)) if vsl_radius0 > 0 else 0.0}
     clamp_start = sched["clamp"]
@@ -388,11 +388,17 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     sync_all()
     kernel_ms, nominal_local, rays_local, shaded_local, samples_local, splat_ms, splat_tiles_ms, usable = [], 0, 0, 0, 0, [], [], 0
     feeder_ms = {"light_trace": [], "primary": []}
-    # Pass statistics synchronise the stream.  The gather workloads (>= 80 ms per step) read them every step; config #4's 0.7 ms
-    # iterations read the HIP events of their passes on ten steps spread over the timed region and count pairs with the library's
-    # device-side running total, read before and after (a read-back per step cost 15 % of the iteration).
-    sample_every = max(1, steps // 10) if wl == "ppm" else 1
+    # Pass statistics synchronise the stream.  The gather workloads (>= 80 ms per step) read them every step.  Config #4's 0.7 ms
+    # iterations run their timed region without a single read-back (the host stays an iteration ahead of the GPU, as in the
+    # technique loop of evplp_render_json); photon-pixel pairs come from the library's device-side running total, read before and
+    # after, and the HIP-event times of the passes from ten more iterations after the timed region.
     pairs_before = sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) if wl != "ir" else 0
+
+    def read_pass_times():
+        if wl != "ir":
+            ss = ctx.pass_stats(ev.PASS_SPLAT)
+            splat_ms.append(ss["ms"]); splat_tiles_ms.append(ss["dominant_kernel_ms"])
+        feeder_ms["light_trace"].append(ctx.pass_stats(ev.PASS_LIGHT_TRACE)["ms"]); feeder_ms["primary"].append(ctx.pass_stats(ev.PASS_PRIMARY)["ms"])
     sync_all()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -403,14 +409,16 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 if c is ranks[0]:
                     kernel_ms.append(st["dominant_kernel_ms"]); usable = st["usable"]
                 nominal_local += st["pairs"]; rays_local += st["rays"]; shaded_local += st.get("shaded", 0); samples_local += st.get("samples", 0)
-        if wl != "ir" and i % sample_every == 0:
-            ss = ctx.pass_stats(ev.PASS_SPLAT)
-            splat_ms.append(ss["ms"]); splat_tiles_ms.append(ss["dominant_kernel_ms"])
-        if i % sample_every == 0 and (wl == "ppm" or i < 10):
-            feeder_ms["light_trace"].append(ctx.pass_stats(ev.PASS_LIGHT_TRACE)["ms"]); feeder_ms["primary"].append(ctx.pass_stats(ev.PASS_PRIMARY)["ms"])
+            if i < 10:
+                read_pass_times()
     sync_all()
     dt = time.perf_counter() - t0
     splat_pairs = (sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) - pairs_before) if wl != "ir" else 0
+    if wl == "ppm":
+        extra = min(10, len(jitters) - (warmup + steps))
+        for i in range(extra):
+            frame(warmup + steps + i); read_pass_times()
+        sync_all()
     kms_local = sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0
     stats = torch.tensor([dt, float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local), float(samples_local)], dtype=torch.float64, device=dev)
     if use_dist:
