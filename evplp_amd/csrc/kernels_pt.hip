@@ -143,7 +143,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
 }
 
 #ifndef EVPLP_PT_WAVES
-#define EVPLP_PT_WAVES 6   // waves per SIMD: 5 = 3.00 ms, 6 = 2.71, 7 = 2.86, 8 = 2.87 per sample per pixel at 1024^2
+#define EVPLP_PT_WAVES 4   // 128 VGPRs, zero scratch (126 needed): 1.61 ms per sample per pixel at 1024^2 against 1.59 ms at 6 waves with 65 spilled registers
 #endif
 __global__ __launch_bounds__(64, EVPLP_PT_WAVES) void path_trace_kernel(PathTraceArgs a) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
