@@ -964,16 +964,26 @@ void evo_vsl_splat_pair(const evo_frame_params *fp, const float wi10[3], const f
 }
 /* :689-722 splatSplotch.  RNG: one substream per (pixel, record) instead of one cuRAND
  * stream per pixel, so any decomposition of the record loop reproduces the same numbers. */
+void evo_gather_vsl_window(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                           int32_t x_begin, int32_t x_end, const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                           const evo_record *records, float *out, uint64_t *pairs_out);
 void evo_gather_vsl(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
                     const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
                     const evo_record *records, float *out, uint64_t *pairs_out) {
+    evo_gather_vsl_window(s, fp, W, H, row_begin, row_end, 0, W, g_pos, g_nrm, g_dif, g_phg, records, out, pairs_out);
+}
+/* the same on the pixels [x_begin, x_end) of the rows only: the estimators of one 2048-pixel row against 12 k VSLs take ~25 s, so the
+ * full-size tests sample windows spread over the frame instead of whole rows */
+void evo_gather_vsl_window(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                           int32_t x_begin, int32_t x_end, const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                           const evo_record *records, float *out, uint64_t *pairs_out) {
     (void)H;
     uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;
     uint64_t pairs = 0;
     v3 cam = ld3(fp->camera_pos);
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs) num_threads(evo_get_threads())
+#pragma omp parallel for collapse(2) schedule(dynamic, 8) reduction(+ : pairs) num_threads(evo_get_threads())
     for (int32_t y = row_begin; y < row_end; y++) {
-        for (int32_t x = 0; x < W; x++) {
+        for (int32_t x = x_begin; x < x_end; x++) {
             size_t p = ((size_t)y * W + x) * 4;
             v3 p1 = ld3(g_pos + p), n1 = ld3(g_nrm + p), rd = ld3(g_dif + p), rs = ld3(g_phg + p); float e = g_phg[p + 3];
             v3 wi10 = normalize(sub(cam, p1));

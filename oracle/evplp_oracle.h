@@ -170,6 +170,10 @@ void evo_gather_vsl(const evo_scene *s, const evo_frame_params *fp, int32_t W, i
                     int32_t row_begin, int32_t row_end,
                     const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
                     const evo_record *records, float *out, uint64_t *pairs_out);
+/* ... on the pixels [x_begin, x_end) of the rows only */
+void evo_gather_vsl_window(const evo_scene *s, const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                           int32_t x_begin, int32_t x_end, const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                           const evo_record *records, float *out, uint64_t *pairs_out);
 /* photonsplatinstanced.frag:146-240 for one (photon, shading point) -- returns 0 if discarded */
 int evo_photon_frag(const evo_frame_params *fp, const evo_record *photon, const evo_record *prev,
                     const float x_pos[3], const float x_nrm[3], const float x_dif[3], const float x_phg[4],

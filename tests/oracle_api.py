@@ -93,6 +93,7 @@ def load():
     l.evo_gather_vpl.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]
     l.evo_gather_vpl_counts.argtypes = [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]
     l.evo_gather_vsl.argtypes = l.evo_gather_vpl.argtypes
+    l.evo_gather_vsl_window.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]
     l.evo_gather_lvc.argtypes = l.evo_gather_vpl.argtypes
     l.evo_photon_frag.restype = C.c_int
     l.evo_photon_frag.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P]
@@ -175,6 +176,13 @@ class Scene:
         r0, r1 = rows if rows else (0, H)
         fn = self.lib.evo_gather_lvc if lvc else self.lib.evo_gather_vsl if vsl else self.lib.evo_gather_vpl
         fn(self.h, C.byref(fp), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), ptr(out), C.byref(pairs))
+        return out, pairs.value
+
+    def gather_vsl_window(self, fp, W, H, gbuf, records, out, rows, xs):
+        """VSL gather on the pixels xs = (x0, x1) of the rows (r0, r1) only"""
+        pairs = C.c_uint64()
+        self.lib.evo_gather_vsl_window(self.h, C.byref(fp), W, H, rows[0], rows[1], xs[0], xs[1], ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]),
+                                       ptr(records), ptr(out), C.byref(pairs))
         return out, pairs.value
 
     def gather_counts(self, fp, W, gbuf, records, rows):
