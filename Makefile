@@ -7,7 +7,7 @@ OUT = evplp_amd/lib
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -munsafe-fp-atomics -fno-slp-vectorize $(EXTRA_HIPFLAGS)
 HOSTFLAGS = -O2 -std=c++17 -fPIC -Wall -Wno-unused-value -ffp-contract=off
 
-HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip $(CSRC)/kernels_pt.hip $(CSRC)/bvh_gpu.hip
+HIP_SRCS = $(CSRC)/kernels_trace.hip $(CSRC)/kernels_gather.hip $(CSRC)/kernels_splat.hip $(CSRC)/kernels_pt.hip $(CSRC)/bvh_gpu.hip $(CSRC)/selftest.hip
 CPP_SRCS = $(CSRC)/context.cpp $(CSRC)/group.cpp $(CSRC)/bvh_build.cpp $(wildcard $(CSRC)/host/*.cpp)
 # VARIANT selects a separate object directory and library name (developer builds, e.g. `make stats`)
 VARIANT ?=

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_accel_builder": (C.c_int, [_P]),
+    "evplp_selftest": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_group_create": (C.c_int, [C.POINTER(Config), _P, C.POINTER(_P)]),
     "evplp_group_destroy": (None, [_P]),
     "evplp_group_last_error": (C.c_char_p, [_P]),
@@ -307,6 +308,11 @@ class Context:
         b = self._lib.evplp_accel_builder(self._h)
         return {"nodes": n.value, "leaves": l.value, "depth": d.value, "build_ms": ms.value,
                 "builder": {0: "lbvh", 1: "sah", 2: "sbvh", 3: "gpu"}.get(b, "none")}
+
+    def selftest(self, which: int = 0) -> np.ndarray:
+        out = np.zeros(8, dtype=np.uint64)
+        n = self._check(self._lib.evplp_selftest(self._h, which, _ptr(out), 8))
+        return out[:n]
 
     # -- passes
     def set_stream(self, stream_ptr: int):

@@ -71,11 +71,28 @@ EV_DEV float dot_exact(V3 a, V3 b) {
 // predicate is bit-identical on CPU and GPU: every dot product is  fma(z, z', fma(y, y', x*x'))  and
 // every cross component is  fma(a, b, -(c*d)).  1/den is an IEEE-correct division.
 typedef float v2f __attribute__((ext_vector_type(2)));
+// 1 / x with the bits of the IEEE division for every normal x below 2^126 -- the division's own refinement of v_rcp_f32 (one
+// Newton-Raphson step, two residual corrections) without the range scaling of v_div_scale / v_div_fixup (7 instructions instead
+// of 11).  tools/ub/rcp_exact.hip compares it with 1.0f / x on all 2^32 bit patterns (tests/test_gpu_parity.py runs it): the
+// two differ only for zero / denormal / infinite x and for |x| >= 2^126.  In the triangle predicates x = n . d: a zero or
+// denormal x makes 1 / x infinite or larger than 2^126 under IEEE and NaN or infinite here -- either way t is infinite, NaN or
+// beyond every segment's range and the predicate is false; |x| >= 2^126 needs coordinates beyond 1e18.  So the predicates
+// return the oracle's booleans for every input, and its t / beta / gamma wherever they report a hit.
+EV_DEV float rcp_exact(float x) {
+#pragma clang fp contract(off)
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float err = __builtin_fmaf(-x, r, 1.0f);
+    float q = __builtin_fmaf(err, r, r);
+    err = __builtin_fmaf(-x, q, 1.0f);
+    return __builtin_fmaf(err, r, q);
+}
 EV_DEV bool tri_test(const TriPair &tp, int h, V3 o, V3 d, float tmin, float tmax, float &t, float &beta, float &gamma) {
 #pragma clang fp contract(off)
     const float nx = tp.n[0][h], ny = tp.n[1][h], nz = tp.n[2][h];
     float den = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
-    float inv = 1.0f / den;
+    float inv = rcp_exact(den);
     float qx = (tp.p0[0][h] - o.x) * inv, qy = (tp.p0[1][h] - o.y) * inv, qz = (tp.p0[2][h] - o.z) * inv;
     float ix = __builtin_fmaf(d.y, qz, -(d.z * qy)), iy = __builtin_fmaf(d.z, qx, -(d.x * qz)), iz = __builtin_fmaf(d.x, qy, -(d.y * qx));
     beta = __builtin_fmaf(iz, tp.e1[2][h], __builtin_fmaf(iy, tp.e1[1][h], ix * tp.e1[0][h]));
@@ -91,7 +108,7 @@ EV_DEV bool tri_test_flat(const TriFlat *tf, V3 o, V3 d, float tmin, float tmax,
     const float4 a = q4[0], b = q4[1], c = q4[2];
     const float p0x = a.x, p0y = a.y, p0z = a.z, e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w, e1z = c.x, nx = c.y, ny = c.z, nz = c.w;
     float den = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
-    float inv = 1.0f / den;
+    float inv = rcp_exact(den);
     float qx = (p0x - o.x) * inv, qy = (p0y - o.y) * inv, qz = (p0z - o.z) * inv;
     float ix = __builtin_fmaf(d.y, qz, -(d.z * qy)), iy = __builtin_fmaf(d.z, qx, -(d.x * qz)), iz = __builtin_fmaf(d.x, qy, -(d.y * qx));
     beta = __builtin_fmaf(iz, e1z, __builtin_fmaf(iy, e1y, ix * e1x));
@@ -343,6 +360,18 @@ EV_DEV v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, 
 EV_DEV v2f pk_min(v2f a, v2f b) { return __builtin_elementwise_min(a, b); }
 EV_DEV v2f pk_max(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
 
+// rcp_exact of both halves: two v_rcp_f32, then the refinement as six packed fmas (a v_pk_fma_f32 rounds each half like v_fma_f32)
+EV_DEV v2f rcp_exact2(v2f x) {
+#pragma clang fp contract(off)
+    v2f r; r.x = __builtin_amdgcn_rcpf(x.x); r.y = __builtin_amdgcn_rcpf(x.y);
+    const v2f one = bc(1.0f);
+    const v2f e = pk_fma(-x, r, one);
+    r = pk_fma(e, r, r);
+    v2f err = pk_fma(-x, r, one);
+    v2f q = pk_fma(err, r, r);
+    err = pk_fma(-x, q, one);
+    return pk_fma(err, r, q);
+}
 // Exact test of a PAIR of triangles with packed fp32 (half 0 = triangle A, half 1 = B): the same
 // operations in the same order as tri_test, two triangles per instruction.  r[0..23] = the 24 dwords
 // of a TriPair.  Returns the two hit flags.
@@ -353,16 +382,19 @@ EV_DEV Hit2 tri_pair_test(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, 
 #pragma clang fp contract(off)
     const v2f dx = bc(d.x), dy = bc(d.y), dz = bc(d.z);
     v2f den = pk_fma(nz, dz, pk_fma(ny, dy, nx * dx));
-    v2f inv; inv.x = 1.0f / den.x; inv.y = 1.0f / den.y;
+    const v2f inv = rcp_exact2(den);
     v2f qx = (p0x - bc(o.x)) * inv, qy = (p0y - bc(o.y)) * inv, qz = (p0z - bc(o.z)) * inv;
     v2f ix = pk_fma(dy, qz, -(dz * qy)), iy = pk_fma(dz, qx, -(dx * qz)), iz = pk_fma(dx, qy, -(dy * qx));
     v2f beta = pk_fma(iz, e1z, pk_fma(iy, e1y, ix * e1x));
     v2f gamma = pk_fma(iz, e0z, pk_fma(iy, e0y, ix * e0x));
     v2f t = pk_fma(nz, qz, pk_fma(ny, qy, nx * qx));
-    v2f bg = beta + gamma;
+    // beta >= 0 & gamma >= 0 & beta + gamma <= 1 as ONE compare: min3(beta, gamma, 1 - (beta + gamma)) >= 0.  (1 - s >= 0 exactly
+    // when s <= 1: the subtraction is exact for s in [1/2, 2] and keeps its sign elsewhere.  A NaN among beta / gamma would be skipped
+    // by v_min3, but they are NaN only when q is not finite, and then t fails its range test.)
+    const v2f rest = bc(1.0f) - (beta + gamma);
     Hit2 h;
-    h.a = (t.x < tmax) & (t.x > tmin) & (beta.x >= 0.0f) & (gamma.x >= 0.0f) & (bg.x <= 1.0f);
-    h.b = (t.y < tmax) & (t.y > tmin) & (beta.y >= 0.0f) & (gamma.y >= 0.0f) & (bg.y <= 1.0f);
+    h.a = (t.x < tmax) & (t.x > tmin) & (__builtin_fminf(__builtin_fminf(beta.x, gamma.x), rest.x) >= 0.0f);
+    h.b = (t.y < tmax) & (t.y > tmin) & (__builtin_fminf(__builtin_fminf(beta.y, gamma.y), rest.y) >= 0.0f);
     return h;
 }
 
@@ -518,7 +550,7 @@ EV_DEV Tri2 tri_pair_eval(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, 
 #pragma clang fp contract(off)
     const v2f dx = bc(d.x), dy = bc(d.y), dz = bc(d.z);
     v2f den = pk_fma(nz, dz, pk_fma(ny, dy, nx * dx));
-    v2f inv; inv.x = 1.0f / den.x; inv.y = 1.0f / den.y;
+    const v2f inv = rcp_exact2(den);
     v2f qx = (p0x - bc(o.x)) * inv, qy = (p0y - bc(o.y)) * inv, qz = (p0z - bc(o.z)) * inv;
     v2f ix = pk_fma(dy, qz, -(dz * qy)), iy = pk_fma(dz, qx, -(dx * qz)), iz = pk_fma(dx, qy, -(dy * qx));
     Tri2 r;

@@ -1,0 +1,48 @@
+// Device-side self checks reachable through the C ABI (evplp_selftest): facts the kernels rely on, verified on the part they
+// run on rather than assumed.
+#include "device_common.hpp"
+#include "context.hpp"
+
+namespace evplp {
+
+// which = 0: rcp_exact(x) against the IEEE division 1.0f / x on ALL 2^32 bit patterns.
+//   out[0] patterns where the bits differ (NaN == NaN), out[1] of them zero / denormal x, out[2] infinite / NaN x, out[3] normal x,
+//   out[4] / out[5] smallest / largest biased exponent among the differing normal x (255 / 0 if none).
+__global__ __launch_bounds__(256) void selftest_rcp_kernel(unsigned long long *out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = tid; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)i;
+        const float x = __uint_as_float(b);
+        const float ref = 1.0f / x, got = rcp_exact(x);
+        v2f xx; xx.x = x; xx.y = -x;
+        const v2f g2 = rcp_exact2(xx);                                   // the packed flavour must agree with the scalar one
+        const bool same = (__float_as_uint(ref) == __float_as_uint(got) || (ref != ref && got != got)) &&
+                          (__float_as_uint(g2.x) == __float_as_uint(got) || (g2.x != g2.x && got != got)) &&
+                          (__float_as_uint(g2.y) == (__float_as_uint(got) ^ 0x80000000u) || (g2.y != g2.y && got != got));
+        if (!same) {
+            const uint32_t ex = (b >> 23) & 0xffu;
+            atomicAdd(&out[0], 1ull);
+            if (ex == 0u) atomicAdd(&out[1], 1ull);
+            else if (ex == 255u) atomicAdd(&out[2], 1ull);
+            else { atomicAdd(&out[3], 1ull); atomicMin(&out[4], (unsigned long long)ex); atomicMax(&out[5], (unsigned long long)ex); }
+        }
+    }
+}
+
+} // namespace evplp
+
+extern "C" int evplp_selftest(evplp_context *c, int32_t which, uint64_t *out, int32_t capacity) {
+    if (!c || !out || capacity < 6 || which != 0) { if (c) c->set_error("evplp_selftest: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return EVPLP_ERR_HIP;
+    unsigned long long *d = nullptr;
+    if (hipMalloc((void **)&d, 8 * sizeof(unsigned long long)) != hipSuccess) return EVPLP_ERR_OOM;
+    const unsigned long long init[8] = { 0, 0, 0, 0, 255, 0, 0, 0 };
+    hipError_t e = hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(evplp::selftest_rcp_kernel, dim3(4096), dim3(256), 0, c->stream, d); e = hipStreamSynchronize(c->stream); }
+    unsigned long long h[8] = {};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { c->set_error("evplp_selftest: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
+    for (int k = 0; k < 6; k++) out[k] = h[k];
+    return 6;
+}

@@ -245,6 +245,12 @@ int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_
 /* The builder evplp_build_accel actually used (an evplp_bvh_builder value): cfg.bvh_builder unless the test override
  * EVPLP_BVH_BUILDER was set when the context was created.  < 0 before the first build. */
 int evplp_accel_builder(const evplp_context *ctx);
+/* Device-side self checks: facts the kernels rely on, verified on the GPU they run on.  which = 0: the 7-instruction exact
+ * reciprocal of the triangle predicates against the IEEE division on all 2^32 float bit patterns (under a second): out[0]
+ * patterns whose bits differ, [1] of them zero / denormal inputs, [2] infinite / NaN inputs, [3] normal inputs, [4] / [5] the
+ * smallest / largest biased exponent among those normal inputs (the kernels need [3] to be confined to exponents >= 253).
+ * Returns the number of words written or a negative status. */
+int evplp_selftest(evplp_context *ctx, int32_t which, uint64_t *out, int32_t capacity);
 
 /* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread drives
  * n_ranks contexts, one per GPU of the node, that own interleaved row strips of the image (see the top of this file); scene and

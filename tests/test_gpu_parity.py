@@ -88,6 +88,17 @@ def test_primary_gbuffer(room, oscene, evplp, builder):
     assert (ref[4][..., 0] > 0).any(), "the light should be visible in this view"
 
 
+def test_exact_reciprocal_of_the_triangle_predicates(ctx):
+    """The triangle predicates divide by n . d with a 7-instruction refinement of v_rcp_f32 instead of the compiler's 11-instruction
+    IEEE division.  Checked on all 2^32 float bit patterns on this GPU: the bits differ only for zero / denormal / infinite inputs and
+    for normal inputs of biased exponent >= 253 (|x| >= 2^126) -- inputs for which the predicate is false under either arithmetic
+    (device_common.hpp rcp_exact)."""
+    r = ctx.selftest(0)
+    total, denorm, infnan, normal, lo, hi = (int(v) for v in r)
+    assert denorm <= 2 ** 24 and infnan <= 2 ** 24 and total == denorm + infnan + normal
+    assert normal == 0 or lo >= 253, (normal, lo, hi)
+
+
 def test_light_image_flags(room, oscene, evplp):
     """rtcomphoton.h:985-995: run.lightRender = false leaves the light image alone; cleareveryframe clears the depth buffer the
     light pass shares with the deferred pass, so the emitter is drawn without a depth test."""

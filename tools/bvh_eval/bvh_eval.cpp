@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
         p = tv(t, 0) * u + tv(t, 1) * v + tv(t, 2) * w; n = norm(cross(tv(t, 1) - tv(t, 0), tv(t, 2) - tv(t, 0)));
     };
     const float tile_r = argc > 4 ? (float)atof(argv[4]) : 0.07f;
+    const int order = argc > 5 ? atoi(argv[5]) : 0;   // descent order when both children are hit: 0 = more lanes first (the kernel), 1.. see below
     Stats S; int done = 0, tries = 0;
     std::vector<int32_t> stack(128);
     while (done < nwalks && tries < nwalks * 50) {
@@ -113,7 +114,23 @@ int main(int argc, char **argv) {
                 if (p0 == 0 && p1 == 0) { cur = kNoChild; break; }
                 if (p0 == 0) { cur = n.c1; continue; }
                 if (p1 == 0) { cur = n.c0; continue; }
-                bool first0 = p0 >= p1; stack[sp++] = first0 ? n.c1 : n.c0; cur = first0 ? n.c0 : n.c1;
+                bool first0 = p0 >= p1;
+                if (order == 1) {            // larger surface area first (SATO)
+                    auto area = [&](int ch) { float dx = n.hal[0][ch], dy = n.hal[1][ch], dz = n.hal[2][ch]; return dx * dy + dy * dz + dz * dx; };
+                    first0 = area(0) >= area(1);
+                } else if (order == 2) {     // always child 0 (the builder's order)
+                    first0 = true;
+                } else if (order == 3) {     // nearer to the VPL first (box centre distance)
+                    auto dist = [&](int ch) { float dx = n.ctr[0][ch] - vp.x, dy = n.ctr[1][ch] - vp.y, dz = n.ctr[2][ch] - vp.z; return dx * dx + dy * dy + dz * dz; };
+                    first0 = dist(0) <= dist(1);
+                } else if (order == 4) {     // nearer to the tile first
+                    auto dist = [&](int ch) { float dx = n.ctr[0][ch] - pp.x, dy = n.ctr[1][ch] - pp.y, dz = n.ctr[2][ch] - pp.z; return dx * dx + dy * dy + dz * dz; };
+                    first0 = dist(0) <= dist(1);
+                } else if (order == 5) {     // smaller box first (denser geometry: more likely to occlude per visit)
+                    auto area = [&](int ch) { float dx = n.hal[0][ch], dy = n.hal[1][ch], dz = n.hal[2][ch]; return dx * dy + dy * dz + dz * dx; };
+                    first0 = area(0) <= area(1);
+                }
+                stack[sp++] = first0 ? n.c1 : n.c0; cur = first0 ? n.c0 : n.c1;
             }
             if (cur != kNoChild) {
                 uint32_t id = (uint32_t)~cur, block = id >> 2, cnt = (id & 3u) + 1u; leaves++; pairs += cnt > 2 ? 2 : 1;
