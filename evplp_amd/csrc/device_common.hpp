@@ -450,6 +450,74 @@ EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 #endif
 struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
 
+// One node visit of the packet walk, hand-scheduled: the slab tests of both children and the decision where to go next (push the
+// other child when both are entered, pop the lane stack when none is).  Written out because the scalar pipe of a CU is as busy as
+// its vector pipe in this loop (a prefetch experiment that added six scalar instructions per visit cost 9 %) and the compiler
+// spends ~17 scalar instructions and 4-5 branches per visit on the decision alone (lane-mask booleans, s_cselect_b64 / s_and exec /
+// s_cbranch_vcc chains); this spends 6-9 and 2-3.  Inline-asm operands cannot name the halves of a register tuple: the node arrives
+// as seven 64-bit scalar operands (sub-registers of the 16-dword tuple the load fills), and the six packed temporaries live in FIXED
+// registers v[VT:VT+11], which the kernels that use this keep free with amdgpu_num_vgpr(VT).
+// Same arithmetic and the same descent order (the child more lanes enter first) as the C++ loop below, which stays as the reference
+// implementation (EVPLP_WALK_ASM=0, and the counters build).  Afterwards cur is the next node, a leaf reference, or kNoChild when
+// nothing was entered and the stack was empty.
+#ifndef EVPLP_WALK_ASM
+#define EVPLP_WALK_ASM 1
+#endif
+#define EV_WALK_VISIT_ASM(T0, T1, T2, T3, T4, T5, T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)                                    \
+    asm volatile(                                                                                                                            \
+        "v_pk_fma_f32 " T0 ", %[cx], %[ivx], %[nox]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T1 ", %[cy], %[ivy], %[noy]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T2 ", %[cz], %[ivz], %[noz]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T3 ", %[hx], %[avx], " T0 " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
+        "v_pk_fma_f32 " T4 ", %[hy], %[avy], " T1 " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
+        "v_pk_fma_f32 " T5 ", %[hz], %[avz], " T2 " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
+        "v_pk_fma_f32 " T0 ", %[hx], %[avx], " T0 "\n\t"                                                                                     \
+        "v_pk_fma_f32 " T1 ", %[hy], %[avy], " T1 "\n\t"                                                                                     \
+        "v_pk_fma_f32 " T2 ", %[hz], %[avz], " T2 "\n\t"                                                                                     \
+        "v_max3_f32 " T3L ", " T3L ", " T4L ", " T5L " clamp\n\t"                                                                            \
+        "v_min3_f32 " T0L ", " T0L ", " T1L ", " T2L " clamp\n\t"                                                                            \
+        "v_max3_f32 " T3H ", " T3H ", " T4H ", " T5H " clamp\n\t"                                                                            \
+        "v_min3_f32 " T0H ", " T0H ", " T1H ", " T2H " clamp\n\t"                                                                            \
+        "v_cmp_lt_f32 vcc, " T3L ", " T0L "\n\t"                                                                                             \
+        "v_cmp_lt_f32 %[m1], " T3H ", " T0H "\n\t"                                                                                           \
+        "s_or_b64 %[t64], vcc, %[m1]\n\t"                                                                                                    \
+        "s_cbranch_scc0 L_pop%=\n\t"                                                                                                         \
+        "s_cmp_eq_u64 vcc, 0\n\t"                                                                                                            \
+        "s_cbranch_scc1 L_c1%=\n\t"                                                                                                          \
+        "s_cmp_eq_u64 %[m1], 0\n\t"                                                                                                          \
+        "s_cbranch_scc1 L_c0%=\n\t"                                                                                                          \
+        "s_bcnt1_i32_b64 %[p0], vcc\n\t"                                                                                                     \
+        "s_bcnt1_i32_b64 %[p1], %[m1]\n\t"                                                                                                   \
+        "s_cmp_ge_i32 %[p0], %[p1]\n\t"                                                                                                      \
+        "s_cselect_b32 %[p0], %[c1], %[c0]\n\t"                                                                                              \
+        "s_cselect_b32 %[cur], %[c0], %[c1]\n\t"                                                                                             \
+        "v_cmp_eq_u32 vcc, %[sp], %[lane]\n\t"                                                                                               \
+        "v_mov_b32 " T0L ", %[p0]\n\t"                                                                                                       \
+        "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                                      \
+        "v_cndmask_b32 %[vstack], %[vstack], " T0L ", vcc\n\t"                                                                               \
+        "s_branch L_end%=\n"                                                                                                                 \
+        "L_c0%=:\n\t"                                                                                                                        \
+        "s_mov_b32 %[cur], %[c0]\n\t"                                                                                                        \
+        "s_branch L_end%=\n"                                                                                                                 \
+        "L_c1%=:\n\t"                                                                                                                        \
+        "s_mov_b32 %[cur], %[c1]\n\t"                                                                                                        \
+        "s_branch L_end%=\n"                                                                                                                 \
+        "L_pop%=:\n\t"                                                                                                                       \
+        "s_brev_b32 %[cur], 1\n\t"                                                                                                           \
+        "s_cmp_eq_u32 %[sp], 0\n\t"                                                                                                          \
+        "s_cbranch_scc1 L_end%=\n\t"                                                                                                         \
+        "s_sub_i32 %[sp], %[sp], 1\n\t"                                                                                                      \
+        "s_nop 0\n\t"                                                                                                                        \
+        "v_readlane_b32 %[cur], %[vstack], %[sp]\n"                                                                                          \
+        "L_end%=:\n"                                                                                                                         \
+        : [cur] "+s"(cur), [sp] "+s"(sp), [vstack] "+v"(vstack), [m1] "=&s"(m1_), [t64] "=&s"(t64_), [p0] "=&s"(p0_), [p1] "=&s"(p1_)          \
+        : [cx] "s"(cx_), [cy] "s"(cy_), [cz] "s"(cz_), [hx] "s"(hx_), [hy] "s"(hy_), [hz] "s"(hz_), [c0] "s"(c0_), [c1] "s"(c1_),              \
+          [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [avx] "v"(avx), [avy] "v"(avy), [avz] "v"(avz),                                     \
+          [nox] "v"(nox), [noy] "v"(noy), [noz] "v"(noz), [lane] "v"(lane_id)                                                                 \
+        : "vcc", "scc", T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)
+
+// VT = first of the twelve reserved temporaries: 60 for the 72-register VPL gather, 116 for the 128-register VSL gather; 0 = the C++ loop
+template <int VT = 0>
 EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
     // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
@@ -474,6 +542,38 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
     int sp = 0;
     int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
+#if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
+    if constexpr (VT != 0) {
+        static_assert(VT == 60 || VT == 116, "reserved temporaries: v[60:71] or v[116:127]");
+        const int lane_id = (int)(threadIdx.x & 63u);
+        for (;;) {
+            while (cur >= 0) {
+                const v16i n = sload16(node_base, (uint32_t)cur << 6);
+                const v2f cx_ = pk(n[0], n[1]), cy_ = pk(n[2], n[3]), cz_ = pk(n[4], n[5]), hx_ = pk(n[6], n[7]), hy_ = pk(n[8], n[9]), hz_ = pk(n[10], n[11]);
+                const int32_t c0_ = n[12], c1_ = n[13];
+                unsigned long long m1_, t64_; int32_t p0_, p1_;
+                if constexpr (VT == 60) EV_WALK_VISIT_ASM("v[60:61]", "v[62:63]", "v[64:65]", "v[66:67]", "v[68:69]", "v[70:71]", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+                else EV_WALK_VISIT_ASM("v[116:117]", "v[118:119]", "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+            }
+            if (cur == kNoChild) break;
+            const uint32_t cnt = (((uint32_t)~cur) & 3u) + 1u;
+            const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cur);
+            bool any = tri_pair_any(L.A, o, d, tmin, tmax);
+            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax);
+            const unsigned long long hm = ballot64(any) & alive;
+            if (hm != 0ull) {
+                hitm |= hm;
+                alive &= ~hm;
+                if (alive == 0ull) break;
+                if (any) { nox = bc(dead); noy = bc(dead); noz = bc(dead); }
+            }
+            if (sp == 0) break;
+            sp--;
+            cur = lane_read(vstack, sp);
+        }
+        return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+    }
+#endif
     for (;;) {
         while (cur >= 0) {
             const v16i n = sload16(node_base, (uint32_t)cur << 6);

@@ -154,6 +154,9 @@ EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
 }
 
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
+#if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
+__attribute__((amdgpu_num_vgpr(60)))      // v[60:71] belong to the hand-written node visit (device_common.hpp)
+#endif
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
     // dynamic LDS: [192] the view directions, then one [192] block per level of the k-split fold (log2 k + 1 of them).  Sized by k
     // because LDS is what limits occupancy next: 7 single-wavefront workgroups per SIMD fit while a workgroup stays within
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 if (ws.hit_leaf != kNoChild) cache_leaf = ws.hit_leaf;
                 prev_all_occ = all_occ;
 #else
-                occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+                occ = occluded_wave<EVPLP_WALK_ASM ? 60 : 0>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active);
 #endif
             }
             const bool lit = active && !occ;
