@@ -456,7 +456,9 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
 // spends ~17 scalar instructions and 4-5 branches per visit on the decision alone (lane-mask booleans, s_cselect_b64 / s_and exec /
 // s_cbranch_vcc chains); this spends 6-9 and 2-3.  Inline-asm operands cannot name the halves of a register tuple: the node arrives
 // as seven 64-bit scalar operands (sub-registers of the 16-dword tuple the load fills), and the six packed temporaries live in FIXED
-// registers v[VT:VT+11], which the kernels that use this keep free with amdgpu_num_vgpr(VT).
+// registers v[VT:VT+11], which the kernels that use this keep free with amdgpu_num_vgpr(VT).  The nine per-lane ray constants ride
+// in five register pairs -- {1/dx, 1/dy} {1/dz, |1/dx|} {|1/dy|, |1/dz|} {-ox/dx, -oy/dy} {-oz/dz, -} -- and op_sel / op_sel_hi
+// broadcast the wanted half to both children (the C++ loop keeps every constant in both halves of a pair of its own: 18 registers).
 // Same arithmetic and the same descent order (the child more lanes enter first) as the C++ loop below, which stays as the reference
 // implementation (EVPLP_WALK_ASM=0, and the counters build).  Afterwards cur is the next node, a leaf reference, or kNoChild when
 // nothing was entered and the stack was empty.
@@ -465,15 +467,15 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
 #endif
 #define EV_WALK_VISIT_ASM(T0, T1, T2, T3, T4, T5, T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)                                    \
     asm volatile(                                                                                                                            \
-        "v_pk_fma_f32 " T0 ", %[cx], %[ivx], %[nox]\n\t"                                                                                     \
-        "v_pk_fma_f32 " T1 ", %[cy], %[ivy], %[noy]\n\t"                                                                                     \
-        "v_pk_fma_f32 " T2 ", %[cz], %[ivz], %[noz]\n\t"                                                                                     \
-        "v_pk_fma_f32 " T3 ", %[hx], %[avx], " T0 " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
-        "v_pk_fma_f32 " T4 ", %[hy], %[avy], " T1 " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
-        "v_pk_fma_f32 " T5 ", %[hz], %[avz], " T2 " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
-        "v_pk_fma_f32 " T0 ", %[hx], %[avx], " T0 "\n\t"                                                                                     \
-        "v_pk_fma_f32 " T1 ", %[hy], %[avy], " T1 "\n\t"                                                                                     \
-        "v_pk_fma_f32 " T2 ", %[hz], %[avz], " T2 "\n\t"                                                                                     \
+        "v_pk_fma_f32 " T0 ", %[cx], %[pa], %[pd] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T1 ", %[cy], %[pa], %[pd] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T2 ", %[cz], %[pb], %[pe] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T3 ", %[hx], %[pb], " T0 " op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
+        "v_pk_fma_f32 " T4 ", %[hy], %[pc], " T1 " op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
+        "v_pk_fma_f32 " T5 ", %[hz], %[pc], " T2 " op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                                                        \
+        "v_pk_fma_f32 " T0 ", %[hx], %[pb], " T0 " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T1 ", %[hy], %[pc], " T1 " op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"                                                                                     \
+        "v_pk_fma_f32 " T2 ", %[hz], %[pc], " T2 " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                                                                     \
         "v_max3_f32 " T3L ", " T3L ", " T4L ", " T5L " clamp\n\t"                                                                            \
         "v_min3_f32 " T0L ", " T0L ", " T1L ", " T2L " clamp\n\t"                                                                            \
         "v_max3_f32 " T3H ", " T3H ", " T4H ", " T5H " clamp\n\t"                                                                            \
@@ -512,11 +514,11 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
         "L_end%=:\n"                                                                                                                         \
         : [cur] "+s"(cur), [sp] "+s"(sp), [vstack] "+v"(vstack), [m1] "=&s"(m1_), [t64] "=&s"(t64_), [p0] "=&s"(p0_), [p1] "=&s"(p1_)          \
         : [cx] "s"(cx_), [cy] "s"(cy_), [cz] "s"(cz_), [hx] "s"(hx_), [hy] "s"(hy_), [hz] "s"(hz_), [c0] "s"(c0_), [c1] "s"(c1_),              \
-          [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [avx] "v"(avx), [avy] "v"(avy), [avz] "v"(avz),                                     \
-          [nox] "v"(nox), [noy] "v"(noy), [noz] "v"(noz), [lane] "v"(lane_id)                                                                 \
+          [pa] "v"(pa_), [pb] "v"(pb_), [pc] "v"(pc_),                                     \
+          [pd] "v"(pd_), [pe] "v"(pe_), [lane] "v"(lane_id)                                                                 \
         : "vcc", "scc", T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)
 
-// VT = first of the twelve reserved temporaries: 60 for the 72-register VPL gather, 116 for the 128-register VSL gather; 0 = the C++ loop
+// VT = first of the twelve reserved temporaries: 52 for the 64-register VPL gather, 116 for the 128-register VSL gather; 0 = the C++ loop
 template <int VT = 0>
 EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
@@ -544,15 +546,18 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
     int32_t cur = 0;  // root is always an inner node
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
     if constexpr (VT != 0) {
-        static_assert(VT == 60 || VT == 116, "reserved temporaries: v[60:71] or v[116:127]");
+        static_assert(VT == 52 || VT == 116, "reserved temporaries: v[52:63] or v[116:127]");
         const int lane_id = (int)(threadIdx.x & 63u);
+        v2f pa_, pb_, pc_, pd_, pe_;
+        pa_.x = ivx.x; pa_.y = ivy.x; pb_.x = ivz.x; pb_.y = avx.x; pc_.x = avy.x; pc_.y = avz.x;
+        pd_.x = nox.x; pd_.y = noy.x; pe_.x = noz.x; pe_.y = noz.x;
         for (;;) {
             while (cur >= 0) {
                 const v16i n = sload16(node_base, (uint32_t)cur << 6);
                 const v2f cx_ = pk(n[0], n[1]), cy_ = pk(n[2], n[3]), cz_ = pk(n[4], n[5]), hx_ = pk(n[6], n[7]), hy_ = pk(n[8], n[9]), hz_ = pk(n[10], n[11]);
                 const int32_t c0_ = n[12], c1_ = n[13];
                 unsigned long long m1_, t64_; int32_t p0_, p1_;
-                if constexpr (VT == 60) EV_WALK_VISIT_ASM("v[60:61]", "v[62:63]", "v[64:65]", "v[66:67]", "v[68:69]", "v[70:71]", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+                if constexpr (VT == 52) EV_WALK_VISIT_ASM("v[52:53]", "v[54:55]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
                 else EV_WALK_VISIT_ASM("v[116:117]", "v[118:119]", "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
             }
             if (cur == kNoChild) break;
@@ -565,7 +570,7 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
                 hitm |= hm;
                 alive &= ~hm;
                 if (alive == 0ull) break;
-                if (any) { nox = bc(dead); noy = bc(dead); noz = bc(dead); }
+                if (any) { pd_ = bc(dead); pe_ = bc(dead); }     // newly occluded lanes stop driving the walk
             }
             if (sp == 0) break;
             sp--;

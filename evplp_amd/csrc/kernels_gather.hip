@@ -127,7 +127,7 @@ EV_DEV uint32_t item_texel(const GatherArgs &a, int lane) {
 }
 
 #ifndef EVPLP_GATHER_WAVES
-#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene: 5 = 106.0 / 54.3 ms, 6 = 94.3 / 48.7, 7 = 91.0 / 47.6, 8 = 94.6 / 50.0
+#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene, round 3 (64 registers, no spills at either): 7 = 70.6 / 29.3 ms, 8 = 70.9 / 30.9
 #endif
 
 // wave-uniform scalar fetch of one 96-byte record (s_load_dwordx16 + s_load_dwordx8)
@@ -155,7 +155,7 @@ EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
 
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
-__attribute__((amdgpu_num_vgpr(60)))      // v[60:71] belong to the hand-written node visit (device_common.hpp)
+__attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
 #endif
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
     // dynamic LDS: [192] the view directions, then one [192] block per level of the k-split fold (log2 k + 1 of them).  Sized by k
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 if (ws.hit_leaf != kNoChild) cache_leaf = ws.hit_leaf;
                 prev_all_occ = all_occ;
 #else
-                occ = occluded_wave<EVPLP_WALK_ASM ? 60 : 0>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+                occ = occluded_wave<EVPLP_WALK_ASM ? 52 : 0>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active);
 #endif
             }
             const bool lit = active && !occ;
