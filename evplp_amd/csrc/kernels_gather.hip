@@ -219,7 +219,9 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 WalkStats ws = { 0u, 0u, 0u, 0u, kNoChild };
                 occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
                 const bool all_occ = ballot64(active && !occ) == 0ull;
+                const unsigned long long occ_m = ballot64(active && occ);
                 if (lane == 0) {
+                    atomicAdd(&a.counters->hist[41], (unsigned long long)__builtin_popcountll(occ_m));
                     atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
                     atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
                     atomicAdd(&a.counters->hist[32], 1ull);
@@ -232,7 +234,6 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                         if (cache_kill == act_m) { atomicAdd(&a.counters->hist[38], 1ull); atomicAdd(&a.counters->hist[39], (unsigned long long)ws.nodes); }
                         if (prev_all_occ) { atomicAdd(&a.counters->hist[44], 1ull); if (cache_kill == act_m) atomicAdd(&a.counters->hist[43], 1ull); }
                     }
-                    atomicAdd(&a.counters->hist[41], (unsigned long long)__builtin_popcountll(ballot64(active && occ)));
                     atomicAdd(&a.counters->hist[45 + min(ws.nodes / 16u, 18u)], 1ull);
                 }
                 if (ws.hit_leaf != kNoChild) cache_leaf = ws.hit_leaf;

@@ -88,7 +88,19 @@ typedef struct evplp_config {
                                   * context's stream after it -- so a preceding evplp_primary overlaps with it (light paths are
                                   * latency-bound, 4.6 waves per SIMD).  Off by default: a caller with kernels of its own on the
                                   * context's stream that read the records between the last such pass and the next light tracing
-                                  * needs them ordered.  The technique loops of evplp_render_json and bench.py switch it on. */
+                                  * needs them ordered.  The technique loops of evplp_render_json and bench.py switch it on.
+                                  * What else it does, and what a caller has to know:
+                                  *  - the library DOUBLE-BUFFERS what the pipelined passes write: EVPLP_BUF_RECORDS (when a call traces
+                                  *    the whole path set), the four G-buffer planes and the tile boxes.  A call that writes one of them
+                                  *    flips EVPLP_BUF_* to the copy nobody reads, so the device address behind an EVPLP_BUF_* id CHANGES
+                                  *    between calls (evplp_download / evplp_upload always see the current one);
+                                  *  - the second copies are allocated on first use: + num_light_paths x photons_per_path x 96 bytes of
+                                  *    records (192 MB at config #3, 115 MB at #4) and + 4 x W x rows x 16 bytes of G-buffer;
+                                  *  - taking a device pointer with evplp_buffer_info, or binding memory with evplp_bind_buffer, pins
+                                  *    that buffer for good: it is never flipped again (the pointer stays valid) and the passes that
+                                  *    write it wait for its readers as they do without this flag;
+                                  *  - up to two photon splats may be waiting for the verdict on their bin sizes; with `deterministic`
+                                  *    set none is ever left pending behind a younger one (bitwise reproducible accumulation). */
     int32_t reserved[2];
 } evplp_config;
 
