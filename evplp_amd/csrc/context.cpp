@@ -323,14 +323,26 @@ extern "C" int evplp_build_accel(evplp_context *c) {
     }
     if (light_count <= 0) { c->set_error("evplp_build_accel: the area-light mesh has no triangles"); return EVPLP_ERR_INVALID; }
     BvhBuild bb;
-    const int builder = c->env_bvh_builder >= 0 ? c->env_bvh_builder : c->cfg.bvh_builder;   // (override read by evplp_create)
+    int builder = c->env_bvh_builder >= 0 ? c->env_bvh_builder : c->cfg.bvh_builder;   // (override read by evplp_create)
     if (builder == EVPLP_BVH_LBVH_GPU) {
         BvhDeviceBuild gb;
         const int e = build_bvh_gpu(verts.data(), (int32_t)attrs.size(), bvh_pad_scale(), c->stream, &gb);
         if (e != 0) { c->set_error("evplp_build_accel: device LBVH build: %s", hipGetErrorString((hipError_t)e)); return EVPLP_ERR_HIP; }
-        c->sc.nodes = gb.nodes; c->sc.leaves = gb.leaves; c->sc.tri_flat = gb.tri_flat; c->sc.tri_index = gb.tri_index;
-        bb.nnodes = gb.nnodes; bb.nleaves = gb.nleaves; bb.depth = gb.depth; bb.build_ms = gb.build_ms; bb.ntris = gb.ntris;
-    } else build_bvh(verts.data(), (int32_t)attrs.size(), builder, &bb);
+        if (gb.depth > kMaxDepth - 2) {
+            // long radix-tree chains (clustered or duplicate Morton codes) can exceed the walks' 64-entry stacks: build the
+            // binned-SAH tree on the host instead of failing the scene
+            hipFree(gb.nodes); hipFree(gb.leaves); hipFree(gb.tri_flat); hipFree(gb.tri_index);
+            builder = EVPLP_BVH_SAH;
+        } else {
+            c->sc.nodes = gb.nodes; c->sc.leaves = gb.leaves; c->sc.tri_flat = gb.tri_flat; c->sc.tri_index = gb.tri_index;
+            bb.nnodes = gb.nnodes; bb.nleaves = gb.nleaves; bb.depth = gb.depth; bb.build_ms = gb.build_ms; bb.ntris = gb.ntris;
+        }
+    }
+    if (builder != EVPLP_BVH_LBVH_GPU) {
+        build_bvh(verts.data(), (int32_t)attrs.size(), builder, &bb);
+        if (bb.depth > kMaxDepth - 2 && builder == EVPLP_BVH_LBVH) { free_bvh(&bb); bb = BvhBuild(); builder = EVPLP_BVH_SAH; build_bvh(verts.data(), (int32_t)attrs.size(), builder, &bb); }
+    }
+    c->accel_builder_used = builder;
     c->accel_nodes = bb.nnodes; c->accel_leaves = bb.nleaves; c->accel_depth = bb.depth; c->accel_build_ms = bb.build_ms;
     if (bb.depth > kMaxDepth - 2) { free_bvh(&bb); free_scene_device(c); c->set_error("BVH depth %d exceeds the traversal stack (%d)", bb.depth, kMaxDepth); return EVPLP_ERR_INVALID; }
     // area-light CDF, rt/rtcommon.h:501-531 (running float sum, then normalised); Triangle::ComputeArea
@@ -409,7 +421,7 @@ extern "C" int evplp_accel_info(evplp_context *c, int32_t *nodes, int32_t *leave
 
 extern "C" int evplp_accel_builder(const evplp_context *c) {
     if (!c || !c->accel_built) return -1;
-    return c->env_bvh_builder >= 0 ? c->env_bvh_builder : c->cfg.bvh_builder;
+    return c->accel_builder_used;
 }
 
 // ---------------------------------------------------------------------------------- passes

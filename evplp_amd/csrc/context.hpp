@@ -36,7 +36,7 @@ struct evplp_context {
     evplp::CamBasis cam{}; evplp_camera cam_in{};
     bool camera_set = false, accel_built = false;
     float bounding_radius = 0.f, total_area = 0.f, light_area = 0.f;
-    int32_t accel_nodes = 0, accel_leaves = 0, accel_depth = 0; float accel_build_ms = 0.f;
+    int32_t accel_nodes = 0, accel_leaves = 0, accel_depth = 0, accel_builder_used = -1; float accel_build_ms = 0.f;
 
     evplp::SceneDev sc{};
     evplp_record *d_vpls = nullptr; uint32_t *d_vpl_src = nullptr;

@@ -255,7 +255,8 @@ int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_
 /* Flattened acceleration structure statistics: nodes, leaves, max depth, build ms */
 int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms);
 /* The builder evplp_build_accel actually used (an evplp_bvh_builder value): cfg.bvh_builder unless the test override
- * EVPLP_BVH_BUILDER was set when the context was created.  < 0 before the first build. */
+ * EVPLP_BVH_BUILDER was set when the context was created, or an LBVH came out deeper than the walks' 64-entry stacks and the
+ * binned-SAH builder took over.  < 0 before the first build. */
 int evplp_accel_builder(const evplp_context *ctx);
 /* Device-side self checks: facts the kernels rely on, verified on the GPU they run on.  which = 0: the 7-instruction exact
  * reciprocal of the triangle predicates against the IEEE division on all 2^32 float bit patterns (under a second): out[0]
