@@ -128,6 +128,9 @@ constexpr int kCompactF4 = 4;        // float4 per compact photon
 // dynamic LDS of the kernels that walk the BVH one ray per lane: an [entry][lane] stack as deep as the tree
 inline size_t lane_stack_bytes(const SceneDev &sc) { return (size_t)(sc.bvh_depth + 2) * 64 * sizeof(int32_t); }
 // (four-wide walk: every second level of the binary tree, up to three pushes per level)
+// (Measured, round 3: this worst-case stack -- 13 KB per wave for a 31-level tree -- is what limits light tracing to 3 waves per SIMD.  An
+// UNSAFE 24-entry stack with 5 waves per SIMD traced config #4's 300 k paths in 0.436 ms instead of 0.514; a safe version needs an
+// overflow area in global memory behind a branch at every push and pop, and buys ~0.05 ms of a 0.66 ms iteration: not done.)
 inline size_t lane_stack_bytes4(const SceneDev &sc) { return (size_t)(3 * ((sc.bvh_depth + 1) / 2) + 4) * 64 * sizeof(int32_t); }
 
 void launch_primary(const PrimaryArgs &a, hipStream_t s);

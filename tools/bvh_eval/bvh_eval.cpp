@@ -35,7 +35,7 @@ static bool tri_hit(const TriFlat &t, V o, V d, float tmin, float tmax) {
 static float clamp01(float x) { return x < 0.f ? 0.f : x > 1.f ? 1.f : x; }
 static float srcp(float d) { float a = std::fabs(d) < 1e-30f ? std::copysign(1e-30f, d) : d; return 1.0f / a; }
 
-struct Stats { double walks = 0, nodes = 0, leaves = 0, pairs = 0, empty = 0, empty_nodes = 0, full = 0, leaf_at_vpl = 0, leaf_at_tile = 0, leaf_hit = 0, node_at_vpl = 0, node_at_tile = 0; };
+struct Stats { double chain_len = 0, walks = 0, nodes = 0, leaves = 0, pairs = 0, empty = 0, empty_nodes = 0, full = 0, leaf_at_vpl = 0, leaf_at_tile = 0, leaf_hit = 0, node_at_vpl = 0, node_at_tile = 0; };
 
 int main(int argc, char **argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: bvh_eval scene.obj [builder] [walks]\n"); return 2; }
@@ -66,9 +66,10 @@ int main(int argc, char **argv) {
         p = tv(t, 0) * u + tv(t, 1) * v + tv(t, 2) * w; n = norm(cross(tv(t, 1) - tv(t, 0), tv(t, 2) - tv(t, 0)));
     };
     const float tile_r = argc > 4 ? (float)atof(argv[4]) : 0.07f;
+    const int chain = argc > 6 ? atoi(argv[6]) : 0; const float margin = argc > 7 ? (float)atof(argv[7]) : 1e-3f;
     const int order = argc > 5 ? atoi(argv[5]) : 0;   // descent order when both children are hit: 0 = more lanes first (the kernel), 1.. see below
     Stats S; int done = 0, tries = 0;
-    std::vector<int32_t> stack(128);
+    std::vector<int32_t> stack(256);
     while (done < nwalks && tries < nwalks * 50) {
         tries++;
         V vp, vn, pp, pn; sample(vp, vn); sample(pp, pn);
@@ -91,9 +92,39 @@ int main(int argc, char **argv) {
         if (nalive == 0) continue;
         done++;
         int sp = 0; int32_t cur = 0; unsigned nodes = 0, leaves = 0, pairs = 0;
+        std::vector<BvhNode> syn;                   // chain mode: synthetic nodes, indices >= bb.nnodes
+        if (chain) {
+            // follow the child whose box holds the VPL strictly inside (by `margin`); the siblings, two at a time, become synthetic nodes
+            std::vector<std::pair<int32_t, int>> sib;          // (parent node, which child) of every sibling subtree
+            int32_t at = 0; int32_t last = 0;
+            for (;;) {
+                const BvhNode &n = bb.nodes[at];
+                auto inside = [&](int ch) { return std::fabs(vp.x - n.ctr[0][ch]) < n.hal[0][ch] - margin && std::fabs(vp.y - n.ctr[1][ch]) < n.hal[1][ch] - margin && std::fabs(vp.z - n.ctr[2][ch]) < n.hal[2][ch] - margin; };
+                const bool i0 = inside(0), i1 = inside(1);
+                if (i0 == i1) { last = at; break; }
+                const int in = i0 ? 0 : 1; const int32_t nxt = in == 0 ? n.c0 : n.c1;
+                sib.push_back({ at, 1 - in });
+                if (nxt < 0) { sib.push_back({ at, in }); last = -1; break; }     // reached a leaf: it is a subtree of its own
+                at = nxt;
+            }
+            S.chain_len += sib.size();
+            auto make = [&](std::pair<int32_t, int> a, const std::pair<int32_t, int> *b) {
+                BvhNode m; std::memset(&m, 0, sizeof m);
+                const BvhNode &pa = bb.nodes[a.first];
+                for (int k = 0; k < 3; k++) { m.ctr[k][0] = pa.ctr[k][a.second]; m.hal[k][0] = pa.hal[k][a.second]; }
+                m.c0 = a.second == 0 ? pa.c0 : pa.c1;
+                if (b) { const BvhNode &pb = bb.nodes[b->first]; for (int k = 0; k < 3; k++) { m.ctr[k][1] = pb.ctr[k][b->second]; m.hal[k][1] = pb.hal[k][b->second]; } m.c1 = b->second == 0 ? pb.c0 : pb.c1; }
+                else { for (int k = 0; k < 3; k++) { m.ctr[k][1] = 0; m.hal[k][1] = -3e38f; } m.c1 = kNoChild; }
+                return m;
+            };
+            for (size_t k = 0; k < sib.size(); k += 2) syn.push_back(make(sib[k], k + 1 < sib.size() ? &sib[k + 1] : nullptr));
+            // initial stack: the synthetic nodes and the node where the chain stopped
+            for (size_t k = 0; k < syn.size(); k++) stack[sp++] = bb.nnodes + (int32_t)k;
+            if (last >= 0) cur = last; else cur = stack[--sp];
+        }
         for (;;) {
             while (cur >= 0) {
-                const BvhNode &n = bb.nodes[cur]; nodes++;
+                const BvhNode &n = cur >= bb.nnodes ? syn[cur - bb.nnodes] : bb.nodes[cur]; nodes++;
                 {   // is this node one of the chain that contains an end point?
                     bool at_v = false, at_t = false;
                     for (int ch = 0; ch < 2; ch++) {
@@ -160,6 +191,7 @@ int main(int argc, char **argv) {
     std::printf("walks %.0f  nodes/walk %.2f  leaves/walk %.2f  pairs/walk %.2f  empty %.3f (nodes %.2f)  fully occluded %.3f  est VALU/walk %.0f\n",
                 S.walks, S.nodes / S.walks, S.leaves / S.walks, S.pairs / S.walks, S.empty / S.walks, S.empty_nodes / std::max(S.empty, 1.0), S.full / S.walks,
                 15.7 * S.nodes / S.walks + 54.0 * S.pairs / S.walks);
+    if (chain) std::printf("   chain: %.2f sibling subtrees per VPL walk\n", S.chain_len / S.walks);
     std::printf("   leaves: at VPL %.2f  at tile %.2f  with a hit %.2f /walk;  node visits with a child box holding the VPL %.2f, the tile centre %.2f\n", S.leaf_at_vpl / S.walks, S.leaf_at_tile / S.walks, S.leaf_hit / S.walks, S.node_at_vpl / S.walks, S.node_at_tile / S.walks);
     return 0;
 }
