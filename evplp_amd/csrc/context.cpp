@@ -178,7 +178,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
-    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial);
+    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
     hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -621,6 +621,7 @@ static int check_fp(evplp_context *c, const evplp_frame_params *fp, const char *
     if (fp->mis_mode > 5u) { c->set_error("%s: mis_mode %u out of range", name, fp->mis_mode); return EVPLP_ERR_INVALID; }
     return EVPLP_OK;
 }
+static size_t nvpl_slots_of(const evplp_context *c) { return std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1); }
 static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) {
     const int pass = vsl ? EVPLP_PASS_GATHER_VSL : EVPLP_PASS_GATHER_VPL;
     const char *name = vsl ? "evplp_gather_vsl" : "evplp_gather_vpl";
@@ -636,15 +637,43 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         if (c->env_gather_k > 0) k = c->env_gather_k;
         const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
         while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
+        if (vsl) while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k > 4095) k >>= 1;      // (the estimator kernel's packed per-lane counters)
     }
     a.splits_per_wave = k;
     if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k)))) return rc;
     if ((rc = pass_begin(c, pass))) return rc;
     const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
     launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
-    HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
-    if (vsl) launch_gather_vsl(a, c->stream); else launch_gather_vpl_items(a, c->stream);
-    HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
+    if (vsl) {
+        // lit masks between the walk and the estimator kernel: 8 bytes per (tile, VSL slot) of a launch; the groups of a tile are
+        // covered in as many launches as keep the buffer within ~1 GB (config #5: 2048^2, 16 384 slots, k = 4: 4 launches of 8 groups)
+        a.masks_per_split = (int32_t)((nvpl_slots_of(c) + kVplSplit - 1) / kVplSplit);
+        const size_t tiles = (size_t)gather_launch_tiles(a), per_item = (size_t)k * (size_t)a.masks_per_split * sizeof(unsigned long long);
+        const int groups = kVplSplit / k;
+        int per_launch = groups;
+        while (per_launch > 1 && tiles * (size_t)per_launch * per_item > ((size_t)1 << 30)) per_launch = (per_launch + 1) / 2;
+        const size_t mask_bytes = tiles * (size_t)per_launch * per_item, ray_bytes = tiles * (size_t)per_launch * sizeof(uint32_t);
+        if (c->vsl_mask_bytes < mask_bytes + ray_bytes) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_vsl_masks); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
+            hipError_t e = hipMalloc((void **)&c->d_vsl_masks, mask_bytes + ray_bytes);
+            if (e != hipSuccess) { c->set_error("gather_vsl: cannot allocate %zu bytes of lit masks: %s", mask_bytes + ray_bytes, hipGetErrorString(e)); return EVPLP_ERR_OOM; }
+            c->vsl_mask_bytes = mask_bytes + ray_bytes;
+        }
+        a.vsl_masks = (unsigned long long *)c->d_vsl_masks;
+        a.vsl_item_rays = (uint32_t *)((char *)c->d_vsl_masks + mask_bytes);
+        HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
+        for (int g0 = 0; g0 < groups; g0 += per_launch) {
+            a.group_first = g0; a.group_count = std::min(per_launch, groups - g0);
+            launch_gather_vsl(a, c->stream);
+        }
+        a.group_first = 0; a.group_count = 0;
+        HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
+    } else {
+        HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
+        launch_gather_vpl_items(a, c->stream);
+        HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
+    }
     launch_gather_reduce(a, vsl ? 0 : 1, c->stream);
     c->pass_has_dom[pass] = true;
     return pass_end(c, pass);

@@ -45,6 +45,7 @@ struct evplp_context {
     float *d_rgb = nullptr;
     // gather workspace, allocated on the first gather (path-tracing / photon-only contexts never pay for it)
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
+    void *d_vsl_masks = nullptr; size_t vsl_mask_bytes = 0;    // VSL gather: lit masks + per-item ray counts of one launch (kernels.h GatherArgs)
 
     // splat workspace
     int32_t tiles_x = 0, tiles_y = 0; uint32_t bin_stride = 0, last_bin_entries = 0, last_bin_max = 0;   // bin_stride: slots per tile bin

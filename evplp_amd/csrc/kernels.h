@@ -46,6 +46,11 @@ struct GatherArgs {
     PassCounters *counters;
     int32_t splits_per_wave;          // k: a wave sums k consecutive splits (a power of two <= 32) and folds them in tree order
     int32_t block_h_log2;             // tiles are enumerated in blocks of 8 x (1 << block_h_log2) tiles
+    // a launch covers the groups [group_first, group_first + group_count) of every tile (group_count = 0: all 128 / k of them)
+    int32_t group_first, group_count;
+    // VSL gather (two kernels): lit-lane masks of every (item, VSL) of the launch, [item][k * masks_per_split], and the shadow rays of
+    // every item, written by gather_vsl_walk_kernel and read by gather_vsl_shade_kernel
+    unsigned long long *vsl_masks; uint32_t *vsl_item_rays; int32_t masks_per_split; int32_t pad1;
 };
 #ifndef EVPLP_VPL_SPLIT
 #define EVPLP_VPL_SPLIT 128
@@ -139,7 +144,8 @@ void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record
                         uint32_t *count_out, hipStream_t s);
 // VPL / VSL gather = the items, then one reduce
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s);
-void launch_gather_vsl(const GatherArgs &a, hipStream_t s);
+void launch_gather_vsl(const GatherArgs &a, hipStream_t s);        // walks, then estimators, of the launch's group range
+int gather_launch_tiles(const GatherArgs &a);                      // tiles a gather launch enumerates (whole blocks)
 void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s);
 void launch_gather_lvc(const GatherArgs &a, const evplp_record *records, hipStream_t s);
 void launch_path_trace(const PathTraceArgs &a, hipStream_t s);

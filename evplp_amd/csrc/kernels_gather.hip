@@ -1,6 +1,6 @@
 // The gather: per-pixel sum over all usable virtual lights with shadow-ray visibility.
 //   gather_vpl_kernel <- splatColor + vplSplat   (rt/lighttracing.cu:348-379, 275-346)
-//   gather_vsl_kernel <- splatSplotch + vslSplat (rt/lighttracing.cu:689-722, 596-686, 395-594)
+//   gather_vsl_walk_kernel + gather_vsl_shade_kernel <- splatSplotch + vslSplat (rt/lighttracing.cu:689-722, 596-686, 395-594)
 //
 // Work decomposition.  One work item = one wavefront = (8x8 pixel tile, split s of kVplSplit): lane =
 // pixel, and the item sums the compacted VPLs i with i % kVplSplit == s.  Items write float4 partial
@@ -89,10 +89,12 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
 // as a row strip keeps adjacent (8 for a whole image) -- so that the tiles in flight at one time are 2-D neighbours and
 // walk the same part of the tree: 107.6 ms against 110.8 ms for row-major order (cfg2, hard scene, same GPU).
 struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   // p: pixel index in the strip (W * local_rows < 2^32)
+// RANGE: the launch covers the groups [group_first, group_first + group_count) only (the VSL kernels; the VPL gather always launches all)
+template <bool RANGE = false>
 EV_DEV Item item_setup(const GatherArgs &a, int lane) {
     const StripDev &st = a.st;
     const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    const int groups = kVplSplit / a.splits_per_wave;
+    const int groups = RANGE ? a.group_count : kVplSplit / a.splits_per_wave;      // groups of this launch
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int tile_j = j / groups;
@@ -102,7 +104,7 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
     const int blk = tile / per_block, l = tile - blk * per_block;
     const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * sh + (l >> 3);
     Item t;
-    t.group = j - tile_j * groups;
+    t.group = (RANGE ? a.group_first : 0) + (j - tile_j * groups);
     t.has_tile = blk < nbx * nby && tx < tiles_x && ty < tiles_y;
     t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
     const int cly = max(min(t.ly, st.local_rows - 1), 0);
@@ -113,10 +115,11 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
 }
 
 // the texel index of item_setup alone (no row-strip division): what a kernel re-derives late instead of carrying it in registers
+template <bool RANGE = false>
 EV_DEV uint32_t item_texel(const GatherArgs &a, int lane) {
     const StripDev &st = a.st;
     const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    const int groups = kVplSplit / a.splits_per_wave;
+    const int groups = RANGE ? a.group_count : kVplSplit / a.splits_per_wave;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int tile = (j / groups) * 8 + xcd;
     const int shl = a.block_h_log2, per_block = 8 << shl, nbx = (tiles_x + 7) >> 3;
@@ -531,41 +534,53 @@ EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, con
 }
 
 #ifndef EVPLP_VSL_WAVES
-#define EVPLP_VSL_WAVES 4   // 128 VGPRs: the estimators need ~125; zero scratch (cfg5-shaped 1024^2 launch: 3 waves 200 ms, 4 waves 176 ms, 6 waves with 40 spills 172 ms)
+#define EVPLP_VSL_WAVES 4   // estimator kernel: 128 VGPRs (it needs ~125), zero scratch
 #endif
-constexpr int kVslChunk = 128;     // VSLs of one split whose lit masks wait in LDS between the two phases (1 KB per wavefront)
-// Two phases per chunk of a split's VSLs, because the walk and the estimators have disjoint register sets and together they
-// do not fit (round 2: one loop, 65 VGPR + 72 SGPR spills at 64 registers, 2-3 TB/s of scratch traffic):
-//   phase 1  the packet walk of every VSL of the chunk; all it keeps per lane is the pixel's position and normal; the 64-bit mask
-//            of lit lanes goes to LDS.  Lanes whose pair has a zero geometry term (c1 c2 <= 1e-9, lighttracing.cu:619) do not
-//            enter the walk: the reference traces their shadow ray and then discards the pair -- same radiance, fewer rays
-//            (the `rays` statistic counts the rays actually traced);
-//   phase 2  the estimators of the lit pairs, with the walk's registers dead, the rest of the G-buffer texel loaded only now
-//            and the VSL record in SGPRs.
-// k consecutive splits per wavefront, folded in the fixed tree of gather_vpl_kernel (the partial sums shrink by k).
-__global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherArgs a) {
-    extern __shared__ float s_lvl[];                   // one [192] block per level of the k-split fold
+// The VSL gather is TWO kernels, because the walk and the estimators have disjoint register sets and different needs (round 2: one
+// loop, 65 VGPR + 72 SGPR spills at 64 registers, 2-3 TB/s of scratch traffic; round 3 first as two phases of one kernel, then split):
+//   gather_vsl_walk_kernel   the packet walk of every VSL of the item, with the VPL gather's register budget (64 registers, 7 waves
+//                            per SIMD) and its hand-scheduled node visit; all it keeps per lane is the pixel's position and normal.
+//                            Lanes whose pair has a zero geometry term (c1 c2 <= 1e-9, lighttracing.cu:619) do not enter the walk:
+//                            the reference traces their shadow ray and then discards the pair -- same radiance, fewer rays (the
+//                            `rays` statistic counts the rays actually traced).  The 64-bit masks of lit lanes go to HBM, 1 KB per
+//                            128 VSLs, coalesced (8 bytes per (tile, VSL): 0.4 % of the estimators' time to write and read back);
+//   gather_vsl_shade_kernel  the estimators of the lit pairs: 128 registers, zero scratch, the VSL record in SGPRs.
+// Items are the VPL gather's: (tile, k consecutive splits), folded in its fixed tree (the partial sums shrink by k); a launch
+// covers a range of groups so that the mask buffer stays small (context.cpp).
+constexpr int kVslChunk = 128;     // lit masks staged in LDS, 1 KB per wavefront
+EV_DEV size_t vsl_mask_base(const GatherArgs &a, int tile_in_launch_order, int group) {
+    const int groups = a.group_count;
+    return ((size_t)tile_in_launch_order * groups + (size_t)(group - a.group_first)) * (size_t)(a.splits_per_wave * a.masks_per_split);
+}
+EV_DEV int launch_tile(const GatherArgs &a) {          // the tile's index in launch order (item_setup: tile = tile_j * 8 + xcd)
+    const int groups = a.group_count;
+    const int b = blockIdx.x;
+    return ((b >> 3) / groups) * 8 + (b & 7);
+}
+
+#if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
+__attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
+#endif
+__global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel(GatherArgs a) {
     __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
-    const int W = a.st.W;
-    const Item t = item_setup(a, lane);
+    const Item t = item_setup<true>(a, lane);
     if (!t.has_tile) return;
     const bool valid = t.in_image;                      // no stencil test in splatSplotch (:694-695)
-    const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
     const uint32_t nvpl = *a.nvpl;
     const int k = a.splits_per_wave;
     const char *node_base = pinned(reinterpret_cast<const char *>(a.sc.nodes)), *leaf_base = pinned(reinterpret_cast<const char *>(a.sc.leaves));
     const evplp_record *vpls = pinned(a.vpls);
     V3 p1, n1;
     { const float4 gp = a.g_pos[t.p], gn = a.g_nrm[t.p]; p1 = v3(gp); n1 = v3(gn); }
-    V3 total = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0, nlit = 0, nsamp = 0;
+    const int tile_l = launch_tile(a);
+    unsigned long long *masks = a.vsl_masks + vsl_mask_base(a, tile_l, t.group);
+    uint32_t rays = 0;
     for (int jj = 0; jj < k; jj++) {
         const uint32_t split = (uint32_t)(t.group * k + jj);
-        V3 result = v3(0.f, 0.f, 0.f);
-        for (uint32_t first = split; first < nvpl; first += (uint32_t)(kVplSplit * kVslChunk)) {
+        uint32_t cbase = 0;
+        for (uint32_t first = split; first < nvpl; first += (uint32_t)(kVplSplit * kVslChunk), cbase += (uint32_t)kVslChunk) {
             const uint32_t n = min((uint32_t)kVslChunk, (nvpl - first + (uint32_t)kVplSplit - 1u) / (uint32_t)kVplSplit);
-            // ---- phase 1: visibility
             for (uint32_t c = 0; c < n; c++) {
                 const uint32_t i = first + c * (uint32_t)kVplSplit;
                 V3 vpos, vn; float vpsel; fetch_vpl_head(vpls, i, vpos, vn, vpsel);
@@ -577,25 +592,59 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
                 unsigned long long lit = 0ull;
                 if (ballot64(pre) != 0ull) {
                     rays += pre ? 1u : 0u;
-                    const bool occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, pre);   // :612-614
+                    const bool occ = occluded_wave<EVPLP_WALK_ASM ? 52 : 0>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, pre);   // :612-614
                     lit = ballot64(pre && !occ);
                 }
                 if (lane == 0) s_lit[c] = lit;          // (single-wavefront workgroup: LDS is in order, no barrier)
             }
-            // ---- phase 2: the estimators of the lit pairs
-            int lane2 = lane;
-            asm volatile("" : "+v"(lane2));             // the texel index is formed again and the texel fetched HERE, not above the walks
-            const uint32_t pidx = item_texel(a, lane2);
-            Pixel px; px.p1 = p1; px.n1 = n1;
-            { const float4 gd = a.g_dif[pidx], gs = a.g_phg[pidx]; px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w; }
-            px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);   // :704
-            VslPixel P;
-            {
-                const float ml = max_color(px.rd), mp = max_color(px.rs);
-                P.dead = ml + mp <= 0.000001f; P.psel = ml / (mp + ml);
-                P.glossy = px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f; P.pdf_glossy = !(px.rs.x <= 0.000001f);
-                P.R1 = reflect(-px.wi10, px.n1);
-            }
+            // the chunk's masks leave as one coalesced store (two per lane)
+            unsigned long long *dst = masks + (size_t)jj * a.masks_per_split + cbase;
+            for (uint32_t q = (uint32_t)lane; q < n; q += 64u) dst[q] = s_lit[q];
+        }
+    }
+    // shadow rays of the item (per lane < 65536), summed over the wavefront for the statistics
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if (lane == 0) a.vsl_item_rays[(size_t)tile_l * a.group_count + (t.group - a.group_first)] = rays;
+}
+
+__global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(GatherArgs a) {
+    extern __shared__ float s_lvl[];                   // one [192] block per level of the k-split fold
+    __shared__ unsigned long long s_lit[kVslChunk];
+    const int lane = threadIdx.x;
+    const int W = a.st.W;
+    const Item t = item_setup<true>(a, lane);
+    if (!t.has_tile) return;
+    const bool valid = t.in_image;
+    const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
+    const uint32_t nvpl = *a.nvpl;
+    const int k = a.splits_per_wave;
+    const evplp_record *vpls = pinned(a.vpls);
+    const int tile_l = launch_tile(a);
+    const unsigned long long *masks = a.vsl_masks + vsl_mask_base(a, tile_l, t.group);
+    Pixel px;
+    { const float4 gp = a.g_pos[t.p], gn = a.g_nrm[t.p], gd = a.g_dif[t.p], gs = a.g_phg[t.p]; px.p1 = v3(gp); px.n1 = v3(gn); px.rd = v3(gd); px.rs = v3(gs); px.e = gs.w; }
+    px.wi10 = normalize(v3(a.fp.camera_pos) - px.p1);   // :704
+    VslPixel P;
+    {
+        const float ml = max_color(px.rd), mp = max_color(px.rs);
+        P.dead = ml + mp <= 0.000001f; P.psel = ml / (mp + ml);
+        P.glossy = px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f; P.pdf_glossy = !(px.rs.x <= 0.000001f);
+        P.R1 = reflect(-px.wi10, px.n1);
+    }
+    V3 total = v3(0.f, 0.f, 0.f);
+    uint32_t cnt = 0;                                   // lit pairs (low 12 bits: context.cpp keeps an item within 4095 VSLs) | sample-iterations << 12 (<= 101 x 4095 < 2^20)
+    for (int jj = 0; jj < k; jj++) {
+        const uint32_t split = (uint32_t)(t.group * k + jj);
+        V3 result = v3(0.f, 0.f, 0.f);
+        uint32_t cbase = 0;
+        for (uint32_t first = split; first < nvpl; first += (uint32_t)(kVplSplit * kVslChunk), cbase += (uint32_t)kVslChunk) {
+            const uint32_t n = min((uint32_t)kVslChunk, (nvpl - first + (uint32_t)kVplSplit - 1u) / (uint32_t)kVplSplit);
+            uint32_t moff = (uint32_t)jj * (uint32_t)a.masks_per_split + cbase;
+            asm volatile("" : "+s"(moff));             // (a scalar offset formed here: as an induction variable the per-lane address was the one spill left)
+            const unsigned long long *src = masks + moff;
+            uint32_t q0 = (uint32_t)lane;
+            asm volatile("" : "+v"(q0));
+            for (uint32_t q = q0; q < n; q += 64u) s_lit[q] = src[q];        // coalesced; single-wavefront workgroup: no barrier
             for (uint32_t c = 0; c < n; c++) {
                 const unsigned long long lit = s_lit[c];
                 const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)lit), hi = __builtin_amdgcn_readfirstlane((uint32_t)(lit >> 32));
@@ -604,7 +653,6 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
                 Vpl v; fetch_vpl_head(vpls, i, v.pos, v.n, v.psel); fetch_vpl_tail(vpls, i, v);
                 const bool lit_lane = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
                 if (lit_lane) {
-                    nlit++;
                     const V3 v12 = v.pos - px.p1;
                     const float dist = sqrtf(dot(v12, v12));
                     const V3 nv12 = v12 / dist;
@@ -616,11 +664,9 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
                     cx.inv_solid_angle = vslm::rcp(cx.solid_angle);
                     cx.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; cx.nd12 = nv12;
                     const int num_samples = (int)(cx.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
-                    nsamp += (uint32_t)num_samples;
+                    cnt += ((uint32_t)num_samples << 12) + 1u;
                     // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
-                    uint32_t pid = pixel_id;
-                    asm volatile("" : "+v"(pid));      // (keeps the seed arithmetic here: hoisted above the loops its 64-bit partial result was the one spill left)
-                    Rng rng; rng_init(rng, pid, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
+                    Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
                     VslLight L;
                     {
                         const float ml = max_color(v.rd), mp = max_color(v.rs);
@@ -655,18 +701,26 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_kernel(GatherA
         total = result;
     }
     // sample-iterations of the item (the unit the estimators' work is priced in): one add per wavefront into 64 counter shards
+    const uint32_t nlit = cnt & 4095u;
+    uint32_t nsamp = cnt >> 12;
     for (int off = 32; off > 0; off >>= 1) nsamp += __shfl_down(nsamp, off);
     if (lane == 0) atomicAdd(&a.counters->hist[blockIdx.x & 63u], (unsigned long long)nsamp);
-    int lane3 = lane;
-    asm volatile("" : "+v"(lane3));                 // (the store address is formed here, not carried through both phases)
-    if (valid) a.partial[(size_t)t.group * a.partial_stride + item_texel(a, lane3)] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (nlit << 16)));
+    // the item's shadow rays were counted by the walk kernel per wavefront: the reduce kernel sums per-pixel words, lane 0's carries them
+    // (an item's rays: at most 64 lanes x 512 VSLs = 32768 < 65536)
+    const uint32_t item_rays = a.vsl_item_rays[(size_t)tile_l * a.group_count + (t.group - a.group_first)];
+    int lane_out = lane, blk_out = (int)blockIdx.x;
+    asm volatile("" : "+v"(lane_out), "+s"(blk_out));   // (the store address is formed here, not carried through the estimators)
+    const int group_out = a.group_first + (blk_out >> 3) % a.group_count;
+    if (valid) a.partial[(size_t)group_out * a.partial_stride + item_texel<true>(a, lane_out)] = make_float4(total.x, total.y, total.z, __uint_as_float((lane == 0 ? item_rays : 0u) | (nlit << 16)));
 }
 
-static dim3 gather_grid(const GatherArgs &a) {
-    const int groups = kVplSplit / a.splits_per_wave;
+int gather_launch_tiles(const GatherArgs &a) {                    // tiles of a launch: whole blocks of 8 x (1 << block_h_log2)
     const int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8, sh = 1 << a.block_h_log2;
-    const int tiles = ((tiles_x + 7) / 8) * ((tiles_y + sh - 1) / sh) * 8 * sh;      // whole blocks
-    return dim3((unsigned)(tiles * groups));                     // tile = tile_j * 8 + xcd
+    return ((tiles_x + 7) / 8) * ((tiles_y + sh - 1) / sh) * 8 * sh;
+}
+static dim3 gather_grid(const GatherArgs &a) {
+    const int groups = a.group_count > 0 ? a.group_count : kVplSplit / a.splits_per_wave;
+    return dim3((unsigned)(gather_launch_tiles(a) * groups));     // tile = tile_j * 8 + xcd
 }
 void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) {
     size_t n = (size_t)a.st.W * a.st.local_rows;
@@ -680,7 +734,8 @@ void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vsl_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
+    hipLaunchKernelGGL(gather_vsl_walk_kernel, gather_grid(a), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(gather_vsl_shade_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
 }
 
 } // namespace evplp
