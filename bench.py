@@ -499,7 +499,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
             else:
                 flop = FLOP_PER_PAIR if mis in ("one", "geometryClamp", "geometryBrdfClamp") else FLOP_PER_PAIR_MIS
                 flop_total = (rays_local / len(ranks)) / steps * flop
-            kname = "gather_vsl_kernel" if wl == "vsl" else "gather_vpl_kernel"
+            kname = "gather_vsl_walk_kernel + gather_vsl_shade_kernel" if wl == "vsl" else "gather_vpl_kernel"
             achieved = flop_total / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             out["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,

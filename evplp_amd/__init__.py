@@ -116,6 +116,7 @@ _SIGNATURES = {
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_accel_builder": (C.c_int, [_P]),
+    "evplp_accel_stack_entries": (C.c_int, [_P]),
     "evplp_selftest": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_group_create": (C.c_int, [C.POINTER(Config), _P, C.POINTER(_P)]),
     "evplp_group_destroy": (None, [_P]),
@@ -307,7 +308,7 @@ class Context:
         self._check(self._lib.evplp_accel_info(self._h, C.byref(n), C.byref(l), C.byref(d), C.byref(ms)))
         b = self._lib.evplp_accel_builder(self._h)
         return {"nodes": n.value, "leaves": l.value, "depth": d.value, "build_ms": ms.value,
-                "builder": {0: "lbvh", 1: "sah", 2: "sbvh", 3: "gpu"}.get(b, "none")}
+                "builder": {0: "lbvh", 1: "sah", 2: "sbvh", 3: "gpu"}.get(b, "none"), "stack4_entries": self._lib.evplp_accel_stack_entries(self._h)}
 
     def selftest(self, which: int = 0) -> np.ndarray:
         out = np.zeros(8, dtype=np.uint64)

@@ -178,7 +178,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
-    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks);
+    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_lt_overflow);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
     hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -383,6 +383,28 @@ extern "C" int evplp_build_accel(evplp_context *c) {
         if ((rc = upload_array(c, bb.tri_flat, (size_t)std::max(bb.nleaves, 1) * 4, &c->sc.tri_flat))) { free_bvh(&bb); return rc; }
     }
     c->sc.ntris = bb.ntris; c->sc.bvh_depth = bb.depth;
+    {
+        // Worst-case stack of the four-wide per-lane walk (closest_lane4: a visit pushes every entered grandchild but the nearest) over
+        // the tree that was built: need(i) = (grandchildren of i) - 1 + max over inner grandchildren g of need(g).  Inner nodes are stored in
+        // pre-order (children after parents), so one backward sweep does it.  The LDS stack is what limits the occupancy of light tracing.
+        std::vector<BvhNode> host_nodes;
+        const BvhNode *hn = bb.nodes;
+        if (!hn) { host_nodes.resize((size_t)bb.nnodes); HIP_TRY(c, hipMemcpy(host_nodes.data(), c->sc.nodes, sizeof(BvhNode) * (size_t)bb.nnodes, hipMemcpyDeviceToHost)); hn = host_nodes.data(); }
+        std::vector<int32_t> need((size_t)bb.nnodes, 0);
+        bool ordered = true;
+        for (int32_t i = bb.nnodes - 1; i >= 0; i--) {
+            int32_t g[4]; int m = 0;
+            const int32_t ch[2] = { hn[i].c0, hn[i].c1 };
+            for (int s2 = 0; s2 < 2; s2++) {
+                if (ch[s2] >= 0) { if (ch[s2] <= i) ordered = false; g[m++] = hn[ch[s2]].c0; g[m++] = hn[ch[s2]].c1; }
+                else if (ch[s2] != kNoChild) g[m++] = ch[s2];
+            }
+            int32_t valid = 0, deepest = 0;
+            for (int q = 0; q < m; q++) if (g[q] != kNoChild) { valid++; if (g[q] >= 0) { if (g[q] <= i) ordered = false; else deepest = std::max(deepest, need[(size_t)g[q]]); } }
+            need[(size_t)i] = std::max(valid - 1, 0) + deepest;
+        }
+        c->sc.stack4_entries = ordered && bb.nnodes > 0 ? need[0] + 2 : 0;      // (0: not pre-ordered -- the generic bound of the depth applies)
+    }
     { BvhNode4 *n4 = nullptr; const int e4 = build_nodes4(c->sc.nodes, bb.nnodes, c->stream, &n4);
       if (e4 != 0) { free_bvh(&bb); c->set_error("evplp_build_accel: four-wide nodes: %s", hipGetErrorString((hipError_t)e4)); return EVPLP_ERR_HIP; }
       c->sc.nodes4 = n4; }
@@ -413,6 +435,7 @@ extern "C" int evplp_scene_metrics(evplp_context *c, float *r, float *total, flo
     if (r) *r = c->bounding_radius; if (total) *total = c->total_area; if (light) *light = c->light_area;
     return EVPLP_OK;
 }
+extern "C" int evplp_accel_stack_entries(const evplp_context *c) { return (c && c->accel_built) ? c->sc.stack4_entries : -1; }
 extern "C" int evplp_accel_info(evplp_context *c, int32_t *nodes, int32_t *leaves, int32_t *depth, float *build_ms) {
     CTX_CHECK(c);
     if (nodes) *nodes = c->accel_nodes; if (leaves) *leaves = c->accel_leaves; if (depth) *depth = c->accel_depth; if (build_ms) *build_ms = c->accel_build_ms;
@@ -552,6 +575,17 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
     LightTraceArgs a; std::memset(&a, 0, sizeof(a));
     a.sc = c->sc; a.rng_seed = rng_seed; a.path_begin = path_begin; a.path_count = path_count; a.photons_per_path = c->cfg.photons_per_path;
     a.records = (evplp_record *)c->buf[EVPLP_BUF_RECORDS];
+    {   // overflow columns of the walk stack (kernels.h): sized for the largest launch so far
+        const size_t threads = ((size_t)path_count + 63) / 64 * 64, need = threads * (size_t)lt_overflow_entries(c->sc) * sizeof(int32_t);
+        if (need > c->lt_overflow_bytes) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); if (c->aux_stream) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+            hipFree(c->d_lt_overflow); c->d_lt_overflow = nullptr; c->lt_overflow_bytes = 0;
+            hipError_t me = hipMalloc((void **)&c->d_lt_overflow, need);
+            if (me != hipSuccess) { c->set_error("evplp_trace_light_paths: stack overflow area: %s", hipGetErrorString(me)); return EVPLP_ERR_OOM; }
+            c->lt_overflow_bytes = need;
+        }
+        a.stack_overflow = c->d_lt_overflow; a.overflow_stride = (uint32_t)threads;
+    }
     if (!c->aux_stream) {
         if ((rc = pass_begin(c, EVPLP_PASS_LIGHT_TRACE))) return rc;
         launch_light_trace(a, c->stream);
@@ -655,7 +689,7 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         const size_t mask_bytes = tiles * (size_t)per_launch * per_item, ray_bytes = tiles * (size_t)per_launch * sizeof(uint32_t);
         if (c->vsl_mask_bytes < mask_bytes + ray_bytes) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_vsl_masks); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
+            hipFree(c->d_vsl_masks); hipFree(c->d_lt_overflow); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
             hipError_t e = hipMalloc((void **)&c->d_vsl_masks, mask_bytes + ray_bytes);
             if (e != hipSuccess) { c->set_error("gather_vsl: cannot allocate %zu bytes of lit masks: %s", mask_bytes + ray_bytes, hipGetErrorString(e)); return EVPLP_ERR_OOM; }
             c->vsl_mask_bytes = mask_bytes + ray_bytes;

@@ -45,6 +45,7 @@ struct evplp_context {
     float *d_rgb = nullptr;
     // gather workspace, allocated on the first gather (path-tracing / photon-only contexts never pay for it)
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
+    int32_t *d_lt_overflow = nullptr; size_t lt_overflow_bytes = 0;   // light tracing: the walk stack beyond its LDS entries (kernels.h)
     void *d_vsl_masks = nullptr; size_t vsl_mask_bytes = 0;    // VSL gather: lit masks + per-item ray counts of one launch (kernels.h GatherArgs)
 
     // splat workspace

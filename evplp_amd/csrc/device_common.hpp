@@ -758,9 +758,20 @@ EV_DEV void node4_slabs(const BvhNode4 &n, V3 inv, V3 noi, float tmin, float tma
         tn[q] = slab_near(lo, hi, inv, noi, tmin, tmax, h[q]);
     }
 }
-template <int STACK_STRIDE>
+// Stack of the four-wide walk: the first LDS_ENTRIES entries in LDS ([entry][lane]), the rest -- reached only by rays that defer more
+// children than any ray of the test scenes ever did -- in a per-thread column of global memory (ovf[k * ovf_stride]).  The worst case
+// for a tree (3 pushes per four-wide level: 46 entries for the 31-level tree of the bench scene, 12 KB of LDS per wave, 3 waves per
+// SIMD) would otherwise set the occupancy of every launch.  LDS_ENTRIES = 0: everything in `stack` (sized for the worst case).
+template <int STACK_STRIDE, int LDS_ENTRIES = 0>
 EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
-                             float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */) {
+                             float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */,
+                             int32_t *ovf = nullptr, uint32_t ovf_stride = 0) {
+    auto push = [&](int sp_, int32_t v) {
+        if (LDS_ENTRIES == 0 || sp_ < LDS_ENTRIES) stack[sp_ * STACK_STRIDE] = v; else ovf[(size_t)(sp_ - LDS_ENTRIES) * ovf_stride] = v;
+    };
+    auto top = [&](int sp_) -> int32_t {
+        return (LDS_ENTRIES == 0 || sp_ < LDS_ENTRIES) ? stack[sp_ * STACK_STRIDE] : ovf[(size_t)(sp_ - LDS_ENTRIES) * ovf_stride];
+    };
     V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int32_t best = -1; float bt = tmax, bb = 0.f, bg = 0.f;
@@ -780,12 +791,12 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
                            const int32_t cc = sw ? c[j_] : c[i_]; c[j_] = sw ? c[i_] : c[j_]; c[i_] = cc; }
             EV_CSWAP(0, 1) EV_CSWAP(2, 3) EV_CSWAP(0, 2) EV_CSWAP(1, 3) EV_CSWAP(1, 2)
 #undef EV_CSWAP
-            if (c[3] != kNoChild) { stack[sp * STACK_STRIDE] = c[3]; sp++; }
-            if (c[2] != kNoChild) { stack[sp * STACK_STRIDE] = c[2]; sp++; }
-            if (c[1] != kNoChild) { stack[sp * STACK_STRIDE] = c[1]; sp++; }
+            if (c[3] != kNoChild) { push(sp, c[3]); sp++; }
+            if (c[2] != kNoChild) { push(sp, c[2]); sp++; }
+            if (c[1] != kNoChild) { push(sp, c[1]); sp++; }
             if (c[0] != kNoChild) cur = c[0];
             else if (sp == 0) { done = true; break; }
-            else { --sp; cur = stack[sp * STACK_STRIDE]; }
+            else { --sp; cur = top(sp); }
         }
         if (done) break;
         if (cur != kNoChild) {
@@ -802,7 +813,7 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
             }
         }
         if (sp == 0) break;
-        --sp; cur = stack[sp * STACK_STRIDE];
+        --sp; cur = top(sp);
     }
     if (best >= 0) { t_out = bt; beta_out = bb; gamma_out = bg; }
     return best;

@@ -90,6 +90,8 @@ struct SceneDev {
     const float *light_cdf;      // normalised area CDF of the light mesh
     int32_t ntris;               // triangles in the BVH (degenerate ones dropped)
     int32_t bvh_depth;           // deepest leaf: sizes the per-lane traversal stacks (dynamic LDS)
+    int32_t stack4_entries;      // worst-case stack of the four-wide per-lane walk over THIS tree (computed at build time; see evplp_build_accel)
+    int32_t pad_sc;
     int32_t light_first, light_count; // ORIGINAL triangle index range of the light mesh
     float light_area;
     float light_intensity[4];    // (I*pi, w)

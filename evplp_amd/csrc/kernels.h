@@ -15,7 +15,15 @@ struct LightTraceArgs {
     SceneDev sc;
     uint32_t rng_seed, path_begin, path_count, photons_per_path;
     evplp_record *records;
+    int32_t *stack_overflow;      // [lt_overflow_entries(sc)][path_count rounded up to 64]: the walk's stack beyond its LDS entries
+    uint32_t overflow_stride, pad;
 };
+constexpr int kLtLdsStack = 20;   // LDS entries of light tracing's walk stack (5 KB per wave); the rest of the worst case lives in global memory
+inline int lt_overflow_entries(const SceneDev &sc) {
+    const int generic = 3 * ((sc.bvh_depth + 1) / 2) + 4;
+    const int worst = sc.stack4_entries > 0 && sc.stack4_entries < generic ? sc.stack4_entries : generic;
+    return worst > kLtLdsStack ? worst - kLtLdsStack : 0;
+}
 
 // Device-side counters of one pass (zeroed by the host before the launch)
 struct PassCounters {
@@ -133,10 +141,13 @@ constexpr int kCompactF4 = 4;        // float4 per compact photon
 // dynamic LDS of the kernels that walk the BVH one ray per lane: an [entry][lane] stack as deep as the tree
 inline size_t lane_stack_bytes(const SceneDev &sc) { return (size_t)(sc.bvh_depth + 2) * 64 * sizeof(int32_t); }
 // (four-wide walk: every second level of the binary tree, up to three pushes per level)
-// (Measured, round 3: this worst-case stack -- 13 KB per wave for a 31-level tree -- is what limits light tracing to 3 waves per SIMD.  An
-// UNSAFE 24-entry stack with 5 waves per SIMD traced config #4's 300 k paths in 0.436 ms instead of 0.514; a safe version needs an
-// overflow area in global memory behind a branch at every push and pop, and buys ~0.05 ms of a 0.66 ms iteration: not done.)
-inline size_t lane_stack_bytes4(const SceneDev &sc) { return (size_t)(3 * ((sc.bvh_depth + 1) / 2) + 4) * 64 * sizeof(int32_t); }
+// (four-wide walk: up to three pushes per visit.  3 x levels / 2 is the bound for ANY tree of that depth -- 13 KB per wave for a 31-level
+// tree, three waves per SIMD; the bound for THE tree that was built, computed once by evplp_build_accel, is about half of it)
+inline size_t lane_stack_bytes4(const SceneDev &sc) {
+    const int generic = 3 * ((sc.bvh_depth + 1) / 2) + 4;
+    const int entries = sc.stack4_entries > 0 ? (sc.stack4_entries < generic ? sc.stack4_entries : generic) : generic;
+    return (size_t)entries * 64 * sizeof(int32_t);
+}
 
 void launch_primary(const PrimaryArgs &a, hipStream_t s);
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s);

@@ -112,10 +112,11 @@ EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float ps
     q[5] = make_float4(rs.x, rs.y, rs.z, e);
 }
 
-// four-wide nodes, 4 waves per SIMD (128 registers, no spills): 300 000 paths are 4.6 waves per SIMD anyway.  Config #4's light
-// tracing: binary nodes 627 us, four-wide at 7 waves (108 B of spills) 587, at 4 waves 553
+// four-wide nodes; 5 waves per SIMD (96 registers, no spills) with the first 20 stack entries in LDS and the rest of the worst case in
+// global memory (closest_lane4): the worst-case LDS stack alone allowed 3 waves per SIMD.  Config #4's light tracing (300 000 paths):
+// round 2 binary nodes 627 us, four-wide 553; round 3 (peeled tree) 511 us at 3 waves per SIMD
 #ifndef EVPLP_LT_WAVES
-#define EVPLP_LT_WAVES 4
+#define EVPLP_LT_WAVES 5
 #endif
 __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTraceArgs a) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTr
     for (uint32_t i = 1; i < P; i++) {
         uint32_t flag = (i != P - 1) ? (EVPLP_USABLE_VPL | EVPLP_USABLE_PHOTON) : EVPLP_USABLE_PHOTON;
         float t, b, g;
-        int32_t tri = closest_lane4<64>(a.sc, next_pos, next_dir, 0.0001f, 3.0e38f, 0, t, b, g, stack);
+        int32_t tri = closest_lane4<64, kLtLdsStack>(a.sc, next_pos, next_dir, 0.0001f, 3.0e38f, 0, t, b, g, stack, a.stack_overflow + local, a.overflow_stride);
         if (tri < 0) break;  // no miss program in the reference; a miss ends the path here
         const TriAttr &ta = a.sc.attrs[tri];
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
@@ -223,7 +224,7 @@ void launch_primary(const PrimaryArgs &a, hipStream_t s) {
 }
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s) {
     if (a.path_count == 0) return;
-    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), lane_stack_bytes4(a.sc), s, a);
+    hipLaunchKernelGGL(light_trace_kernel, dim3((a.path_count + 63) / 64), dim3(64), (size_t)kLtLdsStack * 64 * sizeof(int32_t), s, a);
 }
 void launch_compact_vpl(const evplp_record *records, uint32_t nrec, evplp_record *out, uint32_t *src_index,
                         uint32_t *count_out, hipStream_t s) {

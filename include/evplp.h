@@ -258,6 +258,8 @@ int evplp_accel_info(evplp_context *ctx, int32_t *nodes, int32_t *leaves, int32_
  * EVPLP_BVH_BUILDER was set when the context was created, or an LBVH came out deeper than the walks' 64-entry stacks and the
  * binned-SAH builder took over.  < 0 before the first build. */
 int evplp_accel_builder(const evplp_context *ctx);
+/* Worst-case stack entries of the four-wide per-lane walk over the tree that was built (0: the generic bound of the depth applies). */
+int evplp_accel_stack_entries(const evplp_context *ctx);
 /* Device-side self checks: facts the kernels rely on, verified on the GPU they run on.  which = 0: the 7-instruction exact
  * reciprocal of the triangle predicates against the IEEE division on all 2^32 float bit patterns (under a second): out[0]
  * patterns whose bits differ, [1] of them zero / denormal inputs, [2] infinite / NaN inputs, [3] normal inputs, [4] / [5] the

@@ -124,4 +124,4 @@ def test_bench_default_extras_small():
     assert p["roofline"]["bound"] == "hbm" and p["ms_per_iteration"] > 0 and p["feeders"]["light_trace"]["ms"] > 0 and p["feeders"]["primary"]["ms"] > 0
     assert 0.7 <= p["render_json"]["ratio_to_ms_per_step"] <= 1.4, p["render_json"]
     v = d["vsl"]["roofline"]
-    assert v["kernel"] == "gather_vsl_kernel" and v["sample_iterations_per_frame"] > v["lit_pairs_per_frame"] > 0
+    assert v["kernel"].startswith("gather_vsl_walk_kernel") and v["sample_iterations_per_frame"] > v["lit_pairs_per_frame"] > 0

@@ -12,4 +12,4 @@ for n in [int(x) for x in (sys.argv[1:] or ["75000", "150000", "300000", "600000
         for it in range(6):
             c.trace_light_paths(it); c.synchronize(); ms.append(c.pass_stats(ev.PASS_LIGHT_TRACE)["ms"])
         m = sum(ms[2:]) / len(ms[2:])
-        print(n, "paths: %.3f ms -> %.0f Mpaths/s, %.2f waves/SIMD" % (m, n / m / 1e3, n / 64 / 1024), c.accel_info()["depth"], flush=True)
+        print(n, "paths: %.3f ms -> %.0f Mpaths/s, %.2f waves/SIMD" % (m, n / m / 1e3, n / 64 / 1024), c.accel_info(), flush=True)
