@@ -689,7 +689,7 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         const size_t mask_bytes = tiles * (size_t)per_launch * per_item, ray_bytes = tiles * (size_t)per_launch * sizeof(uint32_t);
         if (c->vsl_mask_bytes < mask_bytes + ray_bytes) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_vsl_masks); hipFree(c->d_lt_overflow); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
+            hipFree(c->d_vsl_masks); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
             hipError_t e = hipMalloc((void **)&c->d_vsl_masks, mask_bytes + ray_bytes);
             if (e != hipSuccess) { c->set_error("gather_vsl: cannot allocate %zu bytes of lit masks: %s", mask_bytes + ray_bytes, hipGetErrorString(e)); return EVPLP_ERR_OOM; }
             c->vsl_mask_bytes = mask_bytes + ray_bytes;
