@@ -492,6 +492,17 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                             "note": "light_trace_kernel (tracePhotons + closest hit, lighttracing.cu:192-250): one light path per lane, <= 3 rays per path; "
                                     "waves_per_simd = wavefronts of the launch / 1024 SIMDs -- far below the ~8 a latency-bound walk wants"},
         }
+        # the feeders against the only roofline their outputs give them (their work is the BVH walk, which has no algorithmic byte or
+        # flop count: SURVEY 8d prices neither): bytes they must write / HIP-event time of the pass
+        px_rank = W * H / max(n_ranks, 1)
+        for key, nbytes, what in (("primary", px_rank * 80.0, "G-buffer 4 x 16 B + light plane 16 B per pixel of this rank's strip"),
+                                  ("light_trace", n_light * float(P) * 96.0 / max(n_ranks if (group is not None or (use_dist and split_paths)) else 1, 1), "96-B record slots written by this rank")):
+            ms = out["feeders"][key]["ms"]
+            if ms:
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                out["feeders"][key]["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                                   "algorithmic_bytes": nbytes, "traffic": None,
+                                                   "note": what + "; the pass is a latency-bound BVH walk (one wave per 8x8 tile / one light path per lane), far from this bound by construction"}
         if wl != "ppm":
             if wl == "vsl":
                 flop_total = samples / steps / max(n_ranks, 1) * FLOP_PER_VSL_SAMPLE      # this rank's launch
