@@ -137,9 +137,11 @@ __device__ __forceinline__ Bx load_box_agent(const Bx *p) {
     }
     return b;
 }
-// bottom-up boxes; also the depth of every leaf in KEPT nodes (more than 4 triangles) -> deepest path
+// bottom-up boxes; also the height of the tree in KEPT nodes (more than 4 triangles), carried up with the boxes: the second
+// arrival at a node owns it and takes max(children) + 1.  (Round 2 let every leaf thread walk its whole ancestor chain to count:
+// O(n depth), quadratic on the long chains that clustered or duplicate Morton codes produce.)
 __global__ __launch_bounds__(256) void refit_kernel(const Bx *tbox, const int32_t *ids, int n, const Topo *topo, const int32_t *parent_int, const int32_t *parent_leaf,
-                                                    Bx *lbox, Bx *ibox, uint32_t *visits, uint32_t *max_depth) {
+                                                    Bx *lbox, Bx *ibox, uint32_t *visits, uint32_t *height, uint32_t *max_depth) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     Bx b = tbox[ids[j]];
@@ -147,21 +149,22 @@ __global__ __launch_bounds__(256) void refit_kernel(const Bx *tbox, const int32_
     if (n == 1) return;
     __threadfence();
     int cur = parent_leaf[j];
-    uint32_t depth_kept = 0;
-    bool owner = true;
-    // count the kept ancestors (every thread), own the boxes (the second arrival)
-    for (int a = cur; a >= 0; a = parent_int[a]) if (topo[a].last - topo[a].first + 1 > kMaxLeafTris) depth_kept++;
-    atomicMax(max_depth, depth_kept);
-    while (cur >= 0 && owner) {
-        if (atomicAdd(&visits[cur], 1u) == 0u) { owner = false; break; }
+    while (cur >= 0) {
+        if (atomicAdd(&visits[cur], 1u) == 0u) break;                    // the first arrival leaves; its subtree is complete and visible
         __threadfence();
         const Topo tp = topo[cur];
         const Bx l = load_box_agent(tp.left < 0 ? &lbox[~tp.left] : &ibox[tp.left]), r = load_box_agent(tp.right < 0 ? &lbox[~tp.right] : &ibox[tp.right]);
+        const uint32_t hl = tp.left < 0 ? 0u : __hip_atomic_load(&height[tp.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t hr = tp.right < 0 ? 0u : __hip_atomic_load(&height[tp.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t h = max(hl, hr) + (tp.last - tp.first + 1 > kMaxLeafTris ? 1u : 0u);
         Bx u;
         for (int k = 0; k < 3; k++) { u.lo[k] = fminf(l.lo[k], r.lo[k]); u.hi[k] = fmaxf(l.hi[k], r.hi[k]); }
         ibox[cur] = u;
+        height[cur] = h;
         __threadfence();
-        cur = parent_int[cur];
+        const int up = parent_int[cur];
+        if (up < 0) *max_depth = h;                                       // the root: one writer
+        cur = up;
     }
 }
 
@@ -342,7 +345,7 @@ int build_bvh_gpu(const float *verts_host, int32_t ntri, float pad_scale, hipStr
     if (n > 0) {
         const unsigned gn = (unsigned)((n + 255) / 256);
         if (n > 1) hipLaunchKernelGGL(hierarchy_kernel, dim3(gn), dim3(256), 0, stream, keys2, n, topo, parent_int, parent_leaf);
-        hipLaunchKernelGGL(refit_kernel, dim3(gn), dim3(256), 0, stream, tbox, ids2, n, topo, parent_int, parent_leaf, lbox, ibox, visits, &scal[0]);
+        hipLaunchKernelGGL(refit_kernel, dim3(gn), dim3(256), 0, stream, tbox, ids2, n, topo, parent_int, parent_leaf, lbox, ibox, visits, new_id /* free until the scan below: node heights */, &scal[0]);
         if (n > 1) hipLaunchKernelGGL(collapse_kernel, dim3(gn), dim3(256), 0, stream, topo, n, kept, head);
         else GB_TRY(hipMemsetAsync(head, 0, 4, stream));
         if (n == 1) { const uint32_t one = 1u; GB_TRY(hipMemcpyAsync(head, &one, 4, hipMemcpyHostToDevice, stream)); }
