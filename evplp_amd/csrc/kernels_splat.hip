@@ -29,6 +29,10 @@ namespace evplp {
 // d^e on the hardware transcendentals (d in (1e-5, 1]): exp2(e log2 d), relative error ~0.7 e |log2 d| 2^-22, i.e. 2e-6 where the lobe is
 // still 1e-4 of its peak, against the stated bars of 1e-5 (image) / 2e-4 (pixel); the library powf is ~170 instructions and ran twice per
 // photon in the bin kernel and once per shaded (photon, pixel) pair of a glossy tile
+// ... and 1-ulp hardware reciprocals / reciprocal square roots instead of the IEEE-correct expansions (~10 instructions each; the bin kernel
+// had eleven divisions and two square roots per photon)
+EV_DEV float rcp_hw(float x) { return __builtin_amdgcn_rcpf(x); }
+EV_DEV V3 normalize_hw(V3 v) { return v * __builtin_amdgcn_rsqf(dot(v, v)); }
 EV_DEV float pow_hw(float d, float e) { return e == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(d)); }
 // GLSL flavours of the BRDF helpers (photonsplatinstanced.frag:42-98; they differ from the CUDA ones)
 EV_DEV V3 g_lambert_eval(V3 w10, V3 w12, V3 n, V3 rd) {
@@ -41,7 +45,7 @@ EV_DEV V3 g_phong_eval(V3 outv, V3 inv_, V3 n, V3 rs, float e) {
     if (d <= 0.00001f) return v3(0.f, 0.f, 0.f);
     return rs * (e + 2.0f) * pow_hw(d, e) * EV_INV_PI * 0.5f;
 }
-EV_DEV float g_lambert_pdf_w(V3 n1, V3 v12) { return fmaxf(dot(n1, normalize(v12)), 0.f) * EV_INV_PI; }
+EV_DEV float g_lambert_pdf_w(V3 n1, V3 v12) { return fmaxf(dot(n1, normalize_hw(v12)), 0.f) * EV_INV_PI; }
 EV_DEV float g_phong_pdf_w(V3 n1, V3 wi12, V3 inv_, V3 rs, float e) {
     V3 r = reflect(-inv_, n1);
     float d = fmaxf(dot(wi12, r), 0.f);
@@ -71,8 +75,8 @@ EV_DEV uint2 photon_rect(const SplatArgs &a, V3 pos) {
     // whole-screen fallback (those few photons used to produce most of the bin entries)
     const float zlo = fmaxf(vz - r, 0.1f), zhi = fminf(vz + r, 100.0f);
     if (zlo > zhi) return none;
-    float sx = 1.0f / (a.cam.aspect * a.cam.tan_half), sy = 1.0f / a.cam.tan_half;
-    float il = 1.0f / zlo, ih = 1.0f / zhi;
+    float sx = rcp_hw(a.cam.aspect * a.cam.tan_half), sy = rcp_hw(a.cam.tan_half);
+    float il = rcp_hw(zlo), ih = rcp_hw(zhi);            // (1 ulp: 1e-4 px at 4 k pixels, the guard below is 1/32 px)
     float nx0 = fminf((vx - r) * il, (vx - r) * ih) * sx + a.fp.jitter[0];
     float nx1 = fmaxf((vx + r) * il, (vx + r) * ih) * sx + a.fp.jitter[0];
     float ny0 = fminf((vy - r) * il, (vy - r) * ih) * sy + a.fp.jitter[1];
@@ -122,18 +126,18 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     const float r = a.fp.photon_radius;
     V3 v12 = prev.pos - ph.pos;                                           // frag:170
     float d2 = dot(v12, v12);
-    V3 w12 = normalize(v12);
+    V3 w12 = normalize_hw(v12);
     float mix_w = g_lambert_pdf_w(prev.n, -w12) * prev.psel;              // frag:184-187
     mix_w += g_phong_pdf_w(prev.n, -w12, prev.fdir, prev.rs, prev.e) * (1.0f - prev.psel);
-    float mix_a = mix_w * fmaxf(dot(ph.n, w12), 0.0f) / d2;               // frag:189
+    float mix_a = mix_w * fmaxf(dot(ph.n, w12), 0.0f) * rcp_hw(d2);       // frag:189
     bool alive = mix_w > 0.0f;                                            // frag:191
-    float k = EV_INV_PI * (1.0f / (r * r));                               // InvPi * uInvPhotonRadius2
-    float inv_n = 1.0f / (float)a.fp.num_light_paths;                     // uInvNumLightPaths
+    float k = EV_INV_PI * rcp_hw(r * r);                                  // InvPi * uInvPhotonRadius2
+    float inv_n = rcp_hw((float)a.fp.num_light_paths);                    // uInvNumLightPaths
     float wgt = 1.0f;
     const uint32_t mode = a.fp.mis_mode;
-    if (mode == 1u) wgt = mix_a / (mix_a + a.fp.pdf_mc);
+    if (mode == 1u) wgt = mix_a * rcp_hw(mix_a + a.fp.pdf_mc);
     else if (mode == 2u) wgt = mix_a > a.fp.pdf_mc ? 1.0f : 0.0f;
-    else if (mode == 3u) { float a2 = mix_a * mix_a, b2 = a.fp.pdf_mc * a.fp.pdf_mc; wgt = a2 / (a2 + b2); }
+    else if (mode == 3u) { float a2 = mix_a * mix_a, b2 = a.fp.pdf_mc * a.fp.pdf_mc; wgt = a2 * rcp_hw(a2 + b2); }
     V3 wflux = ph.flux * (k * inv_n * wgt);
     float cpn = fmaxf(-dot(prev.n, w12), 0.0f);
     V3 brdf2 = g_lambert_eval(-w12, prev.fdir, prev.n, prev.rd) + g_phong_eval(-w12, prev.fdir, prev.n, prev.rs, prev.e);  // frag:182
@@ -496,8 +500,8 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
                         float cc = fmaxf(dot(sn, w12), 0.0f) * c0.w;      // frag:216,226
                         if (cc <= 0.0f) col = v3(0.f, 0.f, 0.f);          // discard
                         else {
-                            float g = cc / c1.w;
-                            if (mode == 4u) col = (brdf1 * v3(c2)) * fmaxf(g - clampv, 0.0f) / g;
+                            float g = cc * rcp_hw(c1.w);
+                            if (mode == 4u) col = (brdf1 * v3(c2)) * (fmaxf(g - clampv, 0.0f) * rcp_hw(g));
                             else {
                                 V3 brdf2 = v3(stage[192 + j]);
                                 V3 num = (brdf1 * brdf2) * g;
@@ -505,8 +509,8 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
                                 V3 den = brdf2 * g;
                                 V3 pre = v3(c2);
                                 // zero denominator contributes 0 (the reference produces NaN here)
-                                col = v3(den.x != 0.f ? pre.x * num.x / den.x : 0.f, den.y != 0.f ? pre.y * num.y / den.y : 0.f,
-                                         den.z != 0.f ? pre.z * num.z / den.z : 0.f);
+                                col = v3(den.x != 0.f ? pre.x * num.x * rcp_hw(den.x) : 0.f, den.y != 0.f ? pre.y * num.y * rcp_hw(den.y) : 0.f,
+                                         den.z != 0.f ? pre.z * num.z * rcp_hw(den.z) : 0.f);
                             }
                         }
                     }
