@@ -596,10 +596,18 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
                 const uint32_t i = first + c * (uint32_t)kVplSplit;
                 V3 vpos, vn; float vpsel; fetch_vpl_head(vpls, i, vpos, vn, vpsel);
                 const V3 v12 = vpos - p1;                                     // :605
-                const float dist = sqrtf(dot(v12, v12));
-                const V3 nv12 = v12 / dist;
-                const float c1c2 = fmaxf(dot(n1, nv12), 0.0f) * fmaxf(-dot(vn, nv12), 0.0f);
-                const bool pre = valid && !(c1c2 <= 0.000000001f);           // :619, taken before the shadow ray instead of after it
+                // c1 c2 <= 1e-9 (:619) decides which pairs exist at all, so it is taken with the reference's roundings (IEEE square root and
+                // three divisions, ~45 instructions) -- but only when some lane is within 1e-3 (relative) of the threshold; everywhere
+                // else the same product through two 1-ulp hardware operations gives the same answer
+                const float d2 = dot(v12, v12), a1 = fmaxf(dot(n1, v12), 0.0f), a2 = fmaxf(-dot(vn, v12), 0.0f);
+                const float quick = a1 * a2 * __builtin_amdgcn_rcpf(d2);
+                bool pre = valid && !(quick <= 0.000000001f);
+                if (ballot64(valid && fabsf(quick - 0.000000001f) <= 0.000000000001f) != 0ull) {
+                    const float dist = sqrtf(d2);
+                    const V3 nv12 = v12 / dist;
+                    const float c1c2 = fmaxf(dot(n1, nv12), 0.0f) * fmaxf(-dot(vn, nv12), 0.0f);
+                    pre = valid && !(c1c2 <= 0.000000001f);                  // taken before the shadow ray instead of after it
+                }
                 unsigned long long lit = 0ull;
                 if (ballot64(pre) != 0ull) {
                     rays += pre ? 1u : 0u;
