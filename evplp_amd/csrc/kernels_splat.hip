@@ -314,27 +314,50 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
         return;
     }
     constexpr int kTilesMax = 1 << kMaxBucketTilesLog2;
+    constexpr uint32_t kNG = 256u * kScatterG;                            // bin-groups of a slice
     __shared__ uint32_t s_cnt[kTilesMax], s_base[kTilesMax], s_max, s_total;
+    __shared__ uint32_t s_start[kNG + 1];                                 // first entry of every group's run in the workgroup's entry numbering
+    __shared__ uint16_t s_beg[kNG];                                       // ... and where that run starts in the group's segment
     const uint32_t ntile = 1u << (a.bucket_w_log2 + a.bucket_h_log2);   // tiles of a bucket
-    const uint32_t tid = threadIdx.x, b = blockIdx.y, group0 = blockIdx.x * (256u * kScatterG) + tid;
-    uint32_t beg[kScatterG], end[kScatterG];
+    const uint32_t tid = threadIdx.x, b = blockIdx.y, group0 = blockIdx.x * kNG;
+    // The runs of this bucket in the segments of the slice's groups are short and uneven (1.6 entries on average at config #3, tens in
+    // the hot buckets): one thread per run (round 2) waited for its entries one after the other, and the longest run set the time of
+    // the launch.  Now the runs are numbered through (a scan of their lengths) and the workgroup walks the ENTRIES, 256 at a time,
+    // each thread finding its run by bisection in LDS: balanced, and every load of a sweep is in flight at once.
 #pragma unroll
     for (int g = 0; g < kScatterG; g++) {
-        const uint32_t group = group0 + 256u * (uint32_t)g;
-        beg[g] = end[g] = 0u;
+        const uint32_t gl = tid + 256u * (uint32_t)g, group = group0 + gl;
+        uint32_t beg = 0u, end = 0u;
         if (group < (uint32_t)a.num_bin_groups) {
             const uint16_t *o = a.seg_off + (size_t)group * (a.num_buckets + 1) + b;
-            beg[g] = o[0]; end[g] = o[1];
+            beg = o[0]; end = o[1];
         }
+        s_beg[gl] = (uint16_t)beg; s_start[gl] = end - beg;               // (lengths first, scanned below)
     }
     for (uint32_t t = tid; t < ntile; t += 256u) s_cnt[t] = 0u;
     if (tid == 0u) { s_max = 0u; s_total = 0u; }
     __syncthreads();
+    if (tid < 64u) {                                                      // exclusive scan of the kNG lengths by one wave
+        constexpr uint32_t per = kNG / 64u;
+        uint32_t v[per], sum = 0u;
 #pragma unroll
-    for (int g = 0; g < kScatterG; g++) {
-        const uint32_t *seg = a.seg + (size_t)(group0 + 256u * (uint32_t)g) * kSegCap;
-        for (uint32_t k = beg[g]; k < end[g]; k++) atomicAdd(&s_cnt[seg[k] >> 10], 1u);
+        for (uint32_t q = 0; q < per; q++) { v[q] = s_start[tid * per + q]; sum += v[q]; }
+        uint32_t x = sum;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if ((int)tid >= off) x += y; }
+        uint32_t run = x - sum;
+#pragma unroll
+        for (uint32_t q = 0; q < per; q++) { s_start[tid * per + q] = run; run += v[q]; }
+        if (tid == 63u) s_start[kNG] = run;
     }
+    __syncthreads();
+    const uint32_t total = s_start[kNG];
+    auto entry_of = [&](uint32_t e, uint32_t &group) -> uint32_t {        // entry e of the workgroup: its group and its word
+        uint32_t lo = 0u, hi = kNG;                                       // last gl with s_start[gl] <= e
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= e) lo = mid; else hi = mid; }
+        group = group0 + lo;
+        return a.seg[(size_t)group * kSegCap + s_beg[lo] + (e - s_start[lo])];
+    };
+    for (uint32_t e = tid; e < total; e += 256u) { uint32_t group; atomicAdd(&s_cnt[entry_of(e, group) >> 10], 1u); }
     __syncthreads();
     const uint32_t bx = b % (uint32_t)a.buckets_x, by = b / (uint32_t)a.buckets_x, bw_mask = (1u << a.bucket_w_log2) - 1u;
     auto tile_of = [&](uint32_t t) -> uint32_t {
@@ -349,14 +372,10 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int g = 0; g < kScatterG; g++) {
-        const uint32_t group = group0 + 256u * (uint32_t)g;
-        const uint32_t *seg = a.seg + (size_t)group * kSegCap;
-        for (uint32_t k = beg[g]; k < end[g]; k++) {
-            const uint32_t e = seg[k], t = e >> 10, pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-            if (pos < a.bin_stride) items[(size_t)tile_of(t) * a.bin_stride + pos] = group * (uint32_t)kBinGroup + (e & 1023u);
-        }
+    for (uint32_t e = tid; e < total; e += 256u) {
+        uint32_t group;
+        const uint32_t w = entry_of(e, group), t = w >> 10, pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+        if (pos < a.bin_stride) items[(size_t)tile_of(t) * a.bin_stride + pos] = group * (uint32_t)kBinGroup + (w & 1023u);
     }
     if (tid == 0u && s_total != 0u) {
         uint32_t *sh = a.summary + ((blockIdx.y * gridDim.x + blockIdx.x) & (uint32_t)(kSummaryShards - 1)) * kSummaryStride;
