@@ -493,10 +493,9 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
         "s_cmp_ge_i32 %[p0], %[p1]\n\t"                                                                                                      \
         "s_cselect_b32 %[p0], %[c1], %[c0]\n\t"                                                                                              \
         "s_cselect_b32 %[cur], %[c0], %[c1]\n\t"                                                                                             \
-        "v_cmp_eq_u32 vcc, %[sp], %[lane]\n\t"                                                                                               \
-        "v_mov_b32 " T0L ", %[p0]\n\t"                                                                                                       \
+        "s_mov_b32 m0, %[sp]\n\t"                                                                                                            \
         "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                                      \
-        "v_cndmask_b32 %[vstack], %[vstack], " T0L ", vcc\n\t"                                                                               \
+        "v_writelane_b32 %[vstack], %[p0], m0\n\t"                                                                                           \
         "s_branch L_end%=\n"                                                                                                                 \
         "L_c0%=:\n\t"                                                                                                                        \
         "s_mov_b32 %[cur], %[c0]\n\t"                                                                                                        \
@@ -516,7 +515,7 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
         : [cx] "s"(cx_), [cy] "s"(cy_), [cz] "s"(cz_), [hx] "s"(hx_), [hy] "s"(hy_), [hz] "s"(hz_), [c0] "s"(c0_), [c1] "s"(c1_),              \
           [pa] "v"(pa_), [pb] "v"(pb_), [pc] "v"(pc_),                                     \
           [pd] "v"(pd_), [pe] "v"(pe_), [lane] "v"(lane_id)                                                                 \
-        : "vcc", "scc", T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)
+        : "vcc", "scc", "m0", T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)
 
 // VT = first of the twelve reserved temporaries: 52 for the 64-register VPL gather, 116 for the 128-register VSL gather; 0 = the C++ loop
 template <int VT = 0>
