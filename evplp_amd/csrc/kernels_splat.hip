@@ -120,8 +120,12 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     const uint2 none = make_uint2(1u, 0u);
     Rec ph = load_rec(s_ph);
     if (!(ph.flags & EVPLP_USABLE_PHOTON)) return none;  // vert:31, geom:20
-    Rec prev = load_rec(s_prev);                    // frag:163
     photon_pos = ph.pos;
+    // a photon whose sphere shows nowhere on the screen (about half of the usable ones at the BASELINE configurations) needs no
+    // compact record: nothing will ever read it
+    const uint2 rect = photon_rect(a, ph.pos);
+    if ((rect.x & 0xffffu) > (rect.x >> 16)) return none;
+    Rec prev = load_rec(s_prev);                    // frag:163
 
     const float r = a.fp.photon_radius;
     V3 v12 = prev.pos - ph.pos;                                           // frag:170
@@ -146,8 +150,7 @@ EV_DEV uint2 splat_prepare_one(const SplatArgs &a, uint32_t i, const float4 *s_p
     c[1] = make_float4(w12.x, w12.y, w12.z, d2);
     c[2] = make_float4(wflux.x, wflux.y, wflux.z, alive ? 1.0f : 0.0f);
     if (mode == 5u) c[3] = make_float4(brdf2.x, brdf2.y, brdf2.z, 0.f);       // read by misMode 5 only
-
-    return photon_rect(a, ph.pos);
+    return rect;
 }
 
 // World-space bounding box of every 8x8-px tile's G-buffer positions (one wave per tile).  A pixel can only receive a
