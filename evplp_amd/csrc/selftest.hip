@@ -29,16 +29,38 @@ __global__ __launch_bounds__(256) void selftest_rcp_kernel(unsigned long long *o
     }
 }
 
+// which = 1: d^e = exp2(e log2 d) on the hardware transcendentals (the Phong lobes of the VPL gather and of the splat) against the
+// double-precision pow, for e = 1, 5, 20, 100, 1000, 10000 and 2^22 values of d in (1e-6, 1]: out[k] = the largest relative error over
+// the d whose lobe is at least 1e-4 of its peak, in units of 1e-12.
+__global__ __launch_bounds__(256) void selftest_pow_kernel(unsigned long long *out) {
+    const float es[6] = { 1.0f, 5.0f, 20.0f, 100.0f, 1000.0f, 10000.0f };
+    const uint32_t n = 1u << 22;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float d = 1.0f - (float)i / (float)n * 0.999999f;
+        for (int k = 0; k < 6; k++) {
+            const double want = pow((double)d, (double)es[k]);
+            if (want < 1e-4) continue;
+            const double got = (double)__builtin_amdgcn_exp2f(es[k] * __builtin_amdgcn_logf(d));
+            const double rel = fabs(got - want) / want;
+            atomicMax(&out[k], (unsigned long long)(rel * 1e12));
+        }
+    }
+}
+
 } // namespace evplp
 
 extern "C" int evplp_selftest(evplp_context *c, int32_t which, uint64_t *out, int32_t capacity) {
-    if (!c || !out || capacity < 6 || which != 0) { if (c) c->set_error("evplp_selftest: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (!c || !out || capacity < 6 || which < 0 || which > 1) { if (c) c->set_error("evplp_selftest: bad arguments"); return EVPLP_ERR_INVALID; }
     if (hipSetDevice(c->cfg.device) != hipSuccess) return EVPLP_ERR_HIP;
     unsigned long long *d = nullptr;
     if (hipMalloc((void **)&d, 8 * sizeof(unsigned long long)) != hipSuccess) return EVPLP_ERR_OOM;
-    const unsigned long long init[8] = { 0, 0, 0, 0, 255, 0, 0, 0 };
+    const unsigned long long init[8] = { 0, 0, 0, 0, which == 0 ? 255ull : 0ull, 0, 0, 0 };
     hipError_t e = hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice);
-    if (e == hipSuccess) { hipLaunchKernelGGL(evplp::selftest_rcp_kernel, dim3(4096), dim3(256), 0, c->stream, d); e = hipStreamSynchronize(c->stream); }
+    if (e == hipSuccess) {
+        if (which == 0) hipLaunchKernelGGL(evplp::selftest_rcp_kernel, dim3(4096), dim3(256), 0, c->stream, d);
+        else hipLaunchKernelGGL(evplp::selftest_pow_kernel, dim3(4096), dim3(256), 0, c->stream, d);
+        e = hipStreamSynchronize(c->stream);
+    }
     unsigned long long h[8] = {};
     if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     hipFree(d);

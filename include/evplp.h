@@ -264,6 +264,9 @@ int evplp_accel_stack_entries(const evplp_context *ctx);
  * reciprocal of the triangle predicates against the IEEE division on all 2^32 float bit patterns (under a second): out[0]
  * patterns whose bits differ, [1] of them zero / denormal inputs, [2] infinite / NaN inputs, [3] normal inputs, [4] / [5] the
  * smallest / largest biased exponent among those normal inputs (the kernels need [3] to be confined to exponents >= 253).
+ * which = 1: d^e as exp2(e log2 d) on the hardware transcendentals (Phong lobes of the VPL gather and the splat) against the
+ * double-precision pow for e = 1, 5, 20, 100, 1000, 10000 over 2^22 values of d in (1e-6, 1]: out[k] = largest relative error
+ * where the lobe is >= 1e-4 of its peak, in units of 1e-12.
  * Returns the number of words written or a negative status. */
 int evplp_selftest(evplp_context *ctx, int32_t which, uint64_t *out, int32_t capacity);
 

@@ -99,6 +99,14 @@ def test_exact_reciprocal_of_the_triangle_predicates(ctx):
     assert normal == 0 or lo >= 253, (normal, lo, hi)
 
 
+def test_hardware_power_function_of_the_phong_lobes(ctx):
+    """The Phong lobes of the VPL gather and of the photon splat are exp2(e log2 d) on v_log_f32 / v_exp_f32 (the library powf is
+    ~170 instructions).  Checked on the part against the double-precision pow: relative error <= 2e-6 for every exponent up to
+    10 000 wherever the lobe is at least 1e-4 of its peak -- a fifth of the image bar (1e-5), a hundredth of the pixel bar (2e-4)."""
+    err = ctx.selftest(1).astype(np.float64) * 1e-12
+    assert len(err) == 6 and (err > 0).all() and err.max() <= 2e-6, err
+
+
 def test_light_image_flags(room, oscene, evplp):
     """rtcomphoton.h:985-995: run.lightRender = false leaves the light image alone; cleareveryframe clears the depth buffer the
     light pass shares with the deferred pass, so the emitter is drawn without a depth test."""
