@@ -673,10 +673,10 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                 const bool lit_lane = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
                 if (lit_lane) {
                     const V3 v12 = v.pos - px.p1;
-                    const float dist = sqrtf(dot(v12, v12));
-                    const V3 nv12 = v12 / dist;
+                    const float inv_dist = vslm::rsq(dot(v12, v12));         // (1-ulp hardware operations: the IEEE square root and four divisions were ~55 instructions per pair)
+                    const V3 nv12 = v12 * inv_dist;
                     VslCtx cx;
-                    const float rdratio = a.fp.vsl_radius / dist;
+                    const float rdratio = a.fp.vsl_radius * inv_dist;
                     cx.half_cone = (rdratio >= 1.0f) ? EV_PI / 2.0f : asinf(rdratio);   // :623
                     cx.cos_half_cone = (rdratio >= 1.0f) ? cosf(EV_PI / 2.0f) : vslm::fsqrt(1.0f - rdratio * rdratio);   // cos(asin x)
                     cx.solid_angle = EV_PI * 2.0f * (1.0f - cx.cos_half_cone);
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                     VslLight L;
                     {
                         const float ml = max_color(v.rd), mp = max_color(v.rs);
-                        L.dead = ml + mp <= 0.000001f; L.psel = ml / (mp + ml);
+                        L.dead = ml + mp <= 0.000001f; L.psel = ml * vslm::rcp(mp + ml);
                         L.glossy = v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f; L.pdf_glossy = !(v.rs.x <= 0.000001f);
                         L.R2 = reflect(-v.fdir, v.n);
                     }
