@@ -580,6 +580,26 @@ def technique_block(wl, n_vpl, n_light, mis, iterations, tag):
     return block
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def c_stdout_to_stderr():
+    """The technique loop prints the reference's progress lines with printf (rtcomphoton.h:1057-1062): keep them off this process's
+    stdout, which carries ONE JSON line."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush(); libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def render_json_time(env, wl, json_path, shape, iterations):
     """The same configuration through evplp_render_json -- what a maintainer of the reference binds in place of
     RtComPhoton::render (host/technique.cpp: the technique loop on an evplp_group of one rank).  Time per iteration from the
@@ -594,7 +614,8 @@ def render_json_time(env, wl, json_path, shape, iterations):
     jp = os.path.join(d, tag + ".json")
     json.dump(root, open(jp, "w"))
     t0 = time.perf_counter()
-    env.ev.render_json(jp, None, env.device_index)
+    with c_stdout_to_stderr():
+        env.ev.render_json(jp, None, env.device_index)
     wall = time.perf_counter() - t0
     stat = json.load(open(os.path.join(d, f"{tag}_stat.json")))
     for f in (jp, os.path.join(d, f"{tag}_stat.json"), os.path.join(d, f"{tag}_combined.pfm"), os.path.join(d, f"{tag}_weightedpm.pfm"), os.path.join(d, f"{tag}_weightedvpl.pfm")):
@@ -616,6 +637,12 @@ def main():
     if a.gpus > 1 and world_env is None and a.front_end == "ranks":
         spawn_ranks(a)
         return
+    # This process's stdout carries ONE line, the JSON.  Everything else that writes to file descriptor 1 -- RCCL's version banner at
+    # communicator start-up, the technique loop's progress lines (printf), Python prints -- goes to stderr: descriptor 1 is pointed
+    # at stderr for the whole run and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     env = Env(a)
     wl = a.workload
     out, json_path, shape = run_workload(env, wl, a.steps, a.warmup, a.scene)
@@ -701,7 +728,7 @@ def main():
     if rank0:
         if env.use_dist and env.world > 1:
             time.sleep(1.0)       # let the other ranks' processes drain whatever they still print while exiting
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

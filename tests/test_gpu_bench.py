@@ -17,7 +17,9 @@ def run_bench(args, env=None):
     e = dict(os.environ); e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    return json.loads(p.stdout.strip().splitlines()[-1])
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, f"bench.py must print ONE line on stdout, got {len(lines)}: {lines[0][:80]!r} ..."
+    return json.loads(lines[0])
 
 
 def test_bench_line_contract_small():
