@@ -23,3 +23,6 @@ for k, d in sorted(res.items(), key=lambda kv: -g0(kv[1], "SQ_WAVE_CYCLES") if g
     print(" frac of wave cycles: wait_any %.3f wait_inst_any %.3f active_valu %.3f active_sca %.3f active_lds %.3f active_any %.3f" % (g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_SCA") / wc, g("SQ_ACTIVE_INST_LDS") / wc, g("SQ_ACTIVE_INST_ANY") / wc))
     print(" scalar cache: req %.4g hits %.4g misses %.4g hit rate %.4f" % (g("SQC_DCACHE_REQ"), g("SQC_DCACHE_HITS"), g("SQC_DCACHE_MISSES"), g("SQC_DCACHE_HITS") / (g("SQC_DCACHE_HITS") + g("SQC_DCACHE_MISSES") + 1e-9)))
     print(" L2: hit %.4g miss %.4g rate %.4f | FETCH_SIZE KB %.5g (x2 for wide streams: MI355X_MICROARCH.md) WRITE_SIZE KB %.5g" % (g("TCC_HIT_sum"), g("TCC_MISS_sum"), g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum") + 1e-9), g("FETCH_SIZE"), g("WRITE_SIZE")))
+    if g("SQ_LDS_IDX_ACTIVE") == g("SQ_LDS_IDX_ACTIVE"):
+        print(" LDS: active cycles %.4g  bank-conflict cycles %.4g (%.3f of active)  address-conflict cycles %.4g  atomic-return cycles %.4g" % (
+            g("SQ_LDS_IDX_ACTIVE"), g("SQ_LDS_BANK_CONFLICT"), g("SQ_LDS_BANK_CONFLICT") / (g("SQ_LDS_IDX_ACTIVE") + 1e-9), g("SQ_LDS_ADDR_CONFLICT"), g("SQ_LDS_ATOMIC_RETURN")))

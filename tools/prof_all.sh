@@ -19,6 +19,7 @@ for wl in ir evplp ppm; do
   pmc $wl d TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
   pmc $wl e FETCH_SIZE
   pmc $wl f WRITE_SIZE
+  pmc $wl g SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN
 done
 cd $ROOT
 python3 tools/pmc_summary.py $O ir > $O/${tag}_bench_ir_pmc.txt 2>&1

@@ -17,6 +17,7 @@ pmc c GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SMEM 
 pmc d TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 pmc e FETCH_SIZE
 pmc f WRITE_SIZE
+pmc g SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN
 cd $ROOT
 python3 tools/pmc_summary.py $O $wl > $O/${tag}_bench_${wl}_pmc.txt 2>&1
 find $O -name "*_agent_info.csv" -delete
