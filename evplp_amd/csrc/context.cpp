@@ -672,6 +672,9 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
         while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
         if (vsl) while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k > 4095) k >>= 1;      // (the estimator kernel's packed per-lane counters)
+        if (vsl && (max_vpls / kVplSplit + 1) > 4095) {      // k = 1 and still more than 4095 VSLs per item: the packed counters would wrap
+            c->set_error("%s: %zu VSL record slots exceed the %d this build can gather in one pass", name, max_vpls, 4094 * kVplSplit); return EVPLP_ERR_INVALID;
+        }
     }
     a.splits_per_wave = k;
     if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k)))) return rc;
@@ -686,16 +689,15 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         const int groups = kVplSplit / k;
         int per_launch = groups;
         while (per_launch > 1 && tiles * (size_t)per_launch * per_item > ((size_t)1 << 30)) per_launch = (per_launch + 1) / 2;
-        const size_t mask_bytes = tiles * (size_t)per_launch * per_item, ray_bytes = tiles * (size_t)per_launch * sizeof(uint32_t);
-        if (c->vsl_mask_bytes < mask_bytes + ray_bytes) {
+        const size_t mask_bytes = tiles * (size_t)per_launch * per_item;
+        if (c->vsl_mask_bytes < mask_bytes) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             hipFree(c->d_vsl_masks); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
-            hipError_t e = hipMalloc((void **)&c->d_vsl_masks, mask_bytes + ray_bytes);
-            if (e != hipSuccess) { c->set_error("gather_vsl: cannot allocate %zu bytes of lit masks: %s", mask_bytes + ray_bytes, hipGetErrorString(e)); return EVPLP_ERR_OOM; }
-            c->vsl_mask_bytes = mask_bytes + ray_bytes;
+            hipError_t e = hipMalloc((void **)&c->d_vsl_masks, mask_bytes);
+            if (e != hipSuccess) { c->set_error("gather_vsl: cannot allocate %zu bytes of lit masks: %s", mask_bytes, hipGetErrorString(e)); return EVPLP_ERR_OOM; }
+            c->vsl_mask_bytes = mask_bytes;
         }
         a.vsl_masks = (unsigned long long *)c->d_vsl_masks;
-        a.vsl_item_rays = (uint32_t *)((char *)c->d_vsl_masks + mask_bytes);
         HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
         for (int g0 = 0; g0 < groups; g0 += per_launch) {
             a.group_first = g0; a.group_count = std::min(per_launch, groups - g0);
@@ -796,6 +798,12 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
 
 // [finalize] composite of this context's strip into d_rgb (device); evplp_resolve downloads it, the group all-gathers it
 namespace evplp {
+// would the next entry point make the host wait for the verdict of a pending photon splat?  (group.cpp feeds such ranks last)
+bool host_would_wait(evplp_context *c) {
+    if (!c || c->npend == 0) return false;
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return false;
+    return hipEventQuery(c->pend[0].ev) == hipErrorNotReady;
+}
 int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
     CTX_CHECK(c);
     { int rc_ = settle_splat(c); if (rc_) return rc_; }

@@ -19,6 +19,7 @@
 
 namespace evplp {
 int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma);   // context.cpp
+bool host_would_wait(evplp_context *c);                                                                        // context.cpp
 }
 
 namespace {
@@ -59,7 +60,16 @@ struct evplp_group {
 static thread_local char g_group_create_error[512] = "";
 
 #define GRP_CHECK(g) do { if (!(g)) return EVPLP_ERR_INVALID; } while (0)
-#define GRP_EACH(g, call) do { for (int r_ = 0; r_ < (g)->n; r_++) { evplp_context *c = (g)->ctx[r_]; int rc_ = (call); if (rc_ < 0) { (g)->set_error("rank %d: %s", r_, evplp_last_error(c)); return rc_; } } } while (0)
+// Every entry point of a context first looks at the verdict of its last photon splat (context.cpp settle_splat) and may wait for
+// it.  One host thread feeds all ranks, so the ranks whose verdict has already arrived are fed FIRST and the ones that would make
+// the host wait last: no GPU idles behind another rank's wait.  (The ranks are independent contexts; the order of the calls does
+// not change any result.)
+static void feed_order(const evplp_group *g, int *order) {
+    int m = 0; bool late[64];
+    for (int r = 0; r < g->n; r++) { late[r] = evplp::host_would_wait(g->ctx[r]); if (!late[r]) order[m++] = r; }
+    for (int r = 0; r < g->n; r++) if (late[r]) order[m++] = r;
+}
+#define GRP_EACH(g, call) do { int order_[64]; feed_order((g), order_); for (int i_ = 0; i_ < (g)->n; i_++) { const int r_ = order_[i_]; evplp_context *c = (g)->ctx[r_]; int rc_ = (call); if (rc_ < 0) { (g)->set_error("rank %d: %s", r_, evplp_last_error(c)); return rc_; } } } while (0)
 
 extern "C" const char *evplp_group_last_error(const evplp_group *g) { return g ? g->error : g_group_create_error; }
 extern "C" int evplp_group_size(const evplp_group *g) { return g ? g->n : EVPLP_ERR_INVALID; }
@@ -149,14 +159,17 @@ extern "C" int evplp_group_primary(evplp_group *g, const float jitter[2], int32_
 extern "C" int evplp_group_trace_light_paths(evplp_group *g, uint32_t rng_seed) {
     GRP_CHECK(g);
     if (!g->split_paths) { GRP_EACH(g, evplp_trace_light_paths(c, rng_seed, 0, c->cfg.num_light_paths)); return EVPLP_OK; }
-    for (int r = 0; r < g->n; r++) {
+    int order[64]; feed_order(g, order);
+    for (int i = 0; i < g->n; i++) {
+        const int r = order[i];
+        // in place: rank r's own slice goes to offset r * chunk of its record buffer.  A partial path range never goes to the second
+        // record buffer of overlap_light_tracing (context.cpp only double-buffers whole path sets), so EVPLP_BUF_RECORDS must be the
+        // same buffer before and after the call -- checked, because the exchange below would otherwise gather the wrong buffer.
+        const void *before = g->ctx[r]->buf[EVPLP_BUF_RECORDS];
         int rc = evplp_trace_light_paths(g->ctx[r], rng_seed, (uint32_t)r * g->per_rank_paths, g->per_rank_paths);
         if (rc < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[r])); return rc; }
+        if (g->ctx[r]->buf[EVPLP_BUF_RECORDS] != before) { g->set_error("evplp_group_trace_light_paths: rank %d traced a partial path range into a flipped record buffer", r); return EVPLP_ERR_INVALID; }
     }
-    // in place: rank r's own slice already sits at offset r * chunk of its record buffer.  (A partial path range never goes to the
-    // second record buffer of overlap_light_tracing -- context.cpp only double-buffers whole path sets -- so EVPLP_BUF_RECORDS is the
-    // buffer the call above wrote; checked, because the exchange below would otherwise gather the wrong buffer.)
-    for (int r = 0; r < g->n; r++) if (g->ctx[r]->records_back && g->per_rank_paths == g->ctx[r]->cfg.num_light_paths) { g->set_error("evplp_group_trace_light_paths: split light paths with a flipped record buffer"); return EVPLP_ERR_INVALID; }
     const size_t chunk = (size_t)g->per_rank_paths * g->ctx[0]->cfg.photons_per_path * (sizeof(evplp_record) / sizeof(float));
     std::vector<const float *> send((size_t)g->n); std::vector<float *> recv((size_t)g->n);
     for (int r = 0; r < g->n; r++) { recv[r] = (float *)g->ctx[r]->buf[EVPLP_BUF_RECORDS]; send[r] = recv[r] + (size_t)r * chunk; }

@@ -56,9 +56,9 @@ struct GatherArgs {
     int32_t block_h_log2;             // tiles are enumerated in blocks of 8 x (1 << block_h_log2) tiles
     // a launch covers the groups [group_first, group_first + group_count) of every tile (group_count = 0: all 128 / k of them)
     int32_t group_first, group_count;
-    // VSL gather (two kernels): lit-lane masks of every (item, VSL) of the launch, [item][k * masks_per_split], and the shadow rays of
-    // every item, written by gather_vsl_walk_kernel and read by gather_vsl_shade_kernel
-    unsigned long long *vsl_masks; uint32_t *vsl_item_rays; int32_t masks_per_split; int32_t pad1;
+    // VSL gather (two kernels): lit-lane masks of every (item, VSL) of the launch, [item][k * masks_per_split], written by
+    // gather_vsl_walk_kernel and read by gather_vsl_shade_kernel
+    unsigned long long *vsl_masks; int32_t masks_per_split; int32_t pad1;
 };
 #ifndef EVPLP_VPL_SPLIT
 #define EVPLP_VPL_SPLIT 128

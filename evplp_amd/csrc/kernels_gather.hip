@@ -601,7 +601,10 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
                 // else the same product through two 1-ulp hardware operations gives the same answer
                 const float d2 = dot(v12, v12), a1 = fmaxf(dot(n1, v12), 0.0f), a2 = fmaxf(-dot(vn, v12), 0.0f);
                 const float quick = a1 * a2 * __builtin_amdgcn_rcpf(d2);
-                bool pre = valid && !(quick <= 0.000000001f);
+                // (written positively: a VSL that sits exactly ON the pixel's point gives 0 * 0 * rcp(0) = NaN, which must not pass --
+                // the reference's fmaxf(NaN, 0) * fmaxf(NaN, 0) = 0 <= 1e-9 drops the pair, and a lit pair at distance 0 would put
+                // rsq(0) = inf into the accumulating image for good)
+                bool pre = valid && (quick > 0.000000001f);
                 if (ballot64(valid && fabsf(quick - 0.000000001f) <= 0.000000000001f) != 0ull) {
                     const float dist = sqrtf(d2);
                     const V3 nv12 = v12 / dist;
@@ -621,9 +624,10 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
             for (uint32_t q = (uint32_t)lane; q < n; q += 64u) dst[q] = s_lit[q];
         }
     }
-    // shadow rays of the item (per lane < 65536), summed over the wavefront for the statistics
+    // shadow rays of the item, summed over the wavefront: one add per item into the pass's 64 counter shards (an item's count can reach
+    // 64 lanes x 4095 VSLs -- it does not fit the 16-bit field the VPL gather's per-pixel statistics word has for it)
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (lane == 0) a.vsl_item_rays[(size_t)tile_l * a.group_count + (t.group - a.group_first)] = rays;
+    if (lane == 0 && rays != 0u) atomicAdd(&a.counters->shard_rays[blockIdx.x & (kCounterShards - 1)], (unsigned long long)rays);
 }
 
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(GatherArgs a) {
@@ -724,13 +728,11 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
     uint32_t nsamp = cnt >> 12;
     for (int off = 32; off > 0; off >>= 1) nsamp += __shfl_down(nsamp, off);
     if (lane == 0) atomicAdd(&a.counters->hist[blockIdx.x & 63u], (unsigned long long)nsamp);
-    // the item's shadow rays were counted by the walk kernel per wavefront: the reduce kernel sums per-pixel words, lane 0's carries them
-    // (an item's rays: at most 64 lanes x 512 VSLs = 32768 < 65536)
-    const uint32_t item_rays = a.vsl_item_rays[(size_t)tile_l * a.group_count + (t.group - a.group_first)];
+    // (the item's shadow rays were counted by the walk kernel; the per-pixel word carries the lit pairs only: < 4096 per item, context.cpp)
     int lane_out = lane, blk_out = (int)blockIdx.x;
     asm volatile("" : "+v"(lane_out), "+s"(blk_out));   // (the store address is formed here, not carried through the estimators)
     const int group_out = a.group_first + (blk_out >> 3) % a.group_count;
-    if (valid) a.partial[(size_t)group_out * a.partial_stride + item_texel<true>(a, lane_out)] = make_float4(total.x, total.y, total.z, __uint_as_float((lane == 0 ? item_rays : 0u) | (nlit << 16)));
+    if (valid) a.partial[(size_t)group_out * a.partial_stride + item_texel<true>(a, lane_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(nlit << 16));
 }
 
 int gather_launch_tiles(const GatherArgs &a) {                    // tiles of a launch: whole blocks of 8 x (1 << block_h_log2)

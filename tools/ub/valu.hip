@@ -1,41 +1,140 @@
-// Micro-benchmark: VALU issue rate of plain vs packed fp32 FMA / min-max on gfx950 (developer tool).
+// Micro-benchmark (developer tool): issue rate of the vector instructions the packet walk is made of, on gfx950, at 1 / 2 / 4 / 8
+// waves per SIMD.  Every body is inline asm on eight independent registers (no dependence between consecutive instructions), so
+// the compiler can neither fuse, pack nor drop anything; cycles are derived from s_memtime stamps around the loop (median over
+// workgroups) AND from the event time at the nominal 2.4 GHz -- the chip lowers its clock under load, the stamps do not care.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ub/valu tools/ub/valu.hip && tools/ub/valu > profiles/ub_valu_r04.txt
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int MODE> __global__ __launch_bounds__(256) void k(float *out, float a, float b, int iters) {
-    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
-    v2f p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7};
-    v2f pa = {a, a}, pb = {b, b};
+
+enum { FMA, PK_FMA, PK_FMA_OPSEL, PK_MUL, MAX3, MAX3_CLAMP, CMP_VCC, CMP_SGPR, EXP, LOG, RCP, MOV, WRITELANE, MIX_VISIT, NMODES };
+static const char *kNames[NMODES] = { "v_fma_f32", "v_pk_fma_f32", "v_pk_fma_f32 op_sel", "v_pk_mul_f32", "v_max3_f32", "v_max3_f32 clamp", "v_cmp_lt_f32 vcc",
+                                      "v_cmp_lt_f32 s[..]", "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_mov_b32", "v_writelane_b32", "node visit (9 pk_fma + 4 max3/min3 + 2 cmp)" };
+static const int kPerIter[NMODES] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 60 };
+
+#define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+template <int MODE> __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, float a, float b, int iters) {
+    float x[8]; v2f p[8];
+    for (int j = 0; j < 8; j++) { x[j] = threadIdx.x + j; p[j].x = x[j]; p[j].y = x[j] + 0.5f; }
+    v2f pa = { a, a * 1.5f }, pb = { b, b * 0.5f };
+    unsigned long long sg = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
-        if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
-                                          x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b); }
-        } else if (MODE == 1) {
+        for (int u = 0; u < 8; u++) {
+            if (MODE == FMA) {
+#define OP(j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b));
+                R8(OP)
+#undef OP
+            } else if (MODE == PK_FMA) {
+#define OP(j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[j]) : "v"(pa), "v"(pb));
+                R8(OP)
+#undef OP
+            } else if (MODE == PK_FMA_OPSEL) {
+#define OP(j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(p[j]) : "v"(pa), "v"(pb));
+                R8(OP)
+#undef OP
+            } else if (MODE == PK_MUL) {
+#define OP(j) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[j]) : "v"(pa));
+                R8(OP)
+#undef OP
+            } else if (MODE == MAX3) {
+#define OP(j) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b));
+                R8(OP)
+#undef OP
+            } else if (MODE == MAX3_CLAMP) {
+#define OP(j) asm volatile("v_max3_f32 %0, %0, %1, %2 clamp" : "+v"(x[j]) : "v"(a), "v"(b));
+                R8(OP)
+#undef OP
+            } else if (MODE == CMP_VCC) {
+#define OP(j) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[j]), "v"(a) : "vcc");
+                R8(OP)
+#undef OP
+            } else if (MODE == CMP_SGPR) {
+#define OP(j) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(sg) : "v"(x[j]), "v"(a));
+                R8(OP)
+#undef OP
+            } else if (MODE == EXP) {
+#define OP(j) asm volatile("v_exp_f32 %0, %0" : "+v"(x[j]));
+                R8(OP)
+#undef OP
+            } else if (MODE == LOG) {
+#define OP(j) asm volatile("v_log_f32 %0, %0" : "+v"(x[j]));
+                R8(OP)
+#undef OP
+            } else if (MODE == RCP) {
+#define OP(j) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[j]));
+                R8(OP)
+#undef OP
+            } else if (MODE == MOV) {
+#define OP(j) asm volatile("v_mov_b32 %0, %1" : "+v"(x[j]) : "v"(a));
+                R8(OP)
+#undef OP
+            } else if (MODE == WRITELANE) {
+                int sp = (i + u) & 63, val = i;
+#define OP(j) asm volatile("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0" : "+v"(x[j]) : "s"(sp), "s"(val) : "m0");
+                R8(OP)
+#undef OP
+            }
+        }
+        if (MODE == MIX_VISIT) {
+            // the vector instructions of one node visit of the packet walk, in its order, on registers of their own (4 copies per iteration)
 #pragma unroll
-            for (int j = 0; j < 16; j++) { p0 = __builtin_elementwise_fma(p0, pa, pb); p1 = __builtin_elementwise_fma(p1, pa, pb); p2 = __builtin_elementwise_fma(p2, pa, pb); p3 = __builtin_elementwise_fma(p3, pa, pb); }
-        } else if (MODE == 2) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) { x0 = fmaxf(x0, a + j); x1 = fminf(x1, b + j); x2 = fmaxf(x2, a - j); x3 = fminf(x3, b - j); x4 = fmaxf(x4, a * j); x5 = fminf(x5, b * j); x6 = fmaxf(x6, a + 2 * j); x7 = fminf(x7, b + 3 * j); }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) { p0 = __builtin_elementwise_max(p0, pa + (float)j); p1 = __builtin_elementwise_min(p1, pb + (float)j); p2 = __builtin_elementwise_max(p2, pa - (float)j); p3 = __builtin_elementwise_min(p3, pb - (float)j); }
+            for (int u = 0; u < 4; u++) {
+                asm volatile(
+                    "v_pk_fma_f32 %0, %10, %11, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_pk_fma_f32 %1, %10, %11, %12 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"
+                    "v_pk_fma_f32 %2, %10, %12, %11 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_pk_fma_f32 %3, %10, %12, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+                    "v_pk_fma_f32 %4, %10, %11, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+                    "v_pk_fma_f32 %5, %10, %11, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+                    "v_pk_fma_f32 %0, %10, %12, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                    "v_pk_fma_f32 %1, %10, %11, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                    "v_pk_fma_f32 %2, %10, %11, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                    "v_max3_f32 %7, %7, %8, %9 clamp\n\t"
+                    "v_min3_f32 %8, %8, %9, %7 clamp\n\t"
+                    "v_max3_f32 %9, %9, %7, %8 clamp\n\t"
+                    "v_min3_f32 %7, %7, %8, %9 clamp\n\t"
+                    "v_cmp_lt_f32 vcc, %7, %8\n\t"
+                    "v_cmp_lt_f32 %6, %9, %7\n\t"
+                    : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+s"(sg), "+v"(x[0]), "+v"(x[1]), "+v"(x[2])
+                    : "s"(pa), "v"(pb), "v"(p[6])
+                    : "vcc");
+            }
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = (float)(sg & 1);
+    for (int j = 0; j < 8; j++) s += x[j] + p[j].x + p[j].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
-template <int MODE> void run(const char *name, int blocks_per_cu) {
-    float *out; hipMalloc(&out, 256 * 256 * 8 * 4 * 4);
-    int iters = 20000; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    int grid = 256 * blocks_per_cu;
-    k<MODE><<<grid, 256>>>(out, 1.0001f, 0.5f, 10);
-    hipEventRecord(e0); k<MODE><<<grid, 256>>>(out, 1.0001f, 0.5f, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+
+template <int MODE> void run(int waves_per_simd, FILE *f) {
+    const int grid = 256 * waves_per_simd, iters = 4000;
+    float *out; unsigned long long *cyc;
+    hipMalloc(&out, (size_t)grid * 256 * 4); hipMalloc(&cyc, (size_t)grid * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<grid, 256>>>(out, cyc, 1.0001f, 0.5f, 10);
+    hipEventRecord(e0); k<MODE><<<grid, 256>>>(out, cyc, 1.0001f, 0.5f, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    double insts = (double)grid * 4 * iters * 64;   // wave-instructions of the unrolled body
-    printf("%-22s %d waves/SIMD: %.2f ms, %.3f wave-instr/cycle/SIMD at 2.4 GHz\n", name, blocks_per_cu, ms, insts / (ms * 1e-3 * 2.4e9) / 1024);
-    hipFree(out);
+    std::vector<unsigned long long> h(grid); hipMemcpy(h.data(), cyc, (size_t)grid * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double per_wave = (double)iters * kPerIter[MODE];             // wave-instructions one wave issued
+    const double stamp_cyc = (double)h[grid / 2];                       // s_memtime ticks (shader cycles) of the median workgroup
+    // all waves of a SIMD issue for the whole loop: SIMD cycles per wave-instruction = loop cycles / (instructions per wave x waves per SIMD)
+    std::fprintf(f, "%-46s %d waves/SIMD: %7.3f ms  %6.2f cycles per wave-instruction per SIMD (s_memtime)  %6.2f (event time at 2.4 GHz)\n", kNames[MODE], waves_per_simd, ms,
+                 stamp_cyc / (per_wave * waves_per_simd), ms * 1e-3 * 2.4e9 / (per_wave * waves_per_simd));
+    hipFree(out); hipFree(cyc);
 }
+template <int M> void all(FILE *f) { for (int w : { 1, 2, 4, 8 }) run<M>(w, f); std::fprintf(f, "\n"); }
 int main() {
-    for (int b : {1, 2, 4, 8}) { run<0>("v_fma_f32", b); run<1>("v_pk_fma_f32", b); run<2>("v_max/min_f32", b); run<3>("v_pk_max/min_f32", b); }
+    FILE *f = stdout;
+    hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+    std::fprintf(f, "# %s, %d CUs, clockRate %d kHz; 256-thread workgroups, one per CU per wave-per-SIMD step; eight independent registers per lane\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate);
+    all<FMA>(f); all<PK_FMA>(f); all<PK_FMA_OPSEL>(f); all<PK_MUL>(f); all<MAX3>(f); all<MAX3_CLAMP>(f); all<CMP_VCC>(f); all<CMP_SGPR>(f);
+    all<EXP>(f); all<LOG>(f); all<RCP>(f); all<MOV>(f); all<WRITELANE>(f); all<MIX_VISIT>(f);
     return 0;
 }
