@@ -1157,6 +1157,132 @@ void evo_splat_photons(const evo_frame_params *fp, int32_t W, int32_t H, int32_t
     if (pairs_out) *pairs_out = pairs;
 }
 
+/* ------------------------------------------------------------------ the reference's splat FOOTPRINT (test infrastructure) */
+/* The reference does not test a sphere: it draws an instanced icosphere mesh of radius r around every photon with the depth test
+ * on (LEQUAL against the deferred pass's depth, no depth writes) and WITHOUT face culling (rtcomphoton.h:653-655: glEnable
+ * (GL_CULL_FACE) is commented out; :789-837; photonsplatinstanced.vert:28-33, .geom:16-32).  A pixel therefore receives the
+ * fragment shader's value once per proxy FACE that the pixel's eye ray crosses in front of the visible surface -- zero times when
+ * the surface point lies inside the sphere but outside (or in front of) the inscribed polyhedron, twice when both faces lie in front
+ * of it -- and the shader itself still discards |X_p - P_i|^2 > r^2 (frag:152-154).  sphere/icosphere.obj is a Git-LFS stub of 2178
+ * bytes: the size of Blender's default icosphere (2 subdivisions: 42 vertices on the unit sphere, 80 faces) exported without normals;
+ * its orientation is unknown (poles on the y axis here, Blender's z-up to y-up export), which moves WHICH silhouette pixels are
+ * missed, not how many.  evo_splat_photons_proxy applies that rule next to the ideal one (evo_splat_photons) so that
+ * the difference -- DESIGN.md section 2, deviation (4) -- is a measured number. */
+static void icosphere42(double v[42][3], int f[80][3]) {
+    /* icosahedron: poles (0, +-1, 0), two rings of five at y = +-1/sqrt(5), the upper ring turned by 36 degrees */
+    double base[12][3]; int nb = 0;
+    const double h = 1.0 / sqrt(5.0), rr = 2.0 / sqrt(5.0), pi = 3.14159265358979323846;
+    base[nb][0] = 0; base[nb][1] = -1; base[nb][2] = 0; nb++;
+    for (int k = 0; k < 5; k++) { double a = 2.0 * pi * k / 5.0; base[nb][0] = rr * cos(a); base[nb][1] = -h; base[nb][2] = rr * sin(a); nb++; }
+    for (int k = 0; k < 5; k++) { double a = 2.0 * pi * (k + 0.5) / 5.0; base[nb][0] = rr * cos(a); base[nb][1] = h; base[nb][2] = rr * sin(a); nb++; }
+    base[nb][0] = 0; base[nb][1] = 1; base[nb][2] = 0; nb++;
+    int bf[20][3], nf = 0;
+    for (int k = 0; k < 5; k++) { bf[nf][0] = 0; bf[nf][1] = 1 + k; bf[nf][2] = 1 + (k + 1) % 5; nf++; }                       /* bottom cap */
+    for (int k = 0; k < 5; k++) { bf[nf][0] = 1 + k; bf[nf][1] = 6 + k; bf[nf][2] = 1 + (k + 1) % 5; nf++; }                   /* belt */
+    for (int k = 0; k < 5; k++) { bf[nf][0] = 6 + k; bf[nf][1] = 6 + (k + 1) % 5; bf[nf][2] = 1 + (k + 1) % 5; nf++; }
+    for (int k = 0; k < 5; k++) { bf[nf][0] = 11; bf[nf][1] = 6 + (k + 1) % 5; bf[nf][2] = 6 + k; nf++; }                      /* top cap */
+    int nv = 12; for (int i = 0; i < 12; i++) for (int k = 0; k < 3; k++) v[i][k] = base[i][k];
+    int mid[12][12]; for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) mid[i][j] = -1;
+    int out = 0;
+    for (int t = 0; t < 20; t++) {
+        int m[3];
+        for (int e = 0; e < 3; e++) {
+            int a = bf[t][e], b = bf[t][(e + 1) % 3];
+            if (mid[a][b] < 0) {
+                double q[3], l = 0; for (int k = 0; k < 3; k++) { q[k] = 0.5 * (base[a][k] + base[b][k]); l += q[k] * q[k]; }
+                l = sqrt(l); for (int k = 0; k < 3; k++) v[nv][k] = q[k] / l;
+                mid[a][b] = mid[b][a] = nv++;
+            }
+            m[e] = mid[a][b];
+        }
+        int tri[4][3] = { { bf[t][0], m[0], m[2] }, { m[0], bf[t][1], m[1] }, { m[2], m[1], bf[t][2] }, { m[0], m[1], m[2] } };
+        for (int q = 0; q < 4; q++) { for (int k = 0; k < 3; k++) f[out][k] = tri[q][k]; out++; }
+    }
+}
+/* faces of the proxy (centre c, radius r) crossed by the ray e + t d with t in [tnear, tfar] (double precision; a ray through an edge
+ * or a vertex of the proxy -- measure zero -- may count a face twice, the rasteriser's fill rule would not) */
+static int proxy_faces_in_front(const double v[42][3], const int f[80][3], const float c[3], float r, const double e[3], const double d[3], double tnear, double tfar) {
+    int n = 0;
+    for (int t = 0; t < 80; t++) {
+        double p0[3], p1[3], p2[3];
+        for (int k = 0; k < 3; k++) { p0[k] = c[k] + (double)r * v[f[t][0]][k]; p1[k] = c[k] + (double)r * v[f[t][1]][k]; p2[k] = c[k] + (double)r * v[f[t][2]][k]; }
+        double e1[3], e2[3], pv[3], tv[3], qv[3];
+        for (int k = 0; k < 3; k++) { e1[k] = p1[k] - p0[k]; e2[k] = p2[k] - p0[k]; tv[k] = e[k] - p0[k]; }
+        pv[0] = d[1] * e2[2] - d[2] * e2[1]; pv[1] = d[2] * e2[0] - d[0] * e2[2]; pv[2] = d[0] * e2[1] - d[1] * e2[0];
+        const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+        if (det == 0.0) continue;
+        const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+        if (u < 0.0 || u > 1.0) continue;
+        qv[0] = tv[1] * e1[2] - tv[2] * e1[1]; qv[1] = tv[2] * e1[0] - tv[0] * e1[2]; qv[2] = tv[0] * e1[1] - tv[1] * e1[0];
+        const double w = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) / det;
+        if (w < 0.0 || u + w > 1.0) continue;
+        const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+        if (tt >= tnear && tt <= tfar) n++;
+    }
+    return n;
+}
+/* Both footprints over the same pixels and photons: out_ideal as evo_splat_photons, out_proxy with the reference's coverage count.
+ * stats[0] = (photon, pixel) pairs inside the radius, [1] = of those with no proxy face in front (missed by the reference),
+ * [2] = with two (counted twice by the reference), [3] = proxy fragments in total. */
+void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                             const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                             const evo_record *records, uint32_t num_records, float *out_ideal, float *out_proxy, uint64_t stats[4]) {
+    double iv[42][3]; int ifc[80][3]; icosphere42(iv, ifc);
+    const cam_basis cb = cam_make(cam);
+    const float r = fp->photon_radius;
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    /* (brute force over the photons per pixel row would be too slow: a uniform grid as in evo_splat_photons) */
+    uint32_t nph = 0; float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+    for (uint32_t i = 0; i < num_records; i++) if (records[i].flags & EVO_USABLE_PHOTON) { nph++; for (int k = 0; k < 3; k++) { lo[k] = minf(lo[k], records[i].pos[k]); hi[k] = maxf(hi[k], records[i].pos[k]); } }
+    if (!nph || !(r > 0.0f)) { if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0; return; }
+    float cell = r; int dim[3];
+    for (;;) { double cells = 1; for (int k = 0; k < 3; k++) { dim[k] = (int)floorf((hi[k] - lo[k]) / cell) + 1; cells *= dim[k]; } if (cells <= 64e6) break; cell *= 2.0f; }
+    size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
+    uint32_t *start = (uint32_t *)calloc(ncell + 1, sizeof(uint32_t)), *items = (uint32_t *)malloc(sizeof(uint32_t) * nph);
+#define CELL_OF(P, k) ((int)floorf(((P)[k] - lo[k]) / cell))
+    for (uint32_t i = 0; i < num_records; i++) if (records[i].flags & EVO_USABLE_PHOTON) start[((size_t)CELL_OF(records[i].pos, 2) * dim[1] + CELL_OF(records[i].pos, 1)) * dim[0] + CELL_OF(records[i].pos, 0) + 1]++;
+    for (size_t c = 0; c < ncell; c++) start[c + 1] += start[c];
+    uint32_t *cur = (uint32_t *)malloc(sizeof(uint32_t) * ncell); memcpy(cur, start, sizeof(uint32_t) * ncell);
+    for (uint32_t i = 0; i < num_records; i++) if (records[i].flags & EVO_USABLE_PHOTON) items[cur[((size_t)CELL_OF(records[i].pos, 2) * dim[1] + CELL_OF(records[i].pos, 1)) * dim[0] + CELL_OF(records[i].pos, 0)]++] = i;
+    free(cur);
+    const int reach = (int)ceilf(r / cell);
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : s0, s1, s2, s3) num_threads(evo_get_threads())
+    for (int32_t y = row_begin; y < row_end; y++) {
+        for (int32_t x = 0; x < W; x++) {
+            const size_t p = ((size_t)y * W + x) * 4;
+            const float *X = g_pos + p;
+            int c0[3], c1[3], skip = 0;
+            for (int k = 0; k < 3; k++) { int c = (int)floorf((X[k] - lo[k]) / cell); c0[k] = c - reach; c1[k] = c + reach; if (c1[k] < 0 || c0[k] >= dim[k]) skip = 1; if (c0[k] < 0) c0[k] = 0; if (c1[k] >= dim[k]) c1[k] = dim[k] - 1; }
+            if (skip) continue;
+            /* the pixel's eye ray under the jittered matrix (the one the deferred pass and the splat draw share, rtcomphoton.h:951, 959, 982) */
+            const float cx = ((float)x + 0.5f) / (float)W * 2.0f - 1.0f, cy = ((float)y + 0.5f) / (float)H * 2.0f - 1.0f;
+            const v3 dj = cam_dir(&cb, cx - fp->jitter[0], cy - fp->jitter[1]);
+            const double e[3] = { cb.eye.x, cb.eye.y, cb.eye.z }, d[3] = { dj.x, dj.y, dj.z };
+            /* view depth of the visible surface along that ray: the direction has camera-space z = -1 */
+            const double tsurf = ((double)X[0] - e[0]) * cb.f.x + ((double)X[1] - e[1]) * cb.f.y + ((double)X[2] - e[2]) * cb.f.z;
+            double si[3] = { 0, 0, 0 }, sp[3] = { 0, 0, 0 };
+            for (int cz = c0[2]; cz <= c1[2]; cz++) for (int cyy = c0[1]; cyy <= c1[1]; cyy++) for (int cxx = c0[0]; cxx <= c1[0]; cxx++) {
+                const size_t c = ((size_t)cz * dim[1] + cyy) * dim[0] + cxx;
+                for (uint32_t j = start[c]; j < start[c + 1]; j++) {
+                    const uint32_t i = items[j]; float col[3];
+                    if (i == 0) continue;
+                    const v3 dv = sub(ld3(records[i].pos), ld3(X));
+                    if (!(dot(dv, dv) <= r * r)) continue;
+                    s0++;
+                    const int kept = evo_photon_frag(fp, &records[i], &records[i - 1], X, g_nrm + p, g_dif + p, g_phg + p, col);
+                    const int faces = proxy_faces_in_front(iv, ifc, records[i].pos, r, e, d, 0.1, tsurf * (1.0 + 1e-7));
+                    if (faces == 0) s1++; if (faces >= 2) s2++; s3 += (uint64_t)faces;
+                    if (kept) for (int k = 0; k < 3; k++) { si[k] += col[k]; sp[k] += (double)faces * col[k]; }
+                }
+            }
+            for (int k = 0; k < 3; k++) { out_ideal[p + k] += (float)si[k]; out_proxy[p + k] += (float)sp[k]; }
+        }
+    }
+#undef CELL_OF
+    free(start); free(items);
+    if (stats) { stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; }
+}
+
 /* ------------------------------------------------------------------ resolve */
 /* final.frag:19-35; the saved images (rtcomphoton.h:1121-1132) use mask_emitter = 0 */
 void evo_resolve(int32_t W, int32_t H, const float *vpl, const float *pm, const float *light,

@@ -183,6 +183,12 @@ int evo_photon_frag(const evo_frame_params *fp, const evo_record *photon, const 
 void evo_splat_photons(const evo_frame_params *fp, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
                        const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
                        const evo_record *records, uint32_t num_records, float *out, uint64_t *pairs_out);
+/* the same pixels and photons under both footprints: the ideal sphere (out_ideal) and the reference's instanced icosphere proxy with
+ * depth test and no face culling (out_proxy; rtcomphoton.h:632-655, 789-837, photonsplatinstanced.vert:28-33).  stats: pairs inside the
+ * radius, of those missed by the proxy, counted twice by it, proxy fragments.  Test infrastructure: quantifies DESIGN.md deviation (4) */
+void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                             const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                             const evo_record *records, uint32_t num_records, float *out_ideal, float *out_proxy, uint64_t stats[4]);
 /* final.frag:19-35 / rtcomphoton.h:1121-1132.  out_rgb: 3 floats per pixel, y = 0 bottom */
 void evo_resolve(int32_t W, int32_t H, const float *vpl, const float *pm, const float *light,
                  float vpl_scale, float pm_scale, float light_scale, int mask_emitter, int gamma,

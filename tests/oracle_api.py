@@ -98,6 +98,7 @@ def load():
     l.evo_photon_frag.restype = C.c_int
     l.evo_photon_frag.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P]
     l.evo_splat_photons.argtypes = [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P]
+    l.evo_splat_photons_proxy.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P]
     l.evo_resolve.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P]
     l.evo_progressive_step.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_int, _P, _P]
     l.evo_path_trace.restype = C.c_uint64
@@ -209,6 +210,18 @@ def splat(fp, W, H, gbuf, records, out=None, rows=None):
     r0, r1 = rows if rows else (0, H)
     l.evo_splat_photons(C.byref(fp), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), records.shape[0], ptr(out), C.byref(pairs))
     return out, pairs.value
+
+
+def splat_proxy(fp, cam, W, H, gbuf, records, rows=None):
+    """Both footprints of the photon splat on the same pixels: (ideal sphere image, reference icosphere-proxy image, stats) -- stats =
+    pairs inside the radius, of those missed by the proxy, counted twice by it, proxy fragments (oracle/evplp_oracle.c)."""
+    l = load()
+    ideal = np.zeros((H, W, 4), dtype=np.float32); proxy = np.zeros((H, W, 4), dtype=np.float32)
+    st = np.zeros(4, dtype=np.uint64)
+    r0, r1 = rows if rows else (0, H)
+    l.evo_splat_photons_proxy(C.byref(fp), C.byref(cam), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), records.shape[0],
+                              ptr(ideal), ptr(proxy), ptr(st))
+    return ideal, proxy, st
 
 
 def frame_params(camera_pos, mis_mode=0, pdf_mc=0.0, clamping_value=0.0, photon_radius=0.0, vsl_radius=0.0,

@@ -1,9 +1,14 @@
 // Developer tool (CPU only): replay of the VPL gather's packet walk (device_common.hpp::occluded_wave) on the REAL walk population
 // of the bench configuration -- G-buffer tiles and usable VPL records dumped on the GPU by tools/dump_proxy_data.py, the scene rebuilt
 // here by the deterministic generator, the tree by the product's host builder (bvh_build.cpp, linked in).  Used to price changes of
-// the walk's entry (per-VPL entry lists, plane culls) in node visits / triangle pairs per walk before they are written for the device.
+// the walk's entry in node visits / triangle pairs per walk before they are written for the device:
+//   mode 0  the walk from the root (the kernel as it is)
+//   mode 1  per-VPL entry lists: the subtrees hanging off the nodes that hold the VPL, two per synthetic node
+//   mode 2  one frustum per (tile, VPL) walks the tree down to the leaves (how loose is it against the 64 rays?)
+//   mode 3  entry cuts per (group of G x G tiles, VPL): a frustum around the group's segments descends the tree to a cut; the
+//           group's tile walks start from the cut (two cut nodes per synthetic node) instead of from the root
 //   g++ -O2 -std=c++17 -I evplp_amd/csrc -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bvh_eval/walk_proxy.cpp evplp_amd/csrc/bvh_build.cpp -o build/walk_proxy
-//   build/walk_proxy proxy.bin scene.obj scene_lights.obj [walks] [mode] [flags...]
+//   build/walk_proxy proxy.bin scene.obj scene_lights.obj [walks] [mode] [a] [b] [c] [d]
 #include "evplp_types.h"
 #include <algorithm>
 #include <cmath>
@@ -19,6 +24,8 @@ static V operator-(V a, V b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
 static V operator+(V a, V b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
 static V operator*(V a, float s) { return { a.x * s, a.y * s, a.z * s }; }
 static float dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static V cross(V a, V b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+static V norm(V a) { float l = std::sqrt(dot(a, a)); return l > 0 ? a * (1.0f / l) : a; }
 
 static bool tri_hit(const TriFlat &t, V o, V d, float tmin, float tmax) {
     float den = t.n[0] * d.x + t.n[1] * d.y + t.n[2] * d.z;
@@ -49,85 +56,30 @@ static void load_obj(const char *path, std::vector<float> &verts) {
 struct Box { float c[3], h[3]; int32_t ref; };
 static Box child_box(const BvhNode &n, int ch) { Box b; for (int k = 0; k < 3; k++) { b.c[k] = n.ctr[k][ch]; b.h[k] = n.hal[k][ch]; } b.ref = ch == 0 ? n.c0 : n.c1; return b; }
 static bool holds(const Box &b, V p, float m) { return std::fabs(p.x - b.c[0]) <= b.h[0] + m && std::fabs(p.y - b.c[1]) <= b.h[1] + m && std::fabs(p.z - b.c[2]) <= b.h[2] + m; }
-
-int main(int argc, char **argv) {
-    if (argc < 4) { std::fprintf(stderr, "usage: walk_proxy proxy.bin scene.obj lights.obj [walks] [mode] [cull] [order]\n"); return 2; }
-    const int nwalks = argc > 4 ? atoi(argv[4]) : 20000;
-    const int mode = argc > 5 ? atoi(argv[5]) : 0;        // 0 root walk; 1 per-VPL entry list (siblings of the nodes that hold the VPL, two per synthetic node)
-    const int cull = argc > 6 ? atoi(argv[6]) : 0;        // 1: drop siblings wholly behind the VPL's plane
-    const int order = argc > 7 ? atoi(argv[7]) : 0;       // entry list: 0 = deepest first (popped first), 1 = top first, 2 = sorted by distance (near first)
-    std::vector<float> verts; load_obj(argv[2], verts); if (std::strcmp(argv[3], "-") != 0) load_obj(argv[3], verts);
-    int ntri = (int)(verts.size() / 9);
-    BvhBuild bb; build_bvh(verts.data(), ntri, 1, &bb);
-    std::printf("tris %d nodes %d leaves %d depth %d build %.0f ms\n", ntri, bb.nnodes, bb.nleaves, bb.depth, bb.build_ms);
-    std::vector<int> depth((size_t)bb.nnodes, 0);
-    for (int i = 0; i < bb.nnodes; i++) { const BvhNode &n = bb.nodes[i]; if (n.c0 >= 0) depth[n.c0] = depth[i] + 1; if (n.c1 >= 0) depth[n.c1] = depth[i] + 1; }   // pre-order: children after parents
-    FILE *f = std::fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 1; }
-    int32_t hdr[2]; if (std::fread(hdr, 4, 2, f) != 2) return 1;
-    const int ntiles = hdr[0], nvpl = hdr[1];
-    std::vector<float> tiles((size_t)ntiles * 64 * 7), vpls((size_t)nvpl * 6);
-    if (std::fread(tiles.data(), 4, tiles.size(), f) != tiles.size() || std::fread(vpls.data(), 4, vpls.size(), f) != vpls.size()) return 1;
-    std::fclose(f);
-    std::printf("tiles %d vpls %d mode %d cull %d order %d\n", ntiles, nvpl, mode, cull, order);
-
-    // per-VPL entry lists (mode 1)
-    std::vector<std::vector<BvhNode>> syn((size_t)nvpl);
-    std::vector<double> list_len;
-    double sib_total = 0, sib_culled = 0;
-    if (mode == 1) {
-        for (int v = 0; v < nvpl; v++) {
-            const V vp = { vpls[6 * v], vpls[6 * v + 1], vpls[6 * v + 2] }, vn = { vpls[6 * v + 3], vpls[6 * v + 4], vpls[6 * v + 5] };
-            std::vector<Box> sib;                   // in discovery order (top first)
-            std::vector<int32_t> todo = { 0 };
-            while (!todo.empty()) {
-                const int32_t at = todo.back(); todo.pop_back();
-                const BvhNode &n = bb.nodes[at];
-                for (int ch = 0; ch < 2; ch++) {
-                    const Box b = child_box(n, ch);
-                    if (b.ref == kNoChild) continue;
-                    if (b.ref >= 0 && holds(b, vp, 0.f)) { todo.push_back(b.ref); continue; }       // an inner node that holds the VPL: its children are tested instead
-                    sib_total++;
-                    if (cull) {
-                        // wholly behind the VPL's plane (every active segment leaves the VPL into the half space n . (x - P) > 0)
-                        const float top = vn.x * (b.c[0] - vp.x) + vn.y * (b.c[1] - vp.y) + vn.z * (b.c[2] - vp.z) + std::fabs(vn.x) * b.h[0] + std::fabs(vn.y) * b.h[1] + std::fabs(vn.z) * b.h[2];
-                        if (top < 0.f) { sib_culled++; continue; }
-                    }
-                    sib.push_back(b);
-                }
-            }
-            if (order == 2) {
-                auto dist = [&](const Box &b) { float d = 0; const float p[3] = { vp.x, vp.y, vp.z }; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(p[k] - b.c[k]) - b.h[k], 0.f); d += e * e; } return d; };
-                std::sort(sib.begin(), sib.end(), [&](const Box &a, const Box &b) { return dist(a) > dist(b); });   // far first = bottom of the stack
-            } else if (order == 1) std::reverse(sib.begin(), sib.end());
-            for (size_t k = 0; k < sib.size(); k += 2) {
-                BvhNode m; std::memset(&m, 0, sizeof m);
-                for (int a = 0; a < 3; a++) { m.ctr[a][0] = sib[k].c[a]; m.hal[a][0] = sib[k].h[a]; }
-                m.c0 = sib[k].ref;
-                if (k + 1 < sib.size()) { for (int a = 0; a < 3; a++) { m.ctr[a][1] = sib[k + 1].c[a]; m.hal[a][1] = sib[k + 1].h[a]; } m.c1 = sib[k + 1].ref; }
-                else { for (int a = 0; a < 3; a++) { m.ctr[a][1] = 0; m.hal[a][1] = -3e38f; } m.c1 = kNoChild; }
-                syn[v].push_back(m);
-            }
-            list_len.push_back((double)syn[v].size());
-        }
-        double s = 0, mx = 0; for (double l : list_len) { s += l; mx = std::max(mx, l); }
-        std::printf("entry lists: %.1f synthetic nodes per VPL (max %.0f), siblings %.1f per VPL, %.1f %% culled by the VPL's plane\n", s / nvpl, mx, sib_total / nvpl, 100.0 * sib_culled / std::max(sib_total, 1.0));
+static std::vector<BvhNode> pair_up(const std::vector<Box> &sib) {
+    std::vector<BvhNode> out;
+    for (size_t k = 0; k < sib.size(); k += 2) {
+        BvhNode m; std::memset(&m, 0, sizeof m);
+        for (int a = 0; a < 3; a++) { m.ctr[a][0] = sib[k].c[a]; m.hal[a][0] = sib[k].h[a]; }
+        m.c0 = sib[k].ref;
+        if (k + 1 < sib.size()) { for (int a = 0; a < 3; a++) { m.ctr[a][1] = sib[k + 1].c[a]; m.hal[a][1] = sib[k + 1].h[a]; } m.c1 = sib[k + 1].ref; }
+        else { for (int a = 0; a < 3; a++) { m.ctr[a][1] = 0; m.hal[a][1] = -3e38f; } m.c1 = kNoChild; }
+        out.push_back(m);
     }
+    return out;
+}
 
-    std::mt19937 rng(4242);
-    double S_walks = 0, S_nodes = 0, S_leaves = 0, S_pairs = 0, S_empty = 0, S_empty_nodes = 0, S_full = 0, S_syn = 0;
-    double S_holdv = 0, S_holdt_all = 0, S_holdt_any = 0, S_holdboth = 0, S_none = 0;
-    std::vector<double> by_depth(80, 0.0);
-    std::vector<int32_t> stack(512);
-    std::vector<int> cand_hist, fvis_hist;
-    double C_n[4] = {}, C_nodes[4] = {}, C_pairs[4] = {}, C_alive0[4] = {}, C_alive1[4] = {}, C_after[4] = {};
-    int done = 0;
-    while (done < nwalks) {
-        const int ti = (int)(rng() % (unsigned)ntiles), vi = (int)(rng() % (unsigned)nvpl);
-        const float *T = &tiles[(size_t)ti * 64 * 7];
-        const V vp = { vpls[6 * vi], vpls[6 * vi + 1], vpls[6 * vi + 2] }, vn = { vpls[6 * vi + 3], vpls[6 * vi + 4], vpls[6 * vi + 5] };
-        V d[64], pp[64]; bool alive[64]; int nalive = 0;
-        float ivx[64], ivy[64], ivz[64], nox[64], noy[64], noz[64];
-        const float tmin = 1e-4f, tmax = 1.f - 1e-4f, ku = 1.0f / (tmax - tmin);
+static BvhBuild bb;
+static std::vector<int> depth_of;
+static const float kTmin = 1e-4f, kTmax = 1.f - 1e-4f;
+
+// the 64 segments of one (tile, VPL) packet
+struct Packet {
+    V vp, vn, d[64], pp[64]; bool alive[64]; int nalive = 0;
+    float ivx[64], ivy[64], ivz[64], nox[64], noy[64], noz[64];
+    void setup(const float *T, const float *vpl) {
+        vp = { vpl[0], vpl[1], vpl[2] }; vn = { vpl[3], vpl[4], vpl[5] }; nalive = 0;
+        const float ku = 1.0f / (kTmax - kTmin);
         for (int l = 0; l < 64; l++) {
             const V p1 = { T[l * 7], T[l * 7 + 1], T[l * 7 + 2] }, pn = { T[l * 7 + 4], T[l * 7 + 5], T[l * 7 + 6] };
             pp[l] = p1;
@@ -137,167 +89,322 @@ int main(int argc, char **argv) {
             d[l] = p1 - vp;
             const float i0x = srcp(d[l].x), i0y = srcp(d[l].y), i0z = srcp(d[l].z);
             ivx[l] = i0x * ku; ivy[l] = i0y * ku; ivz[l] = i0z * ku;
-            nox[l] = alive[l] ? (-(vp.x * i0x) - tmin) * ku : INFINITY; noy[l] = alive[l] ? (-(vp.y * i0y) - tmin) * ku : INFINITY; noz[l] = alive[l] ? (-(vp.z * i0z) - tmin) * ku : INFINITY;
+            nox[l] = alive[l] ? (-(vp.x * i0x) - kTmin) * ku : INFINITY; noy[l] = alive[l] ? (-(vp.y * i0y) - kTmin) * ku : INFINITY; noz[l] = alive[l] ? (-(vp.z * i0z) - kTmin) * ku : INFINITY;
         }
-        if (nalive == 0) continue;     // (the kernel skips these before the walk)
-        done++;
-        if (mode == 2) {
-            // ---- phase 1: one frustum per (tile, VPL) walks the tree alone (on the device: lane = VPL); candidates = the leaves it reaches
-            const int planes_on = cull;      // flags: 1 side planes, 2 end-point planes (VPL normal / mean pixel normal), 4 slabs along m, u, v
-            V cen = { 0, 0, 0 }; int na = 0; V pnm = { 0, 0, 0 };
-            for (int l = 0; l < 64; l++) if (alive[l]) { cen = cen + pp[l]; na++; pnm = pnm + V{ T[l * 7 + 4], T[l * 7 + 5], T[l * 7 + 6] }; }
-            cen = cen * (1.0f / na);
-            V m = cen - vp; { float L = std::sqrt(dot(m, m)); m = m * (1.0f / L); }
-            V ax = std::fabs(m.x) < 0.6f ? V{ 1, 0, 0 } : V{ 0, 1, 0 };
-            V u = { m.y * ax.z - m.z * ax.y, m.z * ax.x - m.x * ax.z, m.x * ax.y - m.y * ax.x }; { float L = std::sqrt(dot(u, u)); u = u * (1.0f / L); }
-            V w = { m.y * u.z - m.z * u.y, m.z * u.x - m.x * u.z, m.x * u.y - m.y * u.x };
-            { float L = std::sqrt(dot(pnm, pnm)); if (L > 0) pnm = pnm * (1.0f / L); }
-            float amin = 1e30f, amax = -1e30f, bmin = 1e30f, bmax = -1e30f; bool wide = false;
-            float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
-            float s_vpl = 1e30f, s_tile = 1e30f, mlo = 1e30f, mhi = -1e30f, ulo = 1e30f, uhi = -1e30f, wlo = 1e30f, whi = -1e30f;
-            for (int l = 0; l < 64; l++) if (alive[l]) {
-                const float dw = dot(m, d[l]), dl = std::sqrt(dot(d[l], d[l]));
-                if (dw <= 0.05f * dl) wide = true;
-                else { const float a = dot(u, d[l]) / dw, b = dot(w, d[l]) / dw; amin = std::min(amin, a); amax = std::max(amax, a); bmin = std::min(bmin, b); bmax = std::max(bmax, b); }
-                const V e0 = vp + d[l] * tmin, e1 = vp + d[l] * tmax;
-                const float q0[3] = { e0.x, e0.y, e0.z }, q1[3] = { e1.x, e1.y, e1.z };
-                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], std::min(q0[k], q1[k])); hi[k] = std::max(hi[k], std::max(q0[k], q1[k])); }
-                s_vpl = std::min(s_vpl, dot(vn, d[l]) * tmin);                       // n_v . (x - P) >= this on every segment
-                s_tile = std::min(s_tile, std::min(dot(pnm, e0), dot(pnm, e1)));     // pnm . x >= this on every segment
-                mlo = std::min(mlo, std::min(dot(m, e0), dot(m, e1))); mhi = std::max(mhi, std::max(dot(m, e0), dot(m, e1)));
-                ulo = std::min(ulo, std::min(dot(u, e0), dot(u, e1))); uhi = std::max(uhi, std::max(dot(u, e0), dot(u, e1)));
-                wlo = std::min(wlo, std::min(dot(w, e0), dot(w, e1))); whi = std::max(whi, std::max(dot(w, e0), dot(w, e1)));
-            }
-            const float eps = 1e-5f;
-            V pl[4] = { u - m * amin, m * amax - u, w - m * bmin, m * bmax - w };
-            auto outside = [&](const Box &b) {
-                const float c[3] = { b.c[0], b.c[1], b.c[2] };
-                for (int k = 0; k < 3; k++) if (c[k] - b.h[k] > hi[k] + eps || c[k] + b.h[k] < lo[k] - eps) return true;
-                const V cc = { c[0], c[1], c[2] }, rel = cc - vp;
-                auto ext = [&](V n) { return std::fabs(n.x) * b.h[0] + std::fabs(n.y) * b.h[1] + std::fabs(n.z) * b.h[2]; };
-                if ((planes_on & 1) && !wide) for (int k = 0; k < 4; k++) if (dot(pl[k], rel) + ext(pl[k]) < -eps) return true;
-                if (planes_on & 2) {
-                    if (dot(vn, rel) + ext(vn) < s_vpl - eps) return true;
-                    if (dot(pnm, cc) + ext(pnm) < s_tile - eps) return true;
-                }
-                if (planes_on & 4) {
-                    if (dot(m, cc) + ext(m) < mlo - eps || dot(m, cc) - ext(m) > mhi + eps) return true;
-                    if (dot(u, cc) + ext(u) < ulo - eps || dot(u, cc) - ext(u) > uhi + eps) return true;
-                    if (dot(w, cc) + ext(w) < wlo - eps || dot(w, cc) - ext(w) > whi + eps) return true;
-                }
-                return false;
-            };
-            std::vector<Box> cand; unsigned fvis = 0; int spf = 0; std::vector<int32_t> fst(256);
-            fst[spf++] = 0;
-            while (spf > 0) {
-                const int32_t at = fst[--spf]; fvis++;
-                const BvhNode &n = bb.nodes[at];
-                for (int ch = 0; ch < 2; ch++) { const Box b = child_box(n, ch); if (b.ref == kNoChild || outside(b)) continue; if (b.ref >= 0) fst[spf++] = b.ref; else cand.push_back(b); }
-            }
-            // ---- phase 2: the wave tests the candidate leaves (64 rays): slab test of the leaf's box, then its triangle pairs
-            unsigned entered = 0, prs = 0, tested = 0;
-            for (const Box &b : cand) {
-                if (nalive == 0) break;
-                tested++;
-                int hitn = 0;
-                for (int l = 0; l < 64; l++) {
-                    float axx = b.c[0] * ivx[l] + nox[l], ay = b.c[1] * ivy[l] + noy[l], az = b.c[2] * ivz[l] + noz[l];
-                    float bx = b.h[0] * std::fabs(ivx[l]), by = b.h[1] * std::fabs(ivy[l]), bz = b.h[2] * std::fabs(ivz[l]);
-                    float tn = clamp01(std::max(std::max(axx - bx, ay - by), az - bz)), tf = clamp01(std::min(std::min(axx + bx, ay + by), az + bz));
-                    if (tn < tf) hitn++;
-                }
-                if (!hitn) continue;
-                entered++;
-                const uint32_t id = (uint32_t)~b.ref, block = id >> 2, cnt = (id & 3u) + 1u; prs += cnt > 2 ? 2 : 1;
-                for (int l = 0; l < 64; l++) if (alive[l]) {
-                    bool h = false;
-                    for (uint32_t k = 0; k < cnt; k++) if (tri_hit(bb.tri_flat[block * 4 + k], vp, d[l], tmin, tmax)) h = true;
-                    if (h) { alive[l] = false; nalive--; nox[l] = noy[l] = noz[l] = INFINITY; }
-                }
-            }
-            cand_hist.push_back((int)cand.size()); fvis_hist.push_back((int)fvis);
-            S_walks++; S_nodes += fvis; S_syn += (double)cand.size(); S_leaves += entered; S_pairs += prs; S_none += tested;
-            if (cand.empty()) S_empty++; if (entered == 0) S_empty_nodes++;
-            if (nalive == 0) S_full++;
-            if (wide) S_holdv++;
-            continue;
+    }
+    int enters(const float *c, const float *h) const {      // lanes whose clamped slab interval of the box is not empty
+        int n = 0;
+        for (int l = 0; l < 64; l++) {
+            float ax = c[0] * ivx[l] + nox[l], ay = c[1] * ivy[l] + noy[l], az = c[2] * ivz[l] + noz[l];
+            float bx = h[0] * std::fabs(ivx[l]), by = h[1] * std::fabs(ivy[l]), bz = h[2] * std::fabs(ivz[l]);
+            float tn = clamp01(std::max(std::max(ax - bx, ay - by), az - bz)), tf = clamp01(std::min(std::min(ax + bx, ay + by), az + bz));
+            if (tn < tf) n++;
         }
-        int sp = 0; int32_t cur = 0; unsigned nodes = 0, leaves = 0, pairs = 0, nodes_at_last_hit = 0;
-        const int nalive0 = nalive;
-        const std::vector<BvhNode> *sy = nullptr;
-        if (mode == 1) {
-            sy = &syn[vi];
-            for (size_t k = 0; k < sy->size(); k++) stack[sp++] = bb.nnodes + (int32_t)k;
-            if (sp == 0) cur = kNoChild; else cur = stack[--sp];
+        return n;
+    }
+    void test_leaf(int32_t ref) {
+        const uint32_t id = (uint32_t)~ref, block = id >> 2, cnt = (id & 3u) + 1u;
+        for (int l = 0; l < 64; l++) if (alive[l]) {
+            bool h = false;
+            for (uint32_t k = 0; k < cnt; k++) if (tri_hit(bb.tri_flat[block * 4 + k], vp, d[l], kTmin, kTmax)) h = true;
+            if (h) { alive[l] = false; nalive--; nox[l] = noy[l] = noz[l] = INFINITY; }
         }
-        for (;;) {
-            while (cur >= 0) {
-                const bool is_syn = cur >= bb.nnodes;
-                const BvhNode &n = is_syn ? (*sy)[cur - bb.nnodes] : bb.nodes[cur]; nodes++;
-                if (is_syn) S_syn++;
-                else {
-                    by_depth[std::min(depth[cur], 79)]++;
+    }
+};
+struct WalkOut { unsigned nodes = 0, syn = 0, leaves = 0, pairs = 0, after = 0; int alive0 = 0, alive1 = 0; };
+static std::vector<double> g_by_depth(80, 0.0);
+static double g_cls[5] = {};
+// occluded_wave's control flow; `init` (may be null) = synthetic nodes preloaded on the stack (last = popped first)
+static WalkOut walk(Packet &P, const std::vector<BvhNode> *init, bool classify) {
+    WalkOut o; o.alive0 = P.nalive;
+    static std::vector<int32_t> stack(1024);
+    int sp = 0; int32_t cur = 0; unsigned at_last_hit = 0;
+    if (init) { for (size_t k = 0; k < init->size(); k++) stack[sp++] = bb.nnodes + (int32_t)k; if (sp == 0) cur = kNoChild; else cur = stack[--sp]; }
+    for (;;) {
+        while (cur >= 0) {
+            const bool is_syn = cur >= bb.nnodes;
+            const BvhNode &n = is_syn ? (*init)[cur - bb.nnodes] : bb.nodes[cur]; o.nodes++;
+            if (is_syn) o.syn++;
+            else {
+                g_by_depth[std::min(depth_of[cur], 79)]++;
+                if (classify) {
                     bool hv = false, ht_all = false, ht_any = false;
                     for (int ch = 0; ch < 2; ch++) {
                         const Box b = child_box(n, ch); if (b.ref == kNoChild) continue;
-                        if (holds(b, vp, 0.f)) hv = true;
-                        int cnt = 0, tot = 0; for (int l = 0; l < 64; l++) if (alive[l]) { tot++; if (holds(b, pp[l], 0.f)) cnt++; }
+                        if (holds(b, P.vp, 0.f)) hv = true;
+                        int cnt = 0, tot = 0; for (int l = 0; l < 64; l++) if (P.alive[l]) { tot++; if (holds(b, P.pp[l], 0.f)) cnt++; }
                         if (cnt > 0) ht_any = true; if (cnt == tot) ht_all = true;
                     }
-                    if (hv && ht_any) S_holdboth++; else if (hv) S_holdv++; else if (ht_all) S_holdt_all++; else if (ht_any) S_holdt_any++; else S_none++;
+                    g_cls[hv && ht_any ? 0 : hv ? 1 : ht_all ? 2 : ht_any ? 3 : 4]++;
                 }
-                int p0 = 0, p1 = 0;
-                for (int l = 0; l < 64; l++) for (int ch = 0; ch < 2; ch++) {
-                    float ax = n.ctr[0][ch] * ivx[l] + nox[l], ay = n.ctr[1][ch] * ivy[l] + noy[l], az = n.ctr[2][ch] * ivz[l] + noz[l];
-                    float bx = n.hal[0][ch] * std::fabs(ivx[l]), by = n.hal[1][ch] * std::fabs(ivy[l]), bz = n.hal[2][ch] * std::fabs(ivz[l]);
-                    float tn = clamp01(std::max(std::max(ax - bx, ay - by), az - bz)), tf = clamp01(std::min(std::min(ax + bx, ay + by), az + bz));
-                    if (tn < tf) { if (ch == 0) p0++; else p1++; }
-                }
-                if (p0 == 0 && p1 == 0) { cur = kNoChild; break; }
-                if (p0 == 0) { cur = n.c1; continue; }
-                if (p1 == 0) { cur = n.c0; continue; }
-                const bool first0 = p0 >= p1;
-                stack[sp++] = first0 ? n.c1 : n.c0; cur = first0 ? n.c0 : n.c1;
             }
-            if (cur != kNoChild) {
-                const uint32_t id = (uint32_t)~cur, block = id >> 2, cnt = (id & 3u) + 1u; leaves++; pairs += cnt > 2 ? 2 : 1;
-                for (int l = 0; l < 64; l++) if (alive[l]) {
-                    bool h = false;
-                    for (uint32_t k = 0; k < cnt; k++) if (tri_hit(bb.tri_flat[block * 4 + k], vp, d[l], tmin, tmax)) h = true;
-                    if (h) { alive[l] = false; nalive--; nox[l] = noy[l] = noz[l] = INFINITY; nodes_at_last_hit = nodes; }
-                }
-                if (nalive == 0) break;
-            }
-            if (sp == 0) break;
-            cur = stack[--sp];
+            float c0[3], h0[3], c1[3], h1[3];
+            for (int k = 0; k < 3; k++) { c0[k] = n.ctr[k][0]; h0[k] = n.hal[k][0]; c1[k] = n.ctr[k][1]; h1[k] = n.hal[k][1]; }
+            const int p0 = P.enters(c0, h0), p1 = P.enters(c1, h1);
+            if (p0 == 0 && p1 == 0) { cur = kNoChild; break; }
+            if (p0 == 0) { cur = n.c1; continue; }
+            if (p1 == 0) { cur = n.c0; continue; }
+            const bool first0 = p0 >= p1;
+            stack[sp++] = first0 ? n.c1 : n.c0; cur = first0 ? n.c0 : n.c1;
         }
-        {
-            const int cls = leaves == 0 ? 0 : nalive == 0 ? 1 : nalive == nalive0 ? 2 : 3;      // empty / fully occluded / leaves touched, nothing hit / partially occluded
-            C_n[cls]++; C_nodes[cls] += nodes; C_pairs[cls] += pairs; C_alive0[cls] += nalive0; C_alive1[cls] += nalive; C_after[cls] += nodes - nodes_at_last_hit;
+        if (cur != kNoChild) {
+            const uint32_t cnt = (((uint32_t)~cur) & 3u) + 1u; o.leaves++; o.pairs += cnt > 2 ? 2 : 1;
+            const int before = P.nalive;
+            P.test_leaf(cur);
+            if (P.nalive != before) at_last_hit = o.nodes;
+            if (P.nalive == 0) break;
         }
-        S_walks++; S_nodes += nodes; S_leaves += leaves; S_pairs += pairs;
-        if (leaves == 0) { S_empty++; S_empty_nodes += nodes; }
-        if (nalive == 0) S_full++;
+        if (sp == 0) break;
+        cur = stack[--sp];
     }
-    if (mode == 2) {
-        std::printf("frustum walk: %.2f node visits / packet, %.2f candidate leaves / packet (%.3f of the packets have none); wave phase: %.2f leaf boxes tested, %.2f entered, %.2f triangle pairs / packet; no leaf entered %.3f; fully occluded %.3f; wide packets %.4f\n",
-                    S_nodes / S_walks, S_syn / S_walks, S_empty / S_walks, S_none / S_walks, S_leaves / S_walks, S_pairs / S_walks, S_empty_nodes / S_walks, S_full / S_walks, S_holdv / S_walks);
-        std::sort(cand_hist.begin(), cand_hist.end()); std::sort(fvis_hist.begin(), fvis_hist.end());
-        auto pc = [&](std::vector<int> &h, double q) { return h[(size_t)(q * (h.size() - 1))]; };
-        std::printf("   candidates percentiles 50/75/90/95/99/max: %d %d %d %d %d %d;  frustum visits: %d %d %d %d %d %d\n", pc(cand_hist, .5), pc(cand_hist, .75), pc(cand_hist, .9), pc(cand_hist, .95), pc(cand_hist, .99), cand_hist.back(),
-                    pc(fvis_hist, .5), pc(fvis_hist, .75), pc(fvis_hist, .9), pc(fvis_hist, .95), pc(fvis_hist, .99), fvis_hist.back());
+    o.alive1 = P.nalive; o.after = o.nodes - at_last_hit;
+    return o;
+}
+
+// conservative bounds of a bundle of segments that share the origin vp: the box of their end points, four planes through the origin
+// around the directions, and two end-point planes (the VPL's own and a mean-normal plane under the far ends)
+struct Frustum {
+    V vp, vn, m, u, w, pnm, pl[4]; bool wide = false; int n = 0;
+    float lo[3], hi[3], s_vpl, s_tile, amin, amax, bmin, bmax;
+    V cen{ 0, 0, 0 };
+    void begin(V vp_, V vn_) { vp = vp_; vn = vn_; n = 0; cen = { 0, 0, 0 }; pnm = { 0, 0, 0 }; }
+    void centre(const Packet &P, const float *T) { for (int l = 0; l < 64; l++) if (P.alive[l]) { cen = cen + P.pp[l]; n++; pnm = pnm + V{ T[l * 7 + 4], T[l * 7 + 5], T[l * 7 + 6] }; } }
+    void axes() {
+        cen = cen * (1.0f / std::max(n, 1)); m = norm(cen - vp);
+        const V ax = std::fabs(m.x) < 0.6f ? V{ 1, 0, 0 } : V{ 0, 1, 0 };
+        u = norm(cross(m, ax)); w = cross(m, u); pnm = norm(pnm);
+        amin = bmin = 1e30f; amax = bmax = -1e30f; s_vpl = s_tile = 1e30f; wide = false;
+        for (int k = 0; k < 3; k++) { lo[k] = 1e30f; hi[k] = -1e30f; }
+    }
+    void bound(const Packet &P) {
+        for (int l = 0; l < 64; l++) if (P.alive[l]) {
+            const V d = P.d[l];
+            const float dw = dot(m, d), dl = std::sqrt(dot(d, d));
+            if (dw <= 0.05f * dl) wide = true;
+            else { const float a = dot(u, d) / dw, b = dot(w, d) / dw; amin = std::min(amin, a); amax = std::max(amax, a); bmin = std::min(bmin, b); bmax = std::max(bmax, b); }
+            const V e0 = vp + d * kTmin, e1 = vp + d * kTmax;
+            const float q0[3] = { e0.x, e0.y, e0.z }, q1[3] = { e1.x, e1.y, e1.z };
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], std::min(q0[k], q1[k])); hi[k] = std::max(hi[k], std::max(q0[k], q1[k])); }
+            s_vpl = std::min(s_vpl, dot(vn, d) * kTmin);
+            s_tile = std::min(s_tile, std::min(dot(pnm, e0), dot(pnm, e1)));
+        }
+    }
+    void finish() { pl[0] = u - m * amin; pl[1] = m * amax - u; pl[2] = w - m * bmin; pl[3] = m * bmax - w; }
+    bool outside(const Box &b, int flags) const {
+        const float eps = 1e-5f;
+        for (int k = 0; k < 3; k++) if (b.c[k] - b.h[k] > hi[k] + eps || b.c[k] + b.h[k] < lo[k] - eps) return true;
+        const V cc = { b.c[0], b.c[1], b.c[2] }, rel = cc - vp;
+        auto ext = [&](V q) { return std::fabs(q.x) * b.h[0] + std::fabs(q.y) * b.h[1] + std::fabs(q.z) * b.h[2]; };
+        if ((flags & 1) && !wide) for (int k = 0; k < 4; k++) if (dot(pl[k], rel) + ext(pl[k]) < -eps) return true;
+        if (flags & 2) {
+            if (dot(vn, rel) + ext(vn) < s_vpl - eps) return true;
+            if (dot(pnm, cc) + ext(pnm) < s_tile - eps) return true;
+        }
+        return false;
+    }
+};
+
+int main(int argc, char **argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: walk_proxy proxy.bin scene.obj lights.obj [walks] [mode] [a] [b] [c] [d]\n"); return 2; }
+    const int nwalks = argc > 4 ? atoi(argv[4]) : 20000;
+    const int mode = argc > 5 ? atoi(argv[5]) : 0;
+    const int pa = argc > 6 ? atoi(argv[6]) : 0, pb = argc > 7 ? atoi(argv[7]) : 0, pc = argc > 8 ? atoi(argv[8]) : 0, pd = argc > 9 ? atoi(argv[9]) : 0;
+    std::vector<float> verts; load_obj(argv[2], verts); if (std::strcmp(argv[3], "-") != 0) load_obj(argv[3], verts);
+    const int ntri = (int)(verts.size() / 9);
+    build_bvh(verts.data(), ntri, 1, &bb);
+    std::printf("tris %d nodes %d leaves %d depth %d build %.0f ms\n", ntri, bb.nnodes, bb.nleaves, bb.depth, bb.build_ms);
+    depth_of.assign((size_t)bb.nnodes, 0);
+    for (int i = 0; i < bb.nnodes; i++) { const BvhNode &n = bb.nodes[i]; if (n.c0 >= 0) depth_of[n.c0] = depth_of[i] + 1; if (n.c1 >= 0) depth_of[n.c1] = depth_of[i] + 1; }   // pre-order: children after parents
+    FILE *f = std::fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 1; }
+    int32_t hdr[2]; if (std::fread(hdr, 4, 2, f) != 2) return 1;
+    const int ntiles = hdr[0], nvpl = hdr[1];
+    std::vector<float> tiles((size_t)ntiles * 64 * 7), vpls((size_t)nvpl * 6);
+    if (std::fread(tiles.data(), 4, tiles.size(), f) != tiles.size() || std::fread(vpls.data(), 4, vpls.size(), f) != vpls.size()) return 1;
+    std::fclose(f);
+    std::printf("tiles %d vpls %d mode %d params %d %d %d %d\n", ntiles, nvpl, mode, pa, pb, pc, pd);
+    std::mt19937 rng(4242);
+
+    // ---------------------------------------------------------------- mode 1: per-VPL entry lists
+    std::vector<std::vector<BvhNode>> syn((size_t)nvpl);
+    if (mode == 1) {
+        const int cull = pa, order = pb;     // cull 1: drop subtrees wholly behind the VPL's plane; order 0 deepest popped first, 1 top first, 2 nearest first
+        double total = 0, culled = 0, len = 0, mx = 0;
+        for (int v = 0; v < nvpl; v++) {
+            const V vp = { vpls[6 * v], vpls[6 * v + 1], vpls[6 * v + 2] }, vn = { vpls[6 * v + 3], vpls[6 * v + 4], vpls[6 * v + 5] };
+            std::vector<Box> sib; std::vector<int32_t> todo = { 0 };
+            while (!todo.empty()) {
+                const int32_t at = todo.back(); todo.pop_back();
+                for (int ch = 0; ch < 2; ch++) {
+                    const Box b = child_box(bb.nodes[at], ch);
+                    if (b.ref == kNoChild) continue;
+                    if (b.ref >= 0 && holds(b, vp, 0.f)) { todo.push_back(b.ref); continue; }       // an inner node that holds the VPL: its children are tested instead
+                    total++;
+                    if (cull) {
+                        const float top = vn.x * (b.c[0] - vp.x) + vn.y * (b.c[1] - vp.y) + vn.z * (b.c[2] - vp.z) + std::fabs(vn.x) * b.h[0] + std::fabs(vn.y) * b.h[1] + std::fabs(vn.z) * b.h[2];
+                        if (top < 0.f) { culled++; continue; }
+                    }
+                    sib.push_back(b);
+                }
+            }
+            if (order == 2) {
+                auto dist = [&](const Box &b) { float d = 0; const float p[3] = { vp.x, vp.y, vp.z }; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(p[k] - b.c[k]) - b.h[k], 0.f); d += e * e; } return d; };
+                std::sort(sib.begin(), sib.end(), [&](const Box &a, const Box &b) { return dist(a) > dist(b); });
+            } else if (order == 1) std::reverse(sib.begin(), sib.end());
+            syn[v] = pair_up(sib); len += (double)syn[v].size(); mx = std::max(mx, (double)syn[v].size());
+        }
+        std::printf("entry lists: %.1f synthetic nodes per VPL (max %.0f), %.1f subtrees per VPL, %.1f %% behind the VPL's plane\n", len / nvpl, mx, total / nvpl, 100.0 * culled / std::max(total, 1.0));
+    }
+
+    double S_walks = 0, S_nodes = 0, S_syn = 0, S_leaves = 0, S_pairs = 0;
+    double C_n[4] = {}, C_nodes[4] = {}, C_pairs[4] = {}, C_alive0[4] = {}, C_alive1[4] = {}, C_after[4] = {};
+    auto account = [&](const WalkOut &o) {
+        const int cls = o.leaves == 0 ? 0 : o.alive1 == 0 ? 1 : o.alive1 == o.alive0 ? 2 : 3;
+        C_n[cls]++; C_nodes[cls] += o.nodes; C_pairs[cls] += o.pairs; C_alive0[cls] += o.alive0; C_alive1[cls] += o.alive1; C_after[cls] += o.after;
+        S_walks++; S_nodes += o.nodes; S_syn += o.syn; S_leaves += o.leaves; S_pairs += o.pairs;
+    };
+    auto report = [&]() {
+        std::printf("walks %.0f  nodes/walk %.2f (synthetic %.2f)  leaves/walk %.2f  pairs/walk %.2f  est VALU/walk %.0f (15 per visit, 46 per pair)\n",
+                    S_walks, S_nodes / S_walks, S_syn / S_walks, S_leaves / S_walks, S_pairs / S_walks, 15.0 * S_nodes / S_walks + 46.0 * S_pairs / S_walks);
+        const char *nm[4] = { "empty", "fully occluded", "leaves touched, no hit", "partially occluded" };
+        for (int c = 0; c < 4; c++) std::printf("   %-24s %.3f of walks: %.1f visits, %.1f pairs, %.1f lanes alive at start, %.1f at end, %.1f visits after the last hit; share of all visits %.3f, of all pairs %.3f\n", nm[c], C_n[c] / S_walks,
+                    C_nodes[c] / std::max(C_n[c], 1.0), C_pairs[c] / std::max(C_n[c], 1.0), C_alive0[c] / std::max(C_n[c], 1.0), C_alive1[c] / std::max(C_n[c], 1.0), C_after[c] / std::max(C_n[c], 1.0), C_nodes[c] / S_nodes, C_pairs[c] / std::max(S_pairs, 1.0));
+    };
+
+    if (mode == 0 || mode == 1) {
+        int done = 0; Packet P;
+        while (done < nwalks) {
+            const int ti = (int)(rng() % (unsigned)ntiles), vi = (int)(rng() % (unsigned)nvpl);
+            P.setup(&tiles[(size_t)ti * 64 * 7], &vpls[(size_t)vi * 6]);
+            if (P.nalive == 0) continue;     // (the kernel skips these before the walk)
+            done++;
+            account(walk(P, mode == 1 ? &syn[vi] : nullptr, true));
+        }
+        report();
+        std::printf("   real-node visits by what a child box holds: VPL+tile point %.2f  VPL only %.2f  all live tile points %.2f  some tile points %.2f  neither %.2f  /walk\n",
+                    g_cls[0] / S_walks, g_cls[1] / S_walks, g_cls[2] / S_walks, g_cls[3] / S_walks, g_cls[4] / S_walks);
+        std::printf("   visits by depth:"); for (int k = 0; k < 32; k++) std::printf(" %.2f", g_by_depth[k] / S_walks); std::printf("\n");
         return 0;
     }
-    std::printf("walks %.0f  nodes/walk %.2f (synthetic %.2f)  leaves/walk %.2f  pairs/walk %.2f  empty %.3f (nodes %.2f)  fully occluded %.3f  est VALU/walk %.0f\n",
-                S_walks, S_nodes / S_walks, S_syn / S_walks, S_leaves / S_walks, S_pairs / S_walks, S_empty / S_walks, S_empty_nodes / std::max(S_empty, 1.0), S_full / S_walks,
-                15.0 * S_nodes / S_walks + 46.0 * S_pairs / S_walks);
-    std::printf("   real-node visits by what a child box holds: VPL+tile point %.2f  VPL only %.2f  all live tile points %.2f  some tile points %.2f  neither %.2f  /walk\n",
-                S_holdboth / S_walks, S_holdv / S_walks, S_holdt_all / S_walks, S_holdt_any / S_walks, S_none / S_walks);
-    { const char *nm[4] = { "empty", "fully occluded", "leaves touched, no hit", "partially occluded" };
-      for (int c = 0; c < 4; c++) std::printf("   %-24s %.3f of walks: %.1f visits, %.1f pairs, %.1f lanes alive at start, %.1f at end, %.1f visits after the last hit; share of all visits %.3f, of all pairs %.3f\n", nm[c], C_n[c] / S_walks,
-                  C_nodes[c] / std::max(C_n[c], 1.0), C_pairs[c] / std::max(C_n[c], 1.0), C_alive0[c] / std::max(C_n[c], 1.0), C_alive1[c] / std::max(C_n[c], 1.0), C_after[c] / std::max(C_n[c], 1.0), C_nodes[c] / S_nodes, C_pairs[c] / std::max(S_pairs, 1.0)); }
-    std::printf("   visits by depth:");
-    for (int k = 0; k < 40; k++) std::printf(" %.2f", by_depth[k] / S_walks);
-    std::printf("\n");
+
+    if (mode == 2) {
+        const int flags = pa;
+        double fvis = 0, cands = 0, none = 0, entered = 0, prs = 0, tested = 0, n = 0; std::vector<int> hist;
+        Packet P; int done = 0;
+        while (done < nwalks) {
+            const int ti = (int)(rng() % (unsigned)ntiles), vi = (int)(rng() % (unsigned)nvpl);
+            const float *T = &tiles[(size_t)ti * 64 * 7];
+            P.setup(T, &vpls[(size_t)vi * 6]);
+            if (P.nalive == 0) continue;
+            done++; n++;
+            Frustum F; F.begin(P.vp, P.vn); F.centre(P, T); F.axes(); F.bound(P); F.finish();
+            std::vector<Box> cand; std::vector<int32_t> st = { 0 };
+            while (!st.empty()) {
+                const int32_t at = st.back(); st.pop_back(); fvis++;
+                for (int ch = 0; ch < 2; ch++) { const Box b = child_box(bb.nodes[at], ch); if (b.ref == kNoChild || F.outside(b, flags)) continue; if (b.ref >= 0) st.push_back(b.ref); else cand.push_back(b); }
+            }
+            cands += (double)cand.size(); hist.push_back((int)cand.size()); if (cand.empty()) none++;
+            for (const Box &b : cand) { if (P.nalive == 0) break; tested++; if (!P.enters(b.c, b.h)) continue; entered++; prs += ((((uint32_t)~b.ref) & 3u) + 1u) > 2 ? 2 : 1; P.test_leaf(b.ref); }
+        }
+        std::sort(hist.begin(), hist.end());
+        auto pq = [&](double q) { return hist[(size_t)(q * (hist.size() - 1))]; };
+        std::printf("frustum walk: %.2f node visits / packet, %.2f candidate leaves / packet (%.3f of the packets have none; percentiles 50/75/90/95/99/max %d %d %d %d %d %d); wave phase: %.2f leaf boxes tested, %.2f entered, %.2f triangle pairs / packet\n",
+                    fvis / n, cands / n, none / n, pq(.5), pq(.75), pq(.9), pq(.95), pq(.99), hist.back(), tested / n, entered / n, prs / n);
+        return 0;
+    }
+
+    if (mode == 3) {
+        // pa = G (tiles per group edge), pb = frustum flags, pc = cut budget (entries; the descent stops refining when the cut would exceed it),
+        // pd = 1: refine the group's cut per tile with the tile's own frustum (no further descent, just drop what the tile cannot reach)
+        const int G = std::max(pa, 1), flags = pb ? pb : 3, budget = pc ? pc : 32, per_tile = pd;
+        const int policy = getenv("POLICY") ? atoi(getenv("POLICY")) : 0, corner_bounds = getenv("CORNERS") ? atoi(getenv("CORNERS")) : 0, nosort = getenv("NOSORT") ? 1 : 0;
+        const int tiles_x = (int)std::lround(std::sqrt((double)ntiles));
+        if (tiles_x * tiles_x != ntiles) { std::fprintf(stderr, "mode 3 needs the full tile grid (dump with --stride 1)\n"); return 1; }
+        double groups = 0, fvis = 0, cut_sum = 0, cut_empty = 0, fallback = 0, tile_cut = 0, tile_walks = 0, tile_skipped = 0; std::vector<int> hist;
+        std::vector<Packet> PK((size_t)G * G);
+        while (S_walks < nwalks) {
+            const int gx = (int)(rng() % (unsigned)(tiles_x / G)), gy = (int)(rng() % (unsigned)(tiles_x / G)), vi = (int)(rng() % (unsigned)nvpl);
+            const float *vpl = &vpls[(size_t)vi * 6];
+            Frustum F; F.begin({ vpl[0], vpl[1], vpl[2] }, { vpl[3], vpl[4], vpl[5] });
+            int live_tiles = 0;
+            for (int j = 0; j < G * G; j++) {
+                const int ti = (gy * G + j / G) * tiles_x + gx * G + j % G;
+                const float *T = &tiles[(size_t)ti * 64 * 7];
+                PK[j].setup(T, vpl); if (PK[j].nalive) { live_tiles++; F.centre(PK[j], T); }
+            }
+            if (!live_tiles) continue;
+            groups++;
+            F.axes();
+            if (!corner_bounds) { for (int j = 0; j < G * G; j++) if (PK[j].nalive) F.bound(PK[j]); }
+            else {
+                // bounds from the eight corners of every tile's position box (what primary_kernel already writes per tile), all valid pixels
+                for (int j = 0; j < G * G; j++) {
+                    float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f }; int nv = 0;
+                    const int ti = (gy * G + j / G) * tiles_x + gx * G + j % G; const float *T = &tiles[(size_t)ti * 64 * 7];
+                    for (int l = 0; l < 64; l++) if (T[l * 7 + 3] != 0.f) { nv++; for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], T[l * 7 + k]); hi[k] = std::max(hi[k], T[l * 7 + k]); } }
+                    if (!nv) continue;
+                    Packet C; C.vp = F.vp; C.vn = F.vn; for (int l = 0; l < 64; l++) C.alive[l] = false;
+                    for (int q = 0; q < 8; q++) { const V p = { (q & 1) ? hi[0] : lo[0], (q & 2) ? hi[1] : lo[1], (q & 4) ? hi[2] : lo[2] }; C.alive[q] = true; C.pp[q] = p; C.d[q] = p - F.vp; }
+                    F.bound(C);
+                }
+            }
+            F.finish();
+            // the cut: refinement of the largest inner entry (policy 0) or of the entries in FIFO order (policy 1: breadth first), while
+            // the cut stays within the budget
+            std::vector<Box> cut; { Box r; std::memset(&r, 0, sizeof r); r.ref = 0; for (int k = 0; k < 3; k++) r.h[k] = 1e30f; cut.push_back(r); }
+            if (policy == 0) {
+                for (;;) {
+                    int best = -1; float best_a = -1.f;
+                    for (size_t k = 0; k < cut.size(); k++) if (cut[k].ref >= 0) { const float a = cut[k].h[0] * cut[k].h[1] + cut[k].h[1] * cut[k].h[2] + cut[k].h[2] * cut[k].h[0]; if (a > best_a) { best_a = a; best = (int)k; } }
+                    if (best < 0) break;
+                    const BvhNode &n = bb.nodes[cut[best].ref]; fvis++;
+                    Box kids[2]; int nk = 0;
+                    for (int ch = 0; ch < 2; ch++) { const Box b = child_box(n, ch); if (b.ref == kNoChild || F.outside(b, flags)) continue; kids[nk++] = b; }
+                    if ((int)cut.size() - 1 + nk > budget) break;
+                    cut.erase(cut.begin() + best); for (int k = 0; k < nk; k++) cut.push_back(kids[k]);
+                }
+            } else {
+                // ring: pop the front; an inner entry is replaced by its surviving children at the back, a leaf goes to the back as it is;
+                // stop when an expansion does not fit, or after a full round without an inner entry
+                size_t leaves_in_row = 0;
+                while (!cut.empty() && leaves_in_row < cut.size()) {
+                    const Box e = cut.front();
+                    if (e.ref < 0) { cut.erase(cut.begin()); cut.push_back(e); leaves_in_row++; continue; }
+                    const BvhNode &n = bb.nodes[e.ref]; fvis++;
+                    Box kids[2]; int nk = 0;
+                    for (int ch = 0; ch < 2; ch++) { const Box b = child_box(n, ch); if (b.ref == kNoChild || F.outside(b, flags)) continue; kids[nk++] = b; }
+                    if ((int)cut.size() - 1 + nk > budget) break;
+                    cut.erase(cut.begin()); for (int k = 0; k < nk; k++) cut.push_back(kids[k]);
+                    leaves_in_row = 0;
+                }
+            }
+            const bool is_root = cut.size() == 1 && cut[0].ref == 0 && cut[0].h[0] > 1e29f;
+            if (is_root) fallback++;
+            cut_sum += (double)cut.size(); hist.push_back((int)cut.size()); if (cut.empty()) cut_empty++;
+            // far entries at the bottom of the stack, near ones popped first
+            if (!nosort) std::sort(cut.begin(), cut.end(), [&](const Box &a, const Box &b) {
+                auto dist = [&](const Box &q) { float s = 0; const float p[3] = { F.vp.x, F.vp.y, F.vp.z }; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(p[k] - q.c[k]) - q.h[k], 0.f); s += e * e; } return s; };
+                return dist(a) > dist(b); });
+            for (int j = 0; j < G * G; j++) if (PK[j].nalive) {
+                if (is_root) { account(walk(PK[j], nullptr, false)); tile_walks++; continue; }
+                std::vector<Box> mine = cut;
+                if (per_tile) {
+                    const int ti = (gy * G + j / G) * tiles_x + gx * G + j % G;
+                    Frustum Ft; Ft.begin(F.vp, F.vn); Ft.centre(PK[j], &tiles[(size_t)ti * 64 * 7]); Ft.axes(); Ft.bound(PK[j]); Ft.finish();
+                    mine.clear(); for (const Box &b : cut) if (!Ft.outside(b, flags)) mine.push_back(b);
+                }
+                tile_cut += (double)mine.size();
+                if (mine.empty()) { tile_skipped++; WalkOut o; o.alive0 = o.alive1 = PK[j].nalive; account(o); continue; }
+                const std::vector<BvhNode> init = pair_up(mine);
+                account(walk(PK[j], &init, false)); tile_walks++;
+            }
+        }
+        std::sort(hist.begin(), hist.end());
+        auto pq = [&](double q) { return hist[(size_t)(q * (hist.size() - 1))]; };
+        std::printf("groups of %dx%d tiles: %.0f (group, VPL) cuts, %.1f refinement steps each, cut size %.2f (percentiles 50/75/90/99/max %d %d %d %d %d), empty %.3f, left at the root %.3f;  per tile walk: %.2f cut entries, %.3f of the walks skipped (empty cut)\n",
+                    G, G, groups, fvis / groups, cut_sum / groups, pq(.5), pq(.75), pq(.9), pq(.99), hist.back(), cut_empty / groups, fallback / groups, tile_cut / std::max(S_walks, 1.0), tile_skipped / std::max(S_walks, 1.0));
+        report();
+        std::printf("   refinement steps per tile walk %.2f\n", fvis / S_walks);
+        return 0;
+    }
     return 0;
 }

@@ -16,7 +16,7 @@ ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--tris", type=int, default=331000)
 ap.add_argument("--paths", type=int, default=1024)
 ap.add_argument("--scene", default="hard")
-ap.add_argument("--stride", type=int, default=3)
+ap.add_argument("--stride", type=int, default=1)
 ap.add_argument("--out", required=True)
 a = ap.parse_args()
 d = "/tmp/evplp_proxy_%s" % a.scene

@@ -55,7 +55,8 @@ hist = raw[4:4 + 32].astype(np.int64)
 walks, pairs, all_occ = int(raw[4 + 32]), int(raw[4 + 33]), int(raw[4 + 34])
 out = {
     "scene": a.scene, "accel": c.accel_info(), "usable_vpls": st["usable"], "rays": rays, "walks": walks,
-    "wave_node_visits": nodes, "node_visits_per_walk": nodes / max(walks, 1), "leaf_blocks_per_walk": float((hist * np.arange(32)).sum()) / max(walks, 1),
+    "wave_node_visits": nodes, "node_visits_per_walk": nodes / max(walks, 1), "synthetic_node_visits_per_walk": int(raw[3]) / max(walks, 1),
+    "entry_cuts": os.environ.get("EVPLP_CUTS", "1") != "0", "leaf_blocks_per_walk": float((hist * np.arange(32)).sum()) / max(walks, 1),
     "tri_pairs_per_walk": pairs / max(walks, 1),
     # per RAY: a wave-level visit tests the node / triangles for its 64 lanes; lanes that are alive at the start of the walk = rays
     "nodes_per_ray": nodes * 64 / max(rays, 1), "tris_per_ray": pairs * 2 * 64 / max(rays, 1),

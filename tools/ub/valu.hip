@@ -1,7 +1,8 @@
 // Micro-benchmark (developer tool): issue rate of the vector instructions the packet walk is made of, on gfx950, at 1 / 2 / 4 / 8
 // waves per SIMD.  Every body is inline asm on eight independent registers (no dependence between consecutive instructions), so
-// the compiler can neither fuse, pack nor drop anything; cycles are derived from s_memtime stamps around the loop (median over
-// workgroups) AND from the event time at the nominal 2.4 GHz -- the chip lowers its clock under load, the stamps do not care.
+// the compiler can neither fuse, pack nor drop anything.  Reported per line: nanoseconds per wave-instruction per SIMD from the event
+// time of the launch (what a kernel pays), the clock the chip held inside the loop (s_memtime ticks / s_memrealtime ticks x 100 MHz,
+// median over workgroups: the chip lowers its clock under load, by instruction mix) and their product, cycles per wave-instruction.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ub/valu tools/ub/valu.hip && tools/ub/valu > profiles/ub_valu_r04.txt
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -20,6 +21,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, unsigne
     for (int j = 0; j < 8; j++) { x[j] = threadIdx.x + j; p[j].x = x[j]; p[j].y = x[j] + 0.5f; }
     v2f pa = { a, a * 1.5f }, pb = { b, b * 0.5f };
     unsigned long long sg = 0;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
 #pragma unroll
@@ -106,27 +108,29 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, unsigne
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = (float)(sg & 1);
     for (int j = 0; j < 8; j++) s += x[j] + p[j].x + p[j].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = t1 - t0; cyc[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
 template <int MODE> void run(int waves_per_simd, FILE *f) {
     const int grid = 256 * waves_per_simd, iters = 4000;
     float *out; unsigned long long *cyc;
-    hipMalloc(&out, (size_t)grid * 256 * 4); hipMalloc(&cyc, (size_t)grid * 8);
+    hipMalloc(&out, (size_t)grid * 256 * 4); hipMalloc(&cyc, (size_t)grid * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<MODE><<<grid, 256>>>(out, cyc, 1.0001f, 0.5f, 10);
     hipEventRecord(e0); k<MODE><<<grid, 256>>>(out, cyc, 1.0001f, 0.5f, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(grid); hipMemcpy(h.data(), cyc, (size_t)grid * 8, hipMemcpyDeviceToHost);
-    std::sort(h.begin(), h.end());
-    const double per_wave = (double)iters * kPerIter[MODE];             // wave-instructions one wave issued
-    const double stamp_cyc = (double)h[grid / 2];                       // s_memtime ticks (shader cycles) of the median workgroup
-    // all waves of a SIMD issue for the whole loop: SIMD cycles per wave-instruction = loop cycles / (instructions per wave x waves per SIMD)
-    std::fprintf(f, "%-46s %d waves/SIMD: %7.3f ms  %6.2f cycles per wave-instruction per SIMD (s_memtime)  %6.2f (event time at 2.4 GHz)\n", kNames[MODE], waves_per_simd, ms,
-                 stamp_cyc / (per_wave * waves_per_simd), ms * 1e-3 * 2.4e9 / (per_wave * waves_per_simd));
+    std::vector<unsigned long long> h((size_t)grid * 2); hipMemcpy(h.data(), cyc, (size_t)grid * 16, hipMemcpyDeviceToHost);
+    std::vector<double> ghz((size_t)grid);
+    for (int b = 0; b < grid; b++) ghz[b] = (double)h[2 * b] / (double)std::max<unsigned long long>(h[2 * b + 1], 1ull) * 0.1;      // s_memrealtime ticks at 100 MHz
+    std::sort(ghz.begin(), ghz.end());
+    const double clock = ghz[grid / 2];
+    const double per_simd = (double)iters * kPerIter[MODE] * waves_per_simd;   // wave-instructions one SIMD issued (every SIMD holds waves_per_simd of the launch's waves)
+    const double ns = ms * 1e6 / per_simd;
+    std::fprintf(f, "%-46s %d waves/SIMD: %7.3f ms  %6.3f ns per wave-instruction per SIMD  clock %.2f GHz  -> %5.2f cycles\n", kNames[MODE], waves_per_simd, ms, ns, clock, ns * clock);
     hipFree(out); hipFree(cyc);
 }
 template <int M> void all(FILE *f) { for (int w : { 1, 2, 4, 8 }) run<M>(w, f); std::fprintf(f, "\n"); }
