@@ -21,14 +21,15 @@ light-tracing and G-buffer kernels), `vsl` (config #5) -- the other scene style,
 path tracer, and `render_json`: the same configuration run through evplp_render_json, the entry a maintainer of the reference
 binds (its per-iteration time must agree with ms_per_step).
 
-N GPUs, two front ends:
-  ranks (default)  one process per GPU (torch.distributed, backend nccl = RCCL).  Launched by the driver as
-        `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; when no launcher set WORLD_SIZE,
-        `python bench.py --gpus N` starts the N rank processes itself (before anything touches a GPU) and relays rank 0's JSON
-        line.  EVPLP_BENCH_BACKEND=gloo stages the collectives through the host and lets the ranks share GPUs (rank r uses
-        device r mod #devices): the N > 1 logic with the real kernels on a one-GPU box.
-  group  one process, `evplp_group` -- the native multi-GPU entry of the C ABI (one host thread, N contexts, RCCL opened by the
-        library; ranks on one device exchange by device copies).
+N GPUs, two front ends (--front-end auto picks `group` whenever the process sees N devices, `ranks` otherwise):
+  group  one process, `evplp_group` -- the native multi-GPU entry of the C ABI, what a maintainer of the reference binds (one host
+        thread, N contexts, RCCL opened by the library; ranks on one device exchange by device copies).  Under the driver's launcher
+        (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) rank 0 drives the group over the N devices and
+        the other N - 1 processes only meet it at a host-side barrier; if the group cannot be opened all of them fall back to `ranks`.
+  ranks  one process per GPU (torch.distributed, backend nccl = RCCL); when no launcher set WORLD_SIZE,
+        `python bench.py --gpus N --front-end ranks` starts the N rank processes itself (before anything touches a GPU) and relays
+        rank 0's JSON line.  EVPLP_BENCH_BACKEND=gloo stages the collectives through the host and lets the ranks share GPUs (rank r
+        uses device r mod #devices): the N > 1 logic with the real kernels on a one-GPU box.
 Either way the image is cut into interleaved 8-row strips (rank r owns row blocks b with b % N == r); the scene and the BVH are
 replicated; large light-path sets are traced 1/N per rank and shared by an all-gather of the record buffer, small ones are traced
 redundantly; each rank gathers / splats its own pixels; the framebuffer strips are all-gathered every frame.  Total work is
@@ -78,7 +79,9 @@ def parse():
     ap.add_argument("--scene", default="hard", choices=["hard", "easy"])
     ap.add_argument("--mis", default="", help="override misMode")
     ap.add_argument("--bvh", default="sah", choices=["sah", "sbvh", "lbvh", "gpu"], help="acceleration-structure builder (same flattened node format)")
-    ap.add_argument("--front-end", default="ranks", choices=["ranks", "group"], help="N > 1: one process per GPU over torch.distributed, or one process driving evplp_group")
+    ap.add_argument("--front-end", default="auto", choices=["auto", "ranks", "group"],
+                    help="N > 1: `group` = one process driving evplp_group, the library's own multi-GPU entry (auto: whenever this process sees N devices); "
+                         "`ranks` = one process per GPU over torch.distributed (auto: fewer devices than ranks, or EVPLP_BENCH_BACKEND=gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (configs #3-#5, other scene, 16384-slot variant, GPU path tracer, render_json)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="path-tracer iterations of the CPU baseline sample (0 = auto, ~12 s)")
@@ -366,6 +369,8 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 ctx.splat_photons(fp)
                 if os.environ.get("EVPLP_DUMP_SPLAT_HIST"):   # stats build: rectangle classes of the photons (tools/debug_splat_hist.py)
                     print("HIST", it, ctx.debug_counters(ev.PASS_SPLAT)[4:4 + 28].tolist(), flush=True)
+            # the frame ends with the composite (rtcomphoton.h:997-1004), as the group front end's present() does
+            ctx.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0)
             if use_dist:
                 if wl != "ppm":
                     env.all_gather(full, strip)
@@ -631,12 +636,55 @@ def render_json_time(env, wl, json_path, shape, iterations):
     return res
 
 
+def group_under_launcher(a):
+    """`--front-end group` when a launcher has started one process per GPU (the driver's N > 1 command): the measurement is rank 0's
+    -- one host thread driving evplp_group over the N devices, as a maintainer's binding would -- and the other processes only keep
+    the launcher's contract (they meet rank 0 at a host-side barrier before and after, and exit 0).  Returns True when this process
+    is done (ranks > 0), False when it is rank 0 and should go on.  If rank 0 cannot open the group (RCCL communicator across the N
+    devices), every process falls back to the `ranks` front end."""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    dist.init_process_group("gloo")
+    ok = [1]
+    if rank == 0:
+        try:
+            import evplp_amd as ev
+            g = ev.Group(64, 64, 64, 64, P, a.gpus, devices=list(range(a.gpus)), strip_rows=STRIP_ROWS)      # opens RCCL on the N devices
+            g.close()
+        except Exception as e:      # noqa: BLE001 -- any failure means "use the other front end"
+            sys.stderr.write(f"bench.py: evplp_group on {a.gpus} devices failed ({e}); falling back to --front-end ranks\n")
+            ok = [0]
+    dist.broadcast_object_list(ok, src=0)
+    if not ok[0]:
+        dist.destroy_process_group()
+        a.front_end = "ranks"
+        return False
+    if rank != 0:
+        dist.barrier()              # rank 0 has finished its measurement and printed
+        dist.destroy_process_group()
+        return True
+    a._launcher_group = dist       # rank 0 releases the others at the end
+    return False
+
+
 def main():
     a = parse()
     world_env = os.environ.get("WORLD_SIZE")
+    if a.front_end == "auto":
+        if a.gpus == 1 or os.environ.get("EVPLP_BENCH_BACKEND") == "gloo" or os.environ.get("EVPLP_BENCH_FORCE_DIST") == "1":
+            a.front_end = "ranks"
+        else:
+            import torch
+            a.front_end = "group" if torch.cuda.device_count() >= a.gpus else "ranks"      # (counting devices does not initialise the GPU)
     if a.gpus > 1 and world_env is None and a.front_end == "ranks":
         spawn_ranks(a)
         return
+    if a.gpus > 1 and world_env is not None and a.front_end == "group":
+        if group_under_launcher(a):
+            return
+        if a.front_end == "group":          # rank 0: the group ignores the launcher's process group
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+                os.environ.pop(k, None)
     # This process's stdout carries ONE line, the JSON.  Everything else that writes to file descriptor 1 -- RCCL's version banner at
     # communicator start-up, the technique loop's progress lines (printf), Python prints -- goes to stderr: descriptor 1 is pointed
     # at stderr for the whole run and the line is written to the saved descriptor at the end.
@@ -715,6 +763,30 @@ def main():
         out["cpu_baseline"] = base
         out["cpu_baseline_like_for_like"] = like
 
+    # A compact digest of every roofline of the line: inside `roofline` (which the driver's record keeps) and once more as the LAST key
+    # (the driver's 2 KB stdout tail), so that the fractions of configs #3 / #4 / #5 are legible without the long notes in between.
+    if rank0 and out is not None:
+        def r3(x):
+            return None if x is None else float(f"{x:.4g}")
+        digest = {}
+        for name, o in ((wl, out),) + tuple((k, out[k]) for k in ("evplp", "ppm", "vsl") if k in out and k != wl):
+            d = {"ms_per_step": r3(o.get("ms_per_step"))}
+            rf = o.get("roofline")
+            if rf:
+                d.update(bound=rf.get("bound"), frac=r3(rf.get("frac")), kernel_ms=r3(rf.get("kernel_ms", rf.get("pass_ms"))))
+                if rf.get("frac_nominal_pairs") is not None:
+                    d["frac_nominal_pairs"] = r3(rf.get("frac_nominal_pairs"))
+            rs = o.get("roofline_splat")
+            if rs:
+                d.update(splat_frac=r3(rs.get("frac")), splat_ms=r3(rs.get("pass_ms")))
+            fd = o.get("feeders") or {}
+            if name == "ppm" and fd:
+                d.update(light_trace_ms=r3((fd.get("light_trace") or {}).get("ms")), primary_ms=r3((fd.get("primary") or {}).get("ms")))
+            digest[name] = d
+        if "roofline" in out:
+            out["roofline"]["digest"] = digest
+        out["summary"] = digest
+
     # The JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio, which is
     # block-buffered on a pipe and would otherwise surface after it at exit.  Every rank pushes its C buffers
     # out, all ranks meet, then rank 0 prints.
@@ -729,6 +801,9 @@ def main():
         if env.use_dist and env.world > 1:
             time.sleep(1.0)       # let the other ranks' processes drain whatever they still print while exiting
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if getattr(a, "_launcher_group", None) is not None:      # --front-end group under a launcher: let the idle ranks go
+        a._launcher_group.barrier()
+        a._launcher_group.destroy_process_group()
 
 
 if __name__ == "__main__":

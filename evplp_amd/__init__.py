@@ -106,6 +106,7 @@ _SIGNATURES = {
     "evplp_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_splat_photons": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
     "evplp_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
+    "evplp_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_clear_accumulators": (C.c_int, [_P]),
     "evplp_local_rows": (C.c_int, [_P]),
     "evplp_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -353,6 +354,10 @@ class Context:
         out = np.empty((self.local_rows, self.W, 3), dtype=np.float32)
         self._check(self._lib.evplp_resolve(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma), _ptr(out)))
         return out
+
+    def present(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=True, gamma=False):
+        """The per-iteration composite (rtcomphoton.h:997-1004): the strip's RGB stays on the device."""
+        self._check(self._lib.evplp_present(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma)))
 
     def clear_accumulators(self):
         self._check(self._lib.evplp_clear_accumulators(self._h))

@@ -69,6 +69,8 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     c->cfg = *cfg; c->cfg.strip_count = strip_count; c->cfg.strip_rows = strip_rows;
     if (const char *env = std::getenv("EVPLP_BVH_BUILDER"))
         c->env_bvh_builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : !std::strcmp(env, "gpu") ? EVPLP_BVH_LBVH_GPU : EVPLP_BVH_SAH;
+    if (const char *env = std::getenv("EVPLP_CUTS")) c->env_cuts = atoi(env) != 0 ? 1 : 0;
+    if (const char *env = std::getenv("EVPLP_CUT_BYTES")) c->env_cut_bytes = (size_t)strtoull(env, nullptr, 10);      // (tests: forces the band path)
     if (const char *env = std::getenv("EVPLP_GATHER_K")) { int v = atoi(env); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) c->env_gather_k = v; }
     if (const char *env = std::getenv("EVPLP_TILE_BLOCK_LOG2")) c->env_tile_block_log2 = std::max(0, atoi(env));
     c->st.W = cfg->res_x; c->st.H = cfg->res_y;
@@ -178,7 +180,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
-    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_lt_overflow);
+    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_cuts); hipFree(c->d_lt_overflow);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
     hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -511,7 +513,7 @@ static int pass_ready(evplp_context *c, const char *name, bool need_camera, bool
 #define EVPLP_TRAVERSAL_STATS 0
 #endif
 static bool pass_uses_counters(int pass) {
-    return pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL || pass == EVPLP_PASS_GATHER_LVC || pass == EVPLP_PASS_PATH_TRACE || EVPLP_TRAVERSAL_STATS;
+    return pass == EVPLP_PASS_GATHER_VPL || pass == EVPLP_PASS_GATHER_VSL || pass == EVPLP_PASS_GATHER_LVC || pass == EVPLP_PASS_PATH_TRACE || EVPLP_TRAVERSAL_STATS || EVPLP_DEBUG_NAN;
 }
 static int pass_begin(evplp_context *c, int pass) {
     if (pass_uses_counters(pass)) HIP_TRY(c, hipMemsetAsync(&c->d_counters[pass], 0, sizeof(PassCounters), c->stream));
@@ -678,18 +680,48 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     }
     a.splits_per_wave = k;
     if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k)))) return rc;
+    // entry cuts (kernels.h CutArgs): one slot per (tile group, VPL slot).  Groups are 2 x 2 tiles where the strip's tile rows are
+    // neighbours in the image (one GPU, or strips of 16 rows and more), 2 x 1 otherwise.  The scratch is bounded (EVPLP_CUT_BYTES, 12 GB
+    // by default): a configuration whose slots need more is gathered band by band -- rows of tile blocks -- cuts first, then the walks.
+    CutArgs ca; std::memset(&ca, 0, sizeof(ca));
+    bool use_cuts = c->env_cuts != 0;
+    const int sh = 1 << a.block_h_log2, nby = (c->tiles_y + sh - 1) / sh;       // rows of tile blocks
+    int band_rows = nby;
+    if (use_cuts && nby > 0) {
+        ca.nodes = c->sc.nodes; ca.tile_box = c->d_tile_box; ca.tiles_x = c->tiles_x; ca.tiles_y = c->tiles_y;
+        ca.gw_log2 = 1; ca.gh_log2 = (sh >= 2 && (c->st.strip_count == 1 || c->st.strip_rows >= 16)) ? 1 : 0;
+        ca.groups_x = (c->tiles_x + (1 << ca.gw_log2) - 1) >> ca.gw_log2;
+        ca.vpls = c->d_vpls; ca.nvpl = &c->d_scalars[0]; ca.vpl_stride = (uint32_t)nvpl_slots_of(c);
+        const size_t per_block_row = (size_t)(sh >> ca.gh_log2) * ca.groups_x * ca.vpl_stride * (size_t)kCutSlotBytes;
+        const size_t cap = c->env_cut_bytes > 0 ? c->env_cut_bytes : ((size_t)12 << 30);
+        band_rows = (int)std::min<size_t>((size_t)nby, std::max<size_t>(cap / std::max<size_t>(per_block_row, 1), 1));
+        const size_t need = per_block_row * (size_t)band_rows;
+        if (need > c->cut_bytes) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_cuts); c->d_cuts = nullptr; c->cut_bytes = 0;
+            if (hipMalloc((void **)&c->d_cuts, need) == hipSuccess) c->cut_bytes = need;
+            else { (void)hipGetLastError(); use_cuts = false; band_rows = nby; }     // (no memory for the scratch: the walks start at the root)
+        }
+        ca.cuts = c->d_cuts;
+    } else use_cuts = false;
     if ((rc = pass_begin(c, pass))) return rc;
     const uint32_t nrec = fp->photons_per_path * fp->num_vpl_light_paths;   // lighttracing.cu:368
     launch_compact_vpl((const evplp_record *)c->buf[EVPLP_BUF_RECORDS], nrec, c->d_vpls, c->d_vpl_src, &c->d_scalars[0], c->stream);
+    if (use_cuts && !c->tile_box_valid) {      // the G-buffer did not come from evplp_primary (or the caller may have written it): boxes of the tiles as they are now
+        launch_tile_boxes(c->st, (const float4 *)c->buf[EVPLP_BUF_GBUF_POSITION], c->d_tile_box, c->tiles_x, c->tiles_y, c->stream);
+        c->tile_box_valid = !c->gbuf_pos_exposed;
+    }
+    int vsl_groups = 0, vsl_per_launch = 0;
     if (vsl) {
         // lit masks between the walk and the estimator kernel: 8 bytes per (tile, VSL slot) of a launch; the groups of a tile are
         // covered in as many launches as keep the buffer within ~1 GB (config #5: 2048^2, 16 384 slots, k = 4: 4 launches of 8 groups)
         a.masks_per_split = (int32_t)((nvpl_slots_of(c) + kVplSplit - 1) / kVplSplit);
+        a.band_first = 0; a.band_rows = band_rows < nby ? band_rows : 0;
         const size_t tiles = (size_t)gather_launch_tiles(a), per_item = (size_t)k * (size_t)a.masks_per_split * sizeof(unsigned long long);
-        const int groups = kVplSplit / k;
-        int per_launch = groups;
-        while (per_launch > 1 && tiles * (size_t)per_launch * per_item > ((size_t)1 << 30)) per_launch = (per_launch + 1) / 2;
-        const size_t mask_bytes = tiles * (size_t)per_launch * per_item;
+        vsl_groups = kVplSplit / k;
+        vsl_per_launch = vsl_groups;
+        while (vsl_per_launch > 1 && tiles * (size_t)vsl_per_launch * per_item > ((size_t)1 << 30)) vsl_per_launch = (vsl_per_launch + 1) / 2;
+        const size_t mask_bytes = tiles * (size_t)vsl_per_launch * per_item;
         if (c->vsl_mask_bytes < mask_bytes) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             hipFree(c->d_vsl_masks); c->d_vsl_masks = nullptr; c->vsl_mask_bytes = 0;
@@ -698,18 +730,30 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
             c->vsl_mask_bytes = mask_bytes;
         }
         a.vsl_masks = (unsigned long long *)c->d_vsl_masks;
-        HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
-        for (int g0 = 0; g0 < groups; g0 += per_launch) {
-            a.group_first = g0; a.group_count = std::min(per_launch, groups - g0);
-            launch_gather_vsl(a, c->stream);
-        }
-        a.group_first = 0; a.group_count = 0;
-        HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
-    } else {
-        HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
-        launch_gather_vpl_items(a, c->stream);
-        HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
     }
+    // (the events bracket the cuts AND the walks: the cut kernel is part of the gather's work)
+    HIP_TRY(c, hipEventRecord(c->ev_dom_begin[pass], c->stream));
+    for (int b0 = 0; b0 < nby; b0 += band_rows) {
+        const int rows = std::min(band_rows, nby - b0);
+        a.band_first = b0; a.band_rows = band_rows < nby ? rows : 0;
+        if (use_cuts) {
+            const int gshift = ca.gh_log2, groups_total_y = (c->tiles_y + (1 << gshift) - 1) >> gshift;
+            ca.group_row_first = (b0 * sh) >> gshift;
+            ca.groups_y = std::min(((b0 + rows) * sh + (1 << gshift) - 1) >> gshift, groups_total_y) - ca.group_row_first;
+            launch_gather_cuts(ca, c->stream);
+            a.cuts = ca.cuts; a.cut_vpl_stride = ca.vpl_stride; a.cut_gw_log2 = ca.gw_log2; a.cut_gh_log2 = ca.gh_log2; a.cut_groups_x = ca.groups_x;
+            a.cut_group_row_first = ca.group_row_first;
+        }
+        if (vsl) {
+            for (int g0 = 0; g0 < vsl_groups; g0 += vsl_per_launch) {
+                a.group_first = g0; a.group_count = std::min(vsl_per_launch, vsl_groups - g0);
+                launch_gather_vsl(a, c->stream);
+            }
+            a.group_first = 0; a.group_count = 0;
+        } else launch_gather_vpl_items(a, c->stream);
+    }
+    a.band_first = 0; a.band_rows = 0;
+    HIP_TRY(c, hipEventRecord(c->ev_dom_end[pass], c->stream));
     launch_gather_reduce(a, vsl ? 0 : 1, c->stream);
     c->pass_has_dom[pass] = true;
     return pass_end(c, pass);
@@ -785,14 +829,16 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     // Measured (tiles kernel, ms): fullest bin 1405 entries (config #3): 0.31 with one wave, 0.18 with four; fullest bin 365
     // (config #4 shape): 0.12 / 0.22.  The fullest bin of the PREVIOUS pass decides (a heuristic either way).
     const bool split_tiles = c->cfg.deterministic ? true : c->last_bin_max >= 768u;
-    launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
+    const bool dom = c->stats_wanted[EVPLP_PASS_SPLAT];
+    c->stats_wanted[EVPLP_PASS_SPLAT] = false;
+    launch_splat_tiles(a, split_tiles, c->stream, dom ? c->ev_dom_begin[EVPLP_PASS_SPLAT] : nullptr, dom ? c->ev_dom_end[EVPLP_PASS_SPLAT] : nullptr);
     // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
     // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
     evplp_context::PendingSplat &slot = c->pend[c->npend];
     HIP_TRY(c, hipMemcpyAsync(slot.h, &c->d_summary[kSummaryFinal], 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));   // entries, fullest bin, overflow
     HIP_TRY(c, hipEventRecord(slot.ev, c->stream));
     slot.args = a; c->npend++;
-    c->pass_has_dom[EVPLP_PASS_SPLAT] = true;
+    c->pass_has_dom[EVPLP_PASS_SPLAT] = dom;
     return pass_end(c, EVPLP_PASS_SPLAT);
 }
 
@@ -804,9 +850,12 @@ bool host_would_wait(evplp_context *c) {
     if (hipSetDevice(c->cfg.device) != hipSuccess) return false;
     return hipEventQuery(c->pend[0].ev) == hipErrorNotReady;
 }
-int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
+// settle = false (the per-iteration composite of a running loop): the composite is enqueued behind the last splat without waiting for
+// the verdict on its bins -- the host does not stall; in the rare iteration whose bins overflowed the presented frame lacks that one
+// pass (it is run again and lands in the accumulator before the next composite).  Results that leave the device always settle.
+int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle) {
     CTX_CHECK(c);
-    { int rc_ = settle_splat(c); if (rc_) return rc_; }
+    if (settle) { int rc_ = settle_splat(c); if (rc_) return rc_; }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     int rc;
     if ((rc = pass_begin(c, EVPLP_PASS_RESOLVE))) return rc;
@@ -819,11 +868,16 @@ int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t ma
 extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
     CTX_CHECK(c);
     if (!out_rgb) { c->set_error("evplp_resolve: null output"); return EVPLP_ERR_INVALID; }
-    int rc = evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma);
+    int rc = evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma, true);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->d_rgb, sizeof(float) * 3 * (size_t)c->st.W * c->st.local_rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EVPLP_OK;
+}
+
+extern "C" int evplp_present(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
+    CTX_CHECK(c);
+    return evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma, !c->aux_stream);      // (overlapped contexts keep the host an iteration ahead)
 }
 
 extern "C" int evplp_clear_accumulators(evplp_context *c) {
@@ -904,6 +958,7 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out) { c->set_error("evplp_pass_stats_get: bad arguments"); return EVPLP_ERR_INVALID; }
     std::memset(out, 0, sizeof(*out));
+    c->stats_wanted[pass] = true;
     if (!c->pass_ran[pass]) return EVPLP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipEventSynchronize(c->ev_end[pass]));

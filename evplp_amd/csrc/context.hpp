@@ -22,6 +22,10 @@ struct evplp_context {
     hipEvent_t ev_begin[EVPLP_PASS_COUNT] = {}, ev_end[EVPLP_PASS_COUNT] = {};
     hipEvent_t ev_dom_begin[EVPLP_PASS_COUNT] = {}, ev_dom_end[EVPLP_PASS_COUNT] = {};
     bool pass_ran[EVPLP_PASS_COUNT] = {}, pass_has_dom[EVPLP_PASS_COUNT] = {};
+    // The events around the dominant kernel of the photon splat sit BETWEEN its three dependent launches and hold them apart (18 us of a
+    // 227 us pass, round 3).  They are recorded only while somebody reads them: on the first pass, and on every pass that follows a
+    // call of evplp_pass_stats_get for it; a loop that never asks runs its launches back to back.
+    bool stats_wanted[EVPLP_PASS_COUNT] = { true, true, true, true, true, true, true, true };
     evplp::HostStats stats_host[EVPLP_PASS_COUNT];
 
     void *buf[EVPLP_BUF_COUNT] = {};
@@ -46,6 +50,7 @@ struct evplp_context {
     // gather workspace, allocated on the first gather (path-tracing / photon-only contexts never pay for it)
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
     int32_t *d_lt_overflow = nullptr; size_t lt_overflow_bytes = 0;   // light tracing: the walk stack beyond its LDS entries (kernels.h)
+    char *d_cuts = nullptr; size_t cut_bytes = 0;               // gathers: entry cuts of every (tile group, VPL) (kernels.h CutArgs), allocated on the first gather
     void *d_vsl_masks = nullptr; size_t vsl_mask_bytes = 0;    // VSL gather: lit masks + per-item ray counts of one launch (kernels.h GatherArgs)
 
     // splat workspace
@@ -80,7 +85,8 @@ struct evplp_context {
 
     // Test / developer overrides, read ONCE by evplp_create (never in a pass): EVPLP_BVH_BUILDER (every suite under every builder),
     // EVPLP_BIN_STRIDE (forces the photon-bin overflow path), EVPLP_GATHER_K, EVPLP_TILE_BLOCK_LOG2.  -1 / 0 = not set.
-    int32_t env_bvh_builder = -1, env_gather_k = 0, env_tile_block_log2 = -1;
+    int32_t env_bvh_builder = -1, env_gather_k = 0, env_tile_block_log2 = -1, env_cuts = -1;      // env_cuts: EVPLP_CUTS=0 walks from the root
+    size_t env_cut_bytes = 0;                  // EVPLP_CUT_BYTES: bound of the entry-cut scratch (default 12 GB)
 
     char error[512] = "";
     void set_error(const char *fmt, ...);

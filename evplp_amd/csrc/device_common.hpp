@@ -350,6 +350,16 @@ EV_DEV void sload16x3(const void *base, uint32_t byte_offset, v16i &a, v16i &b, 
         : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(base), "s"(byte_offset));
 }
 template <class T> EV_DEV const T *pinned(const T *p) { asm("" : "+s"(p)); return p; }
+// Asynchronous copy global -> LDS (global_load_lds_dwordx4: every active lane moves 16 bytes from ITS source address to
+// lds_dst + 16 * lane; no register in between, counted by vmcnt).  The compiler neither sees the LDS write nor counts the load:
+// wait_vmcnt0() before the destination is read.  (M0 carries the LDS base and is compiler-reserved: written in the same statement.)
+EV_DEV void lds_dma16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+EV_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N> EV_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }   // all but the N youngest vector-memory operations
+template <class T> EV_DEV uint32_t lds_offset(const T *p) { return (uint32_t)(uintptr_t)p; }                 // (the low half of a generic pointer into LDS is the LDS address)
 // (Measured and removed: prefetching both children's nodes into the scalar cache with one-dword s_loads into SGPRs kept outside
 // the allocatable set -- cfg2 85.9 ms with, 78.5 ms without on the furnished scene, 36.5 / 32.2 on the box scene.  The scalar
 // pipe of a CU is as busy as its vector pipe in this walk; two more SMEM instructions per visit cost more than they hide.)
@@ -428,6 +438,25 @@ EV_DEV LeafOps fetch_leaf(const char *leaf_base, uint32_t leafref) {
     return L;
 }
 
+// ... in two steps (the any-hit walk): the first pair's 24 dwords, then -- after the first pair has been tested -- the second pair's.
+// All 48 dwords at once are what pushed the walk's scalar registers into VGPR lanes once the entry cuts took six more of them
+// (16 v_writelane + 24 v_readlane per two-pair leaf); the second fetch waits on its own, a latency the other waves of the SIMD cover.
+EV_DEV PairOps fetch_leaf_a(const char *leaf_base, uint32_t off, v16i &b) {
+    v16i a;
+    sload16x2(leaf_base, off, a, b);
+    PairOps A;
+    A.p0x = pk(a[0], a[1]); A.p0y = pk(a[2], a[3]); A.p0z = pk(a[4], a[5]); A.e0x = pk(a[6], a[7]); A.e0y = pk(a[8], a[9]); A.e0z = pk(a[10], a[11]);
+    A.e1x = pk(a[12], a[13]); A.e1y = pk(a[14], a[15]); A.e1z = pk(b[0], b[1]); A.nx = pk(b[2], b[3]); A.ny = pk(b[4], b[5]); A.nz = pk(b[6], b[7]);
+    return A;
+}
+EV_DEV PairOps fetch_leaf_b(const char *leaf_base, uint32_t off, const v16i &b) {
+    const v16i c = sload16(leaf_base, off + 128u);
+    PairOps B;
+    B.p0x = pk(b[8], b[9]); B.p0y = pk(b[10], b[11]); B.p0z = pk(b[12], b[13]); B.e0x = pk(b[14], b[15]); B.e0y = pk(c[0], c[1]); B.e0z = pk(c[2], c[3]);
+    B.e1x = pk(c[4], c[5]); B.e1y = pk(c[6], c[7]); B.e1z = pk(c[8], c[9]); B.nx = pk(c[10], c[11]); B.ny = pk(c[12], c[13]); B.nz = pk(c[14], c[15]);
+    return B;
+}
+
 // Stack-in-a-VGPR helpers: entry k of the wave's stack is lane k of one register.  A push is a
 // compare + select against the lane id (this clang has no v_writelane builtin), a pop is v_readlane
 // with a scalar lane index; neither touches memory.
@@ -448,7 +477,7 @@ EV_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 #ifndef EVPLP_TRAVERSAL_STATS
 #define EVPLP_TRAVERSAL_STATS 0    // 1: count node visits / leaf blocks / triangle pairs per walk (diagnostic build, tools/traversal_stats.py)
 #endif
-struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
+struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; uint32_t syn; };
 
 // One node visit of the packet walk, hand-scheduled: the slab tests of both children and the decision where to go next (push the
 // other child when both are entered, pop the lane stack when none is).  Written out because the scalar pipe of a CU is as busy as
@@ -465,7 +494,10 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
 #ifndef EVPLP_WALK_ASM
 #define EVPLP_WALK_ASM 1
 #endif
-#define EV_WALK_VISIT_ASM(T0, T1, T2, T3, T4, T5, T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)                                    \
+#define EV_WALK_VISIT_ASM(T0, T1, T2, T3, T4, T5, T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H) EV_WALK_VISIT_ASM_("s", T0, T1, T2, T3, T4, T5, T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)
+// NC: where the node's six box operands live -- "s" (a node fetched with s_load) or "v" (a synthetic node of an entry cut, read from LDS
+// with one address for all lanes: the same value in every lane of a VGPR serves as well)
+#define EV_WALK_VISIT_ASM_(NC, T0, T1, T2, T3, T4, T5, T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)                               \
     asm volatile(                                                                                                                            \
         "v_pk_fma_f32 " T0 ", %[cx], %[pa], %[pd] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                                                     \
         "v_pk_fma_f32 " T1 ", %[cy], %[pa], %[pd] op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                                                                                     \
@@ -512,14 +544,18 @@ struct WalkStats { uint32_t nodes, leaves, pairs, exact; int32_t hit_leaf; };
         "v_readlane_b32 %[cur], %[vstack], %[sp]\n"                                                                                          \
         "L_end%=:\n"                                                                                                                         \
         : [cur] "+s"(cur), [sp] "+s"(sp), [vstack] "+v"(vstack), [m1] "=&s"(m1_), [t64] "=&s"(t64_), [p0] "=&s"(p0_), [p1] "=&s"(p1_)          \
-        : [cx] "s"(cx_), [cy] "s"(cy_), [cz] "s"(cz_), [hx] "s"(hx_), [hy] "s"(hy_), [hz] "s"(hz_), [c0] "s"(c0_), [c1] "s"(c1_),              \
+        : [cx] NC(cx_), [cy] NC(cy_), [cz] NC(cz_), [hx] NC(hx_), [hy] NC(hy_), [hz] NC(hz_), [c0] "s"(c0_), [c1] "s"(c1_),              \
           [pa] "v"(pa_), [pb] "v"(pb_), [pc] "v"(pc_),                                     \
           [pd] "v"(pd_), [pe] "v"(pe_), [lane] "v"(lane_id)                                                                 \
         : "vcc", "scc", "m0", T0L, T0H, T1L, T1H, T2L, T2H, T3L, T3H, T4L, T4H, T5L, T5H)
 
-// VT = first of the twelve reserved temporaries: 52 for the 64-register VPL gather, 116 for the 128-register VSL gather; 0 = the C++ loop
-template <int VT = 0>
-EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr) {
+// VT = first of the twelve reserved temporaries: 52 for the 64-register VPL gather, 116 for the 128-register VSL gather; 0 = the C++ loop.
+// CUT: the walk starts from an entry cut (kernels.h CutArgs: `cut` points at the synthetic nodes of this (tile group, VPL), node 0
+// carries their count in its first padding word) instead of from the root: every synthetic node is visited like a node -- its two
+// children are cut entries with their boxes -- and whatever it lets in is walked to the end before the next one is fetched.
+template <int VT = 0, bool CUT = false>
+EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3 d, float tmin, float tmax, bool alive_lane, WalkStats *ws = nullptr, const char *cut = nullptr, uint32_t cut_off = 0u,
+                          const float4 *cut_lds = nullptr) {
     // All control state is wave-uniform (SGPRs): `alive` / `hitm` are 64-bit lane masks, `cur` the
     // node reference, `sp` the stack pointer.  Per-lane registers hold only the ray (1/d, -o/d) and its
     // far bound `tfar`: a lane that is inactive or already occluded carries tfar = -1, so its slab tests
@@ -543,6 +579,21 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
     int sp = 0;
     int vstack = 0;
     int32_t cur = 0;  // root is always an inner node
+    // `cut` + `cut_off` = the slot of this (tile group, VPL); `cut_off` then walks over its synthetic nodes, `cut_end` is where they end
+    uint32_t cut_end = 0u;
+    constexpr bool kCutLds = CUT && VT != 0 && EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS;   // the slot was copied to LDS ahead of the walk (gather kernels)
+    if constexpr (kCutLds) {
+        const int32_t nsyn = __builtin_amdgcn_readfirstlane(__float_as_int(cut_lds[3].z));
+        if (nsyn == 0) return false;                  // nothing between the VPL and the tile group
+        cut_off = 0u; cut_end = (uint32_t)nsyn;       // (here: node indices)
+    } else if constexpr (CUT) {
+        // (the count alone: a synthetic node is fetched right where it is visited -- held across the walk of the previous one the
+        // compiler parks its sixteen dwords in VGPR lanes, 32 cross-lane moves per synthetic node)
+        int32_t nsyn;
+        asm volatile("s_load_dword %0, %1, %2 offset:0x38\n\ts_waitcnt lgkmcnt(0)" : "=s"(nsyn) : "s"(cut), "s"(cut_off) : "memory");
+        if (nsyn == 0) return false;                  // nothing between the VPL and the tile group
+        cut_end = cut_off + ((uint32_t)nsyn << 6);
+    }
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
     if constexpr (VT != 0) {
         static_assert(VT == 52 || VT == 116, "reserved temporaries: v[52:63] or v[116:127]");
@@ -550,99 +601,145 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
         v2f pa_, pb_, pc_, pd_, pe_;
         pa_.x = ivx.x; pa_.y = ivy.x; pb_.x = ivz.x; pb_.y = avx.x; pc_.x = avy.x; pc_.y = avz.x;
         pd_.x = nox.x; pd_.y = noy.x; pe_.x = noz.x; pe_.y = noz.x;
+#define EV_VISIT(N)                                                                                                                          \
+        {                                                                                                                                    \
+            const v2f cx_ = pk(N[0], N[1]), cy_ = pk(N[2], N[3]), cz_ = pk(N[4], N[5]), hx_ = pk(N[6], N[7]), hy_ = pk(N[8], N[9]), hz_ = pk(N[10], N[11]); \
+            const int32_t c0_ = N[12], c1_ = N[13];                                                                                          \
+            unsigned long long m1_, t64_; int32_t p0_, p1_;                                                                                  \
+            if constexpr (VT == 52) EV_WALK_VISIT_ASM("v[52:53]", "v[54:55]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"); \
+            else EV_WALK_VISIT_ASM("v[116:117]", "v[118:119]", "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"); \
+        }
+        for (;;) {
+            if constexpr (CUT) {
+                if (cut_off >= cut_end) break;
+                // the synthetic node from the slot's LDS copy: one address for all lanes (a broadcast read), then into scalar registers like a
+                // fetched node (v_readfirstlane; as VGPR operands of the visit its twelve dwords cost the kernel seven spilled registers)
+                v16i syn;
+                {
+                    const float4 *q = cut_lds + 4u * cut_off;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const float4 qq = q[w];
+                        if (w < 3 || true) { syn[4 * w] = __builtin_amdgcn_readfirstlane(__float_as_int(qq.x)); syn[4 * w + 1] = __builtin_amdgcn_readfirstlane(__float_as_int(qq.y)); }
+                        if (w < 3) { syn[4 * w + 2] = __builtin_amdgcn_readfirstlane(__float_as_int(qq.z)); syn[4 * w + 3] = __builtin_amdgcn_readfirstlane(__float_as_int(qq.w)); }
+                    }
+                    syn[14] = 0; syn[15] = 0;
+                }
+                cut_off++;
+                EV_VISIT(syn)
+            }
+            for (;;) {
+                while (cur >= 0) {
+                    const v16i n = sload16(node_base, (uint32_t)cur << 6);
+                    EV_VISIT(n)
+                }
+                if (cur == kNoChild) break;
+                const uint32_t cnt = (((uint32_t)~cur) & 3u) + 1u, loff = (((uint32_t)~cur) >> 2) * 192u;
+                bool any;
+                if constexpr (CUT) {
+                    v16i lb;
+                    { const PairOps A = fetch_leaf_a(leaf_base, loff, lb); any = tri_pair_any(A, o, d, tmin, tmax); }
+                    if (cnt > 2u) { const PairOps B = fetch_leaf_b(leaf_base, loff, lb); any = any | tri_pair_any(B, o, d, tmin, tmax); }
+                } else {
+                    const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cur);
+                    any = tri_pair_any(L.A, o, d, tmin, tmax);
+                    if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax);
+                }
+                const unsigned long long hm = ballot64(any) & alive;
+                if (hm != 0ull) {
+                    hitm |= hm;
+                    alive &= ~hm;
+                    if (alive == 0ull) return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+                    if (any) { pd_ = bc(dead); pe_ = bc(dead); }     // newly occluded lanes stop driving the walk
+                }
+                if (sp == 0) break;
+                sp--;
+                cur = lane_read(vstack, sp);
+            }
+            if constexpr (!CUT) break;
+        }
+#undef EV_VISIT
+        return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+    }
+#endif
+    // the reference implementation of the same walk in C++ (EVPLP_WALK_ASM=0, and the counters build)
+    auto visit_cpp = [&](const v16i &n) {
+        // both children at once (half 0 = child 0, half 1 = child 1), conservative slab test in
+        // centre / half-size form: A = ctr/d - o/d, B = hal/|d|, entry = A - B, exit = A + B
+        const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
+        const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
+        const v2f enx = pk_fma(hx, -avx, ax), eny = pk_fma(hy, -avy, ay), enz = pk_fma(hz, -avz, az);
+        const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
+        const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
+        const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
+        const unsigned long long m0 = ballot64(tn0 < tf0), m1 = ballot64(tn1 < tf1);
+        const int32_t c0 = n[12], c1 = n[13];
+        // 32-bit scalar compares on purpose: this compiler turns compares of 64-bit masks into lane-mask
+        // booleans (s_cselect_b64 / s_and exec / s_cbranch_vcc, 4-5 instructions per branch)
+        const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
+        if ((a0 | a1) == 0u) { if (sp == 0) cur = kNoChild; else { sp--; cur = lane_read(vstack, sp); } return; }
+        if (a0 == 0u) { cur = c1; return; }
+        if (a1 == 0u) { cur = c0; return; }
+        // both hit: descend into the child wanted by more lanes first, keep the other one on the stack
+        // (scalar popcounts through inline asm: given __builtin_popcountll this compiler widens the counts to 64 bits and
+        // compares them with a VECTOR instruction, v_cmp_lt_u64 on a v_mov'd copy)
+        int p0, p1;
+        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(p0) : "s"(m0) : "scc");
+        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(p1) : "s"(m1) : "scc");
+        const bool first0 = p0 >= p1;
+        const int32_t oth = first0 ? c1 : c0;
+        vstack = lane_write(oth, sp, vstack);
+        sp++;
+        cur = first0 ? c0 : c1;
+    };
+    for (;;) {
+        if constexpr (CUT) {
+            if (cut_off >= cut_end) break;
+            const v16i syn = sload16(cut, cut_off);
+            cut_off += 64u;
+#if EVPLP_TRAVERSAL_STATS
+            if (ws) { ws->nodes++; ws->syn++; }
+#endif
+            visit_cpp(syn);
+        }
         for (;;) {
             while (cur >= 0) {
                 const v16i n = sload16(node_base, (uint32_t)cur << 6);
-                const v2f cx_ = pk(n[0], n[1]), cy_ = pk(n[2], n[3]), cz_ = pk(n[4], n[5]), hx_ = pk(n[6], n[7]), hy_ = pk(n[8], n[9]), hz_ = pk(n[10], n[11]);
-                const int32_t c0_ = n[12], c1_ = n[13];
-                unsigned long long m1_, t64_; int32_t p0_, p1_;
-                if constexpr (VT == 52) EV_WALK_VISIT_ASM("v[52:53]", "v[54:55]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-                else EV_WALK_VISIT_ASM("v[116:117]", "v[118:119]", "v[120:121]", "v[122:123]", "v[124:125]", "v[126:127]", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+#if EVPLP_TRAVERSAL_STATS
+                if (ws) ws->nodes++;
+#endif
+                visit_cpp(n);
             }
             if (cur == kNoChild) break;
-            const uint32_t cnt = (((uint32_t)~cur) & 3u) + 1u;
-            const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cur);
-            bool any = tri_pair_any(L.A, o, d, tmin, tmax);
-            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax);
-            const unsigned long long hm = ballot64(any) & alive;
-            if (hm != 0ull) {
-                hitm |= hm;
-                alive &= ~hm;
-                if (alive == 0ull) break;
-                if (any) { pd_ = bc(dead); pe_ = bc(dead); }     // newly occluded lanes stop driving the walk
+            {
+                const uint32_t id = (uint32_t)~cur;
+                const uint32_t cnt = (id & 3u) + 1u;
+                // a leaf block is two triangle pairs (192 B); fetch all of it before testing
+                const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cur);
+#if EVPLP_TRAVERSAL_STATS
+                if (ws) { ws->leaves++; ws->pairs += cnt > 2u ? 2u : 1u; }
+                uint32_t *ex = ws ? &ws->exact : nullptr;
+#else
+                uint32_t *ex = nullptr;
+#endif
+                bool any = tri_pair_any(L.A, o, d, tmin, tmax, ex);    // an empty slot B is all zeros: never a hit
+                if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, ex);
+                const unsigned long long hm = ballot64(any) & alive;
+                if (hm != 0ull) {
+#if EVPLP_TRAVERSAL_STATS
+                    if (ws) ws->hit_leaf = cur;
+#endif
+                    hitm |= hm;
+                    alive &= ~hm;
+                    if (alive == 0ull) return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+                    if (any) { nox = bc(dead); noy = bc(dead); noz = bc(dead); }   // newly occluded lanes stop driving the walk
+                }
             }
             if (sp == 0) break;
             sp--;
             cur = lane_read(vstack, sp);
         }
-        return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
-    }
-#endif
-    for (;;) {
-        while (cur >= 0) {
-            const v16i n = sload16(node_base, (uint32_t)cur << 6);
-#if EVPLP_TRAVERSAL_STATS
-            if (ws) ws->nodes++;
-#endif
-            // both children at once (half 0 = child 0, half 1 = child 1), conservative slab test in
-            // centre / half-size form: A = ctr/d - o/d, B = hal/|d|, entry = A - B, exit = A + B
-            const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
-            const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
-            const v2f enx = pk_fma(hx, -avx, ax), eny = pk_fma(hy, -avy, ay), enz = pk_fma(hz, -avz, az);
-            const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
-            const float tn0 = clamp01(fmaxf(fmaxf(enx.x, eny.x), enz.x)), tf0 = clamp01(fminf(fminf(exx.x, exy.x), exz.x));
-            const float tn1 = clamp01(fmaxf(fmaxf(enx.y, eny.y), enz.y)), tf1 = clamp01(fminf(fminf(exx.y, exy.y), exz.y));
-            const unsigned long long m0 = ballot64(tn0 < tf0), m1 = ballot64(tn1 < tf1);
-            const int32_t c0 = n[12], c1 = n[13];
-            // 32-bit scalar compares on purpose: this compiler turns compares of 64-bit masks into lane-mask
-            // booleans (s_cselect_b64 / s_and exec / s_cbranch_vcc, 4-5 instructions per branch)
-            const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
-            if ((a0 | a1) == 0u) { cur = kNoChild; break; }
-            if (a0 == 0u) { cur = c1; continue; }
-            if (a1 == 0u) { cur = c0; continue; }
-            {
-                // both hit: descend into the child wanted by more lanes first, keep the other one on the stack
-                // (scalar popcounts through inline asm: given __builtin_popcountll this compiler widens the counts to 64 bits and
-                // compares them with a VECTOR instruction, v_cmp_lt_u64 on a v_mov'd copy)
-                int p0, p1;
-                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(p0) : "s"(m0) : "scc");
-                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(p1) : "s"(m1) : "scc");
-                const bool first0 = p0 >= p1;
-                const int32_t oth = first0 ? c1 : c0;
-                vstack = lane_write(oth, sp, vstack);
-                sp++;
-                cur = first0 ? c0 : c1;
-            }
-        }
-        if (cur != kNoChild) {
-            const uint32_t id = (uint32_t)~cur;
-            const uint32_t cnt = (id & 3u) + 1u;
-            // a leaf block is two triangle pairs (192 B); fetch all of it before testing
-            const LeafOps L = fetch_leaf(leaf_base, (uint32_t)cur);
-#if EVPLP_TRAVERSAL_STATS
-            if (ws) { ws->leaves++; ws->pairs += cnt > 2u ? 2u : 1u; }
-#endif
-#if EVPLP_TRAVERSAL_STATS
-            uint32_t *ex = ws ? &ws->exact : nullptr;
-#else
-            uint32_t *ex = nullptr;
-#endif
-            bool any = tri_pair_any(L.A, o, d, tmin, tmax, ex);    // an empty slot B is all zeros: never a hit
-            if (cnt > 2u) any = any | tri_pair_any(L.B, o, d, tmin, tmax, ex);
-            const unsigned long long hm = ballot64(any) & alive;
-            if (hm != 0ull) {
-#if EVPLP_TRAVERSAL_STATS
-                if (ws) ws->hit_leaf = cur;
-#endif
-                hitm |= hm;
-                alive &= ~hm;
-                if (alive == 0ull) break;
-                if (any) { nox = bc(dead); noy = bc(dead); noz = bc(dead); }   // newly occluded lanes stop driving the walk
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = lane_read(vstack, sp);
+        if constexpr (!CUT) break;
     }
     return ((hitm >> (threadIdx.x & 63u)) & 1ull) != 0ull;
 }

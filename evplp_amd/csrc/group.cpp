@@ -18,7 +18,7 @@
 #include <vector>
 
 namespace evplp {
-int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma);   // context.cpp
+int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle);   // context.cpp
 bool host_would_wait(evplp_context *c);                                                                        // context.cpp
 }
 
@@ -130,6 +130,10 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
 
 // all-gather of equal chunks: rank r contributes `count` floats at send[r] and receives n * count floats at recv[r]
 static int group_all_gather(evplp_group *g, const std::vector<const float *> &send, const std::vector<float *> &recv, size_t count) {
+    if (g->n == 1 && g->virtual_ranks) {       // one rank: its chunk goes to its place in stream order, the host does not wait
+        if (recv[0] != send[0]) { hipError_t e = hipMemcpyAsync(recv[0], send[0], count * sizeof(float), hipMemcpyDeviceToDevice, g->ctx[0]->stream); if (e != hipSuccess) { g->set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; } }
+        return EVPLP_OK;
+    }
     if (!g->virtual_ranks) {
         ncclResult_t nr = g->rccl.GroupStart();
         for (int r = 0; r < g->n && nr == ncclSuccess; r++) nr = g->rccl.AllGather(send[r], recv[r], count, ncclFloat, g->comms[r], g->ctx[r]->stream);
@@ -189,19 +193,22 @@ extern "C" int evplp_group_path_trace(evplp_group *g, const float camera_pos[3],
 
 // Composite every strip on its GPU and all-gather the strips: every GPU then holds the frame, strip by strip.  This is
 // the per-frame exchange of a run that presents every frame; nothing comes to the host.
-extern "C" int evplp_group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
-    GRP_CHECK(g);
-    GRP_EACH(g, evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma));
+static int group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle) {
+    GRP_EACH(g, evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma, settle || !c->aux_stream));
     std::vector<const float *> send((size_t)g->n); std::vector<float *> recv((size_t)g->n);
     for (int r = 0; r < g->n; r++) { send[r] = g->ctx[r]->d_rgb; recv[r] = g->d_frame[r]; }
     return group_all_gather(g, send, recv, g->strip_floats);
+}
+extern "C" int evplp_group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
+    GRP_CHECK(g);
+    return group_present(g, vs, ps, ls, mask_emitter, gamma, false);       // (the per-iteration composite: no wait for the splat's verdict)
 }
 
 // evplp_group_present, then the frame in image order on rank 0's device and one copy to the caller.
 extern "C" int evplp_group_resolve(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
     GRP_CHECK(g);
     if (!out_rgb) { g->set_error("evplp_group_resolve: null output"); return EVPLP_ERR_INVALID; }
-    int rc = evplp_group_present(g, vs, ps, ls, mask_emitter, gamma);
+    int rc = group_present(g, vs, ps, ls, mask_emitter, gamma, true);
     if (rc < 0) return rc;
     // rank 0 puts the strips into image order on the device; one copy lands the frame in the caller's buffer (no host-side assembly:
     // a run that writes every frame resolves every iteration)

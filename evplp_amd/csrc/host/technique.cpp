@@ -323,7 +323,12 @@ private:
             if (do_vpl_splat) check(h, evplp_group_gather(h, &fp, lvc ? 2 : force_vsl ? 1 : 0), "gather");  // :968-972
             // radius 0 (radiusPercentage 0 of the VPL-only configs): the proxy spheres are degenerate, nothing is drawn
             if (do_photon_splat && photon_radius > 0.0f) check(h, evplp_group_splat_photons(h, &fp, frame_mode == 2 ? 1 : 0), "photon splat");    // :974-983
-            // [finalize] renders to the window in the reference (:997-1004); headless: nothing to present
+            // [finalize] runFinalProgram(param, param, 1, true) to the window (:997-1004): headless, the composite still runs -- it is part
+            // of the reference's iteration -- and stays on the device
+            if (do_finalize) {
+                const float param = frame_mode == 2 ? 1.0f : 1.0f / (float)(num_iterations + 1);
+                check(h, evplp_group_present(h, param, param, 1.0f, 1, 0), "finalize");
+            }
             num_iterations++;
             if (num_iterations % 20 == 0) {                                                   // :1008-1031
                 check(h, evplp_group_synchronize(h), "sync");

@@ -37,7 +37,13 @@ struct PassCounters {
     // gather: shadow rays / unoccluded pairs, summed by gather_reduce_kernel into 64 shards (one device-scope atomic per
     // workgroup; a single word saturates near 90 atomics per microsecond)
     unsigned long long shard_rays[64], shard_shaded[64];
+    // -DEVPLP_DEBUG_NAN builds only (`make nan`): pixels whose partial sum / splat sum came out non-finite -- the reference's ASSERT under
+    // DEBUG (realtimetechniques/all.cuh:10-17) as a counter (word 196 of evplp_debug_counters)
+    unsigned long long nonfinite;
 };
+#ifndef EVPLP_DEBUG_NAN
+#define EVPLP_DEBUG_NAN 0
+#endif
 constexpr int kCounterShards = 64;
 
 struct GatherArgs {
@@ -59,7 +65,35 @@ struct GatherArgs {
     // VSL gather (two kernels): lit-lane masks of every (item, VSL) of the launch, [item][k * masks_per_split], written by
     // gather_vsl_walk_kernel and read by gather_vsl_shade_kernel
     unsigned long long *vsl_masks; int32_t masks_per_split; int32_t pad1;
+    // entry cuts (round 4, CutArgs below): the walks of tile (tx, ty) for VPL i start from the cut of its tile group, at
+    // cuts + ((group index) * cut_vpl_stride + i) * kCutSlotBytes; null = walks start at the root
+    const char *cuts; uint32_t cut_vpl_stride; int32_t cut_gw_log2, cut_gh_log2, cut_groups_x;
+    // a launch covers the rows [band_first, band_first + band_rows) of tile BLOCKS only (band_rows = 0: all of them): the entry cuts of a
+    // large configuration are built and consumed band by band so that their scratch stays bounded (config #5: 137 GB for all at once).
+    // cut_group_row_first: the first row of tile groups that has slots in `cuts`
+    int32_t band_first, band_rows, cut_group_row_first, pad2;
 };
+// Entry cuts.  A frustum around ALL segments between one VPL and the pixels of a group of 2 x 2 tiles (the box of their end points
+// + four planes through the VPL) descends the tree breadth-first, dropping every subtree it cannot reach, until the surviving cut
+// would exceed kCutEntries; the group's (tile, VPL) packet walks then start from the cut -- two cut entries per synthetic node, in
+// the BvhNode format, so the walk's node visit tests them -- instead of from the root.  Measured on the walk population of the
+// bench configuration with the CPU replay (tools/bvh_eval/walk_proxy.cpp): 34.8 -> 16.0 node visits per walk, half of the walks
+// start from an empty cut; 8.7 frustum steps per tile walk at ~1.5 vector instructions per step and lane.
+constexpr int kCutEntries = 16;                    // cut entries per (group, VPL)
+constexpr int kCutNodes = kCutEntries / 2;         // synthetic nodes per slot
+constexpr int kCutSlotBytes = kCutNodes * 64;
+struct CutArgs {
+    const BvhNode *nodes;
+    const float4 *tile_box;           // [tiles][2] world-space box of every tile's G-buffer positions (primary_kernel / tile_box_kernel)
+    int32_t tiles_x, tiles_y;         // tiles of this context's strip
+    int32_t gw_log2, gh_log2;         // tiles per group: 2 x 2 (2 x 1 when the strip's tile rows are not neighbours in the image)
+    int32_t groups_x, groups_y;       // groups per row; rows of groups of THIS launch
+    int32_t group_row_first, pad;     // first row of groups of this launch (slot 0 of `cuts` belongs to its first group)
+    const evplp_record *vpls; const uint32_t *nvpl; uint32_t vpl_stride;     // compacted usable VPLs; slots per group in `cuts`
+    char *cuts;
+};
+void launch_gather_cuts(const CutArgs &a, hipStream_t s);
+void launch_tile_boxes(const StripDev &st, const float4 *g_pos, float4 *tile_box, int tiles_x, int tiles_y, hipStream_t s);
 #ifndef EVPLP_VPL_SPLIT
 #define EVPLP_VPL_SPLIT 128
 #endif

@@ -1,0 +1,183 @@
+// Entry cuts of the VPL / VSL gather (kernels.h CutArgs): where the packet walks of a tile group start, per VPL.
+//
+// The shadow segments between one VPL and the pixels of 2 x 2 neighbouring tiles lie inside a thin pyramid with its apex at the VPL.
+// Walking the tree once with that pyramid -- lane = VPL, one box-against-pyramid test per child instead of 64 ray-against-box tests
+// -- finds the few subtrees any of the group's 4 x 64 segments can reach; the four (tile, VPL) packet walks then start there.  Half
+// of all walks of the bench configuration find their cut empty (nothing between the VPL and the tiles) and never touch the tree.
+// The reference has no counterpart: OptiX traced every shadow ray of vplSplat from the root (rt/lighttracing.cu:290-294).
+//
+// Conservative by construction: a segment point x that lies on a triangle lies in that triangle's leaf box and in every ancestor's
+// box (boxes are padded, bvh_build.cpp), inside the box of the segments' end points and on the inner side of the four planes, so no
+// subtree that holds an occluder of any of the segments is ever dropped; all bounds carry margins far above the rounding of their
+// arithmetic.  The walks' results therefore stay bit-identical to a walk from the root (tests/test_gpu_parity.py::
+// test_visibility_is_bit_exact, tests/test_gpu_bvh.py, the configuration tests).
+#include "device_common.hpp"
+#include "kernels.h"
+
+namespace evplp {
+
+struct CutFrustum {
+    V3 p;                        // apex (the VPL)
+    float lo[3], hi[3];          // box of all segment end points, padded
+    V3 pl[4]; float tol[4];      // inner normals of the four side planes (through the apex) and the slack of their tests
+    bool planes;                 // false: the bundle is too wide for a pyramid (a VPL beside or inside the group): box only
+};
+// is the box (centre c, half-size h) outside?
+EV_DEV bool cut_outside(const CutFrustum &F, const float c[3], const float h[3]) {
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) out = out || (c[k] - h[k] > F.hi[k]) || (c[k] + h[k] < F.lo[k]);
+    if (F.planes) {
+        const V3 rel = v3(c[0] - F.p.x, c[1] - F.p.y, c[2] - F.p.z);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const V3 n = F.pl[q];
+            const float far = __builtin_fmaf(n.z, rel.z, __builtin_fmaf(n.y, rel.y, n.x * rel.x)) + __builtin_fmaf(fabsf(n.z), h[2], __builtin_fmaf(fabsf(n.y), h[1], fabsf(n.x) * h[0]));
+            // slack: the rounding of the expression above is a few ulps of |n| (|rel|_1 + |h|_1)
+            const float mag = (fabsf(rel.x) + fabsf(rel.y) + fabsf(rel.z) + h[0] + h[1] + h[2]) * F.tol[q];
+            out = out || (far < -mag);
+        }
+    }
+    return out;
+}
+
+constexpr int kCutRing = kCutEntries;
+// One lane = one (tile group, VPL): build the pyramid, refine the cut breadth-first (ring buffer of its own in LDS), write the
+// synthetic nodes.  Blocks are group-major: the 64-VPL chunks of a group run back to back and share its tile boxes and tree top.
+__global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
+    __shared__ int32_t s_ref[kCutRing][64];      // child reference of a cut entry (inner node index >= 0, leaf < 0)
+    __shared__ uint32_t s_src[kCutRing][64];     // where its box is: parent node index << 1 | child
+    const int lane = threadIdx.x;
+    const uint32_t nvpl = *a.nvpl;
+    const uint32_t chunks = (a.vpl_stride + 63u) / 64u;
+    const uint32_t g = blockIdx.x / chunks, chunk = blockIdx.x - g * chunks;
+    if (chunk * 64u >= nvpl) return;                                     // (wave-uniform)
+    const uint32_t i = chunk * 64u + (uint32_t)lane;
+    const bool live = i < nvpl;
+    const int gx = (int)(g % (uint32_t)a.groups_x), gy = a.group_row_first + (int)(g / (uint32_t)a.groups_x);
+    const float4 pv = reinterpret_cast<const float4 *>(a.vpls + (live ? i : nvpl - 1u))[0];
+    CutFrustum F; F.p = v3(pv.x, pv.y, pv.z);
+
+    // ---- the group's tiles: union box, then the pyramid around the 8 corners of every tile's box
+    const int gw = 1 << a.gw_log2, gh = 1 << a.gh_log2;
+    float ulo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, uhi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (int ty = gy * gh; ty < min((gy + 1) * gh, a.tiles_y); ty++)
+        for (int tx = gx * gw; tx < min((gx + 1) * gw, a.tiles_x); tx++) {
+            const float4 lo = a.tile_box[2 * (ty * a.tiles_x + tx)], hi = a.tile_box[2 * (ty * a.tiles_x + tx) + 1];
+            if (lo.x > hi.x) continue;                                   // a tile without a pixel in the image
+            ulo[0] = fminf(ulo[0], lo.x); ulo[1] = fminf(ulo[1], lo.y); ulo[2] = fminf(ulo[2], lo.z);
+            uhi[0] = fmaxf(uhi[0], hi.x); uhi[1] = fmaxf(uhi[1], hi.y); uhi[2] = fmaxf(uhi[2], hi.z);
+        }
+    const bool any_tile = ulo[0] <= uhi[0];                              // (wave-uniform)
+    char *const slot = a.cuts + ((size_t)g * a.vpl_stride + i) * (size_t)kCutSlotBytes;
+    if (!any_tile) { if (live) reinterpret_cast<float4 *>(slot)[3] = make_float4(0.f, 0.f, 0.f, 0.f); return; }   // count 0 (dwords 12..15: c0, c1, count, -)
+    {
+        // end points of the segments: e = P (1 - t) + t x for t = tmin and t = tmax, x in the union box -- linear in x, so the box of
+        // the end points follows from the box of the pixels; padded by 1e-5 of its size and of the coordinates' magnitude
+        const float pp[3] = { F.p.x, F.p.y, F.p.z };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float t0 = 0.0001f, t1 = 1.0f - 0.0001f;
+            const float a0 = pp[k] * (1.0f - t0) + t0 * ulo[k], b0 = pp[k] * (1.0f - t0) + t0 * uhi[k];
+            const float a1 = pp[k] * (1.0f - t1) + t1 * ulo[k], b1 = pp[k] * (1.0f - t1) + t1 * uhi[k];
+            const float l = fminf(a0, a1), h = fmaxf(b0, b1);
+            const float pad = 1.0e-5f * ((h - l) + fabsf(l) + fabsf(h)) + 1.0e-30f;
+            F.lo[k] = l - pad; F.hi[k] = h + pad;
+        }
+    }
+    {
+        const V3 cen = v3(0.5f * (ulo[0] + uhi[0]), 0.5f * (ulo[1] + uhi[1]), 0.5f * (ulo[2] + uhi[2]));
+        V3 m = cen - F.p;
+        const float ml2 = dot(m, m);
+        bool planes = ml2 > 1.0e-30f;
+        m = m * __builtin_amdgcn_rsqf(fmaxf(ml2, 1.0e-30f));
+        const V3 ax = fabsf(m.x) < 0.6f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
+        V3 u = cross(m, ax); u = u * __builtin_amdgcn_rsqf(fmaxf(dot(u, u), 1.0e-30f));
+        const V3 w = cross(m, u);
+        float amin = 3.0e38f, amax = -3.0e38f, bmin = 3.0e38f, bmax = -3.0e38f;
+        for (int ty = gy * gh; ty < min((gy + 1) * gh, a.tiles_y); ty++)
+            for (int tx = gx * gw; tx < min((gx + 1) * gw, a.tiles_x); tx++) {
+                const float4 lo = a.tile_box[2 * (ty * a.tiles_x + tx)], hi = a.tile_box[2 * (ty * a.tiles_x + tx) + 1];
+                if (lo.x > hi.x) continue;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const V3 d = v3(((q & 1) ? hi.x : lo.x) - F.p.x, ((q & 2) ? hi.y : lo.y) - F.p.y, ((q & 4) ? hi.z : lo.z) - F.p.z);
+                    const float dw = dot(m, d), dl2 = dot(d, d);
+                    // a direction more than ~87 degrees off the axis: no pyramid for this bundle
+                    if (!(dw > 0.0f) || dw * dw <= 0.0025f * dl2) planes = false;
+                    const float r = __builtin_amdgcn_rcpf(dw);
+                    const float ca = dot(u, d) * r, cb = dot(w, d) * r;
+                    amin = fminf(amin, ca); amax = fmaxf(amax, ca); bmin = fminf(bmin, cb); bmax = fmaxf(bmax, cb);
+                }
+            }
+        // the tangents carry ~1e-6 of relative rounding (1-ulp reciprocal, three dot products): opened by 1e-4 (|a| <= 20 here)
+        const float oa = 1.0e-4f * (1.0f + fmaxf(fabsf(amin), fabsf(amax))), ob = 1.0e-4f * (1.0f + fmaxf(fabsf(bmin), fabsf(bmax)));
+        amin -= oa; amax += oa; bmin -= ob; bmax += ob;
+        F.planes = planes;
+        F.pl[0] = u - m * amin; F.pl[1] = m * amax - u; F.pl[2] = w - m * bmin; F.pl[3] = m * bmax - w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) F.tol[q] = 4.0e-6f * (fabsf(F.pl[q].x) + fabsf(F.pl[q].y) + fabsf(F.pl[q].z));
+    }
+
+    // ---- the cut: breadth-first (ring) refinement
+    int head = 0, count = 0;
+    auto ring_push = [&](int32_t ref, uint32_t src) { const int at = (head + count) & (kCutRing - 1); s_ref[at][lane] = ref; s_src[at][lane] = src; count++; };
+    auto expand = [&](int32_t node, int32_t *refs, uint32_t *srcs) -> int {      // surviving children of an inner node
+        const float4 *q4 = reinterpret_cast<const float4 *>(a.nodes + node);
+        const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2], n3 = q4[3];
+        // BvhNode: ctr[3][2] = n0.xyzw n1.xy ; hal[3][2] = n1.zw n2.xyzw ; c0 c1 = n3.xy
+        const float c0[3] = { n0.x, n0.z, n1.x }, c1[3] = { n0.y, n0.w, n1.y };
+        const float h0[3] = { n1.z, n2.x, n2.z }, h1[3] = { n1.w, n2.y, n2.w };
+        const int32_t r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
+        int nk = 0;
+        if (r0 != kNoChild && !cut_outside(F, c0, h0)) { refs[nk] = r0; srcs[nk] = (uint32_t)node << 1; nk++; }
+        if (r1 != kNoChild && !cut_outside(F, c1, h1)) { refs[nk] = r1; srcs[nk] = ((uint32_t)node << 1) | 1u; nk++; }
+        return nk;
+    };
+    if (live) {
+        int32_t refs[2]; uint32_t srcs[2];
+        int nk = expand(0, refs, srcs);
+        for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
+        int leaves_in_row = 0;
+        while (count > 0 && leaves_in_row < count) {
+            const int32_t ref = s_ref[head][lane]; const uint32_t src = s_src[head][lane];
+            if (ref < 0) { head = (head + 1) & (kCutRing - 1); count--; ring_push(ref, src); leaves_in_row++; continue; }    // a leaf stays in the cut
+            nk = expand(ref, refs, srcs);
+            if (count - 1 + nk > kCutEntries) break;
+            head = (head + 1) & (kCutRing - 1); count--;
+            for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
+            leaves_in_row = 0;
+        }
+        // ---- synthetic nodes: entries (2 s, 2 s + 1) -> node s; node 0 carries the node count in its first padding word
+        const int nsyn = (count + 1) >> 1;
+        float4 *out = reinterpret_cast<float4 *>(slot);
+        if (nsyn == 0) out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s2 = 0; s2 < nsyn; s2++) {
+            float c[2][3], h[2][3]; int32_t r[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int k = 2 * s2 + e;
+                if (k < count) {
+                    const int at = (head + k) & (kCutRing - 1);
+                    r[e] = s_ref[at][lane]; const uint32_t src = s_src[at][lane];
+                    const float *nf = reinterpret_cast<const float *>(a.nodes + (src >> 1));
+                    const int ch = (int)(src & 1u);
+                    c[e][0] = nf[0 + ch]; c[e][1] = nf[2 + ch]; c[e][2] = nf[4 + ch];
+                    h[e][0] = nf[6 + ch]; h[e][1] = nf[8 + ch]; h[e][2] = nf[10 + ch];
+                } else { r[e] = kNoChild; c[e][0] = c[e][1] = c[e][2] = 0.f; h[e][0] = h[e][1] = h[e][2] = -3.0e38f; }
+            }
+            out[4 * s2 + 0] = make_float4(c[0][0], c[1][0], c[0][1], c[1][1]);
+            out[4 * s2 + 1] = make_float4(c[0][2], c[1][2], h[0][0], h[1][0]);
+            out[4 * s2 + 2] = make_float4(h[0][1], h[1][1], h[0][2], h[1][2]);
+            out[4 * s2 + 3] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(nsyn), 0.f);
+        }
+    }
+}
+
+void launch_gather_cuts(const CutArgs &a, hipStream_t s) {
+    const uint32_t chunks = (a.vpl_stride + 63u) / 64u, groups = (uint32_t)(a.groups_x * a.groups_y);
+    if (chunks == 0u || groups == 0u) return;
+    hipLaunchKernelGGL(gather_cut_kernel, dim3(groups * chunks), dim3(64), 0, s, a);
+}
+
+} // namespace evplp

@@ -19,6 +19,7 @@
 // staging with a barrier per chunk coupled the waves of a workgroup and measured 5% slower).
 #include "device_common.hpp"
 #include "kernels.h"
+#include <algorithm>
 
 namespace evplp {
 
@@ -112,11 +113,11 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
     const int tile = tile_j * 8 + xcd;                 // index in block order
     const int shl = a.block_h_log2, sh = 1 << shl;     // block = 8 x sh tiles
     const int per_block = 8 << shl, nbx = (tiles_x + 7) >> 3, nby = (tiles_y + sh - 1) >> shl;
-    const int blk = tile / per_block, l = tile - blk * per_block;
+    const int blk = a.band_first * nbx + tile / per_block, l = tile % per_block;      // (a launch may cover a band of block rows only)
     const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * sh + (l >> 3);
     Item t;
     t.group = (RANGE ? a.group_first : 0) + (j - tile_j * groups);
-    t.has_tile = blk < nbx * nby && tx < tiles_x && ty < tiles_y;
+    t.has_tile = blk < nbx * (a.band_rows > 0 ? min(nby, a.band_first + a.band_rows) : nby) && tx < tiles_x && ty < tiles_y;
     t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
     const int cly = max(min(t.ly, st.local_rows - 1), 0);
     t.gy = st.global_row(cly);
@@ -134,12 +135,21 @@ EV_DEV uint32_t item_texel(const GatherArgs &a, int lane) {
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int tile = (j / groups) * 8 + xcd;
     const int shl = a.block_h_log2, per_block = 8 << shl, nbx = (tiles_x + 7) >> 3;
-    const int blk = tile / per_block, l = tile - blk * per_block;
+    const int blk = a.band_first * nbx + tile / per_block, l = tile % per_block;
     const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * (1 << shl) + (l >> 3);
     const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
     return (uint32_t)max(min(ly, st.local_rows - 1), 0) * (uint32_t)st.W + (uint32_t)min(x, st.W - 1);
 }
 
+// index of the item's tile group in the entry-cut buffer (wave-uniform)
+EV_DEV uint32_t item_cut_group(const GatherArgs &a, const Item &t) {
+    const int tx = __builtin_amdgcn_readfirstlane(t.x) >> 3, ty = __builtin_amdgcn_readfirstlane(t.ly) >> 3;
+    return (uint32_t)(((ty >> a.cut_gh_log2) - a.cut_group_row_first) * a.cut_groups_x + (tx >> a.cut_gw_log2));
+}
+
+#ifndef EVPLP_CUT_RING
+#define EVPLP_CUT_RING 3          // LDS buffers of the cut-slot ring of a gather wave (512 B each): EVPLP_CUT_RING - 1 slots in flight ahead of the walk
+#endif
 #ifndef EVPLP_GATHER_WAVES
 #define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene, round 3 (64 registers, no spills at either): 7 = 70.6 / 29.3 ms, 8 = 70.9 / 30.9
 #endif
@@ -168,6 +178,7 @@ EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
 }
 
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
+template <bool CUT>
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
 __attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
 #endif
@@ -199,15 +210,42 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     const int k = a.splits_per_wave;
     const char *node_base = pinned(reinterpret_cast<const char *>(a.sc.nodes)), *leaf_base = pinned(reinterpret_cast<const char *>(a.sc.leaves));
     const evplp_record *vpls = pinned(a.vpls);
+    // entry cuts of this tile's group (kernels.h CutArgs): slot i belongs to VPL i
+    const char *cuts_g = nullptr;
+    if constexpr (CUT) cuts_g = pinned(a.cuts + (size_t)item_cut_group(a, t) * a.cut_vpl_stride * (size_t)kCutSlotBytes);
     V3 total = v3(0.f, 0.f, 0.f);
     uint32_t rays = 0, shaded = 0;
 #if EVPLP_TRAVERSAL_STATS
     int32_t cache_leaf = kNoChild; bool prev_all_occ = false;
 #endif
+    // The cut slots of the item's VPLs stream through a small LDS ring ahead of the walks (global_load_lds: asynchronous, counted by vmcnt,
+    // no register in between).  A walk that fetched its slot itself began with two dependent scalar loads from memory no cache holds
+    // (8.6 GB of slots per frame, each read once per tile): 65.6 ms against 70.6 ms without cuts although the node visits had halved.
+    constexpr bool kRing = CUT && EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS;
+    constexpr int kRingSlots = EVPLP_CUT_RING, kAhead = kRingSlots - 1;
+    __shared__ float4 s_cut[kRing ? kRingSlots : 1][kCutSlotBytes / 16];
+    int pj = 0; uint32_t pi = (uint32_t)(t.group * k), qslot = 0u;       // the prefetch position in the item's VPL sequence (split pj, VPL pi)
+    auto ring_skip_empty = [&]() { while (pj < k && pi >= nvpl) { pj++; pi = (uint32_t)(t.group * k + pj); } };
+    auto ring_issue = [&](uint32_t slot) {
+        if (lane < kCutSlotBytes / 16) lds_dma16(cuts_g + (size_t)pi * kCutSlotBytes + (size_t)lane * 16u, lds_offset(&s_cut[slot][0]));
+        pi += (uint32_t)kVplSplit; ring_skip_empty();
+    };
+    if constexpr (kRing) {
+        ring_skip_empty();
+        for (int q = 0; q < kAhead; q++) if (pj < k) ring_issue((uint32_t)q);
+    }
     for (int jj = 0; jj < k; jj++) {
         const uint32_t split = (uint32_t)(t.group * k + jj);
         V3 result = v3(0.f, 0.f, 0.f);
         for (uint32_t i = split; i < nvpl; i += kVplSplit) {
+            const float4 *cut_lds = nullptr;
+            if constexpr (kRing) {
+                // one more slot goes into flight (into the buffer the previous walk has read), then this walk's slot is waited for
+                if (pj < k) { ring_issue((qslot + (uint32_t)kAhead) % (uint32_t)kRingSlots); wait_vmcnt<kAhead>(); }
+                else wait_vmcnt0();
+                cut_lds = &s_cut[qslot][0];
+                qslot = (qslot + 1u) % (uint32_t)kRingSlots;
+            }
             V3 vpos, vn; float vpsel; fetch_vpl_head(vpls, i, vpos, vn, vpsel);
             V3 v12 = vpos - px.p1;                                         // :282
             float c1 = fmaxf(dot_exact(px.n1, v12), 0.0f);
@@ -230,13 +268,14 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                     if (L.cnt > 2u) any = any | tri_pair_any(L.B, vpos, dd, 0.0001f, 1.0f - 0.0001f);
                     cache_kill = ballot64(any) & act_m;
                 }
-                WalkStats ws = { 0u, 0u, 0u, 0u, kNoChild };
-                occ = occluded_wave(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws);
+                WalkStats ws = { 0u, 0u, 0u, 0u, kNoChild, 0u };
+                occ = occluded_wave<0, CUT>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active, &ws, cuts_g, i * (uint32_t)kCutSlotBytes);
                 const bool all_occ = ballot64(active && !occ) == 0ull;
                 const unsigned long long occ_m = ballot64(active && occ);
                 if (lane == 0) {
                     atomicAdd(&a.counters->hist[41], (unsigned long long)__builtin_popcountll(occ_m));
                     atomicAdd(&a.counters->nodes, (unsigned long long)ws.nodes);
+                    atomicAdd(&a.counters->aux, (unsigned long long)ws.syn);
                     atomicAdd(&a.counters->hist[min(ws.leaves, 31u)], 1ull);
                     atomicAdd(&a.counters->hist[32], 1ull);
                     atomicAdd(&a.counters->hist[33], (unsigned long long)ws.pairs);
@@ -253,7 +292,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
                 if (ws.hit_leaf != kNoChild) cache_leaf = ws.hit_leaf;
                 prev_all_occ = all_occ;
 #else
-                occ = occluded_wave<EVPLP_WALK_ASM ? 52 : 0>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active);
+                occ = occluded_wave<EVPLP_WALK_ASM ? 52 : 0, CUT>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, active, nullptr, cuts_g, i * (uint32_t)kCutSlotBytes, cut_lds);
 #endif
             }
             const bool lit = active && !occ;
@@ -275,6 +314,9 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         }
         total = result;     // after the last jj (k - 1 = all ones) this is the sum of all k splits
     }
+#if EVPLP_DEBUG_NAN
+    if (t.in_image && !(isfinite(total.x) && isfinite(total.y) && isfinite(total.z))) atomicAdd(&a.counters->nonfinite, 1ull);
+#endif
     // per-lane statistics ride in the unused fourth component: shadow rays | unoccluded pairs << 16 (both < 65536 per item)
     int lane_out = lane;
     asm volatile("" : "+v"(lane_out));              // (the store address is formed here, not carried through the walks)
@@ -569,6 +611,7 @@ EV_DEV int launch_tile(const GatherArgs &a) {          // the tile's index in la
     return ((b >> 3) / groups) * 8 + (b & 7);
 }
 
+template <bool CUT>
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
 __attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
 #endif
@@ -586,7 +629,23 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
     { const float4 gp = a.g_pos[t.p], gn = a.g_nrm[t.p]; p1 = v3(gp); n1 = v3(gn); }
     const int tile_l = launch_tile(a);
     unsigned long long *masks = a.vsl_masks + vsl_mask_base(a, tile_l, t.group);
+    const char *cuts_g = nullptr;
+    if constexpr (CUT) cuts_g = pinned(a.cuts + (size_t)item_cut_group(a, t) * a.cut_vpl_stride * (size_t)kCutSlotBytes);
     uint32_t rays = 0;
+    // the cut slots of the item's VSLs stream through an LDS ring ahead of the walks (as in gather_vpl_kernel)
+    constexpr bool kRing = CUT && EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS;
+    constexpr int kRingSlots = EVPLP_CUT_RING, kAhead = kRingSlots - 1;
+    __shared__ float4 s_cut[kRing ? kRingSlots : 1][kCutSlotBytes / 16];
+    int pj = 0; uint32_t pi = (uint32_t)(t.group * k), qslot = 0u;
+    auto ring_skip_empty = [&]() { while (pj < k && pi >= nvpl) { pj++; pi = (uint32_t)(t.group * k + pj); } };
+    auto ring_issue = [&](uint32_t slot) {
+        if (lane < kCutSlotBytes / 16) lds_dma16(cuts_g + (size_t)pi * kCutSlotBytes + (size_t)lane * 16u, lds_offset(&s_cut[slot][0]));
+        pi += (uint32_t)kVplSplit; ring_skip_empty();
+    };
+    if constexpr (kRing) {
+        ring_skip_empty();
+        for (int q = 0; q < kAhead; q++) if (pj < k) ring_issue((uint32_t)q);
+    }
     for (int jj = 0; jj < k; jj++) {
         const uint32_t split = (uint32_t)(t.group * k + jj);
         uint32_t cbase = 0;
@@ -594,6 +653,13 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
             const uint32_t n = min((uint32_t)kVslChunk, (nvpl - first + (uint32_t)kVplSplit - 1u) / (uint32_t)kVplSplit);
             for (uint32_t c = 0; c < n; c++) {
                 const uint32_t i = first + c * (uint32_t)kVplSplit;
+                const float4 *cut_lds = nullptr;
+                if constexpr (kRing) {
+                    if (pj < k) { ring_issue((qslot + (uint32_t)kAhead) % (uint32_t)kRingSlots); wait_vmcnt<kAhead>(); }
+                    else wait_vmcnt0();
+                    cut_lds = &s_cut[qslot][0];
+                    qslot = (qslot + 1u) % (uint32_t)kRingSlots;
+                }
                 V3 vpos, vn; float vpsel; fetch_vpl_head(vpls, i, vpos, vn, vpsel);
                 const V3 v12 = vpos - p1;                                     // :605
                 // c1 c2 <= 1e-9 (:619) decides which pairs exist at all, so it is taken with the reference's roundings (IEEE square root and
@@ -614,7 +680,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
                 unsigned long long lit = 0ull;
                 if (ballot64(pre) != 0ull) {
                     rays += pre ? 1u : 0u;
-                    const bool occ = occluded_wave<EVPLP_WALK_ASM ? 52 : 0>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, pre);   // :612-614
+                    const bool occ = occluded_wave<EVPLP_WALK_ASM ? 52 : 0, CUT>(node_base, leaf_base, vpos, -v12, 0.0001f, 1.0f - 0.0001f, pre, nullptr, cuts_g, i * (uint32_t)kCutSlotBytes, cut_lds);   // :612-614
                     lit = ballot64(pre && !occ);
                 }
                 if (lane == 0) s_lit[c] = lit;          // (single-wavefront workgroup: LDS is in order, no barrier)
@@ -723,6 +789,9 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
         }
         total = result;
     }
+#if EVPLP_DEBUG_NAN
+    if (valid && !(isfinite(total.x) && isfinite(total.y) && isfinite(total.z))) atomicAdd(&a.counters->nonfinite, 1ull);
+#endif
     // sample-iterations of the item (the unit the estimators' work is priced in): one add per wavefront into 64 counter shards
     const uint32_t nlit = cnt & 4095u;
     uint32_t nsamp = cnt >> 12;
@@ -737,7 +806,8 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
 
 int gather_launch_tiles(const GatherArgs &a) {                    // tiles of a launch: whole blocks of 8 x (1 << block_h_log2)
     const int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8, sh = 1 << a.block_h_log2;
-    return ((tiles_x + 7) / 8) * ((tiles_y + sh - 1) / sh) * 8 * sh;
+    const int nby = (tiles_y + sh - 1) / sh, rows = a.band_rows > 0 ? std::min(a.band_rows, nby - a.band_first) : nby;
+    return ((tiles_x + 7) / 8) * std::max(rows, 0) * 8 * sh;
 }
 static dim3 gather_grid(const GatherArgs &a) {
     const int groups = a.group_count > 0 ? a.group_count : kVplSplit / a.splits_per_wave;
@@ -752,10 +822,12 @@ static size_t fold_lds_bytes(const GatherArgs &a, int extra_blocks) {
     return (size_t)(levels + extra_blocks) * 192 * sizeof(float);
 }
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vpl_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
+    if (a.cuts) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
+    else hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(gather_vsl_walk_kernel, gather_grid(a), dim3(64), 0, s, a);
+    if (a.cuts) hipLaunchKernelGGL(gather_vsl_walk_kernel<true>, gather_grid(a), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(gather_vsl_walk_kernel<false>, gather_grid(a), dim3(64), 0, s, a);
     hipLaunchKernelGGL(gather_vsl_shade_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
 }
 

@@ -23,6 +23,7 @@
 //      registers and is written once per pixel with coalesced 16-byte stores -- no atomics, no per-fragment RMW.
 #include "device_common.hpp"
 #include "kernels.h"
+#include <cstring>
 
 namespace evplp {
 
@@ -549,6 +550,9 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
     }
     if (part == 0) {
         if (WAVES == 4) for (int w = 0; w < 3; w++) { float4 q = red[w][lane]; sum = sum + v3(q); if (lane == 0) pairs += __float_as_uint(q.w); }
+#if EVPLP_DEBUG_NAN
+        if (in_image && !(isfinite(sum.x) && isfinite(sum.y) && isfinite(sum.z))) atomicAdd(&a.counters->nonfinite, 1ull);
+#endif
         if (in_image) {
             float4 o = a.out[p];
             a.out[p] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w);   // additive blend ONE, ONE (:793)
@@ -564,6 +568,12 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
 
 // Phase A: tile boxes (+ cleared cursors and summary), compact photons + bucket-sorted segments, segments -> tile bins
 // (+ summary), large photons.
+void launch_tile_boxes(const StripDev &st, const float4 *g_pos, float4 *tile_box, int tiles_x, int tiles_y, hipStream_t s) {
+    SplatArgs a; std::memset(&a, 0, sizeof(a));
+    a.st = st; a.g_pos = g_pos; a.tile_box = tile_box; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+    const uint32_t ntiles = (uint32_t)(tiles_x * tiles_y);
+    if (ntiles) hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);
+}
 void launch_splat_bin(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     if (!a.boxes_valid) hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);   // (else: written by primary_kernel)

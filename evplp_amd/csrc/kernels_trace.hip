@@ -112,6 +112,12 @@ EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float ps
     q[5] = make_float4(rs.x, rs.y, rs.z, e);
 }
 
+// (round 4, measured and removed: light tracing as a PERSISTENT, self-refilling wavefront -- lanes in IDLE / TRAV / HIT states, a wave
+// refilling its idle lanes from a range of paths of its own, leaving the walk when 8 / 16 / 32 lanes wait to be shaded.  Records
+// byte-identical, all GPU tests green, lane utilisation up as intended -- and 300 000 paths took 0.77 / 0.55 / 0.48 / 0.47 ms at 1 / 2 / 3 /
+// 4 resident waves per SIMD (124 registers: no fifth) against 0.44 ms for one path per lane at 5 waves below: the time falls with the
+// number of rays in flight, not with the number of busy lanes.  The kernel is bound by the dependent 128-byte node gathers (8 KB per
+// wave and step out of L2 / Infinity Cache), not by vector-instruction issue; profiles/r04_light_trace_persistent_sweep.txt.)
 // four-wide nodes; 5 waves per SIMD (96 registers, no spills) with the first 20 stack entries in LDS and the rest of the worst case in
 // global memory (closest_lane4): the worst-case LDS stack alone allowed 3 waves per SIMD.  Config #4's light tracing (300 000 paths):
 // round 2 binary nodes 627 us, four-wide 553; round 3 (peeled tree) 511 us at 3 waves per SIMD

@@ -236,6 +236,9 @@ int evplp_splat_photons(evplp_context *ctx, const evplp_frame_params *fp, int32_
  * out_rgb: HOST pointer, 3 floats per pixel, local_rows * W pixels, y = 0 bottom. */
 int evplp_resolve(evplp_context *ctx, float vpl_scale, float photon_scale, float light_scale,
                   int32_t mask_emitter, int32_t gamma, float *out_rgb);
+/* The composite alone (what the reference draws to the screen every iteration, runFinalProgram(param, param, 1, true) :997-1004): the strip's RGB stays in
+ * device memory, nothing is copied to the host.  evplp_resolve = this + the download. */
+int evplp_present(evplp_context *ctx, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma);
 int evplp_clear_accumulators(evplp_context *ctx);
 
 /* ---- buffers / statistics ---- */
