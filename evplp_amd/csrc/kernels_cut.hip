@@ -29,13 +29,13 @@ EV_DEV bool cut_outside(const CutFrustum &F, const float c[3], const float h[3])
     for (int k = 0; k < 3; k++) out = out || (c[k] - h[k] > F.hi[k]) || (c[k] + h[k] < F.lo[k]);
     if (F.planes) {
         const V3 rel = v3(c[0] - F.p.x, c[1] - F.p.y, c[2] - F.p.z);
+        // slack: the rounding of `far` below is a few ulps of |n|_1 (|rel|_1 + |h|_1)
+        const float mag = fabsf(rel.x) + fabsf(rel.y) + fabsf(rel.z) + h[0] + h[1] + h[2];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const V3 n = F.pl[q];
-            const float far = __builtin_fmaf(n.z, rel.z, __builtin_fmaf(n.y, rel.y, n.x * rel.x)) + __builtin_fmaf(fabsf(n.z), h[2], __builtin_fmaf(fabsf(n.y), h[1], fabsf(n.x) * h[0]));
-            // slack: the rounding of the expression above is a few ulps of |n| (|rel|_1 + |h|_1)
-            const float mag = (fabsf(rel.x) + fabsf(rel.y) + fabsf(rel.z) + h[0] + h[1] + h[2]) * F.tol[q];
-            out = out || (far < -mag);
+            const float far = __builtin_fmaf(fabsf(n.z), h[2], __builtin_fmaf(fabsf(n.y), h[1], __builtin_fmaf(fabsf(n.x), h[0], __builtin_fmaf(n.z, rel.z, __builtin_fmaf(n.y, rel.y, n.x * rel.x)))));
+            out = out || (__builtin_fmaf(mag, F.tol[q], far) < 0.0f);
         }
     }
     return out;
@@ -43,34 +43,43 @@ EV_DEV bool cut_outside(const CutFrustum &F, const float c[3], const float h[3])
 
 constexpr int kCutRing = kCutEntries;
 // One lane = one (tile group, VPL): build the pyramid, refine the cut breadth-first (ring buffer of its own in LDS), write the
-// synthetic nodes.  Blocks are group-major: the 64-VPL chunks of a group run back to back and share its tile boxes and tree top.
+// synthetic nodes.  A wave = ONE VPL and a block of 8 x 8 neighbouring tile groups: the 64 pyramids share their apex and point at
+// neighbouring parts of the screen, so they walk the same part of the tree for about the same number of steps (first version, lane =
+// VPL for one group: 64 unrelated apexes per wave, half of them done after a few steps -- 39.5 % of the lanes busy, 7.6 ms; the kernel
+// is bound by vector-instruction issue, profiles/r04a_bench_ir_pmc_first_cuts.txt).  Blocks are ordered VPL-fastest: the waves of a
+// block of groups run back to back.
 __global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
     __shared__ int32_t s_ref[kCutRing][64];      // child reference of a cut entry (inner node index >= 0, leaf < 0)
     __shared__ uint32_t s_src[kCutRing][64];     // where its box is: parent node index << 1 | child
     const int lane = threadIdx.x;
     const uint32_t nvpl = *a.nvpl;
-    const uint32_t chunks = (a.vpl_stride + 63u) / 64u;
-    const uint32_t g = blockIdx.x / chunks, chunk = blockIdx.x - g * chunks;
-    if (chunk * 64u >= nvpl) return;                                     // (wave-uniform)
-    const uint32_t i = chunk * 64u + (uint32_t)lane;
-    const bool live = i < nvpl;
-    const int gx = (int)(g % (uint32_t)a.groups_x), gy = a.group_row_first + (int)(g / (uint32_t)a.groups_x);
-    const float4 pv = reinterpret_cast<const float4 *>(a.vpls + (live ? i : nvpl - 1u))[0];
+    const uint32_t i = blockIdx.x % a.vpl_stride, gb = blockIdx.x / a.vpl_stride;
+    if (i >= nvpl) return;                                               // (wave-uniform)
+    const int gblocks_x = (a.groups_x + 7) >> 3;
+    const int gx = (int)(gb % (uint32_t)gblocks_x) * 8 + (lane & 7), gyl = (int)(gb / (uint32_t)gblocks_x) * 8 + (lane >> 3);
+    const bool live = gx < a.groups_x && gyl < a.groups_y;
+    if (__builtin_amdgcn_ballot_w64(live) == 0ull) return;
+    const uint32_t g = (uint32_t)(min(gyl, a.groups_y - 1) * a.groups_x + min(gx, a.groups_x - 1));
+    const int gy = a.group_row_first + min(gyl, a.groups_y - 1);
+    const int gxc = min(gx, a.groups_x - 1);
+    const float4 pv = reinterpret_cast<const float4 *>(a.vpls + i)[0];
     CutFrustum F; F.p = v3(pv.x, pv.y, pv.z);
 
     // ---- the group's tiles: union box, then the pyramid around the 8 corners of every tile's box
     const int gw = 1 << a.gw_log2, gh = 1 << a.gh_log2;
     float ulo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, uhi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
     for (int ty = gy * gh; ty < min((gy + 1) * gh, a.tiles_y); ty++)
-        for (int tx = gx * gw; tx < min((gx + 1) * gw, a.tiles_x); tx++) {
+        for (int tx = gxc * gw; tx < min((gxc + 1) * gw, a.tiles_x); tx++) {
             const float4 lo = a.tile_box[2 * (ty * a.tiles_x + tx)], hi = a.tile_box[2 * (ty * a.tiles_x + tx) + 1];
             if (lo.x > hi.x) continue;                                   // a tile without a pixel in the image
             ulo[0] = fminf(ulo[0], lo.x); ulo[1] = fminf(ulo[1], lo.y); ulo[2] = fminf(ulo[2], lo.z);
             uhi[0] = fmaxf(uhi[0], hi.x); uhi[1] = fmaxf(uhi[1], hi.y); uhi[2] = fmaxf(uhi[2], hi.z);
         }
-    const bool any_tile = ulo[0] <= uhi[0];                              // (wave-uniform)
+    const bool any_tile = ulo[0] <= uhi[0];
     char *const slot = a.cuts + ((size_t)g * a.vpl_stride + i) * (size_t)kCutSlotBytes;
-    if (!any_tile) { if (live) reinterpret_cast<float4 *>(slot)[3] = make_float4(0.f, 0.f, 0.f, 0.f); return; }   // count 0 (dwords 12..15: c0, c1, count, -)
+    if (live && !any_tile) reinterpret_cast<float4 *>(slot)[3] = make_float4(0.f, 0.f, 0.f, 0.f);    // count 0 (dwords 12..15: c0, c1, count, -)
+    const bool work = live && any_tile;
+    if (!any_tile) { ulo[0] = ulo[1] = ulo[2] = 0.f; uhi[0] = uhi[1] = uhi[2] = 0.f; }              // (keeps the arithmetic below finite; nothing is written)
     {
         // end points of the segments: e = P (1 - t) + t x for t = tmin and t = tmax, x in the union box -- linear in x, so the box of
         // the end points follows from the box of the pixels; padded by 1e-5 of its size and of the coordinates' magnitude
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
         const V3 w = cross(m, u);
         float amin = 3.0e38f, amax = -3.0e38f, bmin = 3.0e38f, bmax = -3.0e38f;
         for (int ty = gy * gh; ty < min((gy + 1) * gh, a.tiles_y); ty++)
-            for (int tx = gx * gw; tx < min((gx + 1) * gw, a.tiles_x); tx++) {
+            for (int tx = gxc * gw; tx < min((gxc + 1) * gw, a.tiles_x); tx++) {
                 const float4 lo = a.tile_box[2 * (ty * a.tiles_x + tx)], hi = a.tile_box[2 * (ty * a.tiles_x + tx) + 1];
                 if (lo.x > hi.x) continue;
 #pragma unroll
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
         if (r1 != kNoChild && !cut_outside(F, c1, h1)) { refs[nk] = r1; srcs[nk] = ((uint32_t)node << 1) | 1u; nk++; }
         return nk;
     };
-    if (live) {
+    if (work) {
         int32_t refs[2]; uint32_t srcs[2];
         int nk = expand(0, refs, srcs);
         for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
@@ -148,36 +157,65 @@ __global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
             for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
             leaves_in_row = 0;
         }
-        // ---- synthetic nodes: entries (2 s, 2 s + 1) -> node s; node 0 carries the node count in its first padding word
+        // ---- the cut, nearest entry first (the walk visits the synthetic nodes in slot order and ends as soon as every lane is occluded:
+        // 14.8 against 16.0 node visits per walk in the CPU replay): distance of every entry's box from the apex, sorting network on
+        // (distance, entry) in registers
+        auto box_of = [&](int k, float c[3], float h[3], int32_t &ref) {
+            const int at = (head + k) & (kCutRing - 1);
+            ref = s_ref[at][lane]; const uint32_t src = s_src[at][lane];
+            const float4 *q4 = reinterpret_cast<const float4 *>(a.nodes + (src >> 1));
+            const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
+            const bool ch = (src & 1u) != 0u;
+            c[0] = ch ? n0.y : n0.x; c[1] = ch ? n0.w : n0.z; c[2] = ch ? n1.y : n1.x;
+            h[0] = ch ? n1.w : n1.z; h[1] = ch ? n2.y : n2.x; h[2] = ch ? n2.w : n2.z;
+        };
+        float dist[kCutEntries]; int order[kCutEntries];
+#pragma unroll
+        for (int k = 0; k < kCutEntries; k++) {
+            order[k] = k; dist[k] = 3.0e38f;
+            if (k < count) {
+                float c[3], h[3]; int32_t r; box_of(k, c, h, r);
+                const float ex = fmaxf(fabsf(F.p.x - c[0]) - h[0], 0.f), ey = fmaxf(fabsf(F.p.y - c[1]) - h[1], 0.f), ez = fmaxf(fabsf(F.p.z - c[2]) - h[2], 0.f);
+                dist[k] = ex * ex + ey * ey + ez * ez;
+            }
+        }
+#define EV_CX(i_, j_) { const bool sw = dist[j_] < dist[i_]; const float td = sw ? dist[j_] : dist[i_]; dist[j_] = sw ? dist[i_] : dist[j_]; dist[i_] = td; \
+                        const int to = sw ? order[j_] : order[i_]; order[j_] = sw ? order[i_] : order[j_]; order[i_] = to; }
+        static_assert(kCutEntries == 8, "the sorting network below is the 19-comparator network for 8 keys");
+        EV_CX(0, 1) EV_CX(2, 3) EV_CX(4, 5) EV_CX(6, 7)
+        EV_CX(0, 2) EV_CX(1, 3) EV_CX(4, 6) EV_CX(5, 7)
+        EV_CX(1, 2) EV_CX(5, 6) EV_CX(0, 4) EV_CX(3, 7)
+        EV_CX(1, 5) EV_CX(2, 6)
+        EV_CX(1, 4) EV_CX(3, 6)
+        EV_CX(2, 4) EV_CX(3, 5)
+        EV_CX(3, 4)
+#undef EV_CX
+        // ---- synthetic nodes: entries (2 s, 2 s + 1) of the sorted cut -> node s; node 0 carries the node count in its first padding word
         const int nsyn = (count + 1) >> 1;
         float4 *out = reinterpret_cast<float4 *>(slot);
         if (nsyn == 0) out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s2 = 0; s2 < nsyn; s2++) {
-            float c[2][3], h[2][3]; int32_t r[2];
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int k = 2 * s2 + e;
-                if (k < count) {
-                    const int at = (head + k) & (kCutRing - 1);
-                    r[e] = s_ref[at][lane]; const uint32_t src = s_src[at][lane];
-                    const float *nf = reinterpret_cast<const float *>(a.nodes + (src >> 1));
-                    const int ch = (int)(src & 1u);
-                    c[e][0] = nf[0 + ch]; c[e][1] = nf[2 + ch]; c[e][2] = nf[4 + ch];
-                    h[e][0] = nf[6 + ch]; h[e][1] = nf[8 + ch]; h[e][2] = nf[10 + ch];
-                } else { r[e] = kNoChild; c[e][0] = c[e][1] = c[e][2] = 0.f; h[e][0] = h[e][1] = h[e][2] = -3.0e38f; }
+        for (int s2 = 0; s2 < kCutNodes; s2++) {
+            if (s2 < nsyn) {
+                float c[2][3], h[2][3]; int32_t r[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (2 * s2 + e < count) box_of(order[2 * s2 + e], c[e], h[e], r[e]);
+                    else { r[e] = kNoChild; c[e][0] = c[e][1] = c[e][2] = 0.f; h[e][0] = h[e][1] = h[e][2] = -3.0e38f; }
+                }
+                out[4 * s2 + 0] = make_float4(c[0][0], c[1][0], c[0][1], c[1][1]);
+                out[4 * s2 + 1] = make_float4(c[0][2], c[1][2], h[0][0], h[1][0]);
+                out[4 * s2 + 2] = make_float4(h[0][1], h[1][1], h[0][2], h[1][2]);
+                out[4 * s2 + 3] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(nsyn), 0.f);
             }
-            out[4 * s2 + 0] = make_float4(c[0][0], c[1][0], c[0][1], c[1][1]);
-            out[4 * s2 + 1] = make_float4(c[0][2], c[1][2], h[0][0], h[1][0]);
-            out[4 * s2 + 2] = make_float4(h[0][1], h[1][1], h[0][2], h[1][2]);
-            out[4 * s2 + 3] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(nsyn), 0.f);
         }
     }
 }
 
 void launch_gather_cuts(const CutArgs &a, hipStream_t s) {
-    const uint32_t chunks = (a.vpl_stride + 63u) / 64u, groups = (uint32_t)(a.groups_x * a.groups_y);
-    if (chunks == 0u || groups == 0u) return;
-    hipLaunchKernelGGL(gather_cut_kernel, dim3(groups * chunks), dim3(64), 0, s, a);
+    const uint32_t gblocks = (uint32_t)(((a.groups_x + 7) >> 3) * ((a.groups_y + 7) >> 3));
+    if (a.vpl_stride == 0u || gblocks == 0u) return;
+    hipLaunchKernelGGL(gather_cut_kernel, dim3(gblocks * a.vpl_stride), dim3(64), 0, s, a);
 }
 
 } // namespace evplp

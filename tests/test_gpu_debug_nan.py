@@ -33,10 +33,11 @@ with ev.Context(W, H, N, N, P, device=0) as c:
         c.splat_photons(fp, clear=True); c.synchronize(); bad += int(c.debug_counters(ev.PASS_SPLAT)[NONFINITE])
     c.gather_vsl(fp); bad += int(c.debug_counters(ev.PASS_GATHER_VSL)[NONFINITE])
     out["clean"] = bad
-    # the trap itself: one pixel's G-buffer position made NaN must be counted
-    g = c.download(ev.BUF_GBUF_POSITION).copy()
-    g[H // 2, W // 2, 0] = np.nan
-    c.upload(ev.BUF_GBUF_POSITION, g)
+    # the trap itself: a usable VPL whose flux is NaN must be counted by every pixel it lights (a NaN POSITION is not enough: the cosine
+    # test fmaxf(NaN, 0) = 0 drops such a pair, in the reference too)
+    rec = c.download(ev.BUF_RECORDS).copy()
+    rec["flux"][0] = np.nan              # record 0: the on-light vertex of path 0, always a usable VPL
+    c.upload(ev.BUF_RECORDS, rec)
     c.gather_vpl(fp)
     out["poisoned"] = int(c.debug_counters(ev.PASS_GATHER_VPL)[NONFINITE])
 print("RESULT " + json.dumps(out))
@@ -51,4 +52,4 @@ def test_no_non_finite_partial_sums_in_the_debug_build():
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["clean"] == 0, f"{res['clean']} non-finite partial sums on a clean frame (six MIS modes, VPL + VSL gather, photon splat)"
-    assert res["poisoned"] >= 1, "the debug build did not count a pixel whose G-buffer position is NaN"
+    assert res["poisoned"] >= 1, "the debug build did not count the pixels lit by a VPL whose flux is NaN"

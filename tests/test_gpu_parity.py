@@ -448,3 +448,34 @@ def test_bins_grow_with_two_passes_in_flight(room, evplp, monkeypatch):
     assert imgs[0].max() > 0
     assert (imgs[0] == imgs[1]).all() and (imgs[1] == imgs[2]).all()
     assert np.abs(imgs[0] - imgs[3]).max() <= 1e-5 * imgs[0].max()
+
+
+def test_entry_cuts_do_not_change_a_bit(evplp, monkeypatch):
+    """The entry cuts (kernels_cut.hip: a frustum per (tile group, VPL) descends the tree to a cut, the packet walks start there) only
+    skip subtrees no segment of the group can reach: the VPL and the VSL gather must give the same bits with the cuts, without them
+    (EVPLP_CUTS=0: every walk from the root) and with the cut scratch so small that the frame is gathered in several bands of tile
+    blocks (three at this size)."""
+    w, h, n = 96, 192, 96
+    tall = scenes.box_room(seed=3, n_boxes=5, tess=2, aspect=w / h)
+    kw = dict(camera_pos=tall.cam_origin, mis_mode=1, pdf_mc=0.35, clamping_value=0.02, photon_radius=0.05, vsl_radius=0.3,
+              vsl_inv_pi_radius2=1.0 / (math.pi * 0.09), num_light_paths=n, num_vpl_light_paths=n, photons_per_path=P, do_accumulate=0, rng_seed=5)
+    images = {}
+    for name, env in (("cuts", {}), ("root", {"EVPLP_CUTS": "0"}), ("bands", {"EVPLP_CUT_BYTES": "1000000"})):
+        for k in ("EVPLP_CUTS", "EVPLP_CUT_BYTES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with evplp.Context(w, h, n, n, P) as c:
+            tall.upload(c)
+            c.primary((0.003, -0.002)); c.trace_light_paths(5)
+            c.gather_vpl(evplp.frame_params(**kw))
+            vpl = c.download(evplp.BUF_VPL_ACCUM)[:h].copy()
+            st = c.pass_stats(evplp.PASS_GATHER_VPL)
+            c.gather_vsl(evplp.frame_params(**kw))
+            vsl = c.download(evplp.BUF_VPL_ACCUM)[:h].copy()
+            images[name] = (vpl, vsl, st["rays"], st["shaded"])
+    assert images["cuts"][0].max() > 0 and images["cuts"][1].max() > 0 and images["cuts"][2] > 0
+    for name in ("root", "bands"):
+        assert images[name][2:] == images["cuts"][2:], (name, images[name][2:], images["cuts"][2:])
+        assert images[name][0].tobytes() == images["cuts"][0].tobytes(), f"VPL gather: {name} differs from cuts"
+        assert images[name][1].tobytes() == images["cuts"][1].tobytes(), f"VSL gather: {name} differs from cuts"

@@ -14,7 +14,7 @@ for f in glob.glob(f"{out}/pmc_{wl}_*/*/*_counter_collection.csv"):
 json.dump(res, open(f"{out}/pmc_{wl}_summary.json", "w"), indent=1)
 g0 = lambda d, n: d.get(n, float("nan"))
 for k, d in sorted(res.items(), key=lambda kv: -g0(kv[1], "SQ_WAVE_CYCLES") if g0(kv[1], "SQ_WAVE_CYCLES") == g0(kv[1], "SQ_WAVE_CYCLES") else 0):
-    if not any(t in k for t in ("gather", "splat")): continue
+    if not any(t in k for t in ("gather", "splat", "light_trace", "primary", "path_trace", "compact_vpl", "resolve")): continue
     print("==", k, "(VGPR, SGPR, LDS, grid, wg) =", d.get("_regs"))
     g = lambda n: g0(d, n)
     wc = g("SQ_WAVE_CYCLES")
