@@ -399,11 +399,17 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     # after, and the HIP-event times of the passes from ten more iterations after the timed region.
     pairs_before = sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) if wl != "ir" else 0
 
-    def read_pass_times():
+    def read_pass_times(profiled=False):
+        # the splat's pass time comes from steps WITHOUT the events around its dominant kernel (they sit between its launches:
+        # evplp_profile_kernels), the dominant kernel's own time from a few extra steps with them
         if wl != "ir":
             ss = ctx.pass_stats(ev.PASS_SPLAT)
-            splat_ms.append(ss["ms"]); splat_tiles_ms.append(ss["dominant_kernel_ms"])
-        feeder_ms["light_trace"].append(ctx.pass_stats(ev.PASS_LIGHT_TRACE)["ms"]); feeder_ms["primary"].append(ctx.pass_stats(ev.PASS_PRIMARY)["ms"])
+            if profiled:
+                splat_tiles_ms.append(ss["dominant_kernel_ms"])
+            else:
+                splat_ms.append(ss["ms"])
+        if not profiled:
+            feeder_ms["light_trace"].append(ctx.pass_stats(ev.PASS_LIGHT_TRACE)["ms"]); feeder_ms["primary"].append(ctx.pass_stats(ev.PASS_PRIMARY)["ms"])
     sync_all()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -419,11 +425,19 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     sync_all()
     dt = time.perf_counter() - t0
     splat_pairs = (sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) - pairs_before) if wl != "ir" else 0
+    extra = min(10, len(jitters) - (warmup + steps))
     if wl == "ppm":
-        extra = min(10, len(jitters) - (warmup + steps))
-        for i in range(extra):
+        for i in range(extra - 3):
             frame(warmup + steps + i); read_pass_times()
         sync_all()
+    if wl != "ir":                     # three more steps with the events around the splat's dominant kernel
+        for c in ranks:
+            c.profile_kernels(True)
+        for i in range(max(extra - (1 if wl == "vsl" else 3), 0), extra):
+            frame(warmup + steps + i); read_pass_times(profiled=True)
+        sync_all()
+        for c in ranks:
+            c.profile_kernels(False)
     kms_local = sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0
     stats = torch.tensor([dt, float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local), float(samples_local)], dtype=torch.float64, device=dev)
     if use_dist:
@@ -552,7 +566,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
             sms = sum(splat_ms) / len(splat_ms)
             rs = {"bound": "hbm", "achieved": nrec_bytes / (sms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": nrec_bytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "photon splat pass (bin + scatter + tiles)", "pass_ms": sms,
-                  "tiles_kernel_ms": sum(splat_tiles_ms) / len(splat_tiles_ms), "pairs_per_frame": spairs / steps, "algorithmic_bytes": nrec_bytes}
+                  "tiles_kernel_ms": (sum(splat_tiles_ms) / len(splat_tiles_ms)) if splat_tiles_ms else None, "pairs_per_frame": spairs / steps, "algorithmic_bytes": nrec_bytes}
             tpath = os.path.join(ROOT, "profiles", "traffic_splat.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath)).get("configs", {}).get(f"{wl}:{scene}:{W}x{H}:{n_ranks}")

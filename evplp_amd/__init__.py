@@ -114,6 +114,7 @@ _SIGNATURES = {
     "evplp_download": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_upload": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
+    "evplp_profile_kernels": (C.c_int, [_P, C.c_int32]),
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_accel_builder": (C.c_int, [_P]),
@@ -225,11 +226,15 @@ class Context:
         self.num_records = num_light_paths * photons_per_path
 
     @classmethod
-    def borrowed(cls, handle, res_x: int, res_y: int, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 8):
+    def borrowed(cls, handle, res_x: int, res_y: int, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 8,
+                 num_light_paths: int = 0, num_vpl_light_paths: int = 0, photons_per_path: int = 0):
         """A view of a context somebody else owns (a rank of an evplp_group): statistics and buffers; close() does not destroy it."""
         self = cls.__new__(cls)
         self._lib = lib(); self._h = C.c_void_p(handle); self._borrowed = True
         self.cfg = Config(); self.cfg.strip_rank = strip_rank; self.cfg.strip_count = strip_count; self.cfg.strip_rows = strip_rows
+        self.cfg.abi_version = ABI_VERSION; self.cfg.res_x = res_x; self.cfg.res_y = res_y
+        self.cfg.num_light_paths = num_light_paths; self.cfg.num_vpl_light_paths = num_vpl_light_paths; self.cfg.photons_per_path = photons_per_path
+        self.num_records = num_light_paths * photons_per_path
         self.W, self.H = res_x, res_y
         self.local_rows = self._lib.evplp_local_rows(self._h)
         return self
@@ -397,6 +402,10 @@ class Context:
                 # VSL gather: the same two words carry the sample-iterations of the estimators (lighttracing.cu:632-640)
                 "samples": (s.reserved[0] | (s.reserved[1] << 32)) if which == PASS_GATHER_VSL else 0}
 
+    def profile_kernels(self, on: bool = True):
+        """Record the events around the photon splat's dominant kernel (pass_stats()["dominant_kernel_ms"]); they sit between its launches."""
+        self._check(self._lib.evplp_profile_kernels(self._h, int(on)))
+
     def debug_counters(self, which: int) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint64)
         n = self._check(self._lib.evplp_debug_counters(self._h, which, _ptr(out), out.size))
@@ -428,6 +437,7 @@ class Group:
             raise EvplpError(rc, self._lib.evplp_group_last_error(None).decode())
         self._h = h; self.W, self.H, self.n = res_x, res_y, n_ranks
         self.strip_rows = strip_rows
+        self._paths = (num_light_paths, num_vpl_light_paths, photons_per_path)
 
     def _check(self, rc):
         if rc < 0:
@@ -476,7 +486,8 @@ class Group:
         h = self._lib.evplp_group_context(self._h, r)
         if not h:
             raise EvplpError(ERR_INVALID, "evplp_group_context: bad rank")
-        return Context.borrowed(h, self.W, self.H, strip_rank=r, strip_count=self.n, strip_rows=self.strip_rows)
+        return Context.borrowed(h, self.W, self.H, strip_rank=r, strip_count=self.n, strip_rows=self.strip_rows,
+                                num_light_paths=self._paths[0], num_vpl_light_paths=self._paths[1], photons_per_path=self._paths[2])
 
     def resolve(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
         out = np.empty((self.H, self.W, 3), dtype=np.float32)

@@ -180,7 +180,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (int b = 0; b < EVPLP_BUF_COUNT; b++) if (c->buf_owned[b]) hipFree(c->buf[b]);
     free_scene_device(c);
-    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_cuts); hipFree(c->d_lt_overflow);
+    hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_cuts); hipFree(c->d_primary_cuts); hipFree(c->d_lt_overflow);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
     hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
@@ -279,7 +279,7 @@ extern "C" int evplp_set_camera(evplp_context *c, const evplp_camera *cam) {
     std::memcpy(c->cam.eye, cam->origin, 12); std::memcpy(c->cam.s, s, 12); std::memcpy(c->cam.u, u, 12); std::memcpy(c->cam.f, f, 12);
     c->cam.tan_half = std::tan(cam->fovy / 2.0f); c->cam.aspect = cam->aspect;
     c->cam_in = *cam;
-    c->camera_set = true;
+    c->camera_set = true; c->primary_cuts_valid = false;
     return EVPLP_OK;
 }
 
@@ -427,7 +427,7 @@ extern "C" int evplp_build_accel(evplp_context *c) {
         for (int k = 0; k < 3; k++) { c->sc.light_lo[k] = llo[k] - pad; c->sc.light_hi[k] = lhi[k] + pad; }
     }
     std::memcpy(c->sc.light_intensity, c->light_scaled, 16); std::memcpy(c->sc.light_unscaled, c->light_unscaled, 16);
-    c->accel_built = true;
+    c->accel_built = true; c->primary_cuts_valid = false;
     return EVPLP_OK;
 }
 
@@ -558,6 +558,24 @@ extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t cl
     a.g_dif = (float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
     a.g_light = (float4 *)c->buf[EVPLP_BUF_LIGHT];
     a.tile_box = c->d_tile_box;
+    if (c->env_cuts != 0 && c->tiles_x * c->tiles_y > 0) {
+        // the eye's entry cuts: once per camera / tree (they hold for every jitter), 256 B per group of 2 x 2 tiles (2 x 1 where a
+        // strip's tile rows are not neighbours in the image)
+        PrimaryCutArgs pc; std::memset(&pc, 0, sizeof(pc));
+        pc.nodes = c->sc.nodes; pc.st = c->st; pc.cam = c->cam; pc.tiles_x = c->tiles_x; pc.tiles_y = c->tiles_y;
+        pc.gw_log2 = 1; pc.gh_log2 = (c->st.strip_count == 1 || c->st.strip_rows >= 16) ? 1 : 0;
+        pc.groups_x = (c->tiles_x + (1 << pc.gw_log2) - 1) >> pc.gw_log2; pc.groups_y = (c->tiles_y + (1 << pc.gh_log2) - 1) >> pc.gh_log2;
+        if (!c->d_primary_cuts) {
+            hipError_t me = hipMalloc((void **)&c->d_primary_cuts, (size_t)pc.groups_x * pc.groups_y * (size_t)kCutSlotBytes);
+            if (me != hipSuccess) { (void)hipGetLastError(); c->d_primary_cuts = nullptr; }
+            c->primary_cuts_valid = false;
+        }
+        if (c->d_primary_cuts) {
+            pc.cuts = c->d_primary_cuts;
+            if (!c->primary_cuts_valid) { launch_primary_cuts(pc, c->stream); c->primary_cuts_valid = true; }
+            a.cuts = c->d_primary_cuts; a.cut_gw_log2 = pc.gw_log2; a.cut_gh_log2 = pc.gh_log2; a.cut_groups_x = pc.groups_x;
+        }
+    }
     if ((rc = pass_begin(c, EVPLP_PASS_PRIMARY))) return rc;
     launch_primary(a, c->stream);
     c->tile_box_valid = !c->gbuf_pos_exposed;
@@ -829,8 +847,7 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     // Measured (tiles kernel, ms): fullest bin 1405 entries (config #3): 0.31 with one wave, 0.18 with four; fullest bin 365
     // (config #4 shape): 0.12 / 0.22.  The fullest bin of the PREVIOUS pass decides (a heuristic either way).
     const bool split_tiles = c->cfg.deterministic ? true : c->last_bin_max >= 768u;
-    const bool dom = c->stats_wanted[EVPLP_PASS_SPLAT];
-    c->stats_wanted[EVPLP_PASS_SPLAT] = false;
+    const bool dom = c->profile_kernels;
     launch_splat_tiles(a, split_tiles, c->stream, dom ? c->ev_dom_begin[EVPLP_PASS_SPLAT] : nullptr, dom ? c->ev_dom_end[EVPLP_PASS_SPLAT] : nullptr);
     // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
     // whole pass is enqueued now; the summary travels to pinned memory and is checked by the next call (settle_splat).
@@ -940,6 +957,8 @@ extern "C" int evplp_upload(evplp_context *c, int32_t which, const void *src, si
 }
 
 // raw device counters of a pass (diagnostic builds fill the histogram part; see kernels.h PassCounters)
+extern "C" int evplp_profile_kernels(evplp_context *c, int32_t on) { CTX_CHECK(c); c->profile_kernels = on != 0; return EVPLP_OK; }
+
 extern "C" int evplp_debug_counters(evplp_context *c, int32_t pass, uint64_t *out, int32_t capacity) {
     CTX_CHECK(c);
     { int rc_ = settle_splat(c); if (rc_) return rc_; }
@@ -958,7 +977,6 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
     { int rc_ = settle_splat(c); if (rc_) return rc_; }
     if (pass < 0 || pass >= EVPLP_PASS_COUNT || !out) { c->set_error("evplp_pass_stats_get: bad arguments"); return EVPLP_ERR_INVALID; }
     std::memset(out, 0, sizeof(*out));
-    c->stats_wanted[pass] = true;
     if (!c->pass_ran[pass]) return EVPLP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipEventSynchronize(c->ev_end[pass]));

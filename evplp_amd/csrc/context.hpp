@@ -23,9 +23,8 @@ struct evplp_context {
     hipEvent_t ev_dom_begin[EVPLP_PASS_COUNT] = {}, ev_dom_end[EVPLP_PASS_COUNT] = {};
     bool pass_ran[EVPLP_PASS_COUNT] = {}, pass_has_dom[EVPLP_PASS_COUNT] = {};
     // The events around the dominant kernel of the photon splat sit BETWEEN its three dependent launches and hold them apart (18 us of a
-    // 227 us pass, round 3).  They are recorded only while somebody reads them: on the first pass, and on every pass that follows a
-    // call of evplp_pass_stats_get for it; a loop that never asks runs its launches back to back.
-    bool stats_wanted[EVPLP_PASS_COUNT] = { true, true, true, true, true, true, true, true };
+    // 227 us pass, round 3): recorded only after evplp_profile_kernels(ctx, 1)
+    bool profile_kernels = false;
     evplp::HostStats stats_host[EVPLP_PASS_COUNT];
 
     void *buf[EVPLP_BUF_COUNT] = {};
@@ -50,6 +49,7 @@ struct evplp_context {
     // gather workspace, allocated on the first gather (path-tracing / photon-only contexts never pay for it)
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
     int32_t *d_lt_overflow = nullptr; size_t lt_overflow_bytes = 0;   // light tracing: the walk stack beyond its LDS entries (kernels.h)
+    char *d_primary_cuts = nullptr; bool primary_cuts_valid = false;   // the eye's entry cuts, one slot per tile group, rebuilt when the camera or the tree changes
     char *d_cuts = nullptr; size_t cut_bytes = 0;               // gathers: entry cuts of every (tile group, VPL) (kernels.h CutArgs), allocated on the first gather
     void *d_vsl_masks = nullptr; size_t vsl_mask_bytes = 0;    // VSL gather: lit masks + per-item ray counts of one launch (kernels.h GatherArgs)
 

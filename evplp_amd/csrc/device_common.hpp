@@ -769,7 +769,9 @@ EV_DEV Tri2 tri_pair_eval(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, 
 // closest_lane (order-independent: ties in t keep the lowest ORIGINAL triangle index).  Replaces the rasteriser's
 // depth test for the G-buffer (rt/rtcomphoton/rtcomphoton.h:710-754).
 EV_DEV int32_t closest_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter, bool active_lane,
-                            float &t_out, float &beta_out, float &gamma_out) {
+                            float &t_out, float &beta_out, float &gamma_out, const char *cut = nullptr) {
+    // cut != nullptr: the walk starts from the entry cut of the tile group (kernels.h PrimaryCutArgs: synthetic nodes, nearest first,
+    // node 0 carries their count) instead of from the root
     const V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
     const v2f avx = bc(fabsf(inv.x)), avy = bc(fabsf(inv.y)), avz = bc(fabsf(inv.z));
@@ -781,61 +783,79 @@ EV_DEV int32_t closest_wave(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
     int32_t cur = 0;
     const char *node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *leaf_base = reinterpret_cast<const char *>(sc.leaves);
+    // one node visit: both children's slab tests against [tmin, best hit so far]; afterwards cur = the next node, a leaf, or kNoChild
+    auto visit = [&](const v16i &n) {
+        const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
+        const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
+        const v2f enx = pk_fma(hx, -avx, ax), eny = pk_fma(hy, -avy, ay), enz = pk_fma(hz, -avz, az);
+        const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
+        const float tn0 = fmaxf(fmaxf(enx.x, eny.x), fmaxf(enz.x, tmin)), tf0 = fminf(fminf(exx.x, exy.x), fminf(exz.x, bt));
+        const float tn1 = fmaxf(fmaxf(enx.y, eny.y), fmaxf(enz.y, tmin)), tf1 = fminf(fminf(exx.y, exy.y), fminf(exz.y, bt));
+        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+        const unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
+        const int32_t c0 = n[12], c1 = n[13];
+        const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
+        if ((a0 | a1) == 0u) { if (sp == 0) cur = kNoChild; else { sp--; cur = lane_read(vstack, sp); } return; }
+        if (a0 == 0u) { cur = c1; return; }
+        if (a1 == 0u) { cur = c0; return; }
+        // both wanted: the child that more lanes enter first goes first, the other one waits on the stack
+        const unsigned long long near0 = ballot64(h0 && (!h1 || tn0 <= tn1)), near1 = ballot64(h1 && (!h0 || tn1 < tn0));
+        const uint32_t p0 = (uint32_t)(__builtin_popcount((uint32_t)near0) + __builtin_popcount((uint32_t)(near0 >> 32)));
+        const uint32_t p1 = (uint32_t)(__builtin_popcount((uint32_t)near1) + __builtin_popcount((uint32_t)(near1 >> 32)));
+        const bool first0 = p0 >= p1;
+        vstack = lane_write(first0 ? c1 : c0, sp, vstack);
+        sp++;
+        cur = first0 ? c0 : c1;
+    };
+    uint32_t cut_off = 0u, cut_end = 0u;
+    if (cut) {
+        const v16i head = *reinterpret_cast<const v16i *>(cut);
+        cut_end = (uint32_t)head[14] << 6;
+        if (cut_end == 0u) return -1;
+    }
     for (;;) {
-        while (cur >= 0) {
-            const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
-            const v2f ax = pk_fma(pk(n[0], n[1]), ivx, nox), ay = pk_fma(pk(n[2], n[3]), ivy, noy), az = pk_fma(pk(n[4], n[5]), ivz, noz);
-            const v2f hx = pk(n[6], n[7]), hy = pk(n[8], n[9]), hz = pk(n[10], n[11]);
-            const v2f enx = pk_fma(hx, -avx, ax), eny = pk_fma(hy, -avy, ay), enz = pk_fma(hz, -avz, az);
-            const v2f exx = pk_fma(hx, avx, ax), exy = pk_fma(hy, avy, ay), exz = pk_fma(hz, avz, az);
-            const float tn0 = fmaxf(fmaxf(enx.x, eny.x), fmaxf(enz.x, tmin)), tf0 = fminf(fminf(exx.x, exy.x), fminf(exz.x, bt));
-            const float tn1 = fmaxf(fmaxf(enx.y, eny.y), fmaxf(enz.y, tmin)), tf1 = fminf(fminf(exx.y, exy.y), fminf(exz.y, bt));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const unsigned long long m0 = ballot64(h0), m1 = ballot64(h1);
-            const int32_t c0 = n[12], c1 = n[13];
-            const uint32_t a0 = (uint32_t)m0 | (uint32_t)(m0 >> 32), a1 = (uint32_t)m1 | (uint32_t)(m1 >> 32);
-            if ((a0 | a1) == 0u) { cur = kNoChild; break; }
-            if (a0 == 0u) { cur = c1; continue; }
-            if (a1 == 0u) { cur = c0; continue; }
-            {
-                // both wanted: the child that more lanes enter first goes first, the other one waits on the stack
-                const unsigned long long near0 = ballot64(h0 && (!h1 || tn0 <= tn1)), near1 = ballot64(h1 && (!h0 || tn1 < tn0));
-                const uint32_t p0 = (uint32_t)(__builtin_popcount((uint32_t)near0) + __builtin_popcount((uint32_t)(near0 >> 32)));
-                const uint32_t p1 = (uint32_t)(__builtin_popcount((uint32_t)near1) + __builtin_popcount((uint32_t)(near1 >> 32)));
-                const bool first0 = p0 >= p1;
-                vstack = lane_write(first0 ? c1 : c0, sp, vstack);
-                sp++;
-                cur = first0 ? c0 : c1;
-            }
+        if (cut) {
+            if (cut_off >= cut_end) break;
+            const v16i syn = *reinterpret_cast<const v16i *>(cut + cut_off);
+            cut_off += 64u;
+            visit(syn);
         }
-        if (cur != kNoChild) {
-            const uint32_t id = (uint32_t)~cur;
-            const uint32_t block = id >> 2, cnt = (id & 3u) + 1u;
-            const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + block * 192u);
-            const int32_t *orig = sc.tri_index + block * 4u;
-            const v16i a = tp[0], b = tp[1];
-            auto take = [&](float t, float be, float ga, bool inside, int32_t tri) {
-                const bool is_light = tri >= sc.light_first && tri < sc.light_first + sc.light_count;    // wave-uniform
-                if ((filter == 1 && is_light) || (filter == 2 && !is_light)) return;
-                if (inside && t > tmin && t < 3.0e38f && (t < bt || (t == bt && best >= 0 && tri < best))) { bt = t; bb = be; bg = ga; best = tri; }
-            };
+        for (;;) {
+            while (cur >= 0) {
+                const v16i n = *reinterpret_cast<const v16i *>(node_base + ((uint32_t)cur << 6));
+                visit(n);
+            }
+            if (cur == kNoChild) break;
             {
-                Tri2 r = tri_pair_eval(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
-                                       pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]), o, d);
-                take(r.t.x, r.beta.x, r.gamma.x, r.in_a, orig[0]);
-                if (cnt > 1u) take(r.t.y, r.beta.y, r.gamma.y, r.in_b, orig[1]);
+                const uint32_t id = (uint32_t)~cur;
+                const uint32_t block = id >> 2, cnt = (id & 3u) + 1u;
+                const v16i *tp = reinterpret_cast<const v16i *>(leaf_base + block * 192u);
+                const int32_t *orig = sc.tri_index + block * 4u;
+                const v16i a = tp[0], b = tp[1];
+                auto take = [&](float t, float be, float ga, bool inside, int32_t tri) {
+                    const bool is_light = tri >= sc.light_first && tri < sc.light_first + sc.light_count;    // wave-uniform
+                    if ((filter == 1 && is_light) || (filter == 2 && !is_light)) return;
+                    if (inside && t > tmin && t < 3.0e38f && (t < bt || (t == bt && best >= 0 && tri < best))) { bt = t; bb = be; bg = ga; best = tri; }
+                };
+                {
+                    Tri2 r = tri_pair_eval(pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7]), pk(a[8], a[9]), pk(a[10], a[11]),
+                                           pk(a[12], a[13]), pk(a[14], a[15]), pk(b[0], b[1]), pk(b[2], b[3]), pk(b[4], b[5]), pk(b[6], b[7]), o, d);
+                    take(r.t.x, r.beta.x, r.gamma.x, r.in_a, orig[0]);
+                    if (cnt > 1u) take(r.t.y, r.beta.y, r.gamma.y, r.in_b, orig[1]);
+                }
+                if (cnt > 2u) {
+                    const v16i c = tp[2];
+                    Tri2 r = tri_pair_eval(pk(b[8], b[9]), pk(b[10], b[11]), pk(b[12], b[13]), pk(b[14], b[15]), pk(c[0], c[1]), pk(c[2], c[3]),
+                                           pk(c[4], c[5]), pk(c[6], c[7]), pk(c[8], c[9]), pk(c[10], c[11]), pk(c[12], c[13]), pk(c[14], c[15]), o, d);
+                    take(r.t.x, r.beta.x, r.gamma.x, r.in_a, orig[2]);
+                    if (cnt > 3u) take(r.t.y, r.beta.y, r.gamma.y, r.in_b, orig[3]);
+                }
             }
-            if (cnt > 2u) {
-                const v16i c = tp[2];
-                Tri2 r = tri_pair_eval(pk(b[8], b[9]), pk(b[10], b[11]), pk(b[12], b[13]), pk(b[14], b[15]), pk(c[0], c[1]), pk(c[2], c[3]),
-                                       pk(c[4], c[5]), pk(c[6], c[7]), pk(c[8], c[9]), pk(c[10], c[11]), pk(c[12], c[13]), pk(c[14], c[15]), o, d);
-                take(r.t.x, r.beta.x, r.gamma.x, r.in_a, orig[2]);
-                if (cnt > 3u) take(r.t.y, r.beta.y, r.gamma.y, r.in_b, orig[3]);
-            }
+            if (sp == 0) break;
+            sp--;
+            cur = lane_read(vstack, sp);
         }
-        if (sp == 0) break;
-        sp--;
-        cur = lane_read(vstack, sp);
+        if (!cut) break;
     }
     if (best >= 0) { t_out = bt; beta_out = bb; gamma_out = bg; }
     return best;

@@ -9,7 +9,17 @@ struct PrimaryArgs {
     float jitter[2]; int32_t clear_light; int32_t pad;
     float4 *g_pos, *g_nrm, *g_dif, *g_phg, *g_light;
     float4 *tile_box;         // [tiles][2] world-space box of every 8x8-px tile's positions (the photon splat's bin cull), or null
+    // entry cuts of the primary rays (one slot per tile group, built once per camera by primary_cut_kernel; null: walks from the root)
+    const char *cuts; int32_t cut_gw_log2, cut_gh_log2, cut_groups_x, pad2;
 };
+// The eye's entry cuts: the pyramid through a tile group's pixels -- opened by one pixel on every side, so that it holds for every
+// anti-aliasing jitter of the camera -- descends the tree like a (tile group, VPL) pyramid (CutArgs below); lane = tile group.
+struct PrimaryCutArgs {
+    const BvhNode *nodes; StripDev st; CamBasis cam;
+    int32_t tiles_x, tiles_y, gw_log2, gh_log2, groups_x, groups_y;
+    char *cuts;
+};
+void launch_primary_cuts(const PrimaryCutArgs &a, hipStream_t s);
 
 struct LightTraceArgs {
     SceneDev sc;

@@ -42,6 +42,93 @@ EV_DEV bool cut_outside(const CutFrustum &F, const float c[3], const float h[3])
 }
 
 constexpr int kCutRing = kCutEntries;
+// The descent and the output of one lane: breadth-first (ring) refinement of the cut of frustum F over the tree, then the cut -- nearest
+// entry first -- as synthetic nodes in `slot`.  s_ref / s_src: the wave's ring buffers in LDS ([entry][lane]).
+EV_DEV void cut_descend_and_store(const BvhNode *nodes, const CutFrustum &F, char *slot, bool work, int lane, int32_t (*s_ref)[64], uint32_t (*s_src)[64]) {
+    // ---- the cut: breadth-first (ring) refinement
+    int head = 0, count = 0;
+    auto ring_push = [&](int32_t ref, uint32_t src) { const int at = (head + count) & (kCutRing - 1); s_ref[at][lane] = ref; s_src[at][lane] = src; count++; };
+    auto expand = [&](int32_t node, int32_t *refs, uint32_t *srcs) -> int {      // surviving children of an inner node
+        const float4 *q4 = reinterpret_cast<const float4 *>(nodes + node);
+        const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2], n3 = q4[3];
+        // BvhNode: ctr[3][2] = n0.xyzw n1.xy ; hal[3][2] = n1.zw n2.xyzw ; c0 c1 = n3.xy
+        const float c0[3] = { n0.x, n0.z, n1.x }, c1[3] = { n0.y, n0.w, n1.y };
+        const float h0[3] = { n1.z, n2.x, n2.z }, h1[3] = { n1.w, n2.y, n2.w };
+        const int32_t r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
+        int nk = 0;
+        if (r0 != kNoChild && !cut_outside(F, c0, h0)) { refs[nk] = r0; srcs[nk] = (uint32_t)node << 1; nk++; }
+        if (r1 != kNoChild && !cut_outside(F, c1, h1)) { refs[nk] = r1; srcs[nk] = ((uint32_t)node << 1) | 1u; nk++; }
+        return nk;
+    };
+    if (work) {
+        int32_t refs[2]; uint32_t srcs[2];
+        int nk = expand(0, refs, srcs);
+        for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
+        int leaves_in_row = 0;
+        while (count > 0 && leaves_in_row < count) {
+            const int32_t ref = s_ref[head][lane]; const uint32_t src = s_src[head][lane];
+            if (ref < 0) { head = (head + 1) & (kCutRing - 1); count--; ring_push(ref, src); leaves_in_row++; continue; }    // a leaf stays in the cut
+            nk = expand(ref, refs, srcs);
+            if (count - 1 + nk > kCutEntries) break;
+            head = (head + 1) & (kCutRing - 1); count--;
+            for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
+            leaves_in_row = 0;
+        }
+        // ---- the cut, nearest entry first (the walk visits the synthetic nodes in slot order and ends as soon as every lane is occluded:
+        // 14.8 against 16.0 node visits per walk in the CPU replay): distance of every entry's box from the apex, sorting network on
+        // (distance, entry) in registers
+        auto box_of = [&](int k, float c[3], float h[3], int32_t &ref) {
+            const int at = (head + k) & (kCutRing - 1);
+            ref = s_ref[at][lane]; const uint32_t src = s_src[at][lane];
+            const float4 *q4 = reinterpret_cast<const float4 *>(nodes + (src >> 1));
+            const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
+            const bool ch = (src & 1u) != 0u;
+            c[0] = ch ? n0.y : n0.x; c[1] = ch ? n0.w : n0.z; c[2] = ch ? n1.y : n1.x;
+            h[0] = ch ? n1.w : n1.z; h[1] = ch ? n2.y : n2.x; h[2] = ch ? n2.w : n2.z;
+        };
+        float dist[kCutEntries]; int order[kCutEntries];
+#pragma unroll
+        for (int k = 0; k < kCutEntries; k++) {
+            order[k] = k; dist[k] = 3.0e38f;
+            if (k < count) {
+                float c[3], h[3]; int32_t r; box_of(k, c, h, r);
+                const float ex = fmaxf(fabsf(F.p.x - c[0]) - h[0], 0.f), ey = fmaxf(fabsf(F.p.y - c[1]) - h[1], 0.f), ez = fmaxf(fabsf(F.p.z - c[2]) - h[2], 0.f);
+                dist[k] = ex * ex + ey * ey + ez * ez;
+            }
+        }
+#define EV_CX(i_, j_) { const bool sw = dist[j_] < dist[i_]; const float td = sw ? dist[j_] : dist[i_]; dist[j_] = sw ? dist[i_] : dist[j_]; dist[i_] = td; \
+                        const int to = sw ? order[j_] : order[i_]; order[j_] = sw ? order[i_] : order[j_]; order[i_] = to; }
+        static_assert(kCutEntries == 8, "the sorting network below is the 19-comparator network for 8 keys");
+        EV_CX(0, 1) EV_CX(2, 3) EV_CX(4, 5) EV_CX(6, 7)
+        EV_CX(0, 2) EV_CX(1, 3) EV_CX(4, 6) EV_CX(5, 7)
+        EV_CX(1, 2) EV_CX(5, 6) EV_CX(0, 4) EV_CX(3, 7)
+        EV_CX(1, 5) EV_CX(2, 6)
+        EV_CX(1, 4) EV_CX(3, 6)
+        EV_CX(2, 4) EV_CX(3, 5)
+        EV_CX(3, 4)
+#undef EV_CX
+        // ---- synthetic nodes: entries (2 s, 2 s + 1) of the sorted cut -> node s; node 0 carries the node count in its first padding word
+        const int nsyn = (count + 1) >> 1;
+        float4 *out = reinterpret_cast<float4 *>(slot);
+        if (nsyn == 0) out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s2 = 0; s2 < kCutNodes; s2++) {
+            if (s2 < nsyn) {
+                float c[2][3], h[2][3]; int32_t r[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (2 * s2 + e < count) box_of(order[2 * s2 + e], c[e], h[e], r[e]);
+                    else { r[e] = kNoChild; c[e][0] = c[e][1] = c[e][2] = 0.f; h[e][0] = h[e][1] = h[e][2] = -3.0e38f; }
+                }
+                out[4 * s2 + 0] = make_float4(c[0][0], c[1][0], c[0][1], c[1][1]);
+                out[4 * s2 + 1] = make_float4(c[0][2], c[1][2], h[0][0], h[1][0]);
+                out[4 * s2 + 2] = make_float4(h[0][1], h[1][1], h[0][2], h[1][2]);
+                out[4 * s2 + 3] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(nsyn), 0.f);
+            }
+        }
+    }
+}
+
 // One lane = one (tile group, VPL): build the pyramid, refine the cut breadth-first (ring buffer of its own in LDS), write the
 // synthetic nodes.  A wave = ONE VPL and a block of 8 x 8 neighbouring tile groups: the 64 pyramids share their apex and point at
 // neighbouring parts of the screen, so they walk the same part of the tree for about the same number of steps (first version, lane =
@@ -128,88 +215,43 @@ __global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
         for (int q = 0; q < 4; q++) F.tol[q] = 4.0e-6f * (fabsf(F.pl[q].x) + fabsf(F.pl[q].y) + fabsf(F.pl[q].z));
     }
 
-    // ---- the cut: breadth-first (ring) refinement
-    int head = 0, count = 0;
-    auto ring_push = [&](int32_t ref, uint32_t src) { const int at = (head + count) & (kCutRing - 1); s_ref[at][lane] = ref; s_src[at][lane] = src; count++; };
-    auto expand = [&](int32_t node, int32_t *refs, uint32_t *srcs) -> int {      // surviving children of an inner node
-        const float4 *q4 = reinterpret_cast<const float4 *>(a.nodes + node);
-        const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2], n3 = q4[3];
-        // BvhNode: ctr[3][2] = n0.xyzw n1.xy ; hal[3][2] = n1.zw n2.xyzw ; c0 c1 = n3.xy
-        const float c0[3] = { n0.x, n0.z, n1.x }, c1[3] = { n0.y, n0.w, n1.y };
-        const float h0[3] = { n1.z, n2.x, n2.z }, h1[3] = { n1.w, n2.y, n2.w };
-        const int32_t r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
-        int nk = 0;
-        if (r0 != kNoChild && !cut_outside(F, c0, h0)) { refs[nk] = r0; srcs[nk] = (uint32_t)node << 1; nk++; }
-        if (r1 != kNoChild && !cut_outside(F, c1, h1)) { refs[nk] = r1; srcs[nk] = ((uint32_t)node << 1) | 1u; nk++; }
-        return nk;
-    };
-    if (work) {
-        int32_t refs[2]; uint32_t srcs[2];
-        int nk = expand(0, refs, srcs);
-        for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
-        int leaves_in_row = 0;
-        while (count > 0 && leaves_in_row < count) {
-            const int32_t ref = s_ref[head][lane]; const uint32_t src = s_src[head][lane];
-            if (ref < 0) { head = (head + 1) & (kCutRing - 1); count--; ring_push(ref, src); leaves_in_row++; continue; }    // a leaf stays in the cut
-            nk = expand(ref, refs, srcs);
-            if (count - 1 + nk > kCutEntries) break;
-            head = (head + 1) & (kCutRing - 1); count--;
-            for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
-            leaves_in_row = 0;
-        }
-        // ---- the cut, nearest entry first (the walk visits the synthetic nodes in slot order and ends as soon as every lane is occluded:
-        // 14.8 against 16.0 node visits per walk in the CPU replay): distance of every entry's box from the apex, sorting network on
-        // (distance, entry) in registers
-        auto box_of = [&](int k, float c[3], float h[3], int32_t &ref) {
-            const int at = (head + k) & (kCutRing - 1);
-            ref = s_ref[at][lane]; const uint32_t src = s_src[at][lane];
-            const float4 *q4 = reinterpret_cast<const float4 *>(a.nodes + (src >> 1));
-            const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
-            const bool ch = (src & 1u) != 0u;
-            c[0] = ch ? n0.y : n0.x; c[1] = ch ? n0.w : n0.z; c[2] = ch ? n1.y : n1.x;
-            h[0] = ch ? n1.w : n1.z; h[1] = ch ? n2.y : n2.x; h[2] = ch ? n2.w : n2.z;
-        };
-        float dist[kCutEntries]; int order[kCutEntries];
+    cut_descend_and_store(a.nodes, F, slot, work, lane, s_ref, s_src);
+}
+
+// The eye's cuts (kernels.h PrimaryCutArgs): lane = tile group, 8 x 8 neighbouring groups per wave.  The pyramid is exact: a pixel's ray
+// is eye + t (S jx + U jy + F) with jx = (ndc_x - jitter_x) aspect tan(fovy / 2), so in the basis (m, u, w) = (F, S, U) its tangents ARE
+// (jx, jy); the group's range of them is opened by one pixel (the jitter moves a ray by at most half a pixel, rtcomphoton.h:949).  No
+// end-point box: the rays end wherever the scene is.
+__global__ __launch_bounds__(64) void primary_cut_kernel(PrimaryCutArgs a) {
+    __shared__ int32_t s_ref[kCutRing][64];
+    __shared__ uint32_t s_src[kCutRing][64];
+    const int lane = threadIdx.x;
+    const int gblocks_x = (a.groups_x + 7) >> 3;
+    const int gx = (int)(blockIdx.x % (uint32_t)gblocks_x) * 8 + (lane & 7), gy = (int)(blockIdx.x / (uint32_t)gblocks_x) * 8 + (lane >> 3);
+    const bool live = gx < a.groups_x && gy < a.groups_y;
+    const int gxc = min(gx, a.groups_x - 1), gyc = min(gy, a.groups_y - 1);
+    const int gw = 8 << a.gw_log2, gh = 8 << a.gh_log2;                 // pixels per group
+    const int x0 = gxc * gw, x1 = min(x0 + gw, a.st.W) - 1;
+    const int ly0 = gyc * gh, ly1 = min(ly0 + gh, a.st.local_rows) - 1;
+    // the group's image rows (a strip's local rows of one group are consecutive image rows: groups never span strip blocks)
+    const int y0 = a.st.global_row(ly0), y1 = a.st.global_row(ly1);
+    CutFrustum F; F.p = v3(a.cam.eye);
+    const V3 S = v3(a.cam.s), U = v3(a.cam.u), Fw = v3(a.cam.f);
+    const float px = 2.0f / (float)a.st.W, py = 2.0f / (float)a.st.H;   // one pixel in NDC
+    const float ax0 = (((float)x0 + 0.5f) * px - 1.0f - px) * a.cam.aspect * a.cam.tan_half, ax1 = (((float)x1 + 0.5f) * px - 1.0f + px) * a.cam.aspect * a.cam.tan_half;
+    const float by0 = (((float)min(y0, y1) + 0.5f) * py - 1.0f - py) * a.cam.tan_half, by1 = (((float)max(y0, y1) + 0.5f) * py - 1.0f + py) * a.cam.tan_half;
 #pragma unroll
-        for (int k = 0; k < kCutEntries; k++) {
-            order[k] = k; dist[k] = 3.0e38f;
-            if (k < count) {
-                float c[3], h[3]; int32_t r; box_of(k, c, h, r);
-                const float ex = fmaxf(fabsf(F.p.x - c[0]) - h[0], 0.f), ey = fmaxf(fabsf(F.p.y - c[1]) - h[1], 0.f), ez = fmaxf(fabsf(F.p.z - c[2]) - h[2], 0.f);
-                dist[k] = ex * ex + ey * ey + ez * ez;
-            }
-        }
-#define EV_CX(i_, j_) { const bool sw = dist[j_] < dist[i_]; const float td = sw ? dist[j_] : dist[i_]; dist[j_] = sw ? dist[i_] : dist[j_]; dist[i_] = td; \
-                        const int to = sw ? order[j_] : order[i_]; order[j_] = sw ? order[i_] : order[j_]; order[i_] = to; }
-        static_assert(kCutEntries == 8, "the sorting network below is the 19-comparator network for 8 keys");
-        EV_CX(0, 1) EV_CX(2, 3) EV_CX(4, 5) EV_CX(6, 7)
-        EV_CX(0, 2) EV_CX(1, 3) EV_CX(4, 6) EV_CX(5, 7)
-        EV_CX(1, 2) EV_CX(5, 6) EV_CX(0, 4) EV_CX(3, 7)
-        EV_CX(1, 5) EV_CX(2, 6)
-        EV_CX(1, 4) EV_CX(3, 6)
-        EV_CX(2, 4) EV_CX(3, 5)
-        EV_CX(3, 4)
-#undef EV_CX
-        // ---- synthetic nodes: entries (2 s, 2 s + 1) of the sorted cut -> node s; node 0 carries the node count in its first padding word
-        const int nsyn = (count + 1) >> 1;
-        float4 *out = reinterpret_cast<float4 *>(slot);
-        if (nsyn == 0) out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 3; k++) { F.lo[k] = -3.0e38f; F.hi[k] = 3.0e38f; }
+    F.planes = true;
+    F.pl[0] = S - Fw * ax0; F.pl[1] = Fw * ax1 - S; F.pl[2] = U - Fw * by0; F.pl[3] = Fw * by1 - U;
 #pragma unroll
-        for (int s2 = 0; s2 < kCutNodes; s2++) {
-            if (s2 < nsyn) {
-                float c[2][3], h[2][3]; int32_t r[2];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    if (2 * s2 + e < count) box_of(order[2 * s2 + e], c[e], h[e], r[e]);
-                    else { r[e] = kNoChild; c[e][0] = c[e][1] = c[e][2] = 0.f; h[e][0] = h[e][1] = h[e][2] = -3.0e38f; }
-                }
-                out[4 * s2 + 0] = make_float4(c[0][0], c[1][0], c[0][1], c[1][1]);
-                out[4 * s2 + 1] = make_float4(c[0][2], c[1][2], h[0][0], h[1][0]);
-                out[4 * s2 + 2] = make_float4(h[0][1], h[1][1], h[0][2], h[1][2]);
-                out[4 * s2 + 3] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(nsyn), 0.f);
-            }
-        }
-    }
+    for (int q = 0; q < 4; q++) F.tol[q] = 4.0e-6f * (fabsf(F.pl[q].x) + fabsf(F.pl[q].y) + fabsf(F.pl[q].z));
+    char *const slot = a.cuts + (size_t)(gyc * a.groups_x + gxc) * (size_t)kCutSlotBytes;
+    cut_descend_and_store(a.nodes, F, slot, live, lane, s_ref, s_src);
+}
+void launch_primary_cuts(const PrimaryCutArgs &a, hipStream_t s) {
+    const uint32_t gblocks = (uint32_t)(((a.groups_x + 7) >> 3) * ((a.groups_y + 7) >> 3));
+    if (gblocks) hipLaunchKernelGGL(primary_cut_kernel, dim3(gblocks), dim3(64), 0, s, a);
 }
 
 void launch_gather_cuts(const CutArgs &a, hipStream_t s) {

@@ -38,7 +38,10 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     float t = 0.f, b = 0.f, g = 0.f, tl = 0.f, bl = 0.f, gl = 0.f;
     // the 64 primary rays of a tile share the eye: packet walk (closest_wave), no per-lane stack.
     // view depth == t because the camera-space z of the direction is -1: near/far = [0.1, 100] (rtcommon.h:586)
-    int32_t tri = closest_wave(a.sc, eye, dj, 0.1f, 100.0f, 1, in_image, t, b, g);
+    // the tile group's entry cut from the eye (primary_cut_kernel, once per camera: kernels.h PrimaryCutArgs), or the root
+    const char *cut = nullptr;
+    if (a.cuts) cut = a.cuts + (size_t)((ty >> a.cut_gh_log2) * a.cut_groups_x + (tx >> a.cut_gw_log2)) * (size_t)kCutSlotBytes;
+    int32_t tri = closest_wave(a.sc, eye, dj, 0.1f, 100.0f, 1, in_image, t, b, g, cut);
     // the light mesh only matters in front of (or at) the scene hit (depth LEQUAL): bound its walk by that depth --
     // both directions have camera-space z = -1, so t is the view depth on either ray
     const bool light_unoccluded = (a.clear_light & EVPLP_LIGHT_UNOCCLUDED) != 0;      // wave-uniform
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
         if (t0 > t1) light_maybe = false;
     }
     const bool walk_light = a.sc.light_count > 0 && __ballot(light_maybe) != 0ull;        // wave-uniform
-    int32_t ltri = walk_light ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl) : -1;
+    int32_t ltri = walk_light ? closest_wave(a.sc, eye, d0, 0.1f, light_far, 2, in_image, tl, bl, gl, cut) : -1;
     bool use_light = ltri >= 0 && (tri < 0 || tl <= t);  // depth LEQUAL, light mesh drawn last
     const bool light_visible = light_unoccluded ? ltri >= 0 : use_light;              // the emitter IMAGE (rtcomphoton.h:985-995)
     if (use_light) { tri = ltri; b = bl; g = gl; }

@@ -252,6 +252,10 @@ int evplp_bind_buffer(evplp_context *ctx, int32_t which, void *device_ptr, size_
 int evplp_download(evplp_context *ctx, int32_t which, void *host_dst, size_t bytes);
 int evplp_upload(evplp_context *ctx, int32_t which, const void *host_src, size_t bytes);
 int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out);
+/* evplp_pass_stats.dominant_kernel_ms of the photon splat needs two HIP events BETWEEN the pass's three dependent launches, and they
+ * hold the launches apart (18 us of a 227 us pass): they are recorded only while this is on (off by default; the gathers' dominant
+ * kernels are bracketed always -- their events sit beside 50 ms kernels).  Off: the splat reports dominant_kernel_ms = ms. */
+int evplp_profile_kernels(evplp_context *ctx, int32_t on);
 /* Raw device-side counters of the last run of `pass` (rays, node visits, pairs, aux, then the traversal histogram that
  * only -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds fill).  Returns the number of 64-bit words written. */
 int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_t capacity);

@@ -334,6 +334,28 @@ def test_gather_vsl(ctx, oscene, evplp, inputs):
     assert_image_close(got[..., :3], ref[..., :3], rel=1e-3, pix=2e-2, what="gather_vsl")
 
 
+def test_gather_vsl_with_a_light_exactly_on_a_pixel(ctx, oscene, evplp, inputs):
+    """A VSL that sits exactly ON a G-buffer point: distance 0, the cone set-up divides by it.  The reference drops the pair
+    (fmaxf(NaN, 0) * fmaxf(NaN, 0) = 0 <= 1e-9, lighttracing.cu:619); the walk kernel's pre-test must drop it too instead of
+    letting a NaN through to the estimators (rsq(0) = inf would stay in the accumulating image for good)."""
+    gbuf, records = inputs
+    rec = records.copy()
+    y0, x0 = H // 2, W // 3
+    assert gbuf[0][y0, x0, 3] != 0
+    rec["pos"][1] = gbuf[0][y0, x0, :3]; rec["normal"][1] = gbuf[1][y0, x0, :3]; rec["flags"][1] |= 1
+    upload_inputs(ctx, evplp, gbuf, rec)
+    r = 0.3
+    kw = dict(camera_pos=oscene.sd.cam_origin, vsl_radius=r, vsl_inv_pi_radius2=1.0 / (math.pi * r * r), num_light_paths=NPATHS,
+              num_vpl_light_paths=4, photons_per_path=P, rng_seed=9)
+    ctx.clear_accumulators()
+    ctx.gather_vsl(evplp.frame_params(**kw))
+    got = ctx.download(evplp.BUF_VPL_ACCUM)[:H]
+    assert np.isfinite(got).all(), "a zero-distance (pixel, VSL) pair put a non-finite value into the image"
+    ref, _ = oscene.gather(oa.frame_params(**kw), W, H, gbuf, rec, vsl=True)
+    assert np.isfinite(ref).all() and ref[..., :3].max() > 0
+    assert_image_close(got[..., :3], ref[..., :3], rel=1e-3, pix=2e-2, what="gather_vsl with a VSL on a pixel")
+
+
 def test_row_strips_reassemble_bitwise(room, evplp, oscene, inputs):
     """N interleaved strips (as N ranks would own them) == the 1-GPU frame, bit for bit (gather) and
     to fp32 reorder tolerance 0 in deterministic splat mode."""

@@ -4,16 +4,22 @@ import json, os, sys
 d, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ir = json.load(open(os.path.join(d, "pmc_ir_summary.json")))
-g = ir["evplp::gather_vpl_kernel"]
+gk = [k for k in ir if "gather_vpl_kernel" in k and "FETCH_SIZE" in ir[k]][-1]      # (round 4: a template, "void evplp::gather_vpl_kernel<true>")
+g = ir[gk]
+cut = next((ir[k] for k in ir if "gather_cut_kernel" in k and "FETCH_SIZE" in ir[k]), None)
 f, w = g["FETCH_SIZE"] * 1024, g["WRITE_SIZE"] * 1024
+if cut:      # the entry cuts are part of the gather: their scratch is written by the cut kernel and read by the walks
+    f += cut["FETCH_SIZE"] * 1024; w += cut["WRITE_SIZE"] * 1024
 json.dump({
     "config": "hard:1024x1024:1024:1",
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_all.sh {tag}) over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`, last launch; summary profiles/{tag}_bench_ir_pmc.txt",
-    "kernel": "evplp::gather_vpl_kernel", "FETCH_SIZE_KB": g["FETCH_SIZE"], "WRITE_SIZE_KB": g["WRITE_SIZE"],
+    "kernel": gk + (" + evplp::gather_cut_kernel" if cut else ""), "round": tag, "FETCH_SIZE_KB": g["FETCH_SIZE"], "WRITE_SIZE_KB": g["WRITE_SIZE"],
+    "cut_kernel": ({"FETCH_SIZE_KB": cut["FETCH_SIZE"], "WRITE_SIZE_KB": cut["WRITE_SIZE"]} if cut else None),
     "hbm_bytes_per_launch": f + w, "hbm_bytes_per_launch_if_fetch_x2": 2 * f + w,
     "note": "FETCH_SIZE raw (MI355X_MICROARCH.md: it reads 1/2 of the bytes of wide 16 B/lane streams; this kernel reads 64-byte scalar node / leaf blocks, "
             "an uncalibrated width, so the x2 figure is given beside it); fabric-side counters, Infinity-Cache hits included (nodes + leaves = 41 MB stay resident). "
-            "WRITE_SIZE = per-item partial sums (128 / splits_per_wave x 16 MB) + prologue register spills. Algorithmic bytes per launch = 1024*1024*(64+16+16) + n_vpl*96 = 101 MB.",
+            "WRITE_SIZE = per-item partial sums (128 / splits_per_wave x 16 MB); round 4: + the entry cuts (256 B per (tile group, VPL slot) written by gather_cut_kernel, read once per tile "
+            "by the walks through their LDS ring: four reads per slot). Algorithmic bytes per launch = 1024*1024*(64+16+16) + n_vpl*96 = 101 MB.",
     "l2_hit_rate": g["TCC_HIT_sum"] / (g["TCC_HIT_sum"] + g["TCC_MISS_sum"]),
     "scalar_cache_hit_rate": g["SQC_DCACHE_HITS"] / (g["SQC_DCACHE_HITS"] + g["SQC_DCACHE_MISSES"]),
     "valu_insts": g["SQ_INSTS_VALU"], "salu_insts": g["SQ_INSTS_SALU"], "lds_insts": g["SQ_INSTS_LDS"],
