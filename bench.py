@@ -30,7 +30,7 @@ N GPUs, two front ends (--front-end auto picks `group` whenever the process sees
         `python bench.py --gpus N --front-end ranks` starts the N rank processes itself (before anything touches a GPU) and relays
         rank 0's JSON line.  EVPLP_BENCH_BACKEND=gloo stages the collectives through the host and lets the ranks share GPUs (rank r
         uses device r mod #devices): the N > 1 logic with the real kernels on a one-GPU box.
-Either way the image is cut into interleaved 8-row strips (rank r owns row blocks b with b % N == r); the scene and the BVH are
+Either way the image is cut into interleaved 16-row strips (rank r owns row blocks b with b % N == r); the scene and the BVH are
 replicated; large light-path sets are traced 1/N per rank and shared by an all-gather of the record buffer, small ones are traced
 redundantly; each rank gathers / splats its own pixels; the framebuffer strips are all-gathered every frame.  Total work is
 fixed ("scaling": "strong").
@@ -64,7 +64,7 @@ WORKLOADS = {
     "vsl": "Progressive VSL gather (forceVsl, 4096 VPL paths = 16384 record slots, radius 5 %) + 300k-path photon splat, 2048x2048 (BASELINE config #5)",
 }
 P = 4                                   # numMaxBounces 3 -> 4 record slots per path
-STRIP_ROWS = 8                          # finest interleave (tiles are 8 rows)
+STRIP_ROWS = 16                         # two tile rows per strip block: a rank's entry-cut groups stay 2 x 2 tiles (8-row strips: 2 x 1, twice the cuts per pixel)
 
 
 def parse():

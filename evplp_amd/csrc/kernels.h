@@ -111,9 +111,10 @@ void launch_tile_boxes(const StripDev &st, const float4 *g_pos, float4 *tile_box
 // split summed in increasing i.  A constant, and a fixed tree: results must not depend on the GPU count or on splits_per_wave.
 constexpr int kVplSplit = EVPLP_VPL_SPLIT;
 #ifndef EVPLP_GATHER_K
-#define EVPLP_GATHER_K 4
+#define EVPLP_GATHER_K 2
 #endif
-// k = 4: 32 partial sums per pixel (512 MB at 1024^2 instead of 2 GB for k = 1) at the same speed (hard scene, cfg2, one GPU:
+// (round 4) k = 2: with the entry cuts an item of four splits is long against its set-up again (k = 2 / 4 / 8: 57.6 / 58.6 / 71.1 ms);
+// 64 partial sums per pixel, 1 GB at 1024^2.  Rounds 1-3, k = 4: 32 partial sums per pixel (512 MB at 1024^2 instead of 2 GB for k = 1) at the same speed (hard scene, cfg2, one GPU:
 // k = 1 113.9 ms, 2 114.3, 4 114.0 on one box); k = 16 was 38 % slower (long items: launch tail)
 constexpr int kDefaultSplitsPerWave = EVPLP_GATHER_K;
 

@@ -48,30 +48,34 @@ EV_DEV void cut_descend_and_store(const BvhNode *nodes, const CutFrustum &F, cha
     // ---- the cut: breadth-first (ring) refinement
     int head = 0, count = 0;
     auto ring_push = [&](int32_t ref, uint32_t src) { const int at = (head + count) & (kCutRing - 1); s_ref[at][lane] = ref; s_src[at][lane] = src; count++; };
-    auto expand = [&](int32_t node, int32_t *refs, uint32_t *srcs) -> int {      // surviving children of an inner node
+    // surviving children of an inner node (no arrays indexed by a count: they would live in scratch)
+    struct Kids { int32_t r0, r1; bool k0, k1; };
+    auto expand = [&](int32_t node) -> Kids {
         const float4 *q4 = reinterpret_cast<const float4 *>(nodes + node);
         const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2], n3 = q4[3];
         // BvhNode: ctr[3][2] = n0.xyzw n1.xy ; hal[3][2] = n1.zw n2.xyzw ; c0 c1 = n3.xy
         const float c0[3] = { n0.x, n0.z, n1.x }, c1[3] = { n0.y, n0.w, n1.y };
         const float h0[3] = { n1.z, n2.x, n2.z }, h1[3] = { n1.w, n2.y, n2.w };
-        const int32_t r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
-        int nk = 0;
-        if (r0 != kNoChild && !cut_outside(F, c0, h0)) { refs[nk] = r0; srcs[nk] = (uint32_t)node << 1; nk++; }
-        if (r1 != kNoChild && !cut_outside(F, c1, h1)) { refs[nk] = r1; srcs[nk] = ((uint32_t)node << 1) | 1u; nk++; }
-        return nk;
+        Kids k; k.r0 = __float_as_int(n3.x); k.r1 = __float_as_int(n3.y);
+        k.k0 = k.r0 != kNoChild && !cut_outside(F, c0, h0);
+        k.k1 = k.r1 != kNoChild && !cut_outside(F, c1, h1);
+        return k;
     };
     if (work) {
-        int32_t refs[2]; uint32_t srcs[2];
-        int nk = expand(0, refs, srcs);
-        for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
+        {
+            const Kids k = expand(0);
+            if (k.k0) ring_push(k.r0, 0u);
+            if (k.k1) ring_push(k.r1, 1u);
+        }
         int leaves_in_row = 0;
         while (count > 0 && leaves_in_row < count) {
             const int32_t ref = s_ref[head][lane]; const uint32_t src = s_src[head][lane];
             if (ref < 0) { head = (head + 1) & (kCutRing - 1); count--; ring_push(ref, src); leaves_in_row++; continue; }    // a leaf stays in the cut
-            nk = expand(ref, refs, srcs);
-            if (count - 1 + nk > kCutEntries) break;
+            const Kids k = expand(ref);
+            if (count - 1 + (int)k.k0 + (int)k.k1 > kCutEntries) break;
             head = (head + 1) & (kCutRing - 1); count--;
-            for (int k = 0; k < nk; k++) ring_push(refs[k], srcs[k]);
+            if (k.k0) ring_push(k.r0, (uint32_t)ref << 1);
+            if (k.k1) ring_push(k.r1, ((uint32_t)ref << 1) | 1u);
             leaves_in_row = 0;
         }
         // ---- the cut, nearest entry first (the walk visits the synthetic nodes in slot order and ends as soon as every lane is occluded:
@@ -88,9 +92,13 @@ EV_DEV void cut_descend_and_store(const BvhNode *nodes, const CutFrustum &F, cha
         };
         float dist[kCutEntries]; int order[kCutEntries];
 #pragma unroll
+        for (int k = 0; k < kCutEntries; k++) { order[k] = k; dist[k] = 3.0e38f; }
+        // (wave-uniform exits: half of the cuts are empty, and whole waves of them -- neighbouring groups, one VPL -- are common)
+        const bool sort_needed = __builtin_amdgcn_ballot_w64(count > 1) != 0ull;
+#pragma unroll
         for (int k = 0; k < kCutEntries; k++) {
-            order[k] = k; dist[k] = 3.0e38f;
-            if (k < count) {
+            // (guards, not breaks: the loop must unroll completely or dist[] / order[] are indexed dynamically and land in scratch)
+            if (sort_needed && __builtin_amdgcn_ballot_w64(k < count) != 0ull && k < count) {
                 float c[3], h[3]; int32_t r; box_of(k, c, h, r);
                 const float ex = fmaxf(fabsf(F.p.x - c[0]) - h[0], 0.f), ey = fmaxf(fabsf(F.p.y - c[1]) - h[1], 0.f), ez = fmaxf(fabsf(F.p.z - c[2]) - h[2], 0.f);
                 dist[k] = ex * ex + ey * ey + ez * ez;
@@ -99,13 +107,15 @@ EV_DEV void cut_descend_and_store(const BvhNode *nodes, const CutFrustum &F, cha
 #define EV_CX(i_, j_) { const bool sw = dist[j_] < dist[i_]; const float td = sw ? dist[j_] : dist[i_]; dist[j_] = sw ? dist[i_] : dist[j_]; dist[i_] = td; \
                         const int to = sw ? order[j_] : order[i_]; order[j_] = sw ? order[i_] : order[j_]; order[i_] = to; }
         static_assert(kCutEntries == 8, "the sorting network below is the 19-comparator network for 8 keys");
-        EV_CX(0, 1) EV_CX(2, 3) EV_CX(4, 5) EV_CX(6, 7)
-        EV_CX(0, 2) EV_CX(1, 3) EV_CX(4, 6) EV_CX(5, 7)
-        EV_CX(1, 2) EV_CX(5, 6) EV_CX(0, 4) EV_CX(3, 7)
-        EV_CX(1, 5) EV_CX(2, 6)
-        EV_CX(1, 4) EV_CX(3, 6)
-        EV_CX(2, 4) EV_CX(3, 5)
-        EV_CX(3, 4)
+        if (sort_needed) {
+            EV_CX(0, 1) EV_CX(2, 3) EV_CX(4, 5) EV_CX(6, 7)
+            EV_CX(0, 2) EV_CX(1, 3) EV_CX(4, 6) EV_CX(5, 7)
+            EV_CX(1, 2) EV_CX(5, 6) EV_CX(0, 4) EV_CX(3, 7)
+            EV_CX(1, 5) EV_CX(2, 6)
+            EV_CX(1, 4) EV_CX(3, 6)
+            EV_CX(2, 4) EV_CX(3, 5)
+            EV_CX(3, 4)
+        }
 #undef EV_CX
         // ---- synthetic nodes: entries (2 s, 2 s + 1) of the sorted cut -> node s; node 0 carries the node count in its first padding word
         const int nsyn = (count + 1) >> 1;
@@ -113,7 +123,7 @@ EV_DEV void cut_descend_and_store(const BvhNode *nodes, const CutFrustum &F, cha
         if (nsyn == 0) out[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int s2 = 0; s2 < kCutNodes; s2++) {
-            if (s2 < nsyn) {
+            if (__builtin_amdgcn_ballot_w64(s2 < nsyn) != 0ull && s2 < nsyn) {
                 float c[2][3], h[2][3]; int32_t r[2];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {

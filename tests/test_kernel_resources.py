@@ -1,0 +1,47 @@
+"""No GPU needed: the code objects hipcc produces for gfx950 must keep the properties the design relies on -- zero scratch in every
+gather / cut / splat / path-tracing kernel (a count-indexed local array in the cut kernel once put 20 bytes per lane into scratch and cost
+30 % of its time) and the register budgets that give the walks their seven waves per SIMD."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-w"]
+
+
+def kernel_table(src):
+    out = subprocess.run([HIPCC] + FLAGS + ["-o", "-", os.path.join(ROOT, "evplp_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    table, cur = {}, {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"\s+\.(name|private_segment_fixed_size|vgpr_count|vgpr_spill_count|sgpr_spill_count|group_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        cur[m.group(1)] = m.group(2)
+        if m.group(1) == "vgpr_spill_count":      # the last of the fields of one kernel's metadata block
+            table[cur.get("name", "?")] = {k: int(v) for k, v in cur.items() if k != "name"}
+            cur = {}
+    return table
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src, zero_scratch, budgets", [
+    ("kernels_gather.hip", ["gather_vpl_kernelILb1", "gather_vpl_kernelILb0", "gather_vsl_walk_kernelILb1", "gather_vsl_walk_kernelILb0", "gather_vsl_shade_kernel", "gather_reduce_kernel"],
+     {"gather_vpl_kernelILb1": 72, "gather_vsl_walk_kernelILb1": 72, "gather_vsl_shade_kernel": 128}),
+    ("kernels_cut.hip", ["gather_cut_kernel", "primary_cut_kernel"], {"gather_cut_kernel": 64}),
+    ("kernels_splat.hip", ["splat_bin_kernel", "splat_scatter_kernel", "splat_tiles_kernelILi1", "splat_tiles_kernelILi4", "resolve_kernel"], {}),
+    ("kernels_pt.hip", ["path_trace_kernel"], {}),
+])
+def test_code_objects_keep_their_budgets(src, zero_scratch, budgets):
+    table = kernel_table(src)
+    for want in zero_scratch:
+        hits = [k for k in table if want in k]
+        assert hits, (want, sorted(table))
+        for k in hits:
+            assert table[k]["private_segment_fixed_size"] == 0 and table[k]["vgpr_spill_count"] == 0, (k, table[k])
+    for want, limit in budgets.items():
+        for k in [k for k in table if want in k]:
+            assert table[k]["vgpr_count"] <= limit, (k, table[k])
