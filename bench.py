@@ -557,6 +557,8 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                     out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_ratio"] = tj.get("hbm_bytes_per_launch") / alg_bytes if tj.get("hbm_bytes_per_launch") else None
                     out["roofline"]["traffic_source"] = f"profiles/traffic_gather_vpl.json ({tj.get('round', 'committed')} PMC summary of this configuration; not measured inside this run)"
+                    if tj.get("valu_active_frac") is not None:      # "issue-saturated" as a number: SIMD cycles in which a vector instruction executes
+                        out["roofline"]["valu_active_frac"] = tj["valu_active_frac"]; out["roofline"]["valu_lane_utilisation"] = tj.get("valu_lane_utilisation")
             out["roofline"]["algorithmic_bytes"] = alg_bytes
             out["roofline_hbm"] = {"bound": "hbm", "achieved": alg_bytes / (kms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": alg_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, "kernel": kname,

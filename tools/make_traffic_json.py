@@ -23,6 +23,11 @@ json.dump({
     "l2_hit_rate": g["TCC_HIT_sum"] / (g["TCC_HIT_sum"] + g["TCC_MISS_sum"]),
     "scalar_cache_hit_rate": g["SQC_DCACHE_HITS"] / (g["SQC_DCACHE_HITS"] + g["SQC_DCACHE_MISSES"]),
     "valu_insts": g["SQ_INSTS_VALU"], "salu_insts": g["SQ_INSTS_SALU"], "lds_insts": g["SQ_INSTS_LDS"],
+    # share of the SIMD cycles of the launch in which a vector instruction executes: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
+    # waves; GRBM_GUI_ACTIVE is the launch's duration in cycles summed over the 8 XCDs; 1024 SIMDs
+    "valu_active_frac": g["SQ_ACTIVE_INST_VALU"] * 4.0 / (g["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+    "valu_lane_utilisation": g["SQ_THREAD_CYCLES_VALU"] / (g["SQ_ACTIVE_INST_VALU"] * 64.0),
+    "valu_insts_per_walk_note": "SQ_INSTS_VALU / (wave, VPL) walks of profiles/<round>_traversal_hard.json",
 }, open(os.path.join(ROOT, "profiles", "traffic_gather_vpl.json"), "w"), indent=1)
 configs = {}
 for wl, key, nrec, px in (("evplp", "evplp:hard:1024x1024:1", 2000000, 1024 * 1024), ("ppm", "ppm:hard:1920x1080:1", 1200000, 1920 * 1080)):
