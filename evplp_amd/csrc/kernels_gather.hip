@@ -472,33 +472,6 @@ EV_DEV Onb fonb_make(V3 n) {                                         // optixu O
     o.t = cross(o.b, o.n);
     return o;
 }
-EV_DEV V3 lambert_sample(V3 &out, float &pdfw, V3 normal, V3 rho_d, Rng &rng) {   // :56-66
-    float u1 = rng_uniform(rng);
-    float u2 = rng_uniform(rng);
-    float r = fsqrt(u1);
-    V3 p; p.x = r * cos2pi(u2); p.y = r * sin2pi(u2);
-    p.z = fsqrt(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
-    Onb o = fonb_make(normal);
-    out = onb_inverse(o, p);
-    pdfw = fmaxf(dot(out, normal), 0.f) * EV_INV_PI;
-    return rho_d;
-}
-EV_DEV V3 phong_sample(V3 &out, float &pdfw, V3 in, V3 normal, V3 rho_s, float e, Rng &rng) {   // :120-154
-    V3 r = reflect(-in, normal);
-    float sx = rng_uniform(rng);
-    float sy = rng_uniform(rng);
-    float cos_t = fpow(sx, rcp(e + 1.f));
-    float sin_t = fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
-    V3 p = v3(sin_t * cos2pi(sy), sin_t * sin2pi(sy), cos_t);
-    Onb o = fonb_make(r);
-    out = onb_inverse(o, p);
-    float unsafe_cos = dot(out, normal);
-    float cos_n = fmaxf(unsafe_cos, 0.f);
-    float cos_r = fmaxf(dot(out, r), 0.f);
-    if (unsafe_cos > 0.0f) pdfw = (e + 1.0f) * 0.5f * fpow(cos_r, e) * EV_INV_PI;
-    else pdfw = 0.0f;
-    return rho_s * ((e + 2.0f) * rcp(e + 1.0f) * cos_n);
-}
 } // namespace vslm
 EV_DEV V3 square_to_solid_angle(float sx, float sy, float cos_half_angle_max) {  // lighttracing.cu:382-390
     float z = 1.0f - sy * (1.0f - cos_half_angle_max);
@@ -533,57 +506,96 @@ EV_DEV void vsl_terms(const Pixel &px, const Vpl &v, const VslPixel &P, const Vs
     pdf1 = c1 * P.psel + pp1 * (1.0f - P.psel);
     pdf2 = c2 * P.psel + pp2;
 }
-EV_DEV V3 vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, float &w, Rng &rng) {  // :395-446
-    const V3 zero = v3(0.f, 0.f, 0.f);
-    if (P.dead) return zero;
+// (round 4) The three estimators of one sample-iteration add their MIS-weighted terms into `acc` WITHOUT the factor every term of a
+// pair shares, flux / (pi r^2): the kernel applies it once per pair after the loop.  What a sample-iteration costs is what the 99.6 %
+// of BRDF samples that miss the VSL's cone cost (half-angles of ~0.06 rad), so those leave as early as possible: the cone test is
+// first taken in the SAMPLING frame -- dot(p, local(nd12)) with nd12 brought into the frame once per pair -- with 1e-5 of slack, and
+// only a sample that passes is turned into a world direction and takes the reference's own test (:470-474, :545-549) on it, so the
+// set of accepted samples is the one the one-step code had.  The cone sample drops the two re-normalisations of vectors that are
+// unit vectors by construction (:401-404: last-ulp differences, toleranced like the transcendentals).
+struct VslFrames { V3 nd_n1, nd_r1, nd_n2, nd_r2; };   // nd12 in the frames of n1 / R1, -nd12 in the frames of n2 / R2 (local coordinates)
+EV_DEV V3 onb_local(const Onb &o, V3 d) { return v3(dot(d, o.t), dot(d, o.b), dot(d, o.n)); }
+constexpr float kConeSlack = 0.00001f;
+EV_DEV V3 select3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }   // (by value: a select between two struct members by address would put the struct into scratch)
+EV_DEV V3 lambert_local(Rng &rng) {                                   // LambertSample's direction in its own frame (rtmaterial.cuh:56-66)
+    float u1 = rng_uniform(rng);
+    float u2 = rng_uniform(rng);
+    float r = vslm::fsqrt(u1);
+    V3 p; p.x = r * vslm::cos2pi(u2); p.y = r * vslm::sin2pi(u2);
+    p.z = vslm::fsqrt(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+    return p;
+}
+EV_DEV V3 phong_local(float e, Rng &rng) {                            // PhongSample's direction in the frame of the reflected direction (:120-154)
+    float sx = rng_uniform(rng);
+    float sy = rng_uniform(rng);
+    float cos_t = vslm::fpow(sx, vslm::rcp(e + 1.f));
+    float sin_t = vslm::fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
+    return v3(sin_t * vslm::cos2pi(sy), sin_t * vslm::sin2pi(sy), cos_t);
+}
+EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const Onb &cone, V3 &acc, Rng &rng) {  // :395-446
+    if (P.dead) return;
     (void)rng_uniform(rng);
     float ua = rng_uniform(rng);
     float ub = rng_uniform(rng);
-    V3 wi12 = vslm::fnormalize(square_to_solid_angle(ua, ub, c.cos_half_cone));
-    Onb o = vslm::fonb_make(c.nd12);
-    wi12 = vslm::fnormalize(onb_inverse(o, wi12));
+    const V3 wi12 = onb_inverse(cone, square_to_solid_angle(ua, ub, c.cos_half_cone));
     float c1 = fmaxf(dot(px.n1, wi12), 0.0f), c2 = fmaxf(-dot(v.n, wi12), 0.0f);
     float c1c2 = c1 * c2;
-    if (c1c2 <= 0.000000001f) return zero;
+    if (c1c2 <= 0.000000001f) return;
     V3 brdf1, brdf2; float pdf1, pdf2;
     vsl_terms(px, v, P, L, wi12, c1, c2, &brdf1, &brdf2, pdf1, pdf2);
-    w = c.inv_solid_angle * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
-    return (((v.flux * c.inv_pi_r2) * c1c2) * brdf1 * brdf2) * c.solid_angle;
+    const float w = c.inv_solid_angle * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
+    acc = acc + (brdf1 * brdf2) * ((c.solid_angle * c1c2) * w);
 }
-EV_DEV V3 vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, float &w, Rng &rng) {  // :448-521
-    const V3 zero = v3(0.f, 0.f, 0.f);
-    if (P.dead) return zero;
+EV_DEV void vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, Rng &rng) {  // :448-521
+    if (P.dead) return;
     float choose = fminf(rng_uniform(rng), 0.999999f);
-    V3 wi12, brdf1; float pdfw;
-    if (choose < P.psel) brdf1 = vslm::lambert_sample(wi12, pdfw, px.n1, px.rd, rng) * vslm::rcp(P.psel);
-    else brdf1 = vslm::phong_sample(wi12, pdfw, px.wi10, px.n1, px.rs, px.e, rng) * vslm::rcp(1.0f - P.psel);
-    if (dot(wi12, c.nd12) <= c.cos_half_cone) return zero;
+    const bool lam = choose < P.psel;
+    V3 p;
+    if (lam) p = lambert_local(rng); else p = phong_local(px.e, rng);
+    if (!(dot(p, select3(lam, F.nd_n1, F.nd_r1)) > c.cos_half_cone - kConeSlack)) return;
+    V3 wi12, brdf1;
+    if (lam) {
+        wi12 = onb_inverse(vslm::fonb_make(px.n1), p);
+        brdf1 = px.rd * vslm::rcp(P.psel);
+    } else {
+        wi12 = onb_inverse(vslm::fonb_make(P.R1), p);
+        brdf1 = (px.rs * ((px.e + 2.0f) * vslm::rcp(px.e + 1.0f) * fmaxf(dot(wi12, px.n1), 0.f))) * vslm::rcp(1.0f - P.psel);
+    }
+    if (dot(wi12, c.nd12) <= c.cos_half_cone) return;
     float cos1 = fmaxf(dot(px.n1, wi12), 0.0f);
-    if (cos1 <= 0.000000001f) return zero;
+    if (cos1 <= 0.000000001f) return;
     float cos2 = fmaxf(-dot(v.n, wi12), 0.0f);
     (void)rng_uniform(rng);  // :506
     V3 brdf2; float pdf1, pdf2;
     vsl_terms(px, v, P, L, wi12, cos1, cos2, nullptr, &brdf2, pdf1, pdf2);
-    w = pdf1 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
-    return ((v.flux * c.inv_pi_r2) * cos2) * brdf1 * brdf2;
+    const float w = pdf1 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
+    acc = acc + (brdf1 * brdf2) * (cos2 * w);
 }
-EV_DEV V3 vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, float &w, Rng &rng) {  // :523-594
-    const V3 zero = v3(0.f, 0.f, 0.f);
-    if (L.dead) return zero;
-    V3 wi21, brdf2; float pdfw;
+EV_DEV void vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, Rng &rng) {  // :523-594
+    if (L.dead) return;
     float choose = fminf(rng_uniform(rng), 0.999999f);
-    if (choose < L.psel) brdf2 = vslm::lambert_sample(wi21, pdfw, v.n, v.rd, rng) * vslm::rcp(L.psel);
-    else brdf2 = vslm::phong_sample(wi21, pdfw, v.fdir, v.n, v.rs, v.e, rng) * vslm::rcp(1.0f - L.psel);
-    if (-dot(wi21, c.nd12) <= c.cos_half_cone) return zero;
+    const bool lam = choose < L.psel;
+    V3 p;
+    if (lam) p = lambert_local(rng); else p = phong_local(v.e, rng);
+    if (!(dot(p, select3(lam, F.nd_n2, F.nd_r2)) > c.cos_half_cone - kConeSlack)) return;
+    V3 wi21, brdf2;
+    if (lam) {
+        wi21 = onb_inverse(vslm::fonb_make(v.n), p);
+        brdf2 = v.rd * vslm::rcp(L.psel);
+    } else {
+        wi21 = onb_inverse(vslm::fonb_make(L.R2), p);
+        brdf2 = (v.rs * ((v.e + 2.0f) * vslm::rcp(v.e + 1.0f) * fmaxf(dot(wi21, v.n), 0.f))) * vslm::rcp(1.0f - L.psel);
+    }
+    if (-dot(wi21, c.nd12) <= c.cos_half_cone) return;
     float cos2 = fmaxf(dot(v.n, wi21), 0.0f);
-    if (cos2 <= 0.00000001f) return zero;
+    if (cos2 <= 0.00000001f) return;
     float cos1 = fmaxf(-dot(px.n1, wi21), 0.0f);
-    if (P.dead) return zero;
+    if (P.dead) return;
     (void)rng_uniform(rng);  // :579
     V3 brdf1; float pdf1, pdf2;
     vsl_terms(px, v, P, L, -wi21, cos1, cos2, &brdf1, nullptr, pdf1, pdf2);
-    w = pdf2 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
-    return ((v.flux * c.inv_pi_r2) * cos1) * brdf1 * brdf2;
+    const float w = pdf2 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
+    acc = acc + (brdf1 * brdf2) * (cos1 * w);
 }
 
 #ifndef EVPLP_VSL_WAVES
@@ -763,16 +775,18 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                         L.glossy = v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f; L.pdf_glossy = !(v.rs.x <= 0.000001f);
                         L.R2 = reflect(-v.fdir, v.n);
                     }
+                    // nd12 in the four sampling frames (the BRDF samples' cone pre-test) and the frame of the cone itself
+                    VslFrames F;
+                    F.nd_n1 = onb_local(vslm::fonb_make(px.n1), nv12); F.nd_r1 = onb_local(vslm::fonb_make(P.R1), nv12);
+                    F.nd_n2 = onb_local(vslm::fonb_make(v.n), -nv12);  F.nd_r2 = onb_local(vslm::fonb_make(L.R2), -nv12);
+                    const Onb cone = vslm::fonb_make(nv12);
                     V3 acc = v3(0.f, 0.f, 0.f);
                     for (int sidx = 0; sidx < num_samples; sidx++) {
-                        float wc = 0.f, w1 = 0.f, w2 = 0.f;
-                        const V3 rc = vsl_sample_cone(px, v, P, L, cx, wc, rng);
-                        const V3 r1 = vsl_sample_brdf1(px, v, P, L, cx, w1, rng);
-                        const V3 r2 = vsl_sample_brdf2(px, v, P, L, cx, w2, rng);
-                        acc = acc + rc * wc;
-                        acc = acc + r1 * w1;
-                        acc = acc + r2 * w2;
+                        vsl_sample_cone(px, v, P, L, cx, cone, acc, rng);
+                        vsl_sample_brdf1(px, v, P, L, cx, F, acc, rng);
+                        vsl_sample_brdf2(px, v, P, L, cx, F, acc, rng);
                     }
+                    acc = (v.flux * cx.inv_pi_r2) * acc;
                     result = result + acc * vslm::rcp((float)num_samples);
                 }
             }

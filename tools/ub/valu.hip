@@ -10,15 +10,16 @@
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum { FMA, PK_FMA, PK_FMA_OPSEL, PK_MUL, MAX3, MAX3_CLAMP, CMP_VCC, CMP_SGPR, EXP, LOG, RCP, MOV, WRITELANE, MIX_VISIT, NMODES };
+enum { FMA, PK_FMA, PK_FMA_OPSEL, PK_MUL, MAX3, MAX3_CLAMP, CMP_VCC, CMP_SGPR, EXP, LOG, RCP, MOV, WRITELANE, MIX_VISIT, MUL_LO_U32, MAD_U64_U32, MUL_F32, SQRT, SIN, ALIGNBIT, NMODES };
 static const char *kNames[NMODES] = { "v_fma_f32", "v_pk_fma_f32", "v_pk_fma_f32 op_sel", "v_pk_mul_f32", "v_max3_f32", "v_max3_f32 clamp", "v_cmp_lt_f32 vcc",
-                                      "v_cmp_lt_f32 s[..]", "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_mov_b32", "v_writelane_b32", "node visit (9 pk_fma + 4 max3/min3 + 2 cmp)" };
-static const int kPerIter[NMODES] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 60 };
+                                      "v_cmp_lt_f32 s[..]", "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_mov_b32", "v_writelane_b32", "node visit (9 pk_fma + 4 max3/min3 + 2 cmp)",
+                                      "v_mul_lo_u32", "v_mad_u64_u32", "v_mul_f32", "v_sqrt_f32", "v_sin_f32", "v_alignbit_b32" };
+static const int kPerIter[NMODES] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 60, 64, 64, 64, 64, 64, 64 };
 
 #define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 template <int MODE> __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, float a, float b, int iters) {
-    float x[8]; v2f p[8];
-    for (int j = 0; j < 8; j++) { x[j] = threadIdx.x + j; p[j].x = x[j]; p[j].y = x[j] + 0.5f; }
+    float x[8]; v2f p[8]; unsigned long long q[8];
+    for (int j = 0; j < 8; j++) { x[j] = threadIdx.x + j; p[j].x = x[j]; p[j].y = x[j] + 0.5f; q[j] = threadIdx.x * 77u + j; }
     v2f pa = { a, a * 1.5f }, pb = { b, b * 0.5f };
     unsigned long long sg = 0;
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -74,6 +75,30 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, unsigne
 #define OP(j) asm volatile("v_mov_b32 %0, %1" : "+v"(x[j]) : "v"(a));
                 R8(OP)
 #undef OP
+            } else if (MODE == MUL_LO_U32) {
+#define OP(j) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[j]) : "v"(a));
+                R8(OP)
+#undef OP
+            } else if (MODE == MAD_U64_U32) {      // the 64-bit multiply-add an LCG step is made of (plus two v_mul_lo_u32 for the high word)
+#define OP(j) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[j]) : "v"(a), "v"(b) : "vcc");
+                R8(OP)
+#undef OP
+            } else if (MODE == MUL_F32) {
+#define OP(j) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[j]) : "v"(a));
+                R8(OP)
+#undef OP
+            } else if (MODE == SQRT) {
+#define OP(j) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[j]));
+                R8(OP)
+#undef OP
+            } else if (MODE == SIN) {
+#define OP(j) asm volatile("v_sin_f32 %0, %0" : "+v"(x[j]));
+                R8(OP)
+#undef OP
+            } else if (MODE == ALIGNBIT) {
+#define OP(j) asm volatile("v_alignbit_b32 %0, %0, %0, %1" : "+v"(x[j]) : "v"(a));
+                R8(OP)
+#undef OP
             } else if (MODE == WRITELANE) {
                 int sp = (i + u) & 63, val = i;
 #define OP(j) asm volatile("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0" : "+v"(x[j]) : "s"(sp), "s"(val) : "m0");
@@ -110,7 +135,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, unsigne
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = (float)(sg & 1);
-    for (int j = 0; j < 8; j++) s += x[j] + p[j].x + p[j].y;
+    for (int j = 0; j < 8; j++) s += x[j] + p[j].x + p[j].y + (float)(q[j] & 0xffull);
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = t1 - t0; cyc[2 * blockIdx.x + 1] = r1 - r0; }
 }
@@ -140,5 +165,6 @@ int main() {
     std::fprintf(f, "# %s, %d CUs, clockRate %d kHz; 256-thread workgroups, one per CU per wave-per-SIMD step; eight independent registers per lane\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate);
     all<FMA>(f); all<PK_FMA>(f); all<PK_FMA_OPSEL>(f); all<PK_MUL>(f); all<MAX3>(f); all<MAX3_CLAMP>(f); all<CMP_VCC>(f); all<CMP_SGPR>(f);
     all<EXP>(f); all<LOG>(f); all<RCP>(f); all<MOV>(f); all<WRITELANE>(f); all<MIX_VISIT>(f);
+    all<MUL_LO_U32>(f); all<MAD_U64_U32>(f); all<MUL_F32>(f); all<SQRT>(f); all<SIN>(f); all<ALIGNBIT>(f);
     return 0;
 }
