@@ -34,7 +34,7 @@ nan:
 
 # the feeders (G-buffer, light tracing) are compiled without floating-point contraction: every operation rounds as in the oracle,
 # so G-buffers and light-path records can be compared bit for bit; the hot kernels keep contraction (radiance is toleranced)
-$(BUILD)/kernels_trace.o: HIPFLAGS += -ffp-contract=off
+$(BUILD)/kernels_trace.o: HIPFLAGS += -ffp-contract=off $(TRACE_FLAGS)
 $(BUILD)/kernels_gather.o: HIPFLAGS += $(GATHER_FLAGS)
 $(BUILD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(dir $@)

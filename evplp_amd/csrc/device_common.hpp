@@ -400,7 +400,11 @@ EV_DEV Hit2 tri_pair_test(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, 
     v2f t = pk_fma(nz, qz, pk_fma(ny, qy, nx * qx));
     // beta >= 0 & gamma >= 0 & beta + gamma <= 1 as ONE compare: min3(beta, gamma, 1 - (beta + gamma)) >= 0.  (1 - s >= 0 exactly
     // when s <= 1: the subtraction is exact for s in [1/2, 2] and keeps its sign elsewhere.  A NaN among beta / gamma would be skipped
-    // by v_min3, but they are NaN only when q is not finite, and then t fails its range test.)
+    // by v_min3, but they are NaN only when q is not finite, and then t fails its range test -- or when a cross term d * q overflows
+    // to inf - inf with q finite, or the denominator is a denormal (the exact reciprocal then returns inf where IEEE division stays
+    // finite): the boolean parity with the oracle therefore holds for scenes whose coordinates and edge lengths stay within about
+    // 1e-15 ... 1e15 units -- products of three of them inside the float range -- which is the range evplp_build_accel's inputs
+    // are expected in; it is not unconditional.)
     const v2f rest = bc(1.0f) - (beta + gamma);
     Hit2 h;
     h.a = (t.x < tmax) & (t.x > tmin) & (__builtin_fminf(__builtin_fminf(beta.x, gamma.x), rest.x) >= 0.0f);
@@ -566,20 +570,11 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
     // both to the same end point; a box that holds part of a triangle inside the range is padded, so its interval
     // is far wider than an ulp).  A lane without a live ray carries +inf as its origin term: every entry and exit
     // distance is +inf, both clamp to 1, and the lane never enters a box -- the ballots need no masking.
-    const V3 inv0 = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    const float ku = 1.0f / (tmax - tmin);
-    const V3 inv = inv0 * ku;
-    const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
-    const v2f avx = bc(fabsf(inv.x)), avy = bc(fabsf(inv.y)), avz = bc(fabsf(inv.z));
-    const float dead = __builtin_inff();
-    v2f nox = bc(alive_lane ? (-(o.x * inv0.x) - tmin) * ku : dead), noy = bc(alive_lane ? (-(o.y * inv0.y) - tmin) * ku : dead),
-        noz = bc(alive_lane ? (-(o.z * inv0.z) - tmin) * ku : dead);
     unsigned long long alive = ballot64(alive_lane), hitm = 0ull;
     if (alive == 0ull) return false;
-    int sp = 0;
-    int vstack = 0;
-    int32_t cur = 0;  // root is always an inner node
-    // `cut` + `cut_off` = the slot of this (tile group, VPL); `cut_off` then walks over its synthetic nodes, `cut_end` is where they end
+    // `cut` + `cut_off` = the slot of this (tile group, VPL); `cut_off` then walks over its synthetic nodes, `cut_end` is where they end.
+    // The count is looked at BEFORE the ray is set up: every second walk of the bench scene starts from an empty cut, and the three
+    // exact reciprocals and the origin terms below are ~50 vector instructions.
     uint32_t cut_end = 0u;
     constexpr bool kCutLds = CUT && VT != 0 && EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS;   // the slot was copied to LDS ahead of the walk (gather kernels)
     if constexpr (kCutLds) {
@@ -594,6 +589,17 @@ EV_DEV bool occluded_wave(const char *node_base, const char *leaf_base, V3 o, V3
         if (nsyn == 0) return false;                  // nothing between the VPL and the tile group
         cut_end = cut_off + ((uint32_t)nsyn << 6);
     }
+    const V3 inv0 = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const float ku = 1.0f / (tmax - tmin);
+    const V3 inv = inv0 * ku;
+    const v2f ivx = bc(inv.x), ivy = bc(inv.y), ivz = bc(inv.z);
+    const v2f avx = bc(fabsf(inv.x)), avy = bc(fabsf(inv.y)), avz = bc(fabsf(inv.z));
+    const float dead = __builtin_inff();
+    v2f nox = bc(alive_lane ? (-(o.x * inv0.x) - tmin) * ku : dead), noy = bc(alive_lane ? (-(o.y * inv0.y) - tmin) * ku : dead),
+        noz = bc(alive_lane ? (-(o.z * inv0.z) - tmin) * ku : dead);
+    int sp = 0;
+    int vstack = 0;
+    int32_t cur = 0;  // root is always an inner node
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
     if constexpr (VT != 0) {
         static_assert(VT == 52 || VT == 116, "reserved temporaries: v[52:63] or v[116:127]");

@@ -10,6 +10,12 @@
 
 namespace evplp {
 
+#ifndef EVPLP_PRIMARY_BLOCKS
+#define EVPLP_PRIMARY_BLOCKS 1
+#endif
+#ifndef EVPLP_PRIMARY_BLOCK_LOG2
+#define EVPLP_PRIMARY_BLOCK_LOG2 2     // 4 x 4 tiles
+#endif
 __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     // ray set-up and the hit point are written without fused multiply-adds, in the oracle's operation order: together
     // with the exact closest hit the G-buffer POSITIONS are then bit-identical to the CPU restatement, and so is every
@@ -17,8 +23,20 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
+#if EVPLP_PRIMARY_BLOCKS
+    // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  Tiles in row-major order gave every XCD every
+    // eighth tile of every row: all eight L2s held the same nodes (hit rate 54 %) and a packet walk is a chain of dependent node
+    // fetches.  The tiles are dealt in square blocks instead (4 x 4): the tiles of a block follow each other on ONE XCD.
+    constexpr int L = EVPLP_PRIMARY_BLOCK_LOG2, B = 1 << L;
+    const int tiles_y = (a.st.local_rows + 7) >> 3, nbx = (tiles_x + B - 1) >> L;
+    const int bj = (int)blockIdx.x >> 3, blk = (bj >> (2 * L)) * 8 + ((int)blockIdx.x & 7), within = bj & (B * B - 1);
+    const int tx = (blk % nbx) * B + (within & (B - 1)), ty = (blk / nbx) * B + (within >> L);
+    if (tx >= tiles_x || ty >= tiles_y) return;                     // padding of the block grid (wave-uniform)
+    const int tile = ty * tiles_x + tx;
+#else
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
+#endif
     const int x = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
     const int y = a.st.global_row(min(ly, a.st.local_rows - 1));
@@ -229,7 +247,14 @@ __global__ __launch_bounds__(1024) void compact_vpl_kernel(const evplp_record *r
 
 void launch_primary(const PrimaryArgs &a, hipStream_t s) {
     int tiles_x = (a.st.W + 7) / 8, tiles_y = (a.st.local_rows + 7) / 8;
+#if EVPLP_PRIMARY_BLOCKS
+    constexpr int B = 1 << EVPLP_PRIMARY_BLOCK_LOG2;
+    const int blocks = ((tiles_x + B - 1) / B) * ((tiles_y + B - 1) / B);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(primary_kernel, dim3((unsigned)((blocks + 7) / 8 * 8 * B * B)), dim3(64), 0, s, a);
+#else
     hipLaunchKernelGGL(primary_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, s, a);
+#endif
 }
 void launch_light_trace(const LightTraceArgs &a, hipStream_t s) {
     if (a.path_count == 0) return;
