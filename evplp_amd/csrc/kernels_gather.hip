@@ -51,8 +51,11 @@ EV_DEV float phong_eval_f_hw(V3 out, V3 in, V3 n, float e) {
 
 // vplSplat after the visibility test (rt/lighttracing.cu:296-345)
 // wi10_lds: where the caller parked the pixel's view direction ([component][lane], LDS) instead of holding it in three VGPRs
-// across the walks -- it is only read for tiles with a glossy pixel
-EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px, const Vpl &v, V3 v12, float c1c2, const float *wi10_lds = nullptr) {
+// across the walks -- it is only read for tiles with a glossy pixel.  PXL (gather_vpl_kernel, EVPLP_PX_LDS): the column continues with
+// the pixel's reflectances -- [3..5] rho_d, [6..8] rho_s, [9] e -- and px.rd / px.rs / px.e are not read; `px_glossy` = some pixel of the
+// tile has a Phong lobe (wave-uniform, computed once per item instead of one ballot per lit VPL).
+template <bool PXL = false>
+EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px, const Vpl &v, V3 v12, float c1c2, const float *wi10_lds = nullptr, bool px_glossy = true) {
     // Radiance is toleranced arithmetic (stated bars: rel. L2 1e-5, 2e-4 per pixel; powf already differs between
     // glibc and ocml): 1-ulp hardware rsq / rcp instead of the IEEE-correct sqrt + 4 divisions (~50 instructions).
     float dist2 = dot(v12, v12);
@@ -66,10 +69,14 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
         else ph2 = phong_eval_f_hw(-wi12, v.fdir, v.n, v.e);
     }
     float ph1 = 0.0f;
-    if (ballot64(px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f) != 0ull)
-        ph1 = phong_eval_f_hw(wi10_lds ? v3(wi10_lds[0], wi10_lds[64], wi10_lds[128]) : px.wi10, wi12, px.n1, px.e);
+    V3 prs = PXL ? v3(0.f, 0.f, 0.f) : px.rs;
+    if (PXL ? px_glossy : ballot64(px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f) != 0ull) {
+        ph1 = phong_eval_f_hw(wi10_lds ? v3(wi10_lds[0], wi10_lds[64], wi10_lds[128]) : px.wi10, wi12, px.n1, PXL ? wi10_lds[576] : px.e);
+        if (PXL) prs = v3(wi10_lds[384], wi10_lds[448], wi10_lds[512]);
+    }
+    const V3 prd = PXL ? v3(wi10_lds[192], wi10_lds[256], wi10_lds[320]) : px.rd;
     V3 brdf2 = v.rd * EV_INV_PI + v.rs * ph2;
-    V3 brdf1 = px.rd * EV_INV_PI + px.rs * ph1;
+    V3 brdf1 = prd * EV_INV_PI + prs * ph1;
     float g21 = c1c2 * __builtin_amdgcn_rcpf(dist2 * dist2);
     const uint32_t mode = fp.mis_mode;
     if (mode == 0u) return v.flux * brdf1 * brdf2 * g21;
@@ -150,8 +157,17 @@ EV_DEV uint32_t item_cut_group(const GatherArgs &a, const Item &t) {
 #ifndef EVPLP_CUT_RING
 #define EVPLP_CUT_RING 3          // LDS buffers of the cut-slot ring of a gather wave (512 B each): EVPLP_CUT_RING - 1 slots in flight ahead of the walk
 #endif
+#ifndef EVPLP_PX_LDS
+#define EVPLP_PX_LDS 1            // the pixel's reflectances parked in LDS beside its view direction: seven registers fewer across the walks
+#endif
+constexpr int kGatherPxFloats = 64 * (EVPLP_PX_LDS ? 10 : 3);      // [192] view direction (+ [192] rho_d, [192] rho_s, [64] e) per wavefront
 #ifndef EVPLP_GATHER_WAVES
-#define EVPLP_GATHER_WAVES 7   // waves per SIMD (1-wave workgroups); cfg2 hard / easy scene, round 3 (64 registers, no spills at either): 7 = 70.6 / 29.3 ms, 8 = 70.9 / 30.9
+// waves per SIMD (1-wave workgroups).  cfg2 hard / easy scene -- round 3 (no cuts, 64 registers at either): 7 = 70.6 / 29.3 ms, 8 = 70.9 / 30.9.
+// Round 4, with the entry cuts the walks are half as long and wait relatively more for their node fetches (76 % of the SIMD cycles issue
+// a vector instruction at 7 waves): 8 waves = 53.5 / 20.5 ms against 56.6 / 21.2 -- once the kernel FITS 64 registers (EVPLP_PX_LDS above:
+// with six spilled registers reloaded from scratch per lit VPL 8 waves gave 55.0 / 22.0).  LDS per wavefront: 2.5 KB of pixel data + 768 B
+// per fold level + the 768-byte cut ring = 4864 B at k = 2, inside the 5120 B that 32 wavefronts per CU leave each (k >= 4: 7 waves).
+#define EVPLP_GATHER_WAVES 8
 #endif
 
 // wave-uniform scalar fetch of one 96-byte record (s_load_dwordx16 + s_load_dwordx8)
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     // because LDS is what limits occupancy next: 7 single-wavefront workgroups per SIMD fit while a workgroup stays within
     // 5120 bytes (the allocation granule of this part is 1280 bytes: 5376 bytes measured 6 % slower, one wave per SIMD fewer)
     extern __shared__ float s_dyn[];
-    float *const s_wi10 = s_dyn, *const s_lvl = s_dyn + 192;
+    float *const s_wi10 = s_dyn, *const s_lvl = s_dyn + kGatherPxFloats;
     const int lane = threadIdx.x;
     const Item t = item_setup(a, lane);
     if (!t.has_tile) return;   // padding of the block grid
@@ -203,6 +219,14 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         const V3 w = normalize(v3(a.fp.camera_pos) - px.p1);
         s_wi10[lane] = w.x; s_wi10[64 + lane] = w.y; s_wi10[128 + lane] = w.z;
         px.wi10 = EVPLP_WI10_LDS ? v3(0.f, 0.f, 0.f) : w;
+    }
+    bool px_glossy = true;
+    if constexpr (EVPLP_PX_LDS != 0) {
+        static_assert(EVPLP_WI10_LDS != 0, "EVPLP_PX_LDS continues the LDS column of the view direction");
+        s_wi10[192 + lane] = px.rd.x; s_wi10[256 + lane] = px.rd.y; s_wi10[320 + lane] = px.rd.z;
+        s_wi10[384 + lane] = px.rs.x; s_wi10[448 + lane] = px.rs.y; s_wi10[512 + lane] = px.rs.z; s_wi10[576 + lane] = px.e;
+        px_glossy = ballot64(px.rs.x != 0.0f || px.rs.y != 0.0f || px.rs.z != 0.0f) != 0ull;
+        px.rd = v3(0.f, 0.f, 0.f); px.rs = v3(0.f, 0.f, 0.f); px.e = 0.0f;
     }
     const bool valid = t.in_image && gp.w != 0.0f;      // stencil test, lighttracing.cu:354
 
@@ -297,8 +321,22 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
             }
             const bool lit = active && !occ;
             if (ballot64(lit) == 0ull) continue;
-            Vpl v; v.pos = vpos; v.n = vn; v.psel = vpsel; fetch_vpl_tail(vpls, i, v);
-            if (lit) { result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2, EVPLP_WI10_LDS ? s_wi10 + lane : nullptr); shaded++; }
+            // (the record's head is fetched AGAIN for the shading -- it is in the scalar cache -- instead of holding its normal and lobe
+            // probability in four scalar registers across the walk, which has none to spare)
+            Vpl v; fetch_vpl_head(vpls, i, v.pos, v.n, v.psel); fetch_vpl_tail(vpls, i, v);
+            // ... and so are the four frame parameters the shading reads (MIS mode, pdfMc, its square, the clamp): from the kernel-argument
+            // segment, right here -- held in scalar registers from the top of the kernel they are spilled to VGPR lanes and read back
+            // lane by lane in every branch of vpl_shade
+            evplp_frame_params fps; float pdf_mc2;
+            {
+                const void *ka = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+                typedef int v4i_ __attribute__((ext_vector_type(4)));
+                v4i_ q; int q2;
+                asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(q), "=&s"(q2)
+                             : "s"(ka), "s"((uint32_t)(offsetof(GatherArgs, fp) + offsetof(evplp_frame_params, mis_mode))), "s"((uint32_t)offsetof(GatherArgs, pdf_mc2)) : "memory");
+                fps.mis_mode = (uint32_t)q[0]; fps.pdf_mc = f_of(q[1]); fps.clamping_value = f_of(q[2]); pdf_mc2 = f_of(q2);
+            }
+            if (lit) { result = result + vpl_shade<EVPLP_PX_LDS != 0>(fps, pdf_mc2, px, v, v12, c1c2, EVPLP_WI10_LDS ? s_wi10 + lane : nullptr, px_glossy); shaded++; }
         }
         // fold the split sums in the fixed balanced-tree order: a binary counter whose level j holds the sum of 2^j splits.
         // The levels live in LDS ([level][component][lane], touched once per split): registers are what limits occupancy here.
@@ -831,13 +869,13 @@ void launch_gather_reduce(const GatherArgs &a, int stencil_test, hipStream_t s) 
     size_t n = (size_t)a.st.W * a.st.local_rows;
     hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, stencil_test);
 }
-static size_t fold_lds_bytes(const GatherArgs &a, int extra_blocks) {
+static size_t fold_lds_bytes(const GatherArgs &a, int extra_floats) {
     int levels = 1; while ((1 << (levels - 1)) < a.splits_per_wave) levels++;       // log2 k + 1
-    return (size_t)(levels + extra_blocks) * 192 * sizeof(float);
+    return (size_t)(levels * 192 + extra_floats) * sizeof(float);
 }
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
-    if (a.cuts) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
-    else hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), fold_lds_bytes(a, 1), s, a);
+    if (a.cuts) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), fold_lds_bytes(a, kGatherPxFloats), s, a);
+    else hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), fold_lds_bytes(a, kGatherPxFloats), s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
     if (a.cuts) hipLaunchKernelGGL(gather_vsl_walk_kernel<true>, gather_grid(a), dim3(64), 0, s, a);
