@@ -108,24 +108,47 @@ EV_DEV V3 vpl_shade(const evplp_frame_params &fp, float pdf_mc2, const Pixel &px
 // as a row strip keeps adjacent (8 for a whole image) -- so that the tiles in flight at one time are 2-D neighbours and
 // walk the same part of the tree: 107.6 ms against 110.8 ms for row-major order (cfg2, hard scene, same GPU).
 struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   // p: pixel index in the strip (W * local_rows < 2^32)
+// Block index -> (tile, group of splits).  EVPLP_GROUP_ORDER (round 4, measured, off): with entry cuts the unit dealt to an XCD is a CUT
+// GROUP of tiles, and the items that read the same cut slots -- the same splits of the group's 2 x 2 tiles -- are neighbours in launch
+// order on one XCD, so that a slot comes from HBM once instead of once per tile (12.7 GB per config-#2 frame).  57.2 ms against 53.6 ms
+// (box scene 21.7 / 20.5, VSL gather at 1024^2 116.2 / 113.2): as in round 1, balance beats locality -- the slots arrive through a ring
+// two walks ahead, nobody waits for them, while four neighbouring tiles of equal cost on one XCD are four times the granularity
+// the XCDs are balanced with.
 // RANGE: the launch covers the groups [group_first, group_first + group_count) only (the VSL kernels; the VPL gather always launches all)
+#ifndef EVPLP_GROUP_ORDER
+#define EVPLP_GROUP_ORDER 0
+#endif
+struct ItemIx { int tx, ty, sg, tile_l, blk; };      // tile, group of splits within the launch, tile index in launch order, tile block
 template <bool RANGE = false>
-EV_DEV Item item_setup(const GatherArgs &a, int lane) {
+EV_DEV ItemIx item_index(const GatherArgs &a, int b) {
+    const int tiles_x = (a.st.W + 7) >> 3;
+    const int groups = RANGE ? a.group_count : kVplSplit / a.splits_per_wave;      // groups of this launch
+    const bool grp = EVPLP_GROUP_ORDER && a.cuts != nullptr;
+    const int gwl = grp ? a.cut_gw_log2 : 0, ghl = grp ? a.cut_gh_log2 : 0, gl = gwl + ghl;
+    const int xcd = b & 7, j = b >> 3;
+    const int q = j & ((1 << gl) - 1), r = j >> gl;            // tile within its cut group (fastest), then the group of splits, then the unit
+    const int unit_j = r / groups;
+    const int unit = unit_j * 8 + xcd;                         // cut group (or tile) in block order
+    const int shl = a.block_h_log2, bwl = 3 - gwl, bhl = shl - ghl, nbx = (tiles_x + 7) >> 3;   // block = 8 x (1 << shl) tiles
+    const int l = unit & ((1 << (bwl + bhl)) - 1);
+    ItemIx ix;
+    ix.blk = a.band_first * nbx + (unit >> (bwl + bhl));       // (a launch may cover a band of block rows only)
+    const int ux = ((ix.blk % nbx) << bwl) | (l & ((1 << bwl) - 1)), uy = ((ix.blk / nbx) << bhl) | (l >> bwl);
+    ix.tx = (ux << gwl) | (q & ((1 << gwl) - 1)); ix.ty = (uy << ghl) | (q >> gwl);
+    ix.sg = r - unit_j * groups;
+    ix.tile_l = (unit << gl) | q;
+    return ix;
+}
+template <bool RANGE = false>
+EV_DEV Item item_setup(const GatherArgs &a, int lane, int b) {
     const StripDev &st = a.st;
     const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    const int groups = RANGE ? a.group_count : kVplSplit / a.splits_per_wave;      // groups of this launch
-    const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int tile_j = j / groups;
-    const int tile = tile_j * 8 + xcd;                 // index in block order
-    const int shl = a.block_h_log2, sh = 1 << shl;     // block = 8 x sh tiles
-    const int per_block = 8 << shl, nbx = (tiles_x + 7) >> 3, nby = (tiles_y + sh - 1) >> shl;
-    const int blk = a.band_first * nbx + tile / per_block, l = tile % per_block;      // (a launch may cover a band of block rows only)
-    const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * sh + (l >> 3);
+    const int sh = 1 << a.block_h_log2, nbx = (tiles_x + 7) >> 3, nby = (tiles_y + sh - 1) >> a.block_h_log2;
+    const ItemIx ix = item_index<RANGE>(a, b);
     Item t;
-    t.group = (RANGE ? a.group_first : 0) + (j - tile_j * groups);
-    t.has_tile = blk < nbx * (a.band_rows > 0 ? min(nby, a.band_first + a.band_rows) : nby) && tx < tiles_x && ty < tiles_y;
-    t.x = tx * 8 + (lane & 7); t.ly = ty * 8 + (lane >> 3);
+    t.group = (RANGE ? a.group_first : 0) + ix.sg;
+    t.has_tile = ix.blk < nbx * (a.band_rows > 0 ? min(nby, a.band_first + a.band_rows) : nby) && ix.tx < tiles_x && ix.ty < tiles_y;
+    t.x = ix.tx * 8 + (lane & 7); t.ly = ix.ty * 8 + (lane >> 3);
     const int cly = max(min(t.ly, st.local_rows - 1), 0);
     t.gy = st.global_row(cly);
     t.in_image = t.has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
@@ -135,16 +158,10 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane) {
 
 // the texel index of item_setup alone (no row-strip division): what a kernel re-derives late instead of carrying it in registers
 template <bool RANGE = false>
-EV_DEV uint32_t item_texel(const GatherArgs &a, int lane) {
+EV_DEV uint32_t item_texel(const GatherArgs &a, int lane, int b) {
     const StripDev &st = a.st;
-    const int tiles_x = (st.W + 7) >> 3, tiles_y = (st.local_rows + 7) >> 3;
-    const int groups = RANGE ? a.group_count : kVplSplit / a.splits_per_wave;
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int tile = (j / groups) * 8 + xcd;
-    const int shl = a.block_h_log2, per_block = 8 << shl, nbx = (tiles_x + 7) >> 3;
-    const int blk = a.band_first * nbx + tile / per_block, l = tile % per_block;
-    const int tx = (blk % nbx) * 8 + (l & 7), ty = (blk / nbx) * (1 << shl) + (l >> 3);
-    const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+    const ItemIx ix = item_index<RANGE>(a, b);
+    const int x = ix.tx * 8 + (lane & 7), ly = ix.ty * 8 + (lane >> 3);
     return (uint32_t)max(min(ly, st.local_rows - 1), 0) * (uint32_t)st.W + (uint32_t)min(x, st.W - 1);
 }
 
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     extern __shared__ float s_dyn[];
     float *const s_wi10 = s_dyn, *const s_lvl = s_dyn + kGatherPxFloats;
     const int lane = threadIdx.x;
-    const Item t = item_setup(a, lane);
+    const Item t = item_setup(a, lane, (int)blockIdx.x);
     if (!t.has_tile) return;   // padding of the block grid
     const uint32_t p = t.p;
 
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     const char *cuts_g = nullptr;
     if constexpr (CUT) cuts_g = pinned(a.cuts + (size_t)item_cut_group(a, t) * a.cut_vpl_stride * (size_t)kCutSlotBytes);
     V3 total = v3(0.f, 0.f, 0.f);
-    uint32_t rays = 0, shaded = 0;
+    uint32_t rays = t.in_image ? 0x80000000u : 0u, shaded = 0;      // (rays: bit 31 = the lane's pixel is in the image, see the end)
 #if EVPLP_TRAVERSAL_STATS
     int32_t cache_leaf = kNoChild; bool prev_all_occ = false;
 #endif
@@ -353,12 +370,14 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
         total = result;     // after the last jj (k - 1 = all ones) this is the sum of all k splits
     }
 #if EVPLP_DEBUG_NAN
-    if (t.in_image && !(isfinite(total.x) && isfinite(total.y) && isfinite(total.z))) atomicAdd(&a.counters->nonfinite, 1ull);
+    if ((rays >> 31) != 0u && !(isfinite(total.x) && isfinite(total.y) && isfinite(total.z))) atomicAdd(&a.counters->nonfinite, 1ull);
 #endif
     // per-lane statistics ride in the unused fourth component: shadow rays | unoccluded pairs << 16 (both < 65536 per item)
-    int lane_out = lane;
-    asm volatile("" : "+v"(lane_out));              // (the store address is formed here, not carried through the walks)
-    if (t.in_image) a.partial[(size_t)t.group * a.partial_stride + item_texel(a, lane_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (shaded << 16)));
+    int lane_out = lane, blk_out = (int)blockIdx.x;
+    asm volatile("" : "+v"(lane_out), "+s"(blk_out));   // (the store address is formed here, not carried through the walks)
+    const bool in_image = (rays >> 31) != 0u;           // (parked in the counter's top bit at the start: one register fewer across the walks)
+    rays &= 0xffffu;
+    if (in_image) a.partial[(size_t)item_index(a, blk_out).sg * a.partial_stride + item_texel(a, lane_out, blk_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (shaded << 16)));
 }
 
 // out = (balanced-tree sum of the per-group partials) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378);
@@ -655,11 +674,7 @@ EV_DEV size_t vsl_mask_base(const GatherArgs &a, int tile_in_launch_order, int g
     const int groups = a.group_count;
     return ((size_t)tile_in_launch_order * groups + (size_t)(group - a.group_first)) * (size_t)(a.splits_per_wave * a.masks_per_split);
 }
-EV_DEV int launch_tile(const GatherArgs &a) {          // the tile's index in launch order (item_setup: tile = tile_j * 8 + xcd)
-    const int groups = a.group_count;
-    const int b = blockIdx.x;
-    return ((b >> 3) / groups) * 8 + (b & 7);
-}
+EV_DEV int launch_tile(const GatherArgs &a) { return item_index<true>(a, (int)blockIdx.x).tile_l; }      // the tile's index in launch order
 
 template <bool CUT>
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
@@ -668,7 +683,7 @@ __attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel(GatherArgs a) {
     __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
-    const Item t = item_setup<true>(a, lane);
+    const Item t = item_setup<true>(a, lane, (int)blockIdx.x);
     if (!t.has_tile) return;
     const bool valid = t.in_image;                      // no stencil test in splatSplotch (:694-695)
     const uint32_t nvpl = *a.nvpl;
@@ -751,7 +766,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
     __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
     const int W = a.st.W;
-    const Item t = item_setup<true>(a, lane);
+    const Item t = item_setup<true>(a, lane, (int)blockIdx.x);
     if (!t.has_tile) return;
     const bool valid = t.in_image;
     const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
@@ -852,8 +867,8 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
     // (the item's shadow rays were counted by the walk kernel; the per-pixel word carries the lit pairs only: < 4096 per item, context.cpp)
     int lane_out = lane, blk_out = (int)blockIdx.x;
     asm volatile("" : "+v"(lane_out), "+s"(blk_out));   // (the store address is formed here, not carried through the estimators)
-    const int group_out = a.group_first + (blk_out >> 3) % a.group_count;
-    if (valid) a.partial[(size_t)group_out * a.partial_stride + item_texel<true>(a, lane_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(nlit << 16));
+    const int group_out = a.group_first + item_index<true>(a, blk_out).sg;
+    if (valid) a.partial[(size_t)group_out * a.partial_stride + item_texel<true>(a, lane_out, blk_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(nlit << 16));
 }
 
 int gather_launch_tiles(const GatherArgs &a) {                    // tiles of a launch: whole blocks of 8 x (1 << block_h_log2)
