@@ -113,7 +113,7 @@ struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   //
 // order on one XCD, so that a slot comes from HBM once instead of once per tile (12.7 GB per config-#2 frame).  57.2 ms against 53.6 ms
 // (box scene 21.7 / 20.5, VSL gather at 1024^2 116.2 / 113.2): as in round 1, balance beats locality -- the slots arrive through a ring
 // two walks ahead, nobody waits for them, while four neighbouring tiles of equal cost on one XCD are four times the granularity
-// the XCDs are balanced with.
+// the XCDs are balanced with.  (The other direction -- a tile's items dealt over ALL XCDs, perfect balance, no tile owns an L2 -- 54.0 / 21.5 ms.)
 // RANGE: the launch covers the groups [group_first, group_first + group_count) only (the VSL kernels; the VPL gather always launches all)
 #ifndef EVPLP_GROUP_ORDER
 #define EVPLP_GROUP_ORDER 0
@@ -123,7 +123,7 @@ template <bool RANGE = false>
 EV_DEV ItemIx item_index(const GatherArgs &a, int b) {
     const int tiles_x = (a.st.W + 7) >> 3;
     const int groups = RANGE ? a.group_count : kVplSplit / a.splits_per_wave;      // groups of this launch
-    const bool grp = EVPLP_GROUP_ORDER && a.cuts != nullptr;
+    const bool grp = EVPLP_GROUP_ORDER == 1 && a.cuts != nullptr;
     const int gwl = grp ? a.cut_gw_log2 : 0, ghl = grp ? a.cut_gh_log2 : 0, gl = gwl + ghl;
     const int xcd = b & 7, j = b >> 3;
     const int q = j & ((1 << gl) - 1), r = j >> gl;            // tile within its cut group (fastest), then the group of splits, then the unit
