@@ -589,7 +589,13 @@ EV_DEV V3 phong_local(float e, Rng &rng) {                            // PhongSa
     float sin_t = vslm::fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
     return v3(sin_t * vslm::cos2pi(sy), sin_t * vslm::sin2pi(sy), cos_t);
 }
-EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const Onb &cone, V3 &acc, Rng &rng) {  // :395-446
+// DIFF (wave-uniform): neither the VSL nor any lit pixel of the tile has a Phong lobe.  Then brdf1 brdf2 = rho_d1 rho_d2 / pi^2 is the same
+// for every sample of a pair, both lobe-selection probabilities are 1 (the `choose` draws only advance the generator) and the MIS
+// denominators are c1 + c2 + 1 / solid angle: a cone sample adds ONE scalar, c1 c2 / (c1 + c2 + 1 / solid angle), and the colour is
+// applied once per pair after the loop.
+EV_DEV void rng_advance(Rng &r) { r.state = r.state * 6364136223846793005ull + r.inc; }
+template <bool DIFF>
+EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const Onb &cone, V3 &acc, float &acc_d, Rng &rng) {  // :395-446
     if (P.dead) return;
     (void)rng_uniform(rng);
     float ua = rng_uniform(rng);
@@ -598,17 +604,20 @@ EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, co
     float c1 = fmaxf(dot(px.n1, wi12), 0.0f), c2 = fmaxf(-dot(v.n, wi12), 0.0f);
     float c1c2 = c1 * c2;
     if (c1c2 <= 0.000000001f) return;
+    if constexpr (DIFF) { acc_d += c1c2 * vslm::rcp((c1 + c2) + c.inv_solid_angle); return; }
     V3 brdf1, brdf2; float pdf1, pdf2;
     vsl_terms(px, v, P, L, wi12, c1, c2, &brdf1, &brdf2, pdf1, pdf2);
     const float w = c.inv_solid_angle * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
     acc = acc + (brdf1 * brdf2) * ((c.solid_angle * c1c2) * w);
 }
+template <bool DIFF>
 EV_DEV void vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, Rng &rng) {  // :448-521
     if (P.dead) return;
-    float choose = fminf(rng_uniform(rng), 0.999999f);
-    const bool lam = choose < P.psel;
+    bool lam = true;
+    if constexpr (DIFF) rng_advance(rng);               // choose < pSel = 1 whatever it is
+    else { float choose = fminf(rng_uniform(rng), 0.999999f); lam = choose < P.psel; }
     V3 p;
-    if (lam) p = lambert_local(rng); else p = phong_local(px.e, rng);
+    if (DIFF || lam) p = lambert_local(rng); else p = phong_local(px.e, rng);
     if (!(dot(p, select3(lam, F.nd_n1, F.nd_r1)) > c.cos_half_cone - kConeSlack)) return;
     V3 wi12, brdf1;
     if (lam) {
@@ -628,12 +637,14 @@ EV_DEV void vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, c
     const float w = pdf1 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
     acc = acc + (brdf1 * brdf2) * (cos2 * w);
 }
+template <bool DIFF>
 EV_DEV void vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, Rng &rng) {  // :523-594
     if (L.dead) return;
-    float choose = fminf(rng_uniform(rng), 0.999999f);
-    const bool lam = choose < L.psel;
+    bool lam = true;
+    if constexpr (DIFF) rng_advance(rng);
+    else { float choose = fminf(rng_uniform(rng), 0.999999f); lam = choose < L.psel; }
     V3 p;
-    if (lam) p = lambert_local(rng); else p = phong_local(v.e, rng);
+    if (DIFF || lam) p = lambert_local(rng); else p = phong_local(v.e, rng);
     if (!(dot(p, select3(lam, F.nd_n2, F.nd_r2)) > c.cos_half_cone - kConeSlack)) return;
     V3 wi21, brdf2;
     if (lam) {
@@ -806,6 +817,8 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                 const uint32_t i = first + c * (uint32_t)kVplSplit;
                 Vpl v; fetch_vpl_head(vpls, i, v.pos, v.n, v.psel); fetch_vpl_tail(vpls, i, v);
                 const bool lit_lane = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
+                // (wave-uniform) no Phong lobe on either side of any lit pair of this VSL: the estimators' diffuse form
+                const bool diffuse_wave = !(v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f) && ballot64(lit_lane && (P.glossy || P.psel < 1.0f)) == 0ull;
                 if (lit_lane) {
                     const V3 v12 = v.pos - px.p1;
                     const float inv_dist = vslm::rsq(dot(v12, v12));         // (1-ulp hardware operations: the IEEE square root and four divisions were ~55 instructions per pair)
@@ -834,10 +847,21 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                     F.nd_n2 = onb_local(vslm::fonb_make(v.n), -nv12);  F.nd_r2 = onb_local(vslm::fonb_make(L.R2), -nv12);
                     const Onb cone = vslm::fonb_make(nv12);
                     V3 acc = v3(0.f, 0.f, 0.f);
-                    for (int sidx = 0; sidx < num_samples; sidx++) {
-                        vsl_sample_cone(px, v, P, L, cx, cone, acc, rng);
-                        vsl_sample_brdf1(px, v, P, L, cx, F, acc, rng);
-                        vsl_sample_brdf2(px, v, P, L, cx, F, acc, rng);
+                    if (diffuse_wave) {
+                        float acc_d = 0.0f;
+                        for (int sidx = 0; sidx < num_samples; sidx++) {
+                            vsl_sample_cone<true>(px, v, P, L, cx, cone, acc, acc_d, rng);
+                            vsl_sample_brdf1<true>(px, v, P, L, cx, F, acc, rng);
+                            vsl_sample_brdf2<true>(px, v, P, L, cx, F, acc, rng);
+                        }
+                        acc = acc + ((px.rd * EV_INV_PI) * (v.rd * EV_INV_PI)) * acc_d;
+                    } else {
+                        float unused = 0.0f;
+                        for (int sidx = 0; sidx < num_samples; sidx++) {
+                            vsl_sample_cone<false>(px, v, P, L, cx, cone, acc, unused, rng);
+                            vsl_sample_brdf1<false>(px, v, P, L, cx, F, acc, rng);
+                            vsl_sample_brdf2<false>(px, v, P, L, cx, F, acc, rng);
+                        }
                     }
                     acc = (v.flux * cx.inv_pi_r2) * acc;
                     result = result + acc * vslm::rcp((float)num_samples);
