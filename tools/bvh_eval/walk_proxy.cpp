@@ -381,9 +381,20 @@ int main(int argc, char **argv) {
             if (is_root) fallback++;
             cut_sum += (double)cut.size(); hist.push_back((int)cut.size()); if (cut.empty()) cut_empty++;
             // far entries at the bottom of the stack, near ones popped first
+            // SORTKEY: 0 distance of the box to the VPL (the device's), 1 distance to the centroid of the group's pixels, 2 the smaller of the two,
+            // 3 surface area of the box (largest first), 4 distance to the VPL, farthest first
+            static const int sortkey = getenv("SORTKEY") ? atoi(getenv("SORTKEY")) : 0;
+            float gc[3] = { 0, 0, 0 }; { int nn = 0; for (int j = 0; j < G * G; j++) for (int l = 0; l < 64; l++) if (PK[j].alive[l]) { gc[0] += PK[j].pp[l].x; gc[1] += PK[j].pp[l].y; gc[2] += PK[j].pp[l].z; nn++; } for (int k = 0; k < 3; k++) gc[k] /= (float)std::max(nn, 1); }
             if (!nosort) std::sort(cut.begin(), cut.end(), [&](const Box &a, const Box &b) {
-                auto dist = [&](const Box &q) { float s = 0; const float p[3] = { F.vp.x, F.vp.y, F.vp.z }; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(p[k] - q.c[k]) - q.h[k], 0.f); s += e * e; } return s; };
-                return dist(a) > dist(b); });
+                auto dist = [&](const Box &q, const float *p) { float s = 0; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(p[k] - q.c[k]) - q.h[k], 0.f); s += e * e; } return s; };
+                const float vp[3] = { F.vp.x, F.vp.y, F.vp.z };
+                auto key = [&](const Box &q) {
+                    if (sortkey == 1) return dist(q, gc);
+                    if (sortkey == 2) return std::min(dist(q, gc), dist(q, vp));
+                    if (sortkey == 3) return -(q.h[0] * q.h[1] + q.h[1] * q.h[2] + q.h[2] * q.h[0]);
+                    if (sortkey == 4) return -dist(q, vp);
+                    return dist(q, vp); };
+                return key(a) > key(b); });
             for (int j = 0; j < G * G; j++) if (PK[j].nalive) {
                 if (is_root) { account(walk(PK[j], nullptr, false)); tile_walks++; continue; }
                 std::vector<Box> mine = cut;
