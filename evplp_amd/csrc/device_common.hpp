@@ -884,7 +884,10 @@ EV_DEV void node4_slabs(const BvhNode4 &n, V3 inv, V3 noi, float tmin, float tma
 // children than any ray of the test scenes ever did -- in a per-thread column of global memory (ovf[k * ovf_stride]).  The worst case
 // for a tree (3 pushes per four-wide level: 46 entries for the 31-level tree of the bench scene, 12 KB of LDS per wave, 3 waves per
 // SIMD) would otherwise set the occupancy of every launch.  LDS_ENTRIES = 0: everything in `stack` (sized for the worst case).
-template <int STACK_STRIDE, int LDS_ENTRIES = 0>
+// SPEC ("speculative while-while", Aila & Laine 2009): a lane that reaches a leaf while other lanes of the wave still descend keeps the
+// leaf for later and goes on with its walk; the wave then tests up to two leaves per lane in one go.  Fewer, fuller trips through both
+// loops; a postponed leaf shrinks the ray later than it could have, so a few more nodes are visited.  Same hits (order-independent).
+template <int STACK_STRIDE, int LDS_ENTRIES = 0, bool SPEC = false>
 EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
                              float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */,
                              int32_t *ovf = nullptr, uint32_t ovf_stride = 0) {
@@ -898,9 +901,21 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int32_t best = -1; float bt = tmax, bb = 0.f, bg = 0.f;
     int sp = 0;
-    int32_t cur = 0;
-    bool done = false;
-    while (!done) {
+    int32_t cur = 0, postponed = kNoChild;
+    auto test_leaf = [&](int32_t leaf) {
+        int32_t id = ~leaf;
+        int32_t block = id >> 2, cnt = (id & 3) + 1;
+        for (int32_t k = 0; k < cnt; k++) {
+            int32_t orig = sc.tri_index[block * 4 + k];
+            bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
+            if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
+            float t, b, g;
+            if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, 3.0e38f, t, b, g)) {
+                if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
+            }
+        }
+    };
+    for (;;) {
         while (cur >= 0) {
             const BvhNode4 &n = sc.nodes4[cur];
             float tn[4]; bool h[4];
@@ -917,23 +932,17 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
             if (c[2] != kNoChild) { push(sp, c[2]); sp++; }
             if (c[1] != kNoChild) { push(sp, c[1]); sp++; }
             if (c[0] != kNoChild) cur = c[0];
-            else if (sp == 0) { done = true; break; }
+            else if (sp == 0) cur = kNoChild;                    // nothing left to visit: out of the loop (and of the walk, below)
             else { --sp; cur = top(sp); }
-        }
-        if (done) break;
-        if (cur != kNoChild) {
-            int32_t id = ~cur;
-            int32_t block = id >> 2, cnt = (id & 3) + 1;
-            for (int32_t k = 0; k < cnt; k++) {
-                int32_t orig = sc.tri_index[block * 4 + k];
-                bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
-                if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
-                float t, b, g;
-                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, 3.0e38f, t, b, g)) {
-                    if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
+            if constexpr (SPEC) {
+                if (cur < 0 && cur != kNoChild && postponed == kNoChild) {
+                    postponed = cur;
+                    if (sp == 0) cur = kNoChild; else { --sp; cur = top(sp); }
                 }
             }
         }
+        if (SPEC && postponed != kNoChild) { test_leaf(postponed); postponed = kNoChild; }
+        if (cur != kNoChild) test_leaf(cur);
         if (sp == 0) break;
         --sp; cur = top(sp);
     }
