@@ -887,7 +887,7 @@ EV_DEV void node4_slabs(const BvhNode4 &n, V3 inv, V3 noi, float tmin, float tma
 // SPEC ("speculative while-while", Aila & Laine 2009): a lane that reaches a leaf while other lanes of the wave still descend keeps the
 // leaf for later and goes on with its walk; the wave then tests up to two leaves per lane in one go.  Fewer, fuller trips through both
 // loops; a postponed leaf shrinks the ray later than it could have, so a few more nodes are visited.  Same hits (order-independent).
-template <int STACK_STRIDE, int LDS_ENTRIES = 0, bool SPEC = false>
+template <int STACK_STRIDE, int LDS_ENTRIES = 0, int SPEC = 0>      // SPEC: leaves a lane may postpone (0, 1 or 2)
 EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
                              float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */,
                              int32_t *ovf = nullptr, uint32_t ovf_stride = 0) {
@@ -901,7 +901,7 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int32_t best = -1; float bt = tmax, bb = 0.f, bg = 0.f;
     int sp = 0;
-    int32_t cur = 0, postponed = kNoChild;
+    int32_t cur = 0, postponed = kNoChild, postponed2 = kNoChild;
     auto test_leaf = [&](int32_t leaf) {
         int32_t id = ~leaf;
         int32_t block = id >> 2, cnt = (id & 3) + 1;
@@ -934,14 +934,15 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
             if (c[0] != kNoChild) cur = c[0];
             else if (sp == 0) cur = kNoChild;                    // nothing left to visit: out of the loop (and of the walk, below)
             else { --sp; cur = top(sp); }
-            if constexpr (SPEC) {
-                if (cur < 0 && cur != kNoChild && postponed == kNoChild) {
-                    postponed = cur;
+            if constexpr (SPEC >= 1) {
+                if (cur < 0 && cur != kNoChild && (postponed == kNoChild || (SPEC >= 2 && postponed2 == kNoChild))) {
+                    if (postponed == kNoChild) postponed = cur; else postponed2 = cur;
                     if (sp == 0) cur = kNoChild; else { --sp; cur = top(sp); }
                 }
             }
         }
-        if (SPEC && postponed != kNoChild) { test_leaf(postponed); postponed = kNoChild; }
+        if (SPEC >= 1 && postponed != kNoChild) { test_leaf(postponed); postponed = kNoChild; }
+        if (SPEC >= 2 && postponed2 != kNoChild) { test_leaf(postponed2); postponed2 = kNoChild; }
         if (cur != kNoChild) test_leaf(cur);
         if (sp == 0) break;
         --sp; cur = top(sp);
@@ -986,18 +987,30 @@ EV_DEV bool occluded_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tma
     return false;
 }
 
-template <int STACK_STRIDE>
+template <int STACK_STRIDE, int SPEC = 0>      // SPEC: leaves a lane may postpone (closest_lane4)
 EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
                             float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */) {
     V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int32_t best = -1; float bt = tmax, bb = 0.f, bg = 0.f;
     int sp = 0;
-    int32_t cur = 0;
-    bool done = false;
+    int32_t cur = 0, postponed = kNoChild, postponed2 = kNoChild;
+    auto test_leaf = [&](int32_t leaf) {
+        int32_t id = ~leaf;
+        int32_t block = id >> 2, cnt = (id & 3) + 1;
+        for (int32_t k = 0; k < cnt; k++) {
+            int32_t orig = sc.tri_index[block * 4 + k];
+            bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
+            if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
+            float t, b, g;
+            if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, 3.0e38f, t, b, g)) {
+                if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
+            }
+        }
+    };
     // "while-while" (Aila & Laine 2009): every lane first descends to its next leaf, then the wave tests leaves together; with one
     // node-or-leaf step per iteration a wave of incoherent rays runs both branches, half empty, every time
-    while (!done) {
+    for (;;) {
         while (cur >= 0) {
             const BvhNode &n = sc.nodes[cur];
             bool h0, h1;
@@ -1013,23 +1026,18 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
                 cur = first0 ? n.c0 : n.c1;
             } else if (h0) cur = n.c0;
             else if (h1) cur = n.c1;
-            else if (sp == 0) { done = true; break; }
+            else if (sp == 0) cur = kNoChild;                    // nothing left to visit
             else { --sp; cur = stack[sp * STACK_STRIDE]; }
-        }
-        if (done) break;
-        if (cur != kNoChild) {
-            int32_t id = ~cur;
-            int32_t block = id >> 2, cnt = (id & 3) + 1;
-            for (int32_t k = 0; k < cnt; k++) {
-                int32_t orig = sc.tri_index[block * 4 + k];
-                bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
-                if ((filter == 1 && is_light) || (filter == 2 && !is_light)) continue;
-                float t, b, g;
-                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, 3.0e38f, t, b, g)) {
-                    if (t < bt || (t == bt && best >= 0 && orig < best)) { bt = t; bb = b; bg = g; best = orig; }
+            if constexpr (SPEC >= 1) {
+                if (cur < 0 && cur != kNoChild && (postponed == kNoChild || (SPEC >= 2 && postponed2 == kNoChild))) {
+                    if (postponed == kNoChild) postponed = cur; else postponed2 = cur;
+                    if (sp == 0) cur = kNoChild; else { --sp; cur = stack[sp * STACK_STRIDE]; }
                 }
             }
         }
+        if (SPEC >= 1 && postponed != kNoChild) { test_leaf(postponed); postponed = kNoChild; }
+        if (SPEC >= 2 && postponed2 != kNoChild) { test_leaf(postponed2); postponed2 = kNoChild; }
+        if (cur != kNoChild) test_leaf(cur);
         if (sp == 0) break;
         --sp; cur = stack[sp * STACK_STRIDE];
     }
@@ -1039,14 +1047,23 @@ EV_DEV int32_t closest_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tm
 
 // Per-lane any-hit walk for incoherent shadow rays (path tracer next-event estimation, light-subpath windows):
 // true iff some triangle has t in (tmin, tmax) -- order independent, so exact against the oracle's evo_occluded.
-template <int STACK_STRIDE>
+template <int STACK_STRIDE, int SPEC = 0>
 EV_DEV bool occluded_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int32_t *stack) {
     V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int sp = 0;
-    int32_t cur = 0;
-    bool done = false;
-    while (!done) {                                                      // while-while, as closest_lane
+    int32_t cur = 0, postponed = kNoChild;
+    auto leaf_hit = [&](int32_t leaf) {
+        int32_t id = ~leaf;
+        int32_t block = id >> 2, cnt = (id & 3) + 1;
+        bool any = false;
+        for (int32_t k = 0; k < cnt; k++) {
+            float t, b, g;
+            any = any | tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, tmax, t, b, g);
+        }
+        return any;
+    };
+    for (;;) {                                                           // while-while, as closest_lane
         while (cur >= 0) {
             const BvhNode &n = sc.nodes[cur];
             const float lo0[3] = { n.ctr[0][0] - n.hal[0][0], n.ctr[1][0] - n.hal[1][0], n.ctr[2][0] - n.hal[2][0] };
@@ -1057,18 +1074,17 @@ EV_DEV bool occluded_lane(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax
             if (h0 && h1) { stack[sp * STACK_STRIDE] = n.c1; sp++; cur = n.c0; }
             else if (h0) cur = n.c0;
             else if (h1) cur = n.c1;
-            else if (sp == 0) { done = true; break; }
+            else if (sp == 0) cur = kNoChild;
             else { --sp; cur = stack[sp * STACK_STRIDE]; }
-        }
-        if (done) break;
-        if (cur != kNoChild) {
-            int32_t id = ~cur;
-            int32_t block = id >> 2, cnt = (id & 3) + 1;
-            for (int32_t k = 0; k < cnt; k++) {
-                float t, b, g;
-                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, tmax, t, b, g)) return true;
+            if constexpr (SPEC >= 1) {
+                if (cur < 0 && cur != kNoChild && postponed == kNoChild) {
+                    postponed = cur;
+                    if (sp == 0) cur = kNoChild; else { --sp; cur = stack[sp * STACK_STRIDE]; }
+                }
             }
         }
+        if (SPEC >= 1 && postponed != kNoChild) { if (leaf_hit(postponed)) return true; postponed = kNoChild; }
+        if (cur != kNoChild) { if (leaf_hit(cur)) return true; }
         if (sp == 0) break;
         --sp; cur = stack[sp * STACK_STRIDE];
     }

@@ -17,9 +17,19 @@
 #if EVPLP_PT_WIDE
 #define PT_OCCLUDED occluded_lane4
 #define PT_CLOSEST closest_lane4
+#ifndef EVPLP_PT_SPEC
+#define EVPLP_PT_SPEC 0
+#endif
+#define PT_SPEC_ARGS , 0, EVPLP_PT_SPEC
+#define PT_OCC_SPEC_ARGS
 #else
 #define PT_OCCLUDED occluded_lane
 #define PT_CLOSEST closest_lane
+#ifndef EVPLP_PT_SPEC
+#define EVPLP_PT_SPEC 0            // speculative while-while (device_common.hpp closest_lane / occluded_lane): 688 against 687 M paths/s -- the path tracer has waves to switch to; off
+#endif
+#define PT_SPEC_ARGS , EVPLP_PT_SPEC
+#define PT_OCC_SPEC_ARGS , EVPLP_PT_SPEC
 #endif
 
 namespace evplp {
@@ -50,7 +60,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
         V3 lval = light_sample(a.sc, lp, ln, lpdf, rng);
         V3 to_light = lp - first_pos;
         V3 tln = normalize(to_light);
-        bool hit = PT_OCCLUDED<64>(a.sc, lp, -to_light, 0.0001f, 1.0f - 0.0001f, stack); rays++;
+        bool hit = PT_OCCLUDED<64 PT_OCC_SPEC_ARGS>(a.sc, lp, -to_light, 0.0001f, 1.0f - 0.0001f, stack); rays++;
         float ml = max_color(rd1), mp = max_color(rs1);
         float psel = ml / (mp + ml);
         if (ml + mp <= 0.000001f) alive = false;
@@ -80,7 +90,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
     for (uint32_t i = 0; alive && i < a.max_bounces; i++) {
         const bool done = (i == a.max_bounces - 1);
         float t, b, g;
-        int32_t tri = PT_CLOSEST<64>(a.sc, prd_pos, dir, 0.00001f, 3.0e38f, 0, t, b, g, stack); rays++;
+        int32_t tri = PT_CLOSEST<64 PT_SPEC_ARGS>(a.sc, prd_pos, dir, 0.00001f, 3.0e38f, 0, t, b, g, stack); rays++;
         if (tri < 0) break;                                               // no miss program: the path ends
         const TriAttr &ta = a.sc.attrs[tri];
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
@@ -103,7 +113,7 @@ EV_DEV unsigned long long path_trace_pixel(const PathTraceArgs &a, int x, int y,
         V3 lval = light_sample(a.sc, lp, ln, lpdf, rng);
         V3 to_light = lp - npos;
         V3 tln = normalize(to_light);
-        bool hit = PT_OCCLUDED<64>(a.sc, lp, -to_light, 0.00001f, 0.99999f, stack); rays++;
+        bool hit = PT_OCCLUDED<64 PT_OCC_SPEC_ARGS>(a.sc, lp, -to_light, 0.00001f, 0.99999f, stack); rays++;
         V3 kd, ks; float ns;
         material_at(a.sc, ta, b, g, kd, ks, ns);
         float ml = max_color(kd), mp = max_color(ks);
