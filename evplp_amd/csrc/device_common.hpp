@@ -950,14 +950,23 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
     if (best >= 0) { t_out = bt; beta_out = bb; gamma_out = bg; }
     return best;
 }
-template <int STACK_STRIDE>
+template <int STACK_STRIDE, int SPEC = 0>
 EV_DEV bool occluded_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int32_t *stack) {
     V3 inv = v3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     V3 noi = v3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
     int sp = 0;
-    int32_t cur = 0;
-    bool done = false;
-    while (!done) {
+    int32_t cur = 0, postponed = kNoChild;
+    auto leaf_hit = [&](int32_t leaf) {
+        int32_t id = ~leaf;
+        int32_t block = id >> 2, cnt = (id & 3) + 1;
+        bool any = false;
+        for (int32_t k = 0; k < cnt; k++) {
+            float t, b, g;
+            any = any | tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, tmax, t, b, g);
+        }
+        return any;
+    };
+    for (;;) {
         while (cur >= 0) {
             const BvhNode4 &n = sc.nodes4[cur];
             float tn[4]; bool h[4];
@@ -969,18 +978,17 @@ EV_DEV bool occluded_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tma
                 if (h[q] && c != kNoChild) { if (next != kNoChild) { stack[sp * STACK_STRIDE] = next; sp++; } next = c; }
             }
             if (next != kNoChild) cur = next;
-            else if (sp == 0) { done = true; break; }
+            else if (sp == 0) cur = kNoChild;
             else { --sp; cur = stack[sp * STACK_STRIDE]; }
-        }
-        if (done) break;
-        if (cur != kNoChild) {
-            int32_t id = ~cur;
-            int32_t block = id >> 2, cnt = (id & 3) + 1;
-            for (int32_t k = 0; k < cnt; k++) {
-                float t, b, g;
-                if (tri_test_flat(sc.tri_flat + block * 4 + k, o, d, tmin, tmax, t, b, g)) return true;
+            if constexpr (SPEC >= 1) {
+                if (cur < 0 && cur != kNoChild && postponed == kNoChild) {
+                    postponed = cur;
+                    if (sp == 0) cur = kNoChild; else { --sp; cur = stack[sp * STACK_STRIDE]; }
+                }
             }
         }
+        if (SPEC >= 1 && postponed != kNoChild) { if (leaf_hit(postponed)) return true; postponed = kNoChild; }
+        if (cur != kNoChild) { if (leaf_hit(cur)) return true; }
         if (sp == 0) break;
         --sp; cur = stack[sp * STACK_STRIDE];
     }

@@ -435,6 +435,9 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 #else
 #define LVC_OCCLUDED occluded_lane
 #endif
+#ifndef EVPLP_LVC_SPEC
+#define EVPLP_LVC_SPEC 1   // speculative while-while (device_common.hpp)
+#endif
 #ifndef EVPLP_LVC_WAVES
 #define EVPLP_LVC_WAVES 6   // 5 = 56.7 ms, 6 = 53.5, 7 = 54.4, 8 = 55.9 (1024^2, 64-path windows)
 #endif
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64, EVPLP_LVC_WAVES) void gather_lvc_kernel(GatherA
             float c1c2 = c1 * c2;
             if (c1c2 <= 0.0f) continue;
             rays++;
-            if (LVC_OCCLUDED<64>(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, stack)) continue;
+            if (LVC_OCCLUDED<64, EVPLP_LVC_SPEC>(a.sc, v.pos, -v12, 0.0001f, 1.0f - 0.0001f, stack)) continue;
             result = result + vpl_shade(a.fp, a.pdf_mc2, px, v, v12, c1c2);
         }
     }
