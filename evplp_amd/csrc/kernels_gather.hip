@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(GatherArgs a, int st
 #define LVC_OCCLUDED occluded_lane
 #endif
 #ifndef EVPLP_LVC_SPEC
-#define EVPLP_LVC_SPEC 1   // speculative while-while (device_common.hpp)
+#define EVPLP_LVC_SPEC 0   // speculative while-while (device_common.hpp): 245 ms against 222 ms (512^2 window gather) -- an any-hit walk wants its leaf NOW; off
 #endif
 #ifndef EVPLP_LVC_WAVES
 #define EVPLP_LVC_WAVES 6   // 5 = 56.7 ms, 6 = 53.5, 7 = 54.4, 8 = 55.9 (1024^2, 64-path windows)
