@@ -19,17 +19,19 @@ ap.add_argument("--vsl", action="store_true")
 ap.add_argument("--pt", action="store_true", help="path tracer: one camera path per pixel per iteration")
 ap.add_argument("--lvc", action="store_true")
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--k", type=int, default=0, help="splits per wavefront of the gathers (0 = the library default)")
+ap.add_argument("--style", default="hard")
 ap.add_argument("--strip-count", type=int, default=1)
 ap.add_argument("--strip-rank", type=int, default=0)
 ap.add_argument("--strip-rows", type=int, default=16)
 a = ap.parse_args()
 d = "/tmp/evplp_synth"
 t0 = time.time()
-jp = ev.synth_scene(d, "conf", a.tris, 1234, a.res, a.res)
+jp = ev.synth_scene(d + "_" + a.style, "conf", a.tris, 1234, a.res, a.res, style=a.style)
 sd, root = scenes.load_obj_scene(jp)
 print("scene load %.1fs tris %d" % (time.time() - t0, sd.triangle_soup()[2].shape[0]))
 P = 4
-c = ev.Context(a.res, a.res, a.paths, a.vpl_paths, P, bvh_builder=a.builder, strip_rank=a.strip_rank, strip_count=a.strip_count, strip_rows=a.strip_rows)
+c = ev.Context(a.res, a.res, a.paths, a.vpl_paths, P, bvh_builder=a.builder, gather_splits_per_wave=a.k, strip_rank=a.strip_rank, strip_count=a.strip_count, strip_rows=a.strip_rows)
 t0 = time.time(); sd.upload(c); print("upload+build %.2fs" % (time.time() - t0), c.accel_info())
 bsr, total, larea = c.scene_metrics()
 radius = 0.003 * bsr
