@@ -501,3 +501,44 @@ def test_entry_cuts_do_not_change_a_bit(evplp, monkeypatch):
         assert images[name][2:] == images["cuts"][2:], (name, images[name][2:], images["cuts"][2:])
         assert images[name][0].tobytes() == images["cuts"][0].tobytes(), f"VPL gather: {name} differs from cuts"
         assert images[name][1].tobytes() == images["cuts"][1].tobytes(), f"VSL gather: {name} differs from cuts"
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_entry_cuts_with_adversarial_vpl_positions(evplp, monkeypatch, seed):
+    """Entry cuts against walks from the root on record sets the light tracer would never produce: VPLs sitting exactly on visible surface
+    points (the apex of the cut's pyramid lies ON its tile group: no pyramid, the end-point box alone), at the eye, at the centre of the
+    room, far outside it, and with flipped normals.  Same bits, same shadow-ray and unoccluded-pair counts."""
+    w, h, n = 96, 96, 64
+    room = scenes.box_room(seed=seed, n_boxes=6, tess=2, aspect=1.0)
+    kw = dict(camera_pos=room.cam_origin, mis_mode=0, pdf_mc=0.35, clamping_value=0.02, photon_radius=0.05, vsl_radius=0.3,
+              vsl_inv_pi_radius2=1.0 / (math.pi * 0.09), num_light_paths=n, num_vpl_light_paths=n, photons_per_path=P, do_accumulate=0, rng_seed=seed)
+    out = {}
+    for name, env in (("cuts", {}), ("root", {"EVPLP_CUTS": "0"})):
+        monkeypatch.delenv("EVPLP_CUTS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with evplp.Context(w, h, n, n, P) as c:
+            room.upload(c)
+            c.primary((0.0, 0.0)); c.trace_light_paths(seed)
+            gpos = c.download(evplp.BUF_GBUF_POSITION)[:h].reshape(-1, 4)
+            rec = c.download(evplp.BUF_RECORDS).copy()
+            rng = np.random.RandomState(seed)
+            usable = np.nonzero(rec["flags"] & evplp.USABLE_VPL)[0]
+            vis = np.nonzero(gpos[:, 3] != 0)[0]
+            lo, hi = gpos[vis, :3].min(0), gpos[vis, :3].max(0)
+            pick = rng.permutation(usable)
+            for j, i in enumerate(pick[:40]):
+                kind = j % 5
+                if kind == 0: rec["pos"][i] = gpos[rng.choice(vis), :3]                    # exactly on a visible surface point
+                elif kind == 1: rec["pos"][i] = np.asarray(room.cam_origin, np.float32)      # at the eye
+                elif kind == 2: rec["pos"][i] = (0.5 * (lo + hi)).astype(np.float32)         # centre of what the camera sees
+                elif kind == 3: rec["pos"][i] = (hi + 1000.0 * (hi - lo)).astype(np.float32)  # far outside
+                else: rec["normal"][i] = -rec["normal"][i]                                  # facing into its own surface
+            c.upload(evplp.BUF_RECORDS, rec)
+            c.gather_vpl(evplp.frame_params(**kw))
+            img = c.download(evplp.BUF_VPL_ACCUM)[:h].copy()
+            st = c.pass_stats(evplp.PASS_GATHER_VPL)
+            out[name] = (img, st["rays"], st["shaded"])
+    assert out["cuts"][1] > 0 and np.isfinite(out["cuts"][0]).all()
+    assert out["root"][1:] == out["cuts"][1:], (out["root"][1:], out["cuts"][1:])
+    assert out["root"][0].tobytes() == out["cuts"][0].tobytes()
