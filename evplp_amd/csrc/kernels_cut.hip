@@ -201,21 +201,18 @@ __global__ __launch_bounds__(64) void gather_cut_kernel(CutArgs a) {
         V3 u = cross(m, ax); u = u * __builtin_amdgcn_rsqf(fmaxf(dot(u, u), 1.0e-30f));
         const V3 w = cross(m, u);
         float amin = 3.0e38f, amax = -3.0e38f, bmin = 3.0e38f, bmax = -3.0e38f;
-        for (int ty = gy * gh; ty < min((gy + 1) * gh, a.tiles_y); ty++)
-            for (int tx = gxc * gw; tx < min((gxc + 1) * gw, a.tiles_x); tx++) {
-                const float4 lo = a.tile_box[2 * (ty * a.tiles_x + tx)], hi = a.tile_box[2 * (ty * a.tiles_x + tx) + 1];
-                if (lo.x > hi.x) continue;
+        // the pyramid around the 8 corners of the UNION box (round 4: the 32 corners of the four tile boxes were 40 % of this kernel and
+        // bought 0.4 % fewer node visits -- 16.73 against 16.79 per walk in the CPU replay)
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const V3 d = v3(((q & 1) ? hi.x : lo.x) - F.p.x, ((q & 2) ? hi.y : lo.y) - F.p.y, ((q & 4) ? hi.z : lo.z) - F.p.z);
-                    const float dw = dot(m, d), dl2 = dot(d, d);
-                    // a direction more than ~87 degrees off the axis: no pyramid for this bundle
-                    if (!(dw > 0.0f) || dw * dw <= 0.0025f * dl2) planes = false;
-                    const float r = __builtin_amdgcn_rcpf(dw);
-                    const float ca = dot(u, d) * r, cb = dot(w, d) * r;
-                    amin = fminf(amin, ca); amax = fmaxf(amax, ca); bmin = fminf(bmin, cb); bmax = fmaxf(bmax, cb);
-                }
-            }
+        for (int q = 0; q < 8; q++) {
+            const V3 d = v3(((q & 1) ? uhi[0] : ulo[0]) - F.p.x, ((q & 2) ? uhi[1] : ulo[1]) - F.p.y, ((q & 4) ? uhi[2] : ulo[2]) - F.p.z);
+            const float dw = dot(m, d), dl2 = dot(d, d);
+            // a direction more than ~87 degrees off the axis: no pyramid for this bundle
+            if (!(dw > 0.0f) || dw * dw <= 0.0025f * dl2) planes = false;
+            const float r = __builtin_amdgcn_rcpf(dw);
+            const float ca = dot(u, d) * r, cb = dot(w, d) * r;
+            amin = fminf(amin, ca); amax = fmaxf(amax, ca); bmin = fminf(bmin, cb); bmax = fmaxf(bmax, cb);
+        }
         // the tangents carry ~1e-6 of relative rounding (1-ulp reciprocal, three dot products): opened by 1e-4 (|a| <= 20 here)
         const float oa = 1.0e-4f * (1.0f + fmaxf(fabsf(amin), fabsf(amax))), ob = 1.0e-4f * (1.0f + fmaxf(fabsf(bmin), fabsf(bmax)));
         amin -= oa; amax += oa; bmin -= ob; bmax += ob;

@@ -335,7 +335,19 @@ int main(int argc, char **argv) {
             groups++;
             F.axes();
             if (!corner_bounds) { for (int j = 0; j < G * G; j++) if (PK[j].nalive) F.bound(PK[j]); }
-            else {
+            else if (corner_bounds == 2) {
+                // bounds from the eight corners of the UNION of the tiles' position boxes (a quarter of the device's set-up)
+                float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f }; int nv = 0;
+                for (int j = 0; j < G * G; j++) {
+                    const int ti = (gy * G + j / G) * tiles_x + gx * G + j % G; const float *T = &tiles[(size_t)ti * 64 * 7];
+                    for (int l = 0; l < 64; l++) if (T[l * 7 + 3] != 0.f) { nv++; for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], T[l * 7 + k]); hi[k] = std::max(hi[k], T[l * 7 + k]); } }
+                }
+                if (nv) {
+                    Packet C; C.vp = F.vp; C.vn = F.vn; for (int l = 0; l < 64; l++) C.alive[l] = false;
+                    for (int q = 0; q < 8; q++) { const V p = { (q & 1) ? hi[0] : lo[0], (q & 2) ? hi[1] : lo[1], (q & 4) ? hi[2] : lo[2] }; C.alive[q] = true; C.pp[q] = p; C.d[q] = p - F.vp; }
+                    F.bound(C);
+                }
+            } else {
                 // bounds from the eight corners of every tile's position box (what primary_kernel already writes per tile), all valid pixels
                 for (int j = 0; j < G * G; j++) {
                     float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f }; int nv = 0;
