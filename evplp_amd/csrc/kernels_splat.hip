@@ -494,16 +494,27 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
             stage[0 * 64 + lane] = c0; stage[1 * 64 + lane] = c1;         // [field][photon]: a lane-per-photon read is conflict-free
             stage[2 * 64 + lane] = c2;
             if (mode == 5u) stage[3 * 64 + lane] = c[3];
-        }
+        } else stage[lane] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);       // (an empty slot of the batch: infinitely far from every pixel)
         __builtin_amdgcn_wave_barrier();
         // Pass 1: the radius test of every (pixel, photon) of the batch -> one 64-bit mask per pixel.  A photon reaches ~3 of a
         // tile's 64 pixels at the radii of a converging run: running the shading under `if (inside)` for every photon that
         // reaches ANY pixel kept 3 lanes of 64 busy.
-        uint64_t mask = 0ull;
-        for (uint32_t j = 0; j < n; j++) {
-            V3 dv = v3(stage[j]) - X;
-            mask |= (uint64_t)(!(dot(dv, dv) > r2)) << j;                 // frag:153-154
+        // (eight photons per trip with literal bits, the trip's byte shifted into place: as one counted loop with a 64-bit shift per
+        // photon the compiler spent 16 vector instructions per photon, seven of them on the loop counter and the shift; unrolled over
+        // all 64 it keeps every photon's position in registers at once and spills)
+        uint32_t mlo = 0u, mhi = 0u;
+#pragma unroll 1
+        for (uint32_t o = 0; o * 8u < n; o++) {
+            const float4 *sp = stage + o * 8u;
+            uint32_t b8 = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const V3 dv = v3(sp[j]) - X;
+                if (!(dot(dv, dv) > r2)) b8 |= 1u << j;                   // frag:153-154
+            }
+            if (o < 4u) mlo |= b8 << (8u * o); else mhi |= b8 << (8u * (o - 4u));
         }
+        uint64_t mask = ((uint64_t)mhi << 32) | (uint64_t)mlo;
         if (!in_image) mask = 0ull;
         pairs += (uint32_t)__builtin_popcountll(mask);
         // Pass 2: every pixel walks ITS photons in ascending order (the accumulation order of the one-photon-at-a-time loop);
