@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
     // the duration of the launch.
     __shared__ float4 lds[4][64 * kCompactF4];
     __shared__ float4 red[3][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile, its bin and every loop bound below are wave-uniform)
     const int part = WAVES == 4 ? wave : 0;                       // this wave's share of the bin
     const int tile = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     if (blockIdx.x == 0 && wave == 0) {                                   // fold the bin kernel's summary shards
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
     const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
     const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
-    const uint32_t b = (uint32_t)tile * a.bin_stride, e = b + min(a.tile_cursor[tile], a.bin_stride);
+    const uint32_t b = (uint32_t)tile * a.bin_stride, e = b + min((uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_cursor[tile]), a.bin_stride);
     if (b >= e) { if (lane == 0 && part == 0) a.tile_pairs[tile] = 0u; return; }
 
     // a wave without a batch of its own (most bins hold one or two) only takes part in the fold below
