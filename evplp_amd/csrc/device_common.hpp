@@ -117,6 +117,20 @@ EV_DEV bool tri_test_flat(const TriFlat *tf, V3 o, V3 d, float tmin, float tmax,
     return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
 }
 
+// ... on a triangle already in registers (the three float4 of its TriFlat)
+EV_DEV bool tri_test_regs(float4 a, float4 b, float4 c, V3 o, V3 d, float tmin, float tmax, float &t, float &beta, float &gamma) {
+#pragma clang fp contract(off)
+    const float p0x = a.x, p0y = a.y, p0z = a.z, e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w, e1z = c.x, nx = c.y, ny = c.z, nz = c.w;
+    float den = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
+    float inv = rcp_exact(den);
+    float qx = (p0x - o.x) * inv, qy = (p0y - o.y) * inv, qz = (p0z - o.z) * inv;
+    float ix = __builtin_fmaf(d.y, qz, -(d.z * qy)), iy = __builtin_fmaf(d.z, qx, -(d.x * qz)), iz = __builtin_fmaf(d.x, qy, -(d.y * qx));
+    beta = __builtin_fmaf(iz, e1z, __builtin_fmaf(iy, e1y, ix * e1x));
+    gamma = __builtin_fmaf(iz, e0z, __builtin_fmaf(iy, e0y, ix * e0x));
+    t = __builtin_fmaf(nz, qz, __builtin_fmaf(ny, qy, nx * qx));
+    return (t < tmax) & (t > tmin) & (beta >= 0.0f) & (gamma >= 0.0f) & (beta + gamma <= 1.0f);
+}
+
 // ------------------------------------------------------------------------------------ RNG
 // Build-defined generator shared bit-for-bit with the oracle: PCG32 XSH-RR seeded through
 // splitmix64; one stream per (index, sequence, substream).  Stands in for
@@ -887,7 +901,7 @@ EV_DEV void node4_slabs(const BvhNode4 &n, V3 inv, V3 noi, float tmin, float tma
 // SPEC ("speculative while-while", Aila & Laine 2009): a lane that reaches a leaf while other lanes of the wave still descend keeps the
 // leaf for later and goes on with its walk; the wave then tests up to two leaves per lane in one go.  Fewer, fuller trips through both
 // loops; a postponed leaf shrinks the ray later than it could have, so a few more nodes are visited.  Same hits (order-independent).
-template <int STACK_STRIDE, int LDS_ENTRIES = 0, int SPEC = 0>      // SPEC: leaves a lane may postpone (0, 1 or 2)
+template <int STACK_STRIDE, int LDS_ENTRIES = 0, int SPEC = 0, bool PAIRS = false>      // SPEC: leaves a lane may postpone (0, 1 or 2); PAIRS: two triangles per trip
 EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float tmax, int filter,
                              float &t_out, float &beta_out, float &gamma_out, int32_t *stack /* stack[k*STACK_STRIDE] */,
                              int32_t *ovf = nullptr, uint32_t ovf_stride = 0) {
@@ -905,6 +919,34 @@ EV_DEV int32_t closest_lane4(const SceneDev &sc, V3 o, V3 d, float tmin, float t
     auto test_leaf = [&](int32_t leaf) {
         int32_t id = ~leaf;
         int32_t block = id >> 2, cnt = (id & 3) + 1;
+        if constexpr (PAIRS) {
+            // two triangles per trip, their six loads (and the four indices) in flight together: a leaf of a latency-bound walk otherwise
+            // waits once per triangle.  An unused slot of the block is all zeros (den = 0: never a hit).
+            const float4 *q = reinterpret_cast<const float4 *>(sc.tri_flat + block * 4);
+            const int4 og = *reinterpret_cast<const int4 *>(sc.tri_index + block * 4);
+            auto take = [&](bool hit, float t, float b, float g, int32_t orig) {
+                const bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;
+                if ((filter == 1 && is_light) || (filter == 2 && !is_light)) return;
+                if (hit && (t < bt || (t == bt && best >= 0 && orig < best))) { bt = t; bb = b; bg = g; best = orig; }
+            };
+            {
+                const float4 a0 = q[0], b0 = q[1], c0 = q[2], a1 = q[3], b1 = q[4], c1 = q[5];
+                float t0, be0, ga0, t1, be1, ga1;
+                const bool h0 = tri_test_regs(a0, b0, c0, o, d, tmin, 3.0e38f, t0, be0, ga0);
+                const bool h1 = tri_test_regs(a1, b1, c1, o, d, tmin, 3.0e38f, t1, be1, ga1);
+                take(h0, t0, be0, ga0, og.x);
+                if (cnt > 1) take(h1, t1, be1, ga1, og.y);
+            }
+            if (cnt > 2) {
+                const float4 a0 = q[6], b0 = q[7], c0 = q[8], a1 = q[9], b1 = q[10], c1 = q[11];
+                float t0, be0, ga0, t1, be1, ga1;
+                const bool h0 = tri_test_regs(a0, b0, c0, o, d, tmin, 3.0e38f, t0, be0, ga0);
+                const bool h1 = tri_test_regs(a1, b1, c1, o, d, tmin, 3.0e38f, t1, be1, ga1);
+                take(h0, t0, be0, ga0, og.z);
+                if (cnt > 3) take(h1, t1, be1, ga1, og.w);
+            }
+            return;
+        }
         for (int32_t k = 0; k < cnt; k++) {
             int32_t orig = sc.tri_index[block * 4 + k];
             bool is_light = orig >= sc.light_first && orig < sc.light_first + sc.light_count;

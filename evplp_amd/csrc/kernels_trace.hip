@@ -143,7 +143,13 @@ EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float ps
 // global memory (closest_lane4): the worst-case LDS stack alone allowed 3 waves per SIMD.  Config #4's light tracing (300 000 paths):
 // round 2 binary nodes 627 us, four-wide 553; round 3 (peeled tree) 511 us at 3 waves per SIMD
 #ifndef EVPLP_LT_WAVES
-#define EVPLP_LT_WAVES 5
+// 300 000 paths, config #4 (kernel alone / the overlapped iteration, ms): 5 waves per SIMD (96 registers) 0.424 / 0.608, 4 waves (128
+// registers, no spill) 0.46 / 0.595 -- alone the kernel loses its full residency (4 688 wavefronts, 4 096 slots), beside the G-buffer pass
+// and the splat it leaves them the registers they need; the iteration is what a frame pays
+#define EVPLP_LT_WAVES 4
+#endif
+#ifndef EVPLP_LT_PAIRS
+#define EVPLP_LT_PAIRS 1         // leaf triangles two at a time (closest_lane4 PAIRS)
 #endif
 #ifndef EVPLP_LT_SPEC
 #define EVPLP_LT_SPEC 1          // speculative while-while: leaves a lane may postpone (closest_lane4 SPEC); 300 000 paths: 0.433 / 0.423 / 0.440 ms for 0 / 1 / 2
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTr
     for (uint32_t i = 1; i < P; i++) {
         uint32_t flag = (i != P - 1) ? (EVPLP_USABLE_VPL | EVPLP_USABLE_PHOTON) : EVPLP_USABLE_PHOTON;
         float t, b, g;
-        int32_t tri = closest_lane4<64, kLtLdsStack, EVPLP_LT_SPEC>(a.sc, next_pos, next_dir, 0.0001f, 3.0e38f, 0, t, b, g, stack, a.stack_overflow + local, a.overflow_stride);
+        int32_t tri = closest_lane4<64, kLtLdsStack, EVPLP_LT_SPEC, EVPLP_LT_PAIRS != 0>(a.sc, next_pos, next_dir, 0.0001f, 3.0e38f, 0, t, b, g, stack, a.stack_overflow + local, a.overflow_stride);
         if (tri < 0) break;  // no miss program in the reference; a miss ends the path here
         const TriAttr &ta = a.sc.attrs[tri];
         V3 p0 = v3(ta.v), p1 = v3(ta.v + 3), p2 = v3(ta.v + 6);
