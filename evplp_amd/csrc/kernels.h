@@ -28,7 +28,10 @@ struct LightTraceArgs {
     int32_t *stack_overflow;      // [lt_overflow_entries(sc)][path_count rounded up to 64]: the walk's stack beyond its LDS entries
     uint32_t overflow_stride, pad;
 };
-constexpr int kLtLdsStack = 20;   // LDS entries of light tracing's walk stack (5 KB per wave); the rest of the worst case lives in global memory
+#ifndef EVPLP_LT_STACK
+#define EVPLP_LT_STACK 20
+#endif
+constexpr int kLtLdsStack = EVPLP_LT_STACK;   // LDS entries of light tracing's walk stack (20: 5 KB per wave); the rest of the worst case lives in global memory
 inline int lt_overflow_entries(const SceneDev &sc) {
     const int generic = 3 * ((sc.bvh_depth + 1) / 2) + 4;
     const int worst = sc.stack4_entries > 0 && sc.stack4_entries < generic ? sc.stack4_entries : generic;
