@@ -118,6 +118,12 @@ struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   //
 #ifndef EVPLP_GROUP_ORDER
 #define EVPLP_GROUP_ORDER 0
 #endif
+#ifndef EVPLP_XCD_TIMES
+#define EVPLP_XCD_TIMES 0
+#endif
+#ifndef EVPLP_XCD_ROTATE
+#define EVPLP_XCD_ROTATE 1
+#endif
 struct ItemIx { int tx, ty, sg, tile_l, blk; };      // tile, group of splits within the launch, tile index in launch order, tile block
 template <bool RANGE = false>
 EV_DEV ItemIx item_index(const GatherArgs &a, int b) {
@@ -133,7 +139,10 @@ EV_DEV ItemIx item_index(const GatherArgs &a, int b) {
     const int l = unit & ((1 << (bwl + bhl)) - 1);
     ItemIx ix;
     ix.blk = a.band_first * nbx + (unit >> (bwl + bhl));       // (a launch may cover a band of block rows only)
-    const int ux = ((ix.blk % nbx) << bwl) | (l & ((1 << bwl) - 1)), uy = ((ix.blk / nbx) << bhl) | (l >> bwl);
+    // (EVPLP_XCD_ROTATE: the column of a block a given XCD takes rotates with the row and the block -- with XCD = column every XCD owned
+    // 8-pixel-wide vertical stripes of the image, and the stripes' costs differ systematically: tools/xcd_balance.py)
+    const int rot = EVPLP_XCD_ROTATE ? (l >> bwl) + ix.blk : 0;
+    const int ux = ((ix.blk % nbx) << bwl) | ((l + rot) & ((1 << bwl) - 1)), uy = ((ix.blk / nbx) << bhl) | (l >> bwl);
     ix.tx = (ux << gwl) | (q & ((1 << gwl) - 1)); ix.ty = (uy << ghl) | (q >> gwl);
     ix.sg = r - unit_j * groups;
     ix.tile_l = (unit << gl) | q;
@@ -371,6 +380,10 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     }
 #if EVPLP_DEBUG_NAN
     if ((rays >> 31) != 0u && !(isfinite(total.x) && isfinite(total.y) && isfinite(total.z))) atomicAdd(&a.counters->nonfinite, 1ull);
+#endif
+#if EVPLP_XCD_TIMES
+    // (developer probe, tools/xcd_balance.py: when did the last item of every XCD end?  s_memrealtime ticks at 100 MHz)
+    if (lane == 0) atomicMax(&a.counters->hist[16 + (blockIdx.x & 7u)], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     // per-lane statistics ride in the unused fourth component: shadow rays | unoccluded pairs << 16 (both < 65536 per item)
     int lane_out = lane, blk_out = (int)blockIdx.x;

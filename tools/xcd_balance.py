@@ -1,0 +1,30 @@
+"""Developer probe: when does the last item of every XCD end in the VPL gather?  Needs the probe build:
+    make VARIANT=xcd EXTRA_HIPFLAGS="-DEVPLP_DEBUG_NAN=1 -DEVPLP_XCD_TIMES=1" evplp_amd/lib/libevplp_hip_xcd.so
+    EVPLP_LIB=evplp_amd/lib/libevplp_hip_xcd.so python3 tools/xcd_balance.py [--scene hard|easy]
+"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("EVPLP_LIB", os.path.join(ROOT, "evplp_amd", "lib", "libevplp_hip_xcd.so"))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa
+import evplp_amd as ev
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="hard")
+ap.add_argument("--res", type=int, default=1024)
+ap.add_argument("--paths", type=int, default=1024)
+a = ap.parse_args()
+jp = ev.synth_scene("/tmp/evplp_xcd_%s" % a.scene, "conf", 331000, 1234, a.res, a.res, style=a.scene)
+c = ev.Context(a.res, a.res, a.paths, a.paths, 4)
+c.load_scene_json(jp)
+cam = c.camera()
+fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=a.paths, num_vpl_light_paths=a.paths, photons_per_path=4, do_accumulate=0)
+for it in range(3):
+    c.primary((0, 0)); c.trace_light_paths(it); c.gather_vpl(fp); c.synchronize()
+    st = c.pass_stats(ev.PASS_GATHER_VPL)
+    raw = c.debug_counters(ev.PASS_GATHER_VPL)
+    ends = raw[4 + 16:4 + 24].astype(np.int64)
+    rel = (ends - ends.min()) / 100.0            # microseconds after the first XCD to finish
+    print("iter %d: kernel %.2f ms; last item of XCD 0..7 ends +%s us after the earliest; spread %.0f us = %.2f %% of the kernel"
+          % (it, st["dominant_kernel_ms"], np.round(rel, 0).astype(int).tolist(), rel.max(), rel.max() / 10.0 / st["dominant_kernel_ms"]))
