@@ -711,7 +711,14 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         ca.groups_x = (c->tiles_x + (1 << ca.gw_log2) - 1) >> ca.gw_log2;
         ca.vpls = c->d_vpls; ca.nvpl = &c->d_scalars[0]; ca.vpl_stride = (uint32_t)nvpl_slots_of(c);
         const size_t per_block_row = (size_t)(sh >> ca.gh_log2) * ca.groups_x * ca.vpl_stride * (size_t)kCutSlotBytes;
-        const size_t cap = c->env_cut_bytes > 0 ? c->env_cut_bytes : ((size_t)12 << 30);
+        // (the scratch is sized for the part: a quarter of its memory -- 72 GB of 288 -- but no more than half of what is free now, and what is
+        // already allocated counts as free; config #5's 68 GB then fit one band: 1.397 -> 1.371 s per iteration against six bands of 12 GB)
+        size_t cap = c->env_cut_bytes;
+        if (cap == 0) {
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)48 << 30; }
+            cap = std::max<size_t>(std::min(mem_total / 4, (mem_free + c->cut_bytes) / 2), (size_t)1 << 30);
+        }
         band_rows = (int)std::min<size_t>((size_t)nby, std::max<size_t>(cap / std::max<size_t>(per_block_row, 1), 1));
         const size_t need = per_block_row * (size_t)band_rows;
         if (need > c->cut_bytes) {
@@ -732,13 +739,20 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     int vsl_groups = 0, vsl_per_launch = 0;
     if (vsl) {
         // lit masks between the walk and the estimator kernel: 8 bytes per (tile, VSL slot) of a launch; the groups of a tile are
-        // covered in as many launches as keep the buffer within ~1 GB (config #5: 2048^2, 16 384 slots, k = 4: 4 launches of 8 groups)
+        // covered in as many launches as keep the buffer within its cap (below)
         a.masks_per_split = (int32_t)((nvpl_slots_of(c) + kVplSplit - 1) / kVplSplit);
         a.band_first = 0; a.band_rows = band_rows < nby ? band_rows : 0;
         const size_t tiles = (size_t)gather_launch_tiles(a), per_item = (size_t)k * (size_t)a.masks_per_split * sizeof(unsigned long long);
         vsl_groups = kVplSplit / k;
         vsl_per_launch = vsl_groups;
-        while (vsl_per_launch > 1 && tiles * (size_t)vsl_per_launch * per_item > ((size_t)1 << 30)) vsl_per_launch = (vsl_per_launch + 1) / 2;
+        size_t mask_cap = 0;
+        if (const char *me = std::getenv("EVPLP_MASK_BYTES")) mask_cap = (size_t)strtoull(me, nullptr, 10);      // (developer switch)
+        if (mask_cap == 0) {                   // a twentieth of the part's memory (14 GB of 288: config #5's 8.6 GB in one launch), at most a quarter of what is free
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)20 << 30; }
+            mask_cap = std::max<size_t>(std::min(mem_total / 20, (mem_free + c->vsl_mask_bytes) / 4), (size_t)1 << 28);
+        }
+        while (vsl_per_launch > 1 && tiles * (size_t)vsl_per_launch * per_item > mask_cap) vsl_per_launch = (vsl_per_launch + 1) / 2;
         const size_t mask_bytes = tiles * (size_t)vsl_per_launch * per_item;
         if (c->vsl_mask_bytes < mask_bytes) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
