@@ -782,6 +782,9 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
             for (uint32_t q = (uint32_t)lane; q < n; q += 64u) dst[q] = s_lit[q];
         }
     }
+#if EVPLP_XCD_TIMES
+    if (lane == 0) atomicMax(&a.counters->hist[24 + (blockIdx.x & 7u)], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     // shadow rays of the item, summed over the wavefront: one add per item into the pass's 64 counter shards (an item's count can reach
     // 64 lanes x 4095 VSLs -- it does not fit the 16-bit field the VPL gather's per-pixel statistics word has for it)
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
@@ -898,6 +901,9 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
     }
 #if EVPLP_DEBUG_NAN
     if (valid && !(isfinite(total.x) && isfinite(total.y) && isfinite(total.z))) atomicAdd(&a.counters->nonfinite, 1ull);
+#endif
+#if EVPLP_XCD_TIMES
+    if (lane == 0) atomicMax(&a.counters->hist[16 + (blockIdx.x & 7u)], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // (tools/xcd_balance.py --vsl; the walk kernel: hist[24 ..])
 #endif
     // sample-iterations of the item (the unit the estimators' work is priced in): one add per wavefront into 64 counter shards
     const uint32_t nlit = cnt & 4095u;

@@ -14,17 +14,24 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="hard")
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--paths", type=int, default=1024)
+ap.add_argument("--vsl", action="store_true", help="the VSL gather (estimator kernel: first row, walk kernel: second row)")
 a = ap.parse_args()
 jp = ev.synth_scene("/tmp/evplp_xcd_%s" % a.scene, "conf", 331000, 1234, a.res, a.res, style=a.scene)
 c = ev.Context(a.res, a.res, a.paths, a.paths, 4)
 c.load_scene_json(jp)
 cam = c.camera()
-fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=a.paths, num_vpl_light_paths=a.paths, photons_per_path=4, do_accumulate=0)
+import math
+bsr, total, larea = c.scene_metrics()
+fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=a.paths, num_vpl_light_paths=a.paths, photons_per_path=4, do_accumulate=0,
+                     vsl_radius=0.05 * bsr, vsl_inv_pi_radius2=1 / (math.pi * (0.05 * bsr) ** 2))
 for it in range(3):
-    c.primary((0, 0)); c.trace_light_paths(it); c.gather_vpl(fp); c.synchronize()
-    st = c.pass_stats(ev.PASS_GATHER_VPL)
-    raw = c.debug_counters(ev.PASS_GATHER_VPL)
-    ends = raw[4 + 16:4 + 24].astype(np.int64)
-    rel = (ends - ends.min()) / 100.0            # microseconds after the first XCD to finish
-    print("iter %d: kernel %.2f ms; last item of XCD 0..7 ends +%s us after the earliest; spread %.0f us = %.2f %% of the kernel"
-          % (it, st["dominant_kernel_ms"], np.round(rel, 0).astype(int).tolist(), rel.max(), rel.max() / 10.0 / st["dominant_kernel_ms"]))
+    c.primary((0, 0)); c.trace_light_paths(it)
+    which = ev.PASS_GATHER_VSL if a.vsl else ev.PASS_GATHER_VPL
+    (c.gather_vsl if a.vsl else c.gather_vpl)(fp); c.synchronize()
+    st = c.pass_stats(which)
+    raw = c.debug_counters(which)
+    for name, off in ((("estimators", 16), ("walks", 24)) if a.vsl else (("gather", 16),)):
+        ends = raw[4 + off:4 + off + 8].astype(np.int64)
+        rel = (ends - ends.min()) / 100.0            # microseconds after the first XCD to finish
+        print("iter %d %s: pass kernels %.2f ms; last item of XCD 0..7 ends +%s us after the earliest; spread %.0f us = %.2f %% of the pass"
+              % (it, name, st["dominant_kernel_ms"], np.round(rel, 0).astype(int).tolist(), rel.max(), rel.max() / 10.0 / st["dominant_kernel_ms"]))
