@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--workload", default="ir", choices=sorted(WORKLOADS))
     ap.add_argument("--scene", default="hard", choices=["hard", "easy"])
     ap.add_argument("--mis", default="", help="override misMode")
+    ap.add_argument("--footprint", default="proxy", choices=["proxy", "ideal"],
+                    help="coverage rule of the photon splat: the reference's proxy mesh (default, as in evplp_render_json) or the radius test alone")
     ap.add_argument("--bvh", default="sah", choices=["sah", "sbvh", "lbvh", "gpu"], help="acceleration-structure builder (same flattened node format)")
     ap.add_argument("--front-end", default="auto", choices=["auto", "ranks", "group"],
                     help="N > 1: `group` = one process driving evplp_group, the library's own multi-GPU entry (auto: whenever this process sees N devices); "
@@ -327,12 +329,17 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
              "vsl_radius": vsl_radius0, "vsl_inv": (1.0 / (math.pi * vsl_radius0 * vsl_radius0)) if vsl_radius0 > 0 else 0.0}
     clamp_start = sched["clamp"]
 
+    # the photon splat's coverage rule: the reference's proxy mesh (the technique loop's default) unless --footprint ideal
+    footprint = [a.footprint]
+    last_jitter = [(0.0, 0.0)]      # (the G-buffer on the device belongs to this jitter: the proxy rule's eye rays go through it)
+
     def frame(it):
         jitter = (float(jitters[it][0]), float(jitters[it][1]))
+        last_jitter[0] = jitter
         fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode=mis, pdf_mc=sched["pdf_mc"], clamping_value=sched["clamp"],
                              photon_radius=sched["radius"], vsl_radius=sched["vsl_radius"], vsl_inv_pi_radius2=sched["vsl_inv"],
                              num_light_paths=n_light, num_vpl_light_paths=n_vpl, photons_per_path=P,
-                             do_accumulate=1, rng_seed=it, jitter=jitter)
+                             do_accumulate=1, rng_seed=it, jitter=jitter, splat_footprint=footprint[0])
         if group is not None:
             # the technique loop of host/technique.cpp on the group, + the per-frame exchange of the strips
             if wl == "ppm":
@@ -393,6 +400,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     sync_all()
     kernel_ms, nominal_local, rays_local, shaded_local, samples_local, splat_ms, splat_tiles_ms, usable = [], 0, 0, 0, 0, [], [], 0
     feeder_ms = {"light_trace": [], "primary": []}
+    other_ms, same_ms, frag_stats = [], [], []
     # Pass statistics synchronise the stream.  The gather workloads (>= 80 ms per step) read them every step.  Config #4's 0.7 ms
     # iterations run their timed region without a single read-back (the host stays an iteration ahead of the GPU, as in the
     # technique loop of evplp_render_json); photon-pixel pairs come from the library's device-side running total, read before and
@@ -438,6 +446,25 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
         sync_all()
         for c in ranks:
             c.profile_kernels(False)
+        # ... and the pass under the other coverage rule, on the frames just rendered (three passes, HIP events of the pass)
+        footprint[0] = "ideal" if a.footprint == "proxy" else "proxy"
+        for i in range(0 if a.dump_frame else 3):          # (not before a frame dump: these passes add to the photon accumulator)
+            for c in ranks:
+                c.splat_photons(ev.frame_params(camera_pos=list(cam.origin), mis_mode=mis, pdf_mc=sched["pdf_mc"], clamping_value=sched["clamp"], photon_radius=sched["radius"],
+                                                num_light_paths=n_light, num_vpl_light_paths=n_vpl, photons_per_path=P, do_accumulate=1, jitter=last_jitter[0],
+                                                splat_footprint=footprint[0]))
+            sync_all()
+            other_ms.append(ctx.pass_stats(ev.PASS_SPLAT)["ms"])
+        # (the same pass, same photons and radius, under the timed rule: the like-for-like denominator of the ratio)
+        for i in range(0 if a.dump_frame else 3):
+            for c in ranks:
+                c.splat_photons(ev.frame_params(camera_pos=list(cam.origin), mis_mode=mis, pdf_mc=sched["pdf_mc"], clamping_value=sched["clamp"], photon_radius=sched["radius"],
+                                                num_light_paths=n_light, num_vpl_light_paths=n_vpl, photons_per_path=P, do_accumulate=1, jitter=last_jitter[0],
+                                                splat_footprint=a.footprint))
+            sync_all()
+            same_ms.append(ctx.pass_stats(ev.PASS_SPLAT)["ms"])
+            frag_stats.append((ctx.pass_stats(ev.PASS_SPLAT)["pairs"], ctx.pass_stats(ev.PASS_SPLAT)["rays"]))
+        footprint[0] = a.footprint
     kms_local = sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0
     stats = torch.tensor([dt, float(nominal_local), float(rays_local), float(splat_pairs), kms_local, float(shaded_local), float(samples_local)], dtype=torch.float64, device=dev)
     if use_dist:
@@ -568,7 +595,18 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
             sms = sum(splat_ms) / len(splat_ms)
             rs = {"bound": "hbm", "achieved": nrec_bytes / (sms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": nrec_bytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "kernel": "photon splat pass (bin + scatter + tiles)", "pass_ms": sms,
-                  "tiles_kernel_ms": (sum(splat_tiles_ms) / len(splat_tiles_ms)) if splat_tiles_ms else None, "pairs_per_frame": spairs / steps, "algorithmic_bytes": nrec_bytes}
+                  "tiles_kernel_ms": (sum(splat_tiles_ms) / len(splat_tiles_ms)) if splat_tiles_ms else None, "pairs_per_frame": spairs / steps, "algorithmic_bytes": nrec_bytes,
+                  "footprint": a.footprint}
+            if other_ms and same_ms:
+                # both coverage rules on the same frame (last radius of the run): pass time by HIP events, mean of three
+                o_ms, s_ms = sum(other_ms) / len(other_ms), sum(same_ms) / len(same_ms)
+                other = "ideal" if a.footprint == "proxy" else "proxy"
+                rs["footprints"] = {a.footprint: {"pass_ms": s_ms, "frac": nrec_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                                    other: {"pass_ms": o_ms, "frac": nrec_bytes / (o_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                                    "proxy_over_ideal": (s_ms / o_ms) if a.footprint == "proxy" else (o_ms / s_ms),
+                                    "pairs": frag_stats[-1][0], "proxy_fragments": frag_stats[-1][1] if a.footprint == "proxy" else None,
+                                    "note": "proxy = the reference's rule: one fragment per face of the radius-scaled proxy mesh (generated 42-vertex icosphere) the eye ray "
+                                            "crosses in front of the surface, un-culled, depth-tested (rtcomphoton.h:653-655, 789-837); ideal = the radius test alone"}
             tpath = os.path.join(ROOT, "profiles", "traffic_splat.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath)).get("configs", {}).get(f"{wl}:{scene}:{W}x{H}:{n_ranks}")
@@ -586,12 +624,13 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     return out, json_path, (W, H, n_vpl, n_light, mis)
 
 
-def technique_block(wl, n_vpl, n_light, mis, iterations, tag):
+def technique_block(wl, n_vpl, n_light, mis, iterations, tag, footprint="proxy"):
     """The `photonfam` block of the scene file for this configuration (keys of rtcomphoton.h:107-223)."""
     block = {"rngOffset": 0, "numMaxIteration": iterations, "timeLimitMs": 1000000000, "frameMode": "accumulate", "renderMode": "vpl", "misMode": mis,
              "combinedFilename": f"{tag}_combined.pfm", "weightedPhotonFilename": f"{tag}_weightedpm.pfm", "weightedVplFilename": f"{tag}_weightedvpl.pfm",
              "statFilename": f"{tag}_stat.json", "useJitter": True, "useStat": True,
-             "numLightPaths": n_light, "numVplLightPaths": n_vpl, "numMaxBounces": 3, "radiusPercentage": 0.0 if wl == "ir" else 0.003}
+             "numLightPaths": n_light, "numVplLightPaths": n_vpl, "numMaxBounces": 3, "radiusPercentage": 0.0 if wl == "ir" else 0.003,
+             "splatFootprint": footprint}
     if wl == "ir":
         block["run"] = {"photonSplat": False}
     if wl in ("ppm", "vsl"):
@@ -628,7 +667,7 @@ def render_json_time(env, wl, json_path, shape, iterations):
     W, H, n_vpl, n_light, mis = shape
     root = json.load(open(json_path))
     tag = f"bench_{wl}_{os.getpid()}"
-    root["photonfam"] = technique_block(wl, n_vpl, n_light, mis, iterations, tag)
+    root["photonfam"] = technique_block(wl, n_vpl, n_light, mis, iterations, tag, env.a.footprint)
     for k in ("pt", "lvcphotonfam"):
         root.pop(k, None)
     d = os.path.dirname(json_path)

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVPLP_LIB") or os.path.join(_HERE, "lib", "libevplp_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # evplp_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_OOM = 0, -1, -2, -3, -4, -5, -6
@@ -49,7 +49,8 @@ class Config(C.Structure):
                 ("strip_rank", C.c_int32), ("strip_count", C.c_int32), ("strip_rows", C.c_int32),
                 ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
                 ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("gather_splits_per_wave", C.c_int32),
-                ("overlap_light_tracing", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("overlap_light_tracing", C.c_int32), ("cut_scratch_bytes", C.c_uint64), ("vsl_mask_bytes", C.c_uint64),
+                ("reserved", C.c_int32 * 2)]
 
 
 class Material(C.Structure):
@@ -67,7 +68,12 @@ class FrameParams(C.Structure):
                 ("clamping_value", C.c_float), ("photon_radius", C.c_float), ("vsl_radius", C.c_float),
                 ("vsl_inv_pi_radius2", C.c_float), ("num_light_paths", C.c_uint32),
                 ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
-                ("do_accumulate", C.c_uint32), ("rng_seed", C.c_uint32), ("jitter", C.c_float * 2)]
+                ("do_accumulate", C.c_uint32), ("rng_seed", C.c_uint32), ("jitter", C.c_float * 2),
+                ("splat_footprint", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FOOTPRINT_IDEAL, FOOTPRINT_PROXY = 0, 1
+FOOTPRINTS = {"ideal": FOOTPRINT_IDEAL, "proxy": FOOTPRINT_PROXY}
 
 
 class GroupConfig(C.Structure):
@@ -105,6 +111,9 @@ _SIGNATURES = {
     "evplp_gather_lvc": (C.c_int, [_P, C.POINTER(FrameParams)]),
     "evplp_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_splat_photons": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
+    "evplp_set_splat_proxy": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32]),
+    "evplp_group_set_splat_proxy": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32]),
+    "evplp_default_splat_proxy": (C.c_int, [_P, _P]),
     "evplp_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_clear_accumulators": (C.c_int, [_P]),
@@ -189,7 +198,7 @@ def _f32(a) -> np.ndarray:
 
 def frame_params(camera_pos, mis_mode=0, pdf_mc=0.0, clamping_value=0.0, photon_radius=0.0, vsl_radius=0.0,
                  vsl_inv_pi_radius2=0.0, num_light_paths=1, num_vpl_light_paths=1, photons_per_path=1,
-                 do_accumulate=0, rng_seed=0, jitter=(0.0, 0.0)) -> FrameParams:
+                 do_accumulate=0, rng_seed=0, jitter=(0.0, 0.0), splat_footprint=0) -> FrameParams:
     fp = FrameParams()
     fp.camera_pos = (C.c_float * 3)(*[float(x) for x in camera_pos])
     fp.mis_mode = MIS_MODES[mis_mode] if isinstance(mis_mode, str) else int(mis_mode)
@@ -198,7 +207,16 @@ def frame_params(camera_pos, mis_mode=0, pdf_mc=0.0, clamping_value=0.0, photon_
     fp.num_light_paths = num_light_paths; fp.num_vpl_light_paths = num_vpl_light_paths
     fp.photons_per_path = photons_per_path; fp.do_accumulate = do_accumulate; fp.rng_seed = rng_seed
     fp.jitter = (C.c_float * 2)(float(jitter[0]), float(jitter[1]))
+    fp.splat_footprint = FOOTPRINTS[splat_footprint] if isinstance(splat_footprint, str) else int(splat_footprint)
     return fp
+
+
+def default_splat_proxy():
+    """(vertices float32 [42, 3], triangles int32 [80, 3]) of the proxy EVPLP_FOOTPRINT_PROXY uses when no mesh was given."""
+    v = np.zeros((42, 3), dtype=np.float32); t = np.zeros((80, 3), dtype=np.int32)
+    n = lib().evplp_default_splat_proxy(_ptr(v), _ptr(t))
+    assert n == 80
+    return v, t
 
 
 class Context:
@@ -355,6 +373,13 @@ class Context:
     def splat_photons(self, fp: FrameParams, clear=False):
         self._check(self._lib.evplp_splat_photons(self._h, C.byref(fp), int(clear)))
 
+    def set_splat_proxy(self, vertices=None, triangles=None):
+        """The proxy mesh of FOOTPRINT_PROXY (None: the generated icosphere); refused unless closed and convex around the origin."""
+        if vertices is None:
+            self._check(self._lib.evplp_set_splat_proxy(self._h, None, 0, None, 0)); return
+        v = _f32(vertices).reshape(-1, 3); t = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        self._check(self._lib.evplp_set_splat_proxy(self._h, _ptr(v), v.shape[0], _ptr(t), t.shape[0]))
+
     def resolve(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False) -> np.ndarray:
         out = np.empty((self.local_rows, self.W, 3), dtype=np.float32)
         self._check(self._lib.evplp_resolve(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma), _ptr(out)))
@@ -472,6 +497,12 @@ class Group:
 
     def splat_photons(self, fp, clear=False):
         self._check(self._lib.evplp_group_splat_photons(self._h, C.byref(fp), int(clear)))
+
+    def set_splat_proxy(self, vertices=None, triangles=None):
+        if vertices is None:
+            self._check(self._lib.evplp_group_set_splat_proxy(self._h, None, 0, None, 0)); return
+        v = _f32(vertices).reshape(-1, 3); t = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        self._check(self._lib.evplp_group_set_splat_proxy(self._h, _ptr(v), v.shape[0], _ptr(t), t.shape[0]))
 
     def synchronize(self):
         self._check(self._lib.evplp_group_synchronize(self._h))

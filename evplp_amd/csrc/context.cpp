@@ -73,6 +73,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if (const char *env = std::getenv("EVPLP_CUT_BYTES")) c->env_cut_bytes = (size_t)strtoull(env, nullptr, 10);      // (tests: forces the band path)
     if (const char *env = std::getenv("EVPLP_GATHER_K")) { int v = atoi(env); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) c->env_gather_k = v; }
     if (const char *env = std::getenv("EVPLP_TILE_BLOCK_LOG2")) c->env_tile_block_log2 = std::max(0, atoi(env));
+    if (const char *env = std::getenv("EVPLP_SPLIT_MIN")) c->env_split_min = std::max(0, atoi(env));
     c->st.W = cfg->res_x; c->st.H = cfg->res_y;
     c->st.strip_rank = cfg->strip_rank; c->st.strip_count = strip_count; c->st.strip_rows = strip_rows;
     int nblocks = (cfg->res_y + strip_rows - 1) / strip_rows;
@@ -147,6 +148,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if ((e = hipMalloc((void **)&c->d_summary, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMalloc(summary)", e);
     if ((e = hipMemset(c->d_summary, 0, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMemset(summary)", e);
     if ((e = hipMalloc((void **)&c->d_tile_pairs, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_pairs)", e);
+    if ((e = hipMalloc((void **)&c->d_tile_frags, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_frags)", e);
     if ((e = hipMalloc((void **)&c->d_tile_cursor, sizeof(uint32_t) * (ntiles + 1))) != hipSuccess) return fail("hipMalloc(tile_cursor)", e);
     const size_t ngroups = std::max(c->num_bin_groups, 1);
     if ((e = hipMalloc((void **)&c->d_seg, sizeof(uint32_t) * ngroups * kSegCap)) != hipSuccess) return fail("hipMalloc(seg)", e);
@@ -183,6 +185,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_cuts); hipFree(c->d_primary_cuts); hipFree(c->d_lt_overflow);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
     hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
+    hipFree(c->d_proxy_slabs); hipFree(c->d_proxy_hm); hipFree(c->d_tile_frags);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if (c->ev_begin[i]) hipEventDestroy(c->ev_begin[i]);
         if (c->ev_end[i]) hipEventDestroy(c->ev_end[i]);
@@ -453,6 +456,13 @@ extern "C" int evplp_accel_builder(const evplp_context *c) {
 // Look at the bin summary of the last photon splat (see context.hpp).  Called at the start of every entry point that
 // enqueues work, reads results or changes buffers.  Overflow is rare (the bins carry 25 % slack over the last pass and the
 // radius only shrinks in a progressive run): then the bins grow and fill + tiles of that pass run again -- they wrote nothing.
+// fullest bin from which the tile kernel runs four waves per tile (evplp_splat_photons explains; EVPLP_SPLIT_MIN: developer override)
+static uint32_t split_threshold(const evplp_context *c, uint32_t footprint) {
+    if (c->env_split_min > 0) return (uint32_t)c->env_split_min;
+    // (the proxy variant keeps its four waves busy only in much fuller bins: at config #3, fullest bin ~1400, one wave per tile takes 136 us
+    // and four take 178; the ideal kernel 87 / 82)
+    return footprint == (uint32_t)EVPLP_FOOTPRINT_PROXY ? 1536u : 768u;
+}
 static int settle_one(evplp_context *c) {                                // the oldest pending pass
     if (c->npend == 0) return EVPLP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -480,7 +490,7 @@ static int settle_one(evplp_context *c) {                                // the 
     }
     HIP_TRY(c, hipEventRecord(c->ev_begin[EVPLP_PASS_SPLAT], c->stream));  // (the pass statistics then describe this re-run as a whole, not a mix of two passes)
     launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
-    const bool split_tiles = c->cfg.deterministic ? true : biggest >= 768u;
+    const bool split_tiles = c->cfg.deterministic ? true : biggest >= split_threshold(c, a.fp.splat_footprint);
     launch_splat_tiles(a, split_tiles, c->stream, c->ev_dom_begin[EVPLP_PASS_SPLAT], c->ev_dom_end[EVPLP_PASS_SPLAT]);
     HIP_TRY(c, hipEventRecord(c->ev_end[EVPLP_PASS_SPLAT], c->stream));
     // (the records this pass read may meanwhile be the BACK buffer of the overlapped light tracing: its readers' event then)
@@ -823,6 +833,40 @@ extern "C" int evplp_path_trace(evplp_context *c, const float camera_pos[3], uin
     return pass_end(c, EVPLP_PASS_PATH_TRACE);
 }
 
+// setupPhotonSplatIcosohedron (rtcomphoton.h:632-644): the proxy mesh of EVPLP_FOOTPRINT_PROXY -> slabs on the device
+static int upload_proxy(evplp_context *c, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris, const char *name) {
+    ProxyHost ph; std::string why;
+    if (!build_proxy_slabs(vertices, nverts, indices, ntris, &ph, &why)) { c->set_error("%s: %s", name, why.c_str()); return EVPLP_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                          // (a splat in flight reads the old slabs)
+    if (!c->d_proxy_slabs) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_proxy_slabs, sizeof(float4) * kMaxProxySlabs));
+        HIP_TRY(c, hipMalloc((void **)&c->d_proxy_hm, sizeof(float) * kMaxProxySlabs));
+    }
+    HIP_TRY(c, hipMemcpy(c->d_proxy_slabs, ph.slabs.data(), sizeof(float4) * ph.slabs.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_proxy_hm, ph.hm.data(), sizeof(float) * ph.hm.size(), hipMemcpyHostToDevice));
+    c->proxy_count = (int32_t)ph.slabs.size(); c->proxy_rin = ph.rin; c->proxy_rout = ph.rout;
+    return EVPLP_OK;
+}
+static int default_proxy(evplp_context *c, const char *name) {
+    std::vector<float> v; std::vector<int32_t> t;
+    default_splat_proxy(v, t);
+    return upload_proxy(c, v.data(), (int32_t)(v.size() / 3), t.data(), (int32_t)(t.size() / 3), name);
+}
+extern "C" int evplp_set_splat_proxy(evplp_context *c, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris) {
+    CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
+    if (!vertices) return default_proxy(c, "evplp_set_splat_proxy");
+    return upload_proxy(c, vertices, nverts, indices, ntris, "evplp_set_splat_proxy");
+}
+extern "C" int evplp_default_splat_proxy(float *vertices, int32_t *indices) {
+    std::vector<float> v; std::vector<int32_t> t;
+    default_splat_proxy(v, t);
+    if (vertices) std::memcpy(vertices, v.data(), sizeof(float) * v.size());
+    if (indices) std::memcpy(indices, t.data(), sizeof(int32_t) * t.size());
+    return (int)(t.size() / 3);
+}
+
 extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *fp, int32_t clear) {
     CTX_CHECK(c);
     // (overlapped mode, accumulating: the previous pass may stay pending -- only look whether its verdict has arrived; a clearing pass
@@ -838,6 +882,8 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     }
     if ((rc = check_fp(c, fp, "evplp_splat_photons"))) return rc;
     if (!(fp->photon_radius > 0.0f)) { c->set_error("evplp_splat_photons: photon_radius must be > 0"); return EVPLP_ERR_INVALID; }
+    if (fp->splat_footprint > (uint32_t)EVPLP_FOOTPRINT_PROXY) { c->set_error("evplp_splat_photons: splat_footprint %u out of range", fp->splat_footprint); return EVPLP_ERR_INVALID; }
+    if (fp->splat_footprint == (uint32_t)EVPLP_FOOTPRINT_PROXY && c->proxy_count == 0 && (rc = default_proxy(c, "evplp_splat_photons"))) return rc;
     SplatArgs a; std::memset(&a, 0, sizeof(a));
     a.st = c->st; a.cam = c->cam; a.fp = *fp;
     a.g_pos = (const float4 *)c->buf[EVPLP_BUF_GBUF_POSITION]; a.g_nrm = (const float4 *)c->buf[EVPLP_BUF_GBUF_NORMAL];
@@ -852,6 +898,8 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.bucket_w_log2 = c->bucket_w_log2; a.bucket_h_log2 = c->bucket_h_log2; a.buckets_x = c->buckets_x; a.num_buckets = c->num_buckets;
     a.tiles_x = c->tiles_x; a.tiles_y = c->tiles_y; a.deterministic = c->cfg.deterministic; a.boxes_valid = c->tile_box_valid ? 1 : 0;
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
+    a.proxy_slabs = c->d_proxy_slabs; a.proxy_hm = c->d_proxy_hm; a.proxy_count = c->proxy_count; a.proxy_rin = c->proxy_rin; a.proxy_rout = c->proxy_rout;
+    a.tile_frags = c->d_tile_frags; c->last_splat_proxy = fp->splat_footprint == (uint32_t)EVPLP_FOOTPRINT_PROXY;
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
     launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
@@ -860,7 +908,7 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     // four waves per tile win.  Deterministic mode always uses one variant: the fold order is part of the result.
     // Measured (tiles kernel, ms): fullest bin 1405 entries (config #3): 0.31 with one wave, 0.18 with four; fullest bin 365
     // (config #4 shape): 0.12 / 0.22.  The fullest bin of the PREVIOUS pass decides (a heuristic either way).
-    const bool split_tiles = c->cfg.deterministic ? true : c->last_bin_max >= 768u;
+    const bool split_tiles = c->cfg.deterministic ? true : c->last_bin_max >= split_threshold(c, fp->splat_footprint);
     const bool dom = c->profile_kernels;
     launch_splat_tiles(a, split_tiles, c->stream, dom ? c->ev_dom_begin[EVPLP_PASS_SPLAT] : nullptr, dom ? c->ev_dom_end[EVPLP_PASS_SPLAT] : nullptr);
     // The number of (photon, tile) bin entries depends on the photon set and the radius and is known on the device only.  The
@@ -1016,7 +1064,12 @@ extern "C" int evplp_pass_stats_get(evplp_context *c, int32_t pass, evplp_pass_s
         std::vector<uint32_t> tp((size_t)c->tiles_x * c->tiles_y);
         HIP_TRY(c, hipMemcpy(tp.data(), c->d_tile_pairs, tp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint64_t sum = 0; for (uint32_t v : tp) sum += v;
-        out->pairs = sum; out->rays = 0; out->usable = 0; out->reserved[0] = c->last_bin_entries; out->reserved[1] = c->last_bin_max;
+        uint64_t fragments = 0;
+        if (c->last_splat_proxy) {                                        // EVPLP_FOOTPRINT_PROXY: fragments of the proxy mesh
+            HIP_TRY(c, hipMemcpy(tp.data(), c->d_tile_frags, tp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t v : tp) fragments += v;
+        }
+        out->pairs = sum; out->rays = fragments; out->usable = 0; out->reserved[0] = c->last_bin_entries; out->reserved[1] = c->last_bin_max;
         // `shaded`: (photon, pixel) pairs of ALL splat passes of this context so far (device-side running total)
         std::vector<uint32_t> sh((size_t)kSummaryFinal);
         HIP_TRY(c, hipMemcpy(sh.data(), c->d_summary, sh.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));

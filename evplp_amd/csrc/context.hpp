@@ -3,6 +3,7 @@
 #include "evplp_types.h"
 #include "kernels.h"
 
+#include <string>
 #include <vector>
 
 namespace evplp {
@@ -12,6 +13,10 @@ int build_nodes4(const BvhNode *d_nodes, int32_t nnodes, hipStream_t stream, Bvh
 struct HostMesh { std::vector<float> verts, uvs; std::vector<int32_t> idx; int32_t material = 0; };
 struct HostTexture { int32_t w = 0, h = 0; std::vector<float> rgba; };
 struct HostStats { uint64_t rays = 0; };
+// host/proxy_mesh.cpp: the proxy mesh of EVPLP_FOOTPRINT_PROXY as slabs (kernels.h ProxyDev)
+struct ProxyHost { std::vector<float4> slabs; std::vector<float> hm; int32_t planes = 0; float rin = 0.f, rout = 0.f; };
+void default_splat_proxy(std::vector<float> &verts, std::vector<int32_t> &tris);
+bool build_proxy_slabs(const float *verts, int32_t nverts, const int32_t *tris, int32_t ntris, ProxyHost *out, std::string *why);
 }
 
 struct evplp_context {
@@ -71,6 +76,9 @@ struct evplp_context {
     uint32_t *d_seg = nullptr, *d_big_list = nullptr, *d_big_count = nullptr; uint16_t *d_seg_off = nullptr;
     uint32_t *d_tile_cursor = nullptr, *d_bin_items = nullptr, *d_bin_items_tmp = nullptr;
     float4 *d_compact = nullptr; float4 *d_tile_box = nullptr; uint32_t *d_tile_pairs = nullptr; uint32_t *d_summary = nullptr;
+    // EVPLP_FOOTPRINT_PROXY: the proxy mesh as slabs on the device (evplp_set_splat_proxy; the generated icosphere on first use)
+    float4 *d_proxy_slabs = nullptr; float *d_proxy_hm = nullptr; int32_t proxy_count = 0; float proxy_rin = 0.f, proxy_rout = 0.f;
+    uint32_t *d_tile_frags = nullptr; bool last_splat_proxy = false;
     // The bin sizes of a splat are known only on the device.  The pass is enqueued completely (fill and tiles kernels do
     // nothing when the bins overflowed); the summary arrives in pinned host memory behind ev_summary and is looked at by the
     // NEXT call on the context (settle_splat): no host round trip, no GPU bubble inside the pass.
@@ -86,6 +94,7 @@ struct evplp_context {
     // Test / developer overrides, read ONCE by evplp_create (never in a pass): EVPLP_BVH_BUILDER (every suite under every builder),
     // EVPLP_BIN_STRIDE (forces the photon-bin overflow path), EVPLP_GATHER_K, EVPLP_TILE_BLOCK_LOG2.  -1 / 0 = not set.
     int32_t env_bvh_builder = -1, env_gather_k = 0, env_tile_block_log2 = -1, env_cuts = -1;      // env_cuts: EVPLP_CUTS=0 walks from the root
+    int32_t env_split_min = 0;                 // EVPLP_SPLIT_MIN: fullest bin from which the splat's tile kernel runs four waves per tile
     size_t env_cut_bytes = 0;                  // EVPLP_CUT_BYTES: bound of the entry-cut scratch (default 12 GB)
 
     char error[512] = "";

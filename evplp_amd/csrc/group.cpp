@@ -187,6 +187,9 @@ extern "C" int evplp_group_gather(evplp_group *g, const evplp_frame_params *fp, 
     return EVPLP_OK;
 }
 extern "C" int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int32_t clear) { GRP_CHECK(g); GRP_EACH(g, evplp_splat_photons(c, fp, clear)); return EVPLP_OK; }
+extern "C" int evplp_group_set_splat_proxy(evplp_group *g, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris) {
+    GRP_CHECK(g); GRP_EACH(g, evplp_set_splat_proxy(c, vertices, nverts, indices, ntris)); return EVPLP_OK;
+}
 extern "C" int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate) {
     GRP_CHECK(g); GRP_EACH(g, evplp_path_trace(c, camera_pos, rng_seed, max_bounces, do_accumulate)); return EVPLP_OK;
 }

@@ -220,6 +220,13 @@ void add_arealight(HostScene &scene, const std::string &obj_path, const float in
     std::memcpy(scene.light_intensity, intensity, 16);
 }
 
+MeshData load_single_mesh_obj(const std::string &obj_path) {
+    HostScene scratch;
+    ObjResult r = read_obj(scratch, obj_path, false);
+    if (r.meshes.size() != 1) throw std::runtime_error("the OBJ must contain exactly one mesh (rtcomphoton.h:635): " + obj_path);
+    return std::move(r.meshes[0]);
+}
+
 static void vec3_from(const Json &j, float out[3], const char *what) {
     if (!j.is_array() || j.size() != 3) throw JsonError(std::string(what) + ": expected an array of 3 numbers");
     for (int k = 0; k < 3; k++) out[k] = j.at((size_t)k).as_float(what);

@@ -34,6 +34,8 @@ struct HostScene {
 void add_obj(HostScene &scene, const std::string &obj_path);
 // RtScene::addAreaLight (rtcommon.h:772-798): the OBJ must yield exactly one mesh.
 void add_arealight(HostScene &scene, const std::string &obj_path, const float intensity[4]);
+// TriangleMesh::LoadMeshes of setupPhotonSplatIcosohedron (rtcomphoton.h:632-644): the OBJ must yield exactly one mesh (:635)
+MeshData load_single_mesh_obj(const std::string &obj_path);
 // RtStableCamera (rtcommon.h:548-571): origin / direction (= look-at point) / up / fovx|fovy (degrees)
 evplp_camera camera_from_json(const Json &j, float aspect);
 // LoadScene (main.cpp:42-85)

@@ -71,6 +71,35 @@ void upload_scene_group(evplp_group *g, const HostScene &scene) {
         if (upload_scene(h, scene) < 0) throw std::runtime_error(std::string("scene upload: ") + evplp_last_error(h));
     }
 }
+// setupPhotonSplatIcosohedron("sphere/icosphere.obj") (rtcomphoton.h:632-644, 677): the proxy mesh the photon splat draws around every
+// photon.  The reference opens the path relative to its working directory; here it is looked for there and next to the scene JSON, and
+// a build-only key "splatProxy" names another file.  The asset is a Git-LFS pointer in the reference's repository: when no mesh file
+// is found (or the file is such a pointer) the generated 42-vertex / 80-face icosphere stands in (evplp_default_splat_proxy) and a
+// note says so.  A file that IS a mesh but not a closed convex one is an error (evplp_set_splat_proxy refuses it).
+// Build-only key "splatFootprint": "proxy" (default: the reference's coverage rule) | "ideal" (the radius test alone).
+uint32_t setup_splat_footprint(evplp_group *g, const Json &json, const std::string &json_dir) {
+    std::string mode = json.has("splatFootprint") ? json.at("splatFootprint").as_string("splatFootprint") : std::string("proxy");
+    if (mode == "ideal") return (uint32_t)EVPLP_FOOTPRINT_IDEAL;
+    if (mode != "proxy") throw JsonError("splatFootprint: expected \"proxy\" or \"ideal\", got \"" + mode + "\"");
+    std::vector<std::string> candidates;
+    const bool named = json.has("splatProxy");
+    if (named) candidates.push_back(join_path(json_dir, json.at("splatProxy").as_string("splatProxy")));
+    else { candidates.push_back("sphere/icosphere.obj"); candidates.push_back(join_path(json_dir, "sphere/icosphere.obj")); }
+    for (const std::string &path : candidates) {
+        { std::ifstream probe(path); if (!probe) { if (named) throw std::runtime_error("Impossible to load the scene: " + path); continue; } }
+        MeshData m;
+        try { m = load_single_mesh_obj(path); }
+        catch (const std::exception &e) {
+            if (std::string(e.what()).find("Git-LFS pointer") == std::string::npos) throw;
+            std::fprintf(stderr, "note: %s is a Git-LFS pointer; the photon splat uses the generated 42-vertex icosphere as its proxy\n", path.c_str());
+            break;
+        }
+        check(g, evplp_group_set_splat_proxy(g, m.verts.data(), (int32_t)(m.verts.size() / 3), m.idx.data(), (int32_t)(m.idx.size() / 3)), ("photon splat proxy " + path).c_str());
+        return (uint32_t)EVPLP_FOOTPRINT_PROXY;
+    }
+    check(g, evplp_group_set_splat_proxy(g, nullptr, 0, nullptr, 0), "photon splat proxy");
+    return (uint32_t)EVPLP_FOOTPRINT_PROXY;
+}
 // Output files named in the technique block.  The shipped scene files carry the authors' Windows paths
 // ("C://result/conference/3_pm.pfm"): off Windows a drive-letter path keeps only its file name and lands next to
 // the scene JSON, so those files run unchanged; every other path is used as the reference would (relative to the
@@ -265,6 +294,7 @@ public:
         cfg.overlap_light_tracing = 1;      // the loop below calls primary, then light tracing: they overlap
         Grp grp; create_group(grp, cfg, json, device);
         upload_scene_group(grp.g, scene);
+        splat_footprint = setup_splat_footprint(grp.g, json, out_dir);                                          // :677
         float bsr = 0.f, total_area = 0.f, light_area = 0.f;
         { evplp_context *h0 = evplp_group_context(grp.g, 0);
           if (evplp_scene_metrics(h0, &bsr, &total_area, &light_area) < 0) throw std::runtime_error(std::string("scene metrics: ") + evplp_last_error(h0)); }
@@ -294,6 +324,7 @@ private:
         fp.photons_per_path = (uint32_t)photons_per_path;
         fp.do_accumulate = frame_mode == 2 ? 0u : 1u;   // :923-930
         fp.rng_seed = seed; fp.jitter[0] = jitter[0]; fp.jitter[1] = jitter[1];
+        fp.splat_footprint = splat_footprint;
         return fp;
     }
 
@@ -392,6 +423,7 @@ private:
     std::string combined_filename, weighted_photon_filename, weighted_vpl_filename, stat_filename;
     bool force_vsl = false; float vsl_radius = 0.f, vsl_inv_pi_radius2 = 0.f;
     bool lvc = false;
+    uint32_t splat_footprint = EVPLP_FOOTPRINT_PROXY;
     int bvh_builder = EVPLP_BVH_SAH;   // measured 9% faster frames than the Morton LBVH on the conference stand-in; "bvhBuilder": "lbvh" selects the LBVH
 };
 

@@ -182,7 +182,16 @@ struct SplatArgs {
                               // folded into [kSummaryFinal + 0] total bin entries, [+1] entries of the fullest bin by the tile kernel
     int32_t tiles_x, tiles_y; int32_t deterministic; int32_t boxes_valid;   // boxes_valid: tile_box was written by the primary pass
     PassCounters *counters;
+    // EVPLP_FOOTPRINT_PROXY (ProxyDev below): the slabs of the proxy mesh in units of the radius, and the per-tile fragment counts
+    const float4 *proxy_slabs; const float *proxy_hm; int32_t proxy_count; float proxy_rin, proxy_rout;
+    uint32_t *tile_frags;     // [ntiles] proxy fragments accepted in the tile (statistics, like tile_pairs)
 };
+// The proxy mesh of the reference's photon splat as the tile kernel wants it.  A convex mesh is the intersection of its face planes
+// n . x <= h; two faces with opposite normals form a SLAB -h- <= n . x <= h+, and a ray's parameters at the two planes of a slab
+// come from one pair of dot products and one reciprocal.  slab i = (n, h+) and hm[i] = h- (kProxyOpen for a face without an opposite
+// one).  rin = the smallest h (radius of the largest sphere around the origin inside the mesh), rout = the largest |vertex|.
+constexpr int kMaxProxySlabs = EVPLP_MAX_PROXY_PLANES;
+constexpr float kProxyOpen = 1.0e15f;
 constexpr int kSplatTile = 8;        // pixels per tile edge (one wave per tile)
 constexpr int kCompactF4 = 4;        // float4 per compact photon
 

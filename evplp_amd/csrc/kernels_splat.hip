@@ -4,8 +4,9 @@
 //   shaders/final.frag:19-35, rtcomphoton.h:756-787                  -> resolve_kernel
 //
 // The reference rasterises one icosphere proxy per record and lets the ROP blend every fragment
-// (one RMW of HBM per fragment).  Here (ideal kernel of SURVEY A.4: photon i adds to pixel p iff
-// |X_p - P_i|^2 <= r^2):
+// (one RMW of HBM per fragment).  Here photon i adds to pixel p iff |X_p - P_i|^2 <= r^2 (frag:152-154) -- once
+// (EVPLP_FOOTPRINT_IDEAL) or once per face of the proxy mesh in front of the surface (EVPLP_FOOTPRINT_PROXY, the
+// reference's coverage; splat_tiles_kernel<.., true>):
 //   0. splat_tile_box : world-space bounding box of the G-buffer positions of every 8x8-pixel tile -- only for G-buffers that
 //      were uploaded: evplp_primary writes the boxes as it writes the G-buffer.
 //   1. splat_bin : one lane per record (records staged through LDS).  Everything of the fragment shader that does not depend
@@ -25,6 +26,9 @@
 #include "kernels.h"
 #include <cstring>
 
+#ifndef EVPLP_PROXY_WAVES
+#define EVPLP_PROXY_WAVES 7
+#endif
 namespace evplp {
 
 // d^e on the hardware transcendentals (d in (1e-5, 1]): exp2(e log2 d), relative error ~0.7 e |log2 d| 2^-22, i.e. 2e-6 where the lobe is
@@ -446,14 +450,51 @@ __global__ __launch_bounds__(256) void splat_sort_kernel(const uint32_t *cursor,
     }
 }
 
-template <int WAVES>   // waves per tile: 1 (four tiles per workgroup) or 4 (one tile per workgroup, for launches with very full bins)
-__global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
+// PROXY (EVPLP_FOOTPRINT_PROXY, include/evplp.h): a (pixel, photon) pair inside the radius counts once per face of the scaled proxy mesh
+// that the pixel's eye ray crosses between the near plane and the visible surface -- the reference's instanced, un-culled, depth-tested
+// draw (rtcomphoton.h:653-655, 789-837; photonsplatinstanced.vert:28-33, .geom:16-32).  For a convex mesh that is an interval question:
+// with R = eye + depth x direction (the point of the pixel's ray at the depth of its G-buffer point), D = depth x direction and
+// x(s) = R + s D (s = 0 at the surface depth, s = -1 at the eye) the ray is inside the mesh for s in [enter, exit], the intersection of its
+// intervals with the mesh's slabs (kernels.h ProxyDev); fragments = [near <= enter <= 0] + [near <= exit <= 0] when enter < exit, else 0.
+// Written around R because R - P_i is small (<= r) where eye - P_i is metres long.
+//   * A pair whose surface point lies within the sphere inscribed in the mesh (|X - P|^2 <= (rin r)^2: 87 % of the pairs for the
+//     icosphere) has it inside the mesh, its entry face in front of the surface and its exit face behind it: one fragment, no test (pixels
+//     closer to the near plane than the proxy is large, and pixels whose G-buffer point is off their ray, take the full test for every pair).
+//   * The others ("rim" pairs) are compacted into a list of up to 64 per trip -- rounds of "every pixel's next rim photon", placed by the
+//     round's ballot -- and tested ONE PAIR PER GROUP OF L LANES (L = 16, 8, 4, 2 or 1, the largest that fits the list into the wave), each
+//     lane of a group taking every L-th slab: 13 vector instructions and one LDS read per (pair, slab), the group's interval folded by
+//     log2 L cross-lane steps.  (With lane = pixel every lane would walk all slabs for the 0.4 rim pairs per pixel and batch.)
+//   * The verdicts go back to the pixels' lanes as two 64-bit masks through LDS (kill: no fragment, dbl: two), and the shading loop below
+//     runs as in the ideal kernel on the pairs that are left, adding a doubled pair's value twice.
+// Measured (configs #3 / #4, tile kernel alone): ideal 82 / 56 us, proxy 136 / 97 us.  What the proxy rule costs, by compiling parts out:
+// the second mask of the radius pass and the per-pixel ray ~15 us, the rim lists ~15, the slab loops 40 / 20, and the occupancy the
+// rest -- the kernel follows its occupancy (the ideal kernel padded to six workgroups per CU: 117 / 66 us), which is why the LDS is sized
+// by the launch, the list and the verdicts share 1 KB per wave, and the variant is held to 72 registers.
+template <int WAVES, bool PROXY>   // waves per tile: 1 (four tiles per workgroup) or 4 (one tile per workgroup, for launches with very full bins)
+__global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : EVPLP_PROXY_WAVES) : 8) void splat_tiles_kernel(SplatArgs a) {
     // One workgroup = one tile; its four waves share the bin (wave w takes the 64-photon batches w, w + 4, ...) and
     // their per-pixel sums are folded in wave order: the fullest bins (tiles that see a floor at grazing angle) set
     // the duration of the launch.
-    __shared__ float4 lds[4][64 * kCompactF4];
-    __shared__ float4 red[3][64];
+    // Dynamic LDS, sized by the launch (splat_tiles_lds_bytes): the tile kernel's speed follows its occupancy (measured with a padded copy of
+    // the ideal kernel: 82 -> 117 us at config #3 when the LDS leaves six workgroups per CU instead of eight), so nothing is reserved that
+    // the pass does not use.  [4 waves][rows x 64] float4 of staged photons (rows = 3; 4 when misMode 5 needs brdf2; after its last batch a
+    // wave's stage carries its sums to the fold), then for PROXY [4 waves][64] float4 shared by the rim list and the verdicts of a trip, and
+    // the mesh's slabs.
+    extern __shared__ float4 dyn_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile, its bin and every loop bound below are wave-uniform)
+    const int stage_rows = a.fp.mis_mode == 5u ? 4 : 3;
+    float4 *const stage_base = dyn_lds;
+    float4 *const aux = dyn_lds + 4 * stage_rows * 64 + wave * 64;          // PROXY: this wave's rim list (float4 entries) / verdicts (4 words per pixel)
+    float4 *const s_slab = dyn_lds + 4 * stage_rows * 64 + 4 * 64;          // PROXY: (n, r h+) ...
+    float *const s_slabw = reinterpret_cast<float *>(s_slab + a.proxy_count);   // ... and r (h+ + h-)
+    if (PROXY) {
+        for (int i = tid; i < a.proxy_count; i += 256) {
+            const float4 sl = a.proxy_slabs[i]; const float hm = a.proxy_hm[i];
+            s_slab[i] = make_float4(sl.x, sl.y, sl.z, sl.w * a.fp.photon_radius);
+            s_slabw[i] = (sl.w + hm) * a.fp.photon_radius;
+        }
+        __syncthreads();
+    }
     const int part = WAVES == 4 ? wave : 0;                       // this wave's share of the bin
     const int tile = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     if (blockIdx.x == 0 && wave == 0) {                                   // fold the bin kernel's summary shards
@@ -468,7 +509,7 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
     const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
     const uint32_t b = (uint32_t)tile * a.bin_stride, e = b + min((uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_cursor[tile]), a.bin_stride);
-    if (b >= e) { if (lane == 0 && part == 0) a.tile_pairs[tile] = 0u; return; }
+    if (b >= e) { if (lane == 0 && part == 0) { a.tile_pairs[tile] = 0u; if (PROXY) a.tile_frags[tile] = 0u; } return; }
 
     // a wave without a batch of its own (most bins hold one or two) only takes part in the fold below
     const bool has_work = b + 64u * (uint32_t)part < e;
@@ -480,8 +521,36 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
     const uint32_t mode = a.fp.mis_mode;
     const float clampv = a.fp.clamping_value;
     V3 sum = v3(0.f, 0.f, 0.f);
-    uint32_t pairs = 0;
-    float4 *stage = lds[wave];
+    uint32_t pairs = 0, frags = 0;
+    float4 *stage = stage_base + wave * stage_rows * 64;
+    // PROXY: the pixel's eye ray is the one through its centre under the jittered matrix of this iteration (uMVP of runPhotonSplat,
+    // rtcomphoton.h:982), the depth it is tested against that of the G-buffer point.  The two differ where the pixel shows the emitter:
+    // the light mesh is drawn through the UN-jittered matrix (:720-727), so its G-buffer point lies a jitter off the pixel's ray.
+    // Dray = depth x direction (the ray's point at the surface depth is eye + Dray); rin2 = the squared radius inside which a pair
+    // needs no test (see above) -- none for a pixel closer to the near plane than the proxy can reach (its entry face may be
+    // clipped) or whose G-buffer point is off its ray.
+    float rin2 = -1.0f;
+    V3 dj = v3(0.f, 0.f, 0.f); double tsd = 0.0;           // the pixel's ray direction (depth 1) and the depth of its G-buffer point
+    if (PROXY) {
+        // The direction in the oracle's operation order, unfused (cam_dir of oracle/evplp_oracle.c; = the deferred pass's ray, kernels_trace.hip).
+        // Whether a rim pair's surface point is inside its proxy is decided within ~1e-7 r of a face for ~1e-7 of the pairs; the point itself is
+        // metres from the origin, so eye + depth x direction - photon is formed in DOUBLE (full rate on this part, six operations per rim pair)
+        // and only the small difference goes on in fp32: in fp32 the point's own rounding (1e-6 m against r ~ 3e-2 m, along a boundary
+        // ~10 r long) moved 2e-5 of the pairs across a face (measured: tools/debug_footprint.py).
+        const int gy = a.st.global_row(min(ly, a.st.local_rows - 1));
+        const float ndx = __fsub_rn(__fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, 0.5f), (float)a.st.W), 2.0f), 1.0f), a.fp.jitter[0]);
+        const float ndy = __fsub_rn(__fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)gy, 0.5f), (float)a.st.H), 2.0f), 1.0f), a.fp.jitter[1]);
+        const float dxs = __fmul_rn(__fmul_rn(ndx, a.cam.aspect), a.cam.tan_half), dys = __fmul_rn(ndy, a.cam.tan_half);
+        dj = v3(__fadd_rn(__fadd_rn(__fmul_rn(a.cam.s[0], dxs), __fmul_rn(a.cam.u[0], dys)), a.cam.f[0]),
+                __fadd_rn(__fadd_rn(__fmul_rn(a.cam.s[1], dxs), __fmul_rn(a.cam.u[1], dys)), a.cam.f[1]),
+                __fadd_rn(__fadd_rn(__fmul_rn(a.cam.s[2], dxs), __fmul_rn(a.cam.u[2], dys)), a.cam.f[2]));
+        tsd = ((double)X.x - (double)a.cam.eye[0]) * (double)a.cam.f[0] + ((double)X.y - (double)a.cam.eye[1]) * (double)a.cam.f[1] +
+              ((double)X.z - (double)a.cam.eye[2]) * (double)a.cam.f[2];
+        const float tsurf = (float)tsd;
+        const V3 off = dj * tsurf - (X - v3(a.cam.eye));
+        const float rin = a.proxy_rin * a.fp.photon_radius * (1.0f - 1.0e-5f) - 4.0e-6f * tsurf;
+        if (tsurf >= 0.1f + (1.0f + a.proxy_rout) * a.fp.photon_radius * 1.001f && dot(off, off) <= 1.0e-11f * tsurf * tsurf && rin > 0.0f) rin2 = rin * rin;
+    }
     // no specular lobe anywhere in the tile: PhongEval is rho_s * (...) = exactly 0, skip its powf (wave-uniform)
     const bool tile_glossy = __ballot(sps.x != 0.0f || sps.y != 0.0f || sps.z != 0.0f) != 0ull;
 
@@ -502,21 +571,92 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
         // (eight photons per trip with literal bits, the trip's byte shifted into place: as one counted loop with a 64-bit shift per
         // photon the compiler spent 16 vector instructions per photon, seven of them on the loop counter and the shift; unrolled over
         // all 64 it keeps every photon's position in registers at once and spills)
-        uint32_t mlo = 0u, mhi = 0u;
+        uint32_t mlo = 0u, mhi = 0u, ilo = 0u, ihi = 0u;
 #pragma unroll 1
         for (uint32_t o = 0; o * 8u < n; o++) {
             const float4 *sp = stage + o * 8u;
-            uint32_t b8 = 0u;
+            uint32_t b8 = 0u, i8 = 0u;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const V3 dv = v3(sp[j]) - X;
-                if (!(dot(dv, dv) > r2)) b8 |= 1u << j;                   // frag:153-154
+                const float d2 = dot(dv, dv);
+                if (!(d2 > r2)) b8 |= 1u << j;                            // frag:153-154
+                if (PROXY && !(d2 > rin2)) i8 |= 1u << j;
             }
-            if (o < 4u) mlo |= b8 << (8u * o); else mhi |= b8 << (8u * (o - 4u));
+            if (o < 4u) { mlo |= b8 << (8u * o); ilo |= i8 << (8u * o); } else { mhi |= b8 << (8u * (o - 4u)); ihi |= i8 << (8u * (o - 4u)); }
         }
         uint64_t mask = ((uint64_t)mhi << 32) | (uint64_t)mlo;
         if (!in_image) mask = 0ull;
         pairs += (uint32_t)__builtin_popcountll(mask);
+        uint64_t dbl = 0ull;
+        if (PROXY) {
+            uint64_t rim = mask & ~(((uint64_t)ihi << 32) | (uint64_t)ilo);
+            uint64_t kill = 0ull;
+            while (__ballot(rim != 0ull) != 0ull) {
+                // The next up to 64 rim pairs of the wave: rounds of "every pixel's next rim photon", compacted by the round's ballot.  The
+                // pixel's lane leaves its pair as (ray point - photon, who) in the list: the pair's lanes need nothing else from it but the ray.
+                uint32_t np = 0u;
+                for (;;) {
+                    const uint64_t have = __ballot(rim != 0ull);
+                    const uint32_t nh = (uint32_t)__builtin_popcountll(have);
+                    if (nh == 0u || np + nh > 64u) break;
+                    if (rim != 0ull) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(rim);
+                        rim &= rim - 1ull;
+                        const float4 pc = stage[j];
+                        const uint32_t at = np + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0u));
+                        aux[at] = make_float4((float)(__builtin_fma(tsd, (double)dj.x, (double)a.cam.eye[0]) - (double)pc.x),
+                                                       (float)(__builtin_fma(tsd, (double)dj.y, (double)a.cam.eye[1]) - (double)pc.y),
+                                                       (float)(__builtin_fma(tsd, (double)dj.z, (double)a.cam.eye[2]) - (double)pc.z), __uint_as_float((uint32_t)lane | (j << 6)));
+                    }
+                    np += nh;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const int lg = np <= 4u ? 4 : np <= 8u ? 3 : np <= 16u ? 2 : np <= 32u ? 1 : 0;      // lanes per pair = 1 << lg
+                const uint32_t pair = (uint32_t)lane >> lg, sub = (uint32_t)lane & ((1u << lg) - 1u), step = 1u << lg;
+                const bool act = pair < np;
+                const float4 ent = aux[act ? pair : 0u];
+                const uint32_t who = __float_as_uint(ent.w), pl = who & 63u, pj = who >> 6;
+                // (every pair has its entry in registers: the same 1 KB now takes the verdicts of this trip, four words per pixel)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                aux[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                uint32_t *const verdict = reinterpret_cast<uint32_t *>(aux);
+                const V3 q = v3(ent);
+                const float tsf = (float)tsd;
+                const V3 D = v3(__shfl(dj.x * tsf, (int)pl), __shfl(dj.y * tsf, (int)pl), __shfl(dj.z * tsf, (int)pl));
+                float enter = -3.0e38f, exitp = 3.0e38f;
+                for (uint32_t i = sub; i < (uint32_t)a.proxy_count; i += step) {
+                    const float4 sl = s_slab[i]; const float w = s_slabw[i];
+                    const V3 nn = v3(sl);
+                    const float av = dot(nn, q), bv = dot(nn, D);
+                    // (a ray parallel to the slab: the clamped reciprocal keeps both parameters finite and on the right sides)
+                    const float rb = __builtin_amdgcn_fmed3f(rcp_hw(bv), -1.0e30f, 1.0e30f);
+                    const float tp = (sl.w - av) * rb, tm = __builtin_fmaf(-w, rb, tp);
+                    enter = fmaxf(enter, fminf(tp, tm)); exitp = fminf(exitp, fmaxf(tp, tm));
+                }
+                for (uint32_t off = 1u; off < step; off <<= 1) {
+                    enter = fmaxf(enter, __shfl_xor(enter, (int)off)); exitp = fminf(exitp, __shfl_xor(exitp, (int)off));
+                }
+                if (act && sub == 0u) {
+                    // s = -1 at the eye; the near plane (view depth 0.1, rtcommon.h:586) at 0.1 / depth(X) - 1; LEQUAL with the
+                    // oracle's relative slack
+                    const float nearp = 0.1f * rcp_hw(dot(D, v3(a.cam.f))) - 1.0f, slack = 1.0e-7f;
+                    int count = 0;
+                    if (enter < exitp) count = ((enter >= nearp && enter <= slack) ? 1 : 0) + ((exitp >= nearp && exitp <= slack) ? 1 : 0);
+                    const uint32_t bit = 1u << (pj & 31u), word = pj >> 5;
+                    if (count == 0) atomicOr(&verdict[pl * 4u + word], bit);
+                    else if (count == 2) atomicOr(&verdict[pl * 4u + 2u + word], bit);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const float4 vd = aux[lane];
+                kill |= ((uint64_t)__float_as_uint(vd.y) << 32) | (uint64_t)__float_as_uint(vd.x);
+                dbl |= ((uint64_t)__float_as_uint(vd.w) << 32) | (uint64_t)__float_as_uint(vd.z);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+            mask &= ~kill;
+            frags += (uint32_t)__builtin_popcountll(mask) + (uint32_t)__builtin_popcountll(dbl);
+        }
         // Pass 2: every pixel walks ITS photons in ascending order (the accumulation order of the one-photon-at-a-time loop);
         // the wave runs max-over-pixels iterations instead of one per photon.
         while (__ballot(mask != 0ull) != 0ull) {
@@ -549,18 +689,25 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
                         }
                     }
                     sum = sum + col;
+                    if (PROXY && ((dbl >> j) & 1ull) != 0ull) sum = sum + col;   // both faces of the proxy lie in front of the surface: two fragments, blended one after the other
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    for (int off = 32; off > 0; off >>= 1) pairs += __shfl_down(pairs, off);
+    for (int off = 32; off > 0; off >>= 1) { pairs += __shfl_down(pairs, off); if (PROXY) frags += __shfl_down(frags, off); }
     if (WAVES == 4) {
-        if (wave != 0) red[wave - 1][lane] = make_float4(sum.x, sum.y, sum.z, lane == 0 ? __uint_as_float(pairs) : 0.f);
+        // (.w: lane 0 carries the wave's pairs; lane 1 -- whose own count went into lane 0's -- the wave's proxy fragments)
+        const uint32_t frags0 = (uint32_t)__shfl((int)frags, 0);
+        if (wave != 0) stage[lane] = make_float4(sum.x, sum.y, sum.z, lane == 0 ? __uint_as_float(pairs) : lane == 1 ? __uint_as_float(frags0) : 0.f);
         __syncthreads();
     }
     if (part == 0) {
-        if (WAVES == 4) for (int w = 0; w < 3; w++) { float4 q = red[w][lane]; sum = sum + v3(q); if (lane == 0) pairs += __float_as_uint(q.w); }
+        if (WAVES == 4) for (int w = 1; w < 4; w++) {
+            const float4 *other = stage_base + w * stage_rows * 64;
+            float4 q = other[lane]; sum = sum + v3(q);
+            if (lane == 0) { pairs += __float_as_uint(q.w); if (PROXY) frags += __float_as_uint(other[1].w); }
+        }
 #if EVPLP_DEBUG_NAN
         if (in_image && !(isfinite(sum.x) && isfinite(sum.y) && isfinite(sum.z))) atomicAdd(&a.counters->nonfinite, 1ull);
 #endif
@@ -570,6 +717,7 @@ __global__ __launch_bounds__(256, 8) void splat_tiles_kernel(SplatArgs a) {
         }
         if (lane == 0) {
             a.tile_pairs[tile] = pairs;
+            if (PROXY) a.tile_frags[tile] = frags;
             // running total of the context (never cleared; words 4-5 of the 1024 summary lines): lets a caller count pairs over many
             // passes without reading anything back in between
             if (pairs) atomicAdd(reinterpret_cast<unsigned long long *>(&a.summary[((uint32_t)tile & (uint32_t)(kSummaryShards - 1)) * kSummaryStride + 4]), (unsigned long long)pairs);
@@ -598,8 +746,11 @@ void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hip
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     if (a.deterministic) hipLaunchKernelGGL(splat_sort_kernel, dim3(ntiles), dim3(256), 0, s, a.tile_cursor, a.bin_stride, a.bin_items_tmp, a.bin_items, a.overflow);
     if (dom_begin) hipEventRecord(dom_begin, s);
-    if (split_tiles) hipLaunchKernelGGL(splat_tiles_kernel<4>, dim3(ntiles), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(splat_tiles_kernel<1>, dim3((ntiles + 3) / 4), dim3(256), 0, s, a);
+    const bool proxy = a.fp.splat_footprint == (uint32_t)EVPLP_FOOTPRINT_PROXY;
+    // dynamic LDS of the tile kernel (its layout is at the top of splat_tiles_kernel)
+    const size_t lds_bytes = sizeof(float4) * (size_t)(4 * (a.fp.mis_mode == 5u ? 4 : 3) * 64) + (proxy ? sizeof(float4) * (size_t)(4 * 64 + a.proxy_count) + sizeof(float) * (size_t)a.proxy_count : 0);
+    if (split_tiles) { if (proxy) hipLaunchKernelGGL((splat_tiles_kernel<4, true>), dim3(ntiles), dim3(256), lds_bytes, s, a); else hipLaunchKernelGGL((splat_tiles_kernel<4, false>), dim3(ntiles), dim3(256), lds_bytes, s, a); }
+    else { if (proxy) hipLaunchKernelGGL((splat_tiles_kernel<1, true>), dim3((ntiles + 3) / 4), dim3(256), lds_bytes, s, a); else hipLaunchKernelGGL((splat_tiles_kernel<1, false>), dim3((ntiles + 3) / 4), dim3(256), lds_bytes, s, a); }
     if (dom_end) hipEventRecord(dom_end, s);
 }
 

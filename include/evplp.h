@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EVPLP_ABI_VERSION 2
+#define EVPLP_ABI_VERSION 3
 
 typedef enum evplp_status {
     EVPLP_OK = 0,
@@ -101,6 +101,16 @@ typedef struct evplp_config {
                                   *    write it wait for its readers as they do without this flag;
                                   *  - up to two photon splats may be waiting for the verdict on their bin sizes; with `deterministic`
                                   *    set none is ever left pending behind a younger one (bitwise reproducible accumulation). */
+    /* Upper bounds of the two large scratch buffers of the gathers, in bytes; 0 = the library's default.  Both are allocated on the first
+     * gather that needs them, grow to what the configuration asks for within the bound, and live until evplp_destroy.
+     *  cut_scratch_bytes: the entry cuts of the VPL / VSL gathers, 256 bytes per (group of 2 x 2 tiles, VPL record slot): 4.3 GB at
+     *    config #2, 68 GB at config #5.  Default: a quarter of the device's memory, at most half of what is free at the first gather.
+     *    A configuration that needs more is gathered in bands of tile rows (same results); a bound too small for one row of tile
+     *    blocks, or an allocation that fails, makes the walks start at the root (same results, slower).
+     *  vsl_mask_bytes: the lit-lane masks between the two kernels of the VSL gather (8 bytes per (tile, VSL slot) of a launch).
+     *    Default: a twentieth of the device's memory, at most a quarter of what is free; smaller bounds mean more launches. */
+    uint64_t cut_scratch_bytes;
+    uint64_t vsl_mask_bytes;
     int32_t reserved[2];
 } evplp_config;
 
@@ -134,7 +144,21 @@ typedef struct evplp_frame_params {
     uint32_t do_accumulate;      /* doAccumulate */
     uint32_t rng_seed;           /* rngSeed = numIterations + rngOffset (rtcomphoton.h:965) */
     float jitter[2];             /* NDC translation of the jitter matrix (rtcomphoton.h:949) */
+    uint32_t splat_footprint;    /* evplp_splat_footprint: which pixels a photon reaches (evplp_splat_photons only) */
+    uint32_t reserved;
 } evplp_frame_params;
+
+/* The footprint of a photon in evplp_splat_photons.
+ *  EVPLP_FOOTPRINT_IDEAL: pixel p receives photon i once iff |X_p - P_i|^2 <= r^2 (the radius test of photonsplatinstanced.frag:152-154
+ *    alone).
+ *  EVPLP_FOOTPRINT_PROXY: the reference's coverage rule.  It draws an instanced proxy mesh (sphere/icosphere.obj, rtcomphoton.h:677,
+ *    632-644) scaled by the radius around every photon (photonsplatinstanced.vert:28-33), un-culled (glEnable(GL_CULL_FACE) is commented
+ *    out, rtcomphoton.h:653-655), depth-tested LEQUAL against the deferred pass without depth writes (:789-837), and runs the fragment
+ *    shader once per rasterised FACE fragment (.geom:16-32, .frag:146-240): a pixel inside the radius receives the photon once per
+ *    face of the scaled proxy that its eye ray crosses between the near plane and the visible surface -- 0, 1 or 2 times for a convex
+ *    mesh.  The mesh is the one given to evplp_set_splat_proxy, or the generated 42-vertex / 80-face icosphere
+ *    (evplp_default_splat_proxy) if none was given. */
+typedef enum evplp_splat_footprint { EVPLP_FOOTPRINT_IDEAL = 0, EVPLP_FOOTPRINT_PROXY = 1 } evplp_splat_footprint;
 
 /* Device buffers a caller may read back, bind to external memory, or hand to a collective. */
 typedef enum evplp_buffer {
@@ -153,7 +177,7 @@ typedef enum evplp_buffer {
 typedef struct evplp_pass_stats {
     float ms;                /* device time of the pass */
     uint64_t pairs;          /* gather: (pixel, usable record) pairs; splat: (photon, covered pixel) pairs */
-    uint64_t rays;           /* rays traced by the pass */
+    uint64_t rays;           /* rays traced by the pass; photon splat with EVPLP_FOOTPRINT_PROXY: fragments of the proxy mesh (0, 1 or 2 per pair) */
     uint64_t usable;         /* usable VPL / photon records consumed */
     float dominant_kernel_ms;/* device time of the pass's dominant kernel alone (summed over its launches) */
     uint32_t reserved[3];    /* [0], [1]: a 64-bit count -- VSL gather: sample-iterations of the estimators; diagnostic builds: node visits; splat: bin entries, fullest bin */
@@ -229,8 +253,15 @@ int evplp_gather_lvc(evplp_context *ctx, const evplp_frame_params *fp);
  * visible pixel continued from the G-buffer for at most max_bounces bounces, next-event estimation at every
  * vertex; radiance is ADDED to EVPLP_BUF_VPL_ACCUM when do_accumulate != 0, else replaces it ("outputBuffer"). */
 int evplp_path_trace(evplp_context *ctx, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
-/* [photonSplat]: runPhotonSplat (:789-837); clear != 0 = cleareveryframe (:978-981) */
+/* [photonSplat]: runPhotonSplat (:789-837); clear != 0 = cleareveryframe (:978-981); fp->splat_footprint selects the coverage rule */
 int evplp_splat_photons(evplp_context *ctx, const evplp_frame_params *fp, int32_t clear);
+/* setupPhotonSplatIcosohedron (rtcomphoton.h:632-644, called with "sphere/icosphere.obj" at :677): the proxy mesh of
+ * EVPLP_FOOTPRINT_PROXY, in units of the photon radius around the photon (vertices float3[nverts], triangles int3[ntris]; any winding).
+ * The mesh must be closed and convex with the origin strictly inside, and have at most EVPLP_MAX_PROXY_PLANES distinct face planes
+ * (coplanar triangles count once: a ray crosses one of them); anything else is refused with EVPLP_ERR_INVALID -- the fragment count
+ * of a non-convex proxy is not the entry / exit rule the kernel implements.  vertices = NULL restores the generated icosphere. */
+#define EVPLP_MAX_PROXY_PLANES 128
+int evplp_set_splat_proxy(evplp_context *ctx, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris);
 /* [finalize] / dumpImage: runFinalProgram(vplScale, photonScale, lightScale, gamma) (:756-787,
  * final.frag:19-35).  mask_emitter = on-screen composite (1) or saved-image sum (0, :1121-1132).
  * out_rgb: HOST pointer, 3 floats per pixel, local_rows * W pixels, y = 0 bottom. */
@@ -304,6 +335,7 @@ int evplp_group_primary(evplp_group *g, const float jitter[2], int32_t light_fla
 int evplp_group_trace_light_paths(evplp_group *g, uint32_t rng_seed);
 int evplp_group_gather(evplp_group *g, const evplp_frame_params *fp, int32_t kind);   /* 0 evplp_gather_vpl, 1 _vsl, 2 _lvc */
 int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int32_t clear);
+int evplp_group_set_splat_proxy(evplp_group *g, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris);
 int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
 int evplp_group_synchronize(evplp_group *g);
 /* evplp_resolve for the whole frame: out_rgb = HOST pointer, res_y * res_x * 3 floats, y = 0 bottom */
@@ -319,6 +351,10 @@ int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, flo
  * (2 u - 1) / resolution with u = IndependentSampler(rngOffset).nextVec2() (rtcomphoton.h:887, 946-952) -- the reference's own
  * sampler headers as they behave under g++ / libstdc++ (tests/golden/jitter.npz); out_ndc_xy: 2 * count floats. */
 int evplp_jitter_sequence(uint32_t rng_offset, int32_t count, int32_t res_x, int32_t res_y, float *out_ndc_xy);
+/* The proxy EVPLP_FOOTPRINT_PROXY uses when no mesh was given: an icosahedron subdivided once onto the unit sphere (42 vertices, 80
+ * faces -- the shape the 2178 bytes of the reference's sphere/icosphere.obj, a Git-LFS stub, imply), poles on the y axis.
+ * vertices: 42 x 3 floats, indices: 80 x 3 ints (either may be NULL).  Returns the number of triangles (80). */
+int evplp_default_splat_proxy(float *vertices, int32_t *indices);
 /* The library's JSON reader as the technique blocks use it, for checking it against the reference's (vendored nlohmann::json
  * 2.1.1; main.cpp:105-121, rtcomphoton.h:107-223 -- tests/golden/json_pins.json): `path` = keys separated by '/', decimal indices
  * into arrays.  want: 0 `int v = json[..]`, 1 float, 2 bool, 3 std::string (into str, cap bytes), 4 size(), 5 kind (0 null, 1 bool,

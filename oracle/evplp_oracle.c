@@ -1199,13 +1199,20 @@ static void icosphere42(double v[42][3], int f[80][3]) {
         for (int q = 0; q < 4; q++) { for (int k = 0; k < 3; k++) f[out][k] = tri[q][k]; out++; }
     }
 }
-/* faces of the proxy (centre c, radius r) crossed by the ray e + t d with t in [tnear, tfar] (double precision; a ray through an edge
- * or a vertex of the proxy -- measure zero -- may count a face twice, the rasteriser's fill rule would not) */
-static int proxy_faces_in_front(const double v[42][3], const int f[80][3], const float c[3], float r, const double e[3], const double d[3], double tnear, double tfar) {
+/* the generated mesh as floats, for callers that hand the same mesh to the product (evplp_set_splat_proxy) */
+void evo_icosphere42(float *verts, int32_t *tris) {
+    double v[42][3]; int f[80][3]; icosphere42(v, f);
+    for (int i = 0; i < 42; i++) for (int k = 0; k < 3; k++) verts[3 * i + k] = (float)v[i][k];
+    for (int t = 0; t < 80; t++) for (int k = 0; k < 3; k++) tris[3 * t + k] = f[t][k];
+}
+/* faces of the proxy mesh (vertices in units of the radius r around the centre c) crossed by the ray e + t d with t in [tnear, tfar]:
+ * one ray / triangle test per face, in double precision (a ray through an edge or a vertex of the proxy -- measure zero -- may count a
+ * face twice, the rasteriser's fill rule would not) */
+int evo_proxy_faces_in_front(const float *mv, const int32_t *mf, int32_t nf, const float c[3], float r, const double e[3], const double d[3], double tnear, double tfar) {
     int n = 0;
-    for (int t = 0; t < 80; t++) {
+    for (int t = 0; t < nf; t++) {
         double p0[3], p1[3], p2[3];
-        for (int k = 0; k < 3; k++) { p0[k] = c[k] + (double)r * v[f[t][0]][k]; p1[k] = c[k] + (double)r * v[f[t][1]][k]; p2[k] = c[k] + (double)r * v[f[t][2]][k]; }
+        for (int k = 0; k < 3; k++) { p0[k] = c[k] + (double)r * mv[3 * mf[3 * t] + k]; p1[k] = c[k] + (double)r * mv[3 * mf[3 * t + 1] + k]; p2[k] = c[k] + (double)r * mv[3 * mf[3 * t + 2] + k]; }
         double e1[3], e2[3], pv[3], tv[3], qv[3];
         for (int k = 0; k < 3; k++) { e1[k] = p1[k] - p0[k]; e2[k] = p2[k] - p0[k]; tv[k] = e[k] - p0[k]; }
         pv[0] = d[1] * e2[2] - d[2] * e2[1]; pv[1] = d[2] * e2[0] - d[0] * e2[2]; pv[2] = d[0] * e2[1] - d[1] * e2[0];
@@ -1221,13 +1228,14 @@ static int proxy_faces_in_front(const double v[42][3], const int f[80][3], const
     }
     return n;
 }
-/* Both footprints over the same pixels and photons: out_ideal as evo_splat_photons, out_proxy with the reference's coverage count.
+/* Both footprints over the same pixels and photons: out_ideal as evo_splat_photons, out_proxy with the reference's coverage count for
+ * the proxy mesh (mesh_verts: float3 per vertex in units of the radius, mesh_tris: int3 per face).
  * stats[0] = (photon, pixel) pairs inside the radius, [1] = of those with no proxy face in front (missed by the reference),
  * [2] = with two (counted twice by the reference), [3] = proxy fragments in total. */
-void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
-                             const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
-                             const evo_record *records, uint32_t num_records, float *out_ideal, float *out_proxy, uint64_t stats[4]) {
-    double iv[42][3]; int ifc[80][3]; icosphere42(iv, ifc);
+void evo_splat_photons_proxy_mesh(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                                  const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                                  const evo_record *records, uint32_t num_records, const float *mesh_verts, const int32_t *mesh_tris, int32_t mesh_ntris,
+                                  float *out_ideal, float *out_proxy, uint64_t stats[4]) {
     const cam_basis cb = cam_make(cam);
     const float r = fp->photon_radius;
     uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -1248,6 +1256,7 @@ void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, 
     const int reach = (int)ceilf(r / cell);
 #pragma omp parallel for schedule(dynamic, 2) reduction(+ : s0, s1, s2, s3) num_threads(evo_get_threads())
     for (int32_t y = row_begin; y < row_end; y++) {
+        uint32_t cand[4096];
         for (int32_t x = 0; x < W; x++) {
             const size_t p = ((size_t)y * W + x) * 4;
             const float *X = g_pos + p;
@@ -1260,27 +1269,47 @@ void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, 
             const double e[3] = { cb.eye.x, cb.eye.y, cb.eye.z }, d[3] = { dj.x, dj.y, dj.z };
             /* view depth of the visible surface along that ray: the direction has camera-space z = -1 */
             const double tsurf = ((double)X[0] - e[0]) * cb.f.x + ((double)X[1] - e[1]) * cb.f.y + ((double)X[2] - e[2]) * cb.f.z;
-            double si[3] = { 0, 0, 0 }, sp[3] = { 0, 0, 0 };
+            /* candidates in ascending record order: the accumulation order of evo_splat_photons (and of a deterministic product context) */
+            uint32_t nc = 0; uint32_t *cp = cand; uint32_t cap = 4096;
             for (int cz = c0[2]; cz <= c1[2]; cz++) for (int cyy = c0[1]; cyy <= c1[1]; cyy++) for (int cxx = c0[0]; cxx <= c1[0]; cxx++) {
                 const size_t c = ((size_t)cz * dim[1] + cyy) * dim[0] + cxx;
                 for (uint32_t j = start[c]; j < start[c + 1]; j++) {
-                    const uint32_t i = items[j]; float col[3];
-                    if (i == 0) continue;
-                    const v3 dv = sub(ld3(records[i].pos), ld3(X));
-                    if (!(dot(dv, dv) <= r * r)) continue;
-                    s0++;
-                    const int kept = evo_photon_frag(fp, &records[i], &records[i - 1], X, g_nrm + p, g_dif + p, g_phg + p, col);
-                    const int faces = proxy_faces_in_front(iv, ifc, records[i].pos, r, e, d, 0.1, tsurf * (1.0 + 1e-7));
-                    if (faces == 0) s1++; if (faces >= 2) s2++; s3 += (uint64_t)faces;
-                    if (kept) for (int k = 0; k < 3; k++) { si[k] += col[k]; sp[k] += (double)faces * col[k]; }
+                    if (nc == cap) { uint32_t *np_ = (uint32_t *)malloc(sizeof(uint32_t) * cap * 2); memcpy(np_, cp, sizeof(uint32_t) * nc); if (cp != cand) free(cp); cp = np_; cap *= 2; }
+                    cp[nc++] = items[j];
                 }
             }
-            for (int k = 0; k < 3; k++) { out_ideal[p + k] += (float)si[k]; out_proxy[p + k] += (float)sp[k]; }
+            for (uint32_t a = 1; a < nc; a++) { uint32_t v = cp[a]; uint32_t b = a; while (b > 0 && cp[b - 1] > v) { cp[b] = cp[b - 1]; b--; } cp[b] = v; }
+            v3 si = V3(0, 0, 0), sp = V3(0, 0, 0);
+            for (uint32_t a = 0; a < nc; a++) {
+                const uint32_t i = cp[a]; float col[3];
+                if (i == 0) continue;
+                const v3 dv = sub(ld3(records[i].pos), ld3(X));
+                if (!(dot(dv, dv) <= r * r)) continue;
+                s0++;
+                const int kept = evo_photon_frag(fp, &records[i], &records[i - 1], X, g_nrm + p, g_dif + p, g_phg + p, col);
+                const int faces = evo_proxy_faces_in_front(mesh_verts, mesh_tris, mesh_ntris, records[i].pos, r, e, d, 0.1, tsurf * (1.0 + 1e-7));
+                if (faces == 0) s1++; if (faces >= 2) s2++; s3 += (uint64_t)faces;
+                if (kept) {
+                    si = add(si, V3(col[0], col[1], col[2]));
+                    for (int f = 0; f < faces; f++) sp = add(sp, V3(col[0], col[1], col[2]));     /* one blend per fragment */
+                }
+            }
+            if (cp != cand) free(cp);
+            out_ideal[p + 0] += si.x; out_ideal[p + 1] += si.y; out_ideal[p + 2] += si.z;
+            out_proxy[p + 0] += sp.x; out_proxy[p + 1] += sp.y; out_proxy[p + 2] += sp.z;
         }
     }
 #undef CELL_OF
     free(start); free(items);
     if (stats) { stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; }
+}
+/* ... with the generated 42-vertex / 80-face icosphere */
+void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                             const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                             const evo_record *records, uint32_t num_records, float *out_ideal, float *out_proxy, uint64_t stats[4]) {
+    float mv[42 * 3]; int32_t mf[80 * 3];
+    evo_icosphere42(mv, mf);
+    evo_splat_photons_proxy_mesh(fp, cam, W, H, row_begin, row_end, g_pos, g_nrm, g_dif, g_phg, records, num_records, mv, mf, 80, out_ideal, out_proxy, stats);
 }
 
 /* ------------------------------------------------------------------ resolve */

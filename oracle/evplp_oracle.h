@@ -186,6 +186,14 @@ void evo_splat_photons(const evo_frame_params *fp, int32_t W, int32_t H, int32_t
 /* the same pixels and photons under both footprints: the ideal sphere (out_ideal) and the reference's instanced icosphere proxy with
  * depth test and no face culling (out_proxy; rtcomphoton.h:632-655, 789-837, photonsplatinstanced.vert:28-33).  stats: pairs inside the
  * radius, of those missed by the proxy, counted twice by it, proxy fragments.  Test infrastructure: quantifies DESIGN.md deviation (4) */
+void evo_icosphere42(float *verts42x3, int32_t *tris80x3);
+/* faces of the proxy mesh (vertices in units of r around c) that the ray e + t d crosses with t in [tnear, tfar] */
+int evo_proxy_faces_in_front(const float *mesh_verts, const int32_t *mesh_tris, int32_t mesh_ntris, const float c[3], float r, const double e[3], const double d[3], double tnear, double tfar);
+/* ... for any proxy mesh (vertices in units of the radius; the product's evplp_set_splat_proxy takes the same arrays) */
+void evo_splat_photons_proxy_mesh(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
+                                  const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
+                                  const evo_record *records, uint32_t num_records, const float *mesh_verts, const int32_t *mesh_tris, int32_t mesh_ntris,
+                                  float *out_ideal, float *out_proxy, uint64_t stats[4]);
 void evo_splat_photons_proxy(const evo_frame_params *fp, const evo_camera *cam, int32_t W, int32_t H, int32_t row_begin, int32_t row_end,
                              const float *g_pos, const float *g_nrm, const float *g_dif, const float *g_phg,
                              const evo_record *records, uint32_t num_records, float *out_ideal, float *out_proxy, uint64_t stats[4]);

@@ -99,6 +99,8 @@ def load():
     l.evo_photon_frag.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P]
     l.evo_splat_photons.argtypes = [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P]
     l.evo_splat_photons_proxy.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P]
+    l.evo_splat_photons_proxy_mesh.argtypes = [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, C.c_int32, _P, _P, _P]
+    l.evo_icosphere42.argtypes = [_P, _P]
     l.evo_resolve.argtypes = [C.c_int32, C.c_int32, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P]
     l.evo_progressive_step.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_int, _P, _P]
     l.evo_path_trace.restype = C.c_uint64
@@ -212,15 +214,26 @@ def splat(fp, W, H, gbuf, records, out=None, rows=None):
     return out, pairs.value
 
 
-def splat_proxy(fp, cam, W, H, gbuf, records, rows=None):
-    """Both footprints of the photon splat on the same pixels: (ideal sphere image, reference icosphere-proxy image, stats) -- stats =
-    pairs inside the radius, of those missed by the proxy, counted twice by it, proxy fragments (oracle/evplp_oracle.c)."""
+def icosphere42():
+    """the oracle's generated proxy mesh: (vertices float32 [42, 3], triangles int32 [80, 3])"""
+    v = np.zeros((42, 3), dtype=np.float32); t = np.zeros((80, 3), dtype=np.int32)
+    load().evo_icosphere42(ptr(v), ptr(t))
+    return v, t
+
+
+def splat_proxy(fp, cam, W, H, gbuf, records, rows=None, mesh=None, out=None):
+    """Both footprints of the photon splat on the same pixels: (ideal sphere image, reference proxy-mesh image, stats) -- stats =
+    pairs inside the radius, of those missed by the proxy, counted twice by it, proxy fragments (oracle/evplp_oracle.c).
+    mesh = (vertices, triangles) of the proxy in units of the radius (default: the generated icosphere); out: accumulate the proxy
+    image into this array."""
     l = load()
-    ideal = np.zeros((H, W, 4), dtype=np.float32); proxy = np.zeros((H, W, 4), dtype=np.float32)
+    ideal = np.zeros((H, W, 4), dtype=np.float32); proxy = np.zeros((H, W, 4), dtype=np.float32) if out is None else out
     st = np.zeros(4, dtype=np.uint64)
     r0, r1 = rows if rows else (0, H)
-    l.evo_splat_photons_proxy(C.byref(fp), C.byref(cam), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), records.shape[0],
-                              ptr(ideal), ptr(proxy), ptr(st))
+    v, t = mesh if mesh is not None else icosphere42()
+    v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3); t = np.ascontiguousarray(t, dtype=np.int32).reshape(-1, 3)
+    l.evo_splat_photons_proxy_mesh(C.byref(fp), C.byref(cam), W, H, r0, r1, ptr(gbuf[0]), ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(records), records.shape[0],
+                                   ptr(v), ptr(t), t.shape[0], ptr(ideal), ptr(proxy), ptr(st))
     return ideal, proxy, st
 
 

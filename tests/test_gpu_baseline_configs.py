@@ -130,14 +130,22 @@ def test_config3_evplp_hard_scene_rows(evplp, hard_scene):
         vpl = c.download(evplp.BUF_VPL_ACCUM)[ok]; pm = c.download(evplp.BUF_PHOTON_ACCUM)[ok]
         rec = c.download(evplp.BUF_RECORDS)
         pairs = c.pass_stats(evplp.PASS_SPLAT)["pairs"]
+        # ... and under the reference's coverage rule (the generated icosphere as the proxy mesh, EVPLP_FOOTPRINT_PROXY)
+        c.splat_photons(evplp.frame_params(**kw, splat_footprint="proxy"), clear=True)
+        pmx = c.download(evplp.BUF_PHOTON_ACCUM)[ok]
+        stx = c.pass_stats(evplp.PASS_SPLAT)
     # 2 M record slots, every byte as the oracle traces them
     assert rec.tobytes() == osc.trace_light_paths(3, N, P).tobytes()
     okw = dict(kw); okw["mis_mode"] = 1
-    ovpl = np.zeros((H, W, 4), np.float32); opm = np.zeros((H, W, 4), np.float32); opairs = 0
+    ovpl = np.zeros((H, W, 4), np.float32); opm = np.zeros((H, W, 4), np.float32); opmx = np.zeros((H, W, 4), np.float32); opairs = 0; ofrags = 0
     for r0, r1 in row_blocks(rows):
         osc.gather(oa.frame_params(**okw), W, H, gbuf, rec, out=ovpl, rows=(r0, r1))
-        _, n = oa.splat(oa.frame_params(**okw), W, H, gbuf, rec, out=opm, rows=(r0, r1)); opairs += n
+        ideal, _, ost = oa.splat_proxy(oa.frame_params(**okw), osc.camera(), W, H, gbuf, rec, rows=(r0, r1), out=opmx)
+        opm += ideal; opairs += int(ost[0]); ofrags += int(ost[3])
     assert (rec["flags"] & 2).astype(bool).sum() > 1_000_000 and opairs > 1000 and pairs == opairs
+    # a pair whose eye ray meets an edge of its proxy to within rounding may fall either way (fp32 planes here, fp64 triangles there)
+    assert stx["pairs"] == opairs and abs(stx["rays"] - ofrags) <= max(2, ofrags // 100_000), (stx["rays"], ofrags)
+    assert 0.9 < ofrags / opairs < 1.0 and rel_l2(pmx[..., :3], opmx[rows][..., :3]) <= (1e-5 if stx["rays"] == ofrags else 1e-3)
     for got, ref in ((vpl, ovpl[rows]), (pm, opm[rows])):
         assert ref[..., :3].max() > 0
         assert rel_l2(got[..., :3], ref[..., :3]) <= 1e-5
@@ -187,8 +195,8 @@ def test_config4_progressive_photon_mapping_1080p_loop(evplp, tmp_path):
             gy = osc.primary(W, H, jitter, rows=(y, y + 1))
             for k in range(5):
                 g[k][y] = gy[k][y]
-        for y in rows:
-            oa.splat(oa.frame_params(**kw), W, H, g, rec, out=pm, rows=(y, y + 1))
+        for y in rows:                                         # the technique's default footprint: the reference's proxy rule
+            oa.splat_proxy(oa.frame_params(**kw), osc.camera(), W, H, g, rec, rows=(y, y + 1), out=pm)
         r, c_, p_, vr, vi = (C.c_float(x) for x in (radius, clamp, pdf_mc, 0.0, 0.0))
         l.evo_progressive_step(it + 1, 0.7, float(clamp_start), 0, NL, C.byref(r), C.byref(c_), C.byref(p_), 0, C.byref(vr), C.byref(vi))
         radius, clamp, pdf_mc = f32(r.value), f32(c_.value), f32(p_.value)
@@ -197,8 +205,12 @@ def test_config4_progressive_photon_mapping_1080p_loop(evplp, tmp_path):
     assert ref.max() > 0 and (ref.sum(-1) > 0).mean() > 0.5
     # G-buffer and light-path records are bit-identical to the oracle's (feeders without contraction, shared direction-sampling
     # math); the fragment arithmetic is toleranced and the bins are accumulated in atomic-cursor order (not deterministic mode)
-    assert rel_l2(mine, ref) <= 5e-6, rel_l2(mine, ref)
-    assert (np.abs(mine - ref) <= 2e-4 * np.maximum(ref, 1e-3 * ref.max()) + 1e-9).all()
+    # Proxy footprint: whether the eye ray crosses a face of the proxy in front of the surface is decided in fp32 here and in fp64 by the
+    # oracle; a pair within ~1e-7 of a face (or of the proxy's silhouette) may fall either way: 4e-6 of the pairs (measured,
+    # tools/debug_footprint.py: 7 pairs in 100 iterations of these two rows), each a whole contribution of one pixel in one iteration.
+    # Everything else agrees to round-off; the bar of the accumulated image is a quarter of the north star's 1e-3.
+    assert rel_l2(mine, ref) <= 2.5e-4, rel_l2(mine, ref)
+    assert (np.abs(mine - ref) <= 2e-4 * np.maximum(ref, 1e-3 * ref.max()) + 1e-9).mean() > 0.998
 
 
 def test_config5_progressive_vsl_and_photons_2048(evplp, tmp_path_factory):

@@ -138,7 +138,10 @@ def oracle_technique(json_path, block, lvc=False):
         if radius > 0 and run["photonSplat"]:
             if not accumulate:
                 pm[:] = 0
-            oa.splat(oa.frame_params(**kw), W, H, g, rec, out=pm)
+            if block.get("splatFootprint", "proxy") == "proxy":     # the technique's default: the reference's proxy-mesh coverage
+                oa.splat_proxy(oa.frame_params(**kw), osc.camera(), W, H, g, rec, out=pm)
+            else:
+                oa.splat(oa.frame_params(**kw), W, H, g, rec, out=pm)
         n_it += 1
         if block.get("DoProgressive", False):
             r, c, p, vr, vi = (C.c_float(x) for x in (radius, clamp, pdf_mc, 0.0, 0.0))

@@ -295,6 +295,114 @@ def test_photon_splat_modes(ctx, oscene, evplp, inputs, mode):
     assert np.allclose(twice[..., :3], 2 * got[..., :3], rtol=1e-6, atol=1e-9)
 
 
+def _proxy_meshes():
+    """Convex proxies beside the generated icosphere: a cube (coplanar triangle pairs, three slabs), a tetrahedron (no opposite
+    faces: four open slabs), the hull of 40 random points (no symmetry at all), an icosphere squashed and pushed off centre."""
+    from scipy.spatial import ConvexHull
+    ico_v, ico_t = oa.icosphere42()
+    c = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32) * np.float32(0.55)
+    cube_t = ConvexHull(c).simplices.astype(np.int32)
+    tet = np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], np.float32) * np.float32(0.5)
+    tet_t = np.array([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]], np.int32)
+    rng = np.random.default_rng(7)
+    pts = rng.normal(size=(40, 3)); pts = (pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.7, 1.0, (40, 1))).astype(np.float32)
+    hull = ConvexHull(pts)
+    keep = np.unique(hull.simplices); remap = -np.ones(40, np.int64); remap[keep] = np.arange(keep.size)
+    squashed = (ico_v * np.array([1.0, 0.6, 0.8], np.float32) + np.array([0.1, 0.05, -0.15], np.float32)).astype(np.float32)
+    return {"icosphere": (ico_v, ico_t), "cube": (c, cube_t), "tetrahedron": (tet, tet_t),
+            "hull40": (pts[keep], remap[hull.simplices].astype(np.int32)), "squashed": (squashed, ico_t)}
+
+
+def _splat_both_ways(ctx, evplp, oscene, gbuf, records, kw, mesh, cam=None):
+    fp = evplp.frame_params(**kw, splat_footprint="proxy")
+    ctx.splat_photons(fp, clear=True)
+    got = ctx.download(evplp.BUF_PHOTON_ACCUM)[:H]
+    st = ctx.pass_stats(evplp.PASS_SPLAT)
+    ideal, proxy, ost = oa.splat_proxy(oa.frame_params(**kw), cam or oscene.camera(), W, H, gbuf, records, mesh=mesh)
+    return got, st, ideal, proxy, ost
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_photon_splat_proxy_footprint_modes(ctx, oscene, evplp, inputs, mode):
+    """EVPLP_FOOTPRINT_PROXY: the reference's coverage rule -- one fragment per face of the radius-scaled proxy mesh that the pixel's eye
+    ray crosses in front of the visible surface, un-culled, depth test LEQUAL (rtcomphoton.h:653-655, 789-837;
+    photonsplatinstanced.vert:28-33, .geom:16-32) -- against the oracle's ray / triangle count over the same mesh
+    (evo_splat_photons_proxy_mesh): equal pair and fragment counts, images to the splat's bar."""
+    gbuf, records = inputs
+    ctx.primary((0.003, -0.002)); upload_inputs(ctx, evplp, gbuf, records)
+    ctx.set_splat_proxy()                                                   # the generated icosphere
+    radius = 0.35
+    kw = dict(camera_pos=oscene.sd.cam_origin, mis_mode=mode, pdf_mc=NPATHS / NPATHS / math.pi / radius ** 2, clamping_value=0.02,
+              photon_radius=radius, num_light_paths=NPATHS, num_vpl_light_paths=NPATHS, photons_per_path=P, jitter=(0.003, -0.002))
+    got, st, ideal, proxy, ost = _splat_both_ways(ctx, evplp, oscene, gbuf, records, kw, oa.icosphere42())
+    assert int(ost[0]) > 200 and st["pairs"] == int(ost[0]) and int(ost[1]) > 0 and int(ost[2]) > 0
+    # a pair whose eye ray meets an edge of the proxy to within rounding may fall either way: none here
+    assert st["rays"] == int(ost[3]), (st["rays"], ost)
+    assert_image_close(got[..., :3], proxy[..., :3], what=f"proxy splat mode {mode}")
+    assert mode == 2 or rel_l2(proxy[..., :3], ideal[..., :3]) > 1e-3      # ... and the two rules do differ (the max heuristic keeps only pairs deep inside their proxies here)
+    # the ideal rule is untouched by a proxy being set
+    ctx.splat_photons(evplp.frame_params(**kw), clear=True)
+    assert_image_close(ctx.download(evplp.BUF_PHOTON_ACCUM)[:H][..., :3], ideal[..., :3], what=f"ideal splat mode {mode}")
+
+
+@pytest.mark.parametrize("name", ["cube", "tetrahedron", "hull40", "squashed"])
+def test_photon_splat_proxy_meshes(ctx, oscene, evplp, inputs, name):
+    """evplp_set_splat_proxy with meshes that are not the icosphere: coplanar faces, faces without an opposite one, no symmetry, the
+    origin off centre -- and radii that bring the near plane into the proxies (every pair takes the full test)."""
+    gbuf, records = inputs
+    ctx.primary((0.003, -0.002)); upload_inputs(ctx, evplp, gbuf, records)
+    mesh = _proxy_meshes()[name]
+    ctx.set_splat_proxy(*mesh)
+    try:
+        for radius in (0.3, 1.5):
+            kw = dict(camera_pos=oscene.sd.cam_origin, mis_mode=1, pdf_mc=1.0 / math.pi / radius ** 2, photon_radius=radius, num_light_paths=NPATHS,
+                      num_vpl_light_paths=NPATHS, photons_per_path=P, jitter=(0.003, -0.002))
+            got, st, ideal, proxy, ost = _splat_both_ways(ctx, evplp, oscene, gbuf, records, kw, mesh)
+            assert st["pairs"] == int(ost[0]) and int(ost[0]) > 200
+            assert abs(st["rays"] - int(ost[3])) <= max(1, int(ost[3]) // 50000), (name, radius, st["rays"], ost)
+            if st["rays"] == int(ost[3]):
+                assert_image_close(got[..., :3], proxy[..., :3], what=f"proxy {name} r={radius}")
+            else:
+                assert rel_l2(got[..., :3], proxy[..., :3]) <= 1e-3
+    finally:
+        ctx.set_splat_proxy()
+
+
+def test_photon_splat_proxy_one_wave_per_tile(room, oscene, evplp, inputs):
+    """A context that is not `deterministic` takes the tile kernel with one wave per tile while its bins are short (the module's context
+    always takes the four-wave variant): the same fragments, the same image up to the order of the sums."""
+    gbuf, records = inputs
+    radius = 0.35
+    kw = dict(camera_pos=oscene.sd.cam_origin, mis_mode=1, pdf_mc=1.0 / math.pi / radius ** 2, photon_radius=radius, num_light_paths=NPATHS,
+              num_vpl_light_paths=NPATHS, photons_per_path=P, jitter=(0.003, -0.002))
+    with evplp.Context(W, H, NPATHS, NPATHS, P) as c:
+        room.upload(c)
+        c.primary((0.003, -0.002)); upload_inputs(c, evplp, gbuf, records)
+        for _ in range(2):
+            got, st, ideal, proxy, ost = _splat_both_ways(c, evplp, oscene, gbuf, records, kw, None)
+            assert st["pairs"] == int(ost[0]) and st["rays"] == int(ost[3])
+            assert_image_close(got[..., :3], proxy[..., :3], what="proxy splat, one wave per tile")
+
+
+def test_splat_proxy_mesh_is_validated(ctx, evplp):
+    """A mesh whose fragment count is not the entry / exit rule of a convex body is refused, with the reason."""
+    v, t = oa.icosphere42()
+    dent = v.copy(); dent[20] *= 0.5                                        # a vertex pulled inside: not convex
+    far = v + np.float32(2.0)                                               # the photon outside its own proxy
+    big_v, big_t = None, None
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(1); pts = rng.normal(size=(120, 3)); pts = (pts / np.linalg.norm(pts, axis=1, keepdims=True)).astype(np.float32)
+    big_t = ConvexHull(pts).simplices.astype(np.int32)                      # 236 faces, no two parallel
+    for verts, tris, why in ((dent, t, "convex"), (v, t[:-1], "closed"), (far, t, "origin"), (pts, big_t, "planes"), (v[:3], t[:1], "4 vertices")):
+        with pytest.raises(evplp.EvplpError) as e:
+            ctx.set_splat_proxy(verts, tris)
+        assert e.value.status == evplp.ERR_INVALID and why in str(e.value), (why, str(e.value))
+    dv, dt = evplp.default_splat_proxy()                                    # the product's generated mesh is the oracle's
+    assert np.array_equal(dt, t) and np.abs(dv - v).max() <= 1e-7
+    ctx.set_splat_proxy(dv, dt)
+    ctx.set_splat_proxy()
+
+
 def test_photon_bins_grow_and_the_pass_reruns(room, oscene, evplp, inputs, monkeypatch):
     """The splat is enqueued without knowing the bin sizes; a pass whose bins overflow writes nothing and is run again by the
     next call with larger bins (context.cpp settle_splat).  Force that path with two-slot bins."""

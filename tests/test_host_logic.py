@@ -23,13 +23,36 @@ def test_library_exports_every_declared_symbol(evplp):
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in include/evplp.h but not exported: {missing}"
     assert declared == set(evplp._SIGNATURES), declared ^ set(evplp._SIGNATURES)
-    assert lib.evplp_abi_version() == 2
+    assert lib.evplp_abi_version() == 3 == evplp.ABI_VERSION
 
 
-def test_struct_layouts_match_the_header(evplp):
-    assert C.sizeof(evplp.FrameParams) == 64 and C.sizeof(evplp.Config) == 64
+def test_struct_layouts_match_the_header(evplp, tmp_path):
+    """The ctypes mirrors against the header itself: a C program prints sizeof / offsetof of what include/evplp.h declares."""
+    assert C.sizeof(evplp.FrameParams) == 72 and C.sizeof(evplp.Config) == 80
     assert C.sizeof(evplp.Material) == 40 and C.sizeof(evplp.Camera) == 44 and C.sizeof(evplp.PassStats) == 64
     assert evplp.RECORD_DTYPE.itemsize == 96
+    src = tmp_path / "layout.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "evplp.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(evplp_config), sizeof(evplp_frame_params), sizeof(evplp_material), sizeof(evplp_camera), sizeof(evplp_pass_stats),
+           sizeof(evplp_record), sizeof(evplp_group_config));
+    printf("%zu %zu %zu %zu %zu\\n", offsetof(evplp_config, cut_scratch_bytes), offsetof(evplp_config, vsl_mask_bytes), offsetof(evplp_frame_params, jitter),
+           offsetof(evplp_frame_params, splat_footprint), offsetof(evplp_pass_stats, shaded));
+    printf("%d %d\\n", EVPLP_ABI_VERSION, EVPLP_MAX_PROXY_PLANES);
+    return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    sizes = [int(x) for x in lines[0].split()]
+    assert sizes == [C.sizeof(evplp.Config), C.sizeof(evplp.FrameParams), C.sizeof(evplp.Material), C.sizeof(evplp.Camera), C.sizeof(evplp.PassStats), 96, C.sizeof(evplp.GroupConfig)]
+    offs = [int(x) for x in lines[1].split()]
+    assert offs == [evplp.Config.cut_scratch_bytes.offset, evplp.Config.vsl_mask_bytes.offset, evplp.FrameParams.jitter.offset,
+                    evplp.FrameParams.splat_footprint.offset, evplp.PassStats.shaded.offset]
+    assert [int(x) for x in lines[2].split()] == [evplp.ABI_VERSION, 128]
 
 
 def test_create_fails_loudly_without_a_gpu(evplp):
@@ -47,7 +70,7 @@ def test_create_rejects_bad_configs(evplp):
     cfg.abi_version = 99
     assert evplp.lib().evplp_create(C.byref(cfg), C.byref(h)) == evplp.ERR_INVALID
     assert b"ABI version" in evplp.lib().evplp_last_error(None)
-    cfg.abi_version = 2; cfg.res_x = cfg.res_y = 8; cfg.num_light_paths = 4; cfg.num_vpl_light_paths = 8; cfg.photons_per_path = 4
+    cfg.abi_version = evplp.ABI_VERSION; cfg.res_x = cfg.res_y = 8; cfg.num_light_paths = 4; cfg.num_vpl_light_paths = 8; cfg.photons_per_path = 4
     assert evplp.lib().evplp_create(C.byref(cfg), C.byref(h)) == evplp.ERR_INVALID
     assert b"num_vpl_light_paths" in evplp.lib().evplp_last_error(None)
     assert evplp.lib().evplp_create(None, C.byref(h)) == evplp.ERR_INVALID

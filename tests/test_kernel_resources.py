@@ -33,7 +33,9 @@ def kernel_table(src):
     ("kernels_gather.hip", ["gather_vpl_kernelILb1", "gather_vpl_kernelILb0", "gather_vsl_walk_kernelILb1", "gather_vsl_walk_kernelILb0", "gather_vsl_shade_kernel", "gather_reduce_kernel"],
      {"gather_vpl_kernelILb1": 64, "gather_vpl_kernelILb0": 64, "gather_vsl_walk_kernelILb1": 64, "gather_vsl_walk_kernelILb0": 64, "gather_vsl_shade_kernel": 128}),
     ("kernels_cut.hip", ["gather_cut_kernel", "primary_cut_kernel"], {"gather_cut_kernel": 64}),
-    ("kernels_splat.hip", ["splat_bin_kernel", "splat_scatter_kernel", "splat_tiles_kernelILi1", "splat_tiles_kernelILi4", "resolve_kernel"], {}),
+    # (the proxy-footprint variants of the tile kernel, ILb1, are held to seven / six waves per SIMD below)
+    ("kernels_splat.hip", ["splat_bin_kernel", "splat_scatter_kernel", "splat_tiles_kernelILi1ELb0", "splat_tiles_kernelILi4ELb0", "splat_tiles_kernelILi4ELb1", "resolve_kernel"],
+     {"splat_tiles_kernelILi1ELb0": 64, "splat_tiles_kernelILi4ELb0": 64, "splat_tiles_kernelILi1ELb1": 72, "splat_tiles_kernelILi4ELb1": 80}),
     ("kernels_pt.hip", ["path_trace_kernel"], {}),
     ("kernels_trace.hip", ["light_trace_kernel", "primary_kernel"], {"light_trace_kernel": 128, "primary_kernel": 64}),
 ])
@@ -47,3 +49,9 @@ def test_code_objects_keep_their_budgets(src, zero_scratch, budgets):
     for want, limit in budgets.items():
         for k in [k for k in table if want in k]:
             assert table[k]["vgpr_count"] <= limit, (k, table[k])
+    if src == "kernels_splat.hip":
+        # splat_tiles_kernel<1, true> at seven waves per SIMD (72 registers; it wants 78): two values wait in scratch -- the pixel's address
+        # for the final store (written before the batch loop, read after it) and one 16-byte value re-read once per 64-photon batch;
+        # none inside the radius-test, slab or shading loops (measured: seven waves with these beat six without, 96.6 vs 102 us at config #4)
+        for k in [k for k in table if "splat_tiles_kernelILi1ELb1" in k]:
+            assert table[k]["private_segment_fixed_size"] <= 32 and table[k]["vgpr_spill_count"] <= 8, (k, table[k])
