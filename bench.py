@@ -352,7 +352,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 group.gather(fp, 1)
             if wl != "ir":
                 group.splat_photons(fp)
-            group.present(1.0, 1.0, 1.0)
+            group.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True)      # runFinalProgram(param, param, 1, true), rtcomphoton.h:997-1004
         else:
             def light_paths():
                 if split_paths:
@@ -377,7 +377,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 if os.environ.get("EVPLP_DUMP_SPLAT_HIST"):   # stats build: rectangle classes of the photons (tools/debug_splat_hist.py)
                     print("HIST", it, ctx.debug_counters(ev.PASS_SPLAT)[4:4 + 28].tolist(), flush=True)
             # the frame ends with the composite (rtcomphoton.h:997-1004), as the group front end's present() does
-            ctx.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0)
+            ctx.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True)
             if use_dist:
                 if wl != "ppm":
                     env.all_gather(full, strip)
@@ -691,6 +691,31 @@ def render_json_time(env, wl, json_path, shape, iterations):
     return res
 
 
+def count_devices():
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime in THIS process (spawn_ranks' contract: the parent has not
+    initialised a GPU): a short-lived child process asks the runtime; the kernel driver's topology is the fallback."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:      # noqa: BLE001
+        pass
+    n = 0
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:          # (CPU nodes have none)
+                n += 1
+    except OSError:
+        n = 0
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
+    if vis is not None and vis.strip() != "":
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n
+
+
 def group_under_launcher(a):
     """`--front-end group` when a launcher has started one process per GPU (the driver's N > 1 command): the measurement is rank 0's
     -- one host thread driving evplp_group over the N devices, as a maintainer's binding would -- and the other processes only keep
@@ -698,8 +723,11 @@ def group_under_launcher(a):
     is done (ranks > 0), False when it is rank 0 and should go on.  If rank 0 cannot open the group (RCCL communicator across the N
     devices), every process falls back to the `ranks` front end."""
     import torch.distributed as dist
+    import datetime
     rank = int(os.environ.get("RANK", "0"))
-    dist.init_process_group("gloo")
+    # (the idle ranks wait at a barrier while rank 0 runs the whole benchmark -- extras, CPU baseline, render_json: hours, not the
+    # default 30 minutes, before they may give up and take rank 0 down with them)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(hours=6))
     ok = [1]
     if rank == 0:
         try:
@@ -729,8 +757,7 @@ def main():
         if a.gpus == 1 or os.environ.get("EVPLP_BENCH_BACKEND") == "gloo" or os.environ.get("EVPLP_BENCH_FORCE_DIST") == "1":
             a.front_end = "ranks"
         else:
-            import torch
-            a.front_end = "group" if torch.cuda.device_count() >= a.gpus else "ranks"      # (counting devices does not initialise the GPU)
+            a.front_end = "group" if count_devices() >= a.gpus else "ranks"
     if a.gpus > 1 and world_env is None and a.front_end == "ranks":
         spawn_ranks(a)
         return

@@ -142,6 +142,7 @@ _SIGNATURES = {
     "evplp_group_splat_photons": (C.c_int, [_P, C.POINTER(FrameParams), C.c_int32]),
     "evplp_group_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_group_synchronize": (C.c_int, [_P]),
+    "evplp_group_host_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double * 3)]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_group_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_jitter_sequence": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -446,7 +447,7 @@ class Context:
 class Group:
     """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
 
-    def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=8,
+    def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=16,
                  use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False):
         self._lib = lib()
         cfg = Config()
@@ -506,6 +507,12 @@ class Group:
 
     def synchronize(self):
         self._check(self._lib.evplp_group_synchronize(self._h))
+
+    def host_stats(self, r: int) -> dict:
+        """host time of rank r's worker thread (ms inside pass calls, ms inside exchanges, commands run)"""
+        out = (C.c_double * 3)()
+        self._check(self._lib.evplp_group_host_stats(self._h, r, C.byref(out)))
+        return {"calls_ms": out[0], "exchange_ms": out[1], "commands": int(out[2])}
 
     def present(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
         """composite + all-gather of the strips on the devices (the per-frame exchange); nothing comes to the host"""

@@ -20,7 +20,7 @@ void evplp_context::set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-#define CTX_CHECK(ctx) do { if (!(ctx)) return EVPLP_ERR_INVALID; } while (0)
+#define CTX_CHECK(ctx) do { if (!(ctx)) return EVPLP_ERR_INVALID; if ((ctx)->quiesce && std::this_thread::get_id() != (ctx)->worker_tid) (ctx)->quiesce((ctx)->quiesce_arg); } while (0)
 #define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return EVPLP_ERR_HIP; } } while (0)
 
 static size_t buffer_bytes(const evplp_context *c, int which) {
@@ -568,8 +568,13 @@ extern "C" int evplp_primary(evplp_context *c, const float jitter[2], int32_t cl
     a.g_dif = (float4 *)c->buf[EVPLP_BUF_GBUF_DIFFUSE]; a.g_phg = (float4 *)c->buf[EVPLP_BUF_GBUF_PHONG];
     a.g_light = (float4 *)c->buf[EVPLP_BUF_LIGHT];
     a.tile_box = c->d_tile_box;
-    if (c->env_cuts != 0 && c->tiles_x * c->tiles_y > 0) {
-        // the eye's entry cuts: once per camera / tree (they hold for every jitter), 256 B per group of 2 x 2 tiles (2 x 1 where a
+    if (!std::isfinite(a.jitter[0]) || !std::isfinite(a.jitter[1])) { c->set_error("evplp_primary: jitter is not finite"); return EVPLP_ERR_INVALID; }
+    // The eye's cuts are built for a pyramid opened by ONE PIXEL (2 / W, 2 / H in NDC) around every tile group (primary_cut_kernel): they
+    // hold for the reference's jitter, (2u - 1) / resolution -- half a pixel at most (rtcomphoton.h:949) -- and for anything up to a whole
+    // pixel.  A larger translation (the ABI takes any float) moves rays out of their group's pyramid: that call walks from the root.
+    const bool jitter_within_cuts = std::fabs(a.jitter[0]) <= 1.99f / (float)c->st.W && std::fabs(a.jitter[1]) <= 1.99f / (float)c->st.H;
+    if (c->env_cuts != 0 && c->tiles_x * c->tiles_y > 0 && jitter_within_cuts) {
+        // the eye's entry cuts: once per camera / tree (they hold for every jitter up to a pixel), 256 B per group of 2 x 2 tiles (2 x 1 where a
         // strip's tile rows are not neighbours in the image)
         PrimaryCutArgs pc; std::memset(&pc, 0, sizeof(pc));
         pc.nodes = c->sc.nodes; pc.st = c->st; pc.cam = c->cam; pc.tiles_x = c->tiles_x; pc.tiles_y = c->tiles_y;
@@ -709,8 +714,8 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     a.splits_per_wave = k;
     if ((rc = ensure_gather_workspace(c, a, (size_t)(kVplSplit / k)))) return rc;
     // entry cuts (kernels.h CutArgs): one slot per (tile group, VPL slot).  Groups are 2 x 2 tiles where the strip's tile rows are
-    // neighbours in the image (one GPU, or strips of 16 rows and more), 2 x 1 otherwise.  The scratch is bounded (EVPLP_CUT_BYTES, 12 GB
-    // by default): a configuration whose slots need more is gathered band by band -- rows of tile blocks -- cuts first, then the walks.
+    // neighbours in the image (one GPU, or strips of 16 rows and more), 2 x 1 otherwise.  The scratch is bounded (evplp_config.
+    // cut_scratch_bytes; below): a configuration whose slots need more is gathered band by band -- rows of tile blocks -- cuts first, then the walks.
     CutArgs ca; std::memset(&ca, 0, sizeof(ca));
     bool use_cuts = c->env_cuts != 0;
     const int sh = 1 << a.block_h_log2, nby = (c->tiles_y + sh - 1) / sh;       // rows of tile blocks
@@ -721,17 +726,21 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         ca.groups_x = (c->tiles_x + (1 << ca.gw_log2) - 1) >> ca.gw_log2;
         ca.vpls = c->d_vpls; ca.nvpl = &c->d_scalars[0]; ca.vpl_stride = (uint32_t)nvpl_slots_of(c);
         const size_t per_block_row = (size_t)(sh >> ca.gh_log2) * ca.groups_x * ca.vpl_stride * (size_t)kCutSlotBytes;
-        // (the scratch is sized for the part: a quarter of its memory -- 72 GB of 288 -- but no more than half of what is free now, and what is
-        // already allocated counts as free; config #5's 68 GB then fit one band: 1.397 -> 1.371 s per iteration against six bands of 12 GB)
-        size_t cap = c->env_cut_bytes;
-        if (cap == 0) {
-            size_t mem_free = 0, mem_total = 0;
-            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)48 << 30; }
-            cap = std::max<size_t>(std::min(mem_total / 4, (mem_free + c->cut_bytes) / 2), (size_t)1 << 30);
+        // The bound of the scratch: evplp_config.cut_scratch_bytes, or -- looked up ONCE per context, at its first gather -- a quarter of the
+        // device's memory (72 GB of 288) but no more than half of what is free then (config #5's 68 GB fit one band: 1.397 -> 1.371 s per
+        // iteration against six bands of 12 GB).  EVPLP_CUT_BYTES: test override (forces the band path).
+        if (c->cut_cap == 0) {
+            c->cut_cap = c->env_cut_bytes ? c->env_cut_bytes : (size_t)c->cfg.cut_scratch_bytes;
+            if (c->cut_cap == 0) {
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)48 << 30; }
+                c->cut_cap = std::max<size_t>(std::min(mem_total / 4, mem_free / 2), (size_t)1 << 30);
+            }
         }
-        band_rows = (int)std::min<size_t>((size_t)nby, std::max<size_t>(cap / std::max<size_t>(per_block_row, 1), 1));
-        const size_t need = per_block_row * (size_t)band_rows;
-        if (need > c->cut_bytes) {
+        band_rows = (int)std::min<size_t>((size_t)nby, c->cut_cap / std::max<size_t>(per_block_row, 1));
+        if (band_rows < 1) { use_cuts = false; band_rows = nby; }            // (the bound does not hold one row of tile blocks: walks from the root)
+        const size_t need = use_cuts ? per_block_row * (size_t)band_rows : 0;
+        if (use_cuts && need > c->cut_bytes) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             hipFree(c->d_cuts); c->d_cuts = nullptr; c->cut_bytes = 0;
             if (hipMalloc((void **)&c->d_cuts, need) == hipSuccess) c->cut_bytes = need;
@@ -755,13 +764,18 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         const size_t tiles = (size_t)gather_launch_tiles(a), per_item = (size_t)k * (size_t)a.masks_per_split * sizeof(unsigned long long);
         vsl_groups = kVplSplit / k;
         vsl_per_launch = vsl_groups;
-        size_t mask_cap = 0;
-        if (const char *me = std::getenv("EVPLP_MASK_BYTES")) mask_cap = (size_t)strtoull(me, nullptr, 10);      // (developer switch)
-        if (mask_cap == 0) {                   // a twentieth of the part's memory (14 GB of 288: config #5's 8.6 GB in one launch), at most a quarter of what is free
-            size_t mem_free = 0, mem_total = 0;
-            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)20 << 30; }
-            mask_cap = std::max<size_t>(std::min(mem_total / 20, (mem_free + c->vsl_mask_bytes) / 4), (size_t)1 << 28);
+        // the bound of the mask buffer: evplp_config.vsl_mask_bytes, or -- once per context -- a twentieth of the device's memory (14 GB of 288:
+        // config #5's 8.6 GB in one launch), at most a quarter of what is free then
+        if (c->mask_cap == 0) {
+            c->mask_cap = (size_t)c->cfg.vsl_mask_bytes;
+            if (const char *me = std::getenv("EVPLP_MASK_BYTES")) c->mask_cap = (size_t)strtoull(me, nullptr, 10);      // (developer switch)
+            if (c->mask_cap == 0) {
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)20 << 30; }
+                c->mask_cap = std::max<size_t>(std::min(mem_total / 20, mem_free / 4), (size_t)1 << 28);
+            }
         }
+        const size_t mask_cap = c->mask_cap;
         while (vsl_per_launch > 1 && tiles * (size_t)vsl_per_launch * per_item > mask_cap) vsl_per_launch = (vsl_per_launch + 1) / 2;
         const size_t mask_bytes = tiles * (size_t)vsl_per_launch * per_item;
         if (c->vsl_mask_bytes < mask_bytes) {
@@ -923,12 +937,6 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
 
 // [finalize] composite of this context's strip into d_rgb (device); evplp_resolve downloads it, the group all-gathers it
 namespace evplp {
-// would the next entry point make the host wait for the verdict of a pending photon splat?  (group.cpp feeds such ranks last)
-bool host_would_wait(evplp_context *c) {
-    if (!c || c->npend == 0) return false;
-    if (hipSetDevice(c->cfg.device) != hipSuccess) return false;
-    return hipEventQuery(c->pend[0].ev) == hipErrorNotReady;
-}
 // settle = false (the per-iteration composite of a running loop): the composite is enqueued behind the last splat without waiting for
 // the verdict on its bins -- the host does not stall; in the rare iteration whose bins overflowed the presented frame lacks that one
 // pass (it is run again and lands in the accumulator before the next composite).  Results that leave the device always settle.

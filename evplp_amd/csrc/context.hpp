@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace evplp {
@@ -55,7 +56,8 @@ struct evplp_context {
     float4 *d_partial = nullptr; size_t partial_groups = 0;    // [groups][local_rows * W] per-item partial sums
     int32_t *d_lt_overflow = nullptr; size_t lt_overflow_bytes = 0;   // light tracing: the walk stack beyond its LDS entries (kernels.h)
     char *d_primary_cuts = nullptr; bool primary_cuts_valid = false;   // the eye's entry cuts, one slot per tile group, rebuilt when the camera or the tree changes
-    char *d_cuts = nullptr; size_t cut_bytes = 0;               // gathers: entry cuts of every (tile group, VPL) (kernels.h CutArgs), allocated on the first gather
+    char *d_cuts = nullptr; size_t cut_bytes = 0, cut_cap = 0;  // gathers: entry cuts of every (tile group, VPL) (kernels.h CutArgs), allocated on the first gather; cut_cap: their bound, fixed at the first gather
+    size_t mask_cap = 0;                                       // bound of d_vsl_masks, fixed at the first VSL gather
     void *d_vsl_masks = nullptr; size_t vsl_mask_bytes = 0;    // VSL gather: lit masks + per-item ray counts of one launch (kernels.h GatherArgs)
 
     // splat workspace
@@ -95,7 +97,11 @@ struct evplp_context {
     // EVPLP_BIN_STRIDE (forces the photon-bin overflow path), EVPLP_GATHER_K, EVPLP_TILE_BLOCK_LOG2.  -1 / 0 = not set.
     int32_t env_bvh_builder = -1, env_gather_k = 0, env_tile_block_log2 = -1, env_cuts = -1;      // env_cuts: EVPLP_CUTS=0 walks from the root
     int32_t env_split_min = 0;                 // EVPLP_SPLIT_MIN: fullest bin from which the splat's tile kernel runs four waves per tile
-    size_t env_cut_bytes = 0;                  // EVPLP_CUT_BYTES: bound of the entry-cut scratch (default 12 GB)
+    size_t env_cut_bytes = 0;                  // EVPLP_CUT_BYTES: test override of evplp_config.cut_scratch_bytes
+
+    // A context that belongs to an evplp_group is driven by that rank's worker thread (group.cpp).  A call from any other thread -- the
+    // caller reading statistics or buffers through evplp_group_context -- first waits until the worker has nothing queued for it.
+    void (*quiesce)(void *) = nullptr; void *quiesce_arg = nullptr; std::thread::id worker_tid{};
 
     char error[512] = "";
     void set_error(const char *fmt, ...);

@@ -368,9 +368,20 @@ template <class T> EV_DEV const T *pinned(const T *p) { asm("" : "+s"(p)); retur
 // Asynchronous copy global -> LDS (global_load_lds_dwordx4: every active lane moves 16 bytes from ITS source address to
 // lds_dst + 16 * lane; no register in between, counted by vmcnt).  The compiler neither sees the LDS write nor counts the load:
 // wait_vmcnt0() before the destination is read.  (M0 carries the LDS base and is compiler-reserved: written in the same statement.)
+#ifndef EVPLP_RING_NT
+#define EVPLP_RING_NT 1
+#endif
 EV_DEV void lds_dma16(const void *gsrc, uint32_t lds_dst) {
     unsigned keep;
+    // (nt: the cut slots are read once per tile and never again -- a stream that should not displace the tree in the XCD's L2: gather at
+    // config #2 52.5 -> 51.9 ms, box scene 20.7 -> 20.0.  Measured with it and not kept: sc1 (drop-from-L2) stores of the slots and of the
+    // partial sums, 54.3 / 23.5 ms; one emptiness bit per (tile group, VPL) so that empty cuts are neither written nor fetched, 53.8 / 21.7 ms --
+    // profiles/r05_cut_stream_experiments.txt)
+#if EVPLP_RING_NT
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 EV_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N> EV_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }   // all but the N youngest vector-memory operations

@@ -1,25 +1,41 @@
-// evplp_group: the multi-GPU entry of the C ABI (SURVEY 8b "Threading", 8e).  One caller thread drives n contexts -- one per GPU
-// of the node -- that own interleaved row strips of the image (include/evplp.h); the scene and the BVH are replicated; large
-// light-path sets are traced 1/n per rank and shared by an in-place all-gather of the record buffers; every rank gathers /
-// splats its own rows; the composited strips are all-gathered so that every GPU holds the frame.  No other exchange exists on
-// the path.  The collectives are RCCL (ncclAllGather over xGMI, one communicator per GPU, issued between ncclGroupStart / End by
-// the one host thread); the library is opened at run time so that hosts without it can still use single contexts.  Ranks that
+// evplp_group: the multi-GPU entry of the C ABI (SURVEY 8b "Threading", 8e).  n contexts -- one per GPU of the node -- own interleaved
+// row strips of the image (include/evplp.h); the scene and the BVH are replicated; large light-path sets are traced 1/n per rank and
+// shared by an in-place all-gather of the record buffers; every rank gathers / splats its own rows; the composited strips are
+// all-gathered so that every GPU holds the frame.  No other exchange exists on the path.  The collectives are RCCL (ncclAllGather over
+// xGMI, one communicator per GPU; the library is opened at run time so that hosts without it can still use single contexts).  Ranks that
 // share one device ("virtual ranks": tests, single-GPU boxes) exchange by device-to-device copies instead.
+//
+// (round 5) ONE WORKER THREAD PER RANK.  Until round 4 the caller's thread issued every rank's launches in turn: at eight ranks that is
+// ~50 enqueue calls per iteration against config #4's 0.15-0.6 ms iteration -- the host, not the GPUs, would have set that
+// configuration's pace.  Now a group call only POSTS a small command record to each rank's single-producer ring (no lock taken by a
+// waiting party, no system call while the workers are awake) and returns; every worker is bound to its device, runs its rank's calls in
+// order -- waits for a photon splat's verdict included: nobody else waits with it -- and issues its rank's side of a collective itself
+// (RCCL's one-thread-per-GPU model).  Per-pixel results do not depend on any of this: the same calls reach every context in the same order.
+//   * errors are sticky: the first failing call of a rank is kept, every later command of that rank is skipped, and the next group call
+//     (at the latest evplp_group_synchronize / evplp_group_resolve) returns it;
+//   * every worker meets the others at a host-side barrier in front of a collective and looks at the group's failure flag THERE, so that
+//     either all ranks enter the collective or none does;
+//   * a call made directly on a rank's context (evplp_group_context: statistics, buffers) first waits until that rank's worker has
+//     nothing queued (evplp_context::quiesce).
 #include "context.hpp"
 
 #include <rccl/rccl.h>      // types only: the entry points are resolved with dlsym
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace evplp {
 int resolve_to_device(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle);   // context.cpp
-bool host_would_wait(evplp_context *c);                                                                        // context.cpp
 }
 
 namespace {
@@ -28,20 +44,53 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool open(std::string &err) {
         for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
         if (!lib) { err = std::string("cannot open RCCL (librccl.so.1): ") + dlerror(); return false; }
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
-        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather"); GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
-        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd"); GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) { err = "librccl lacks an expected entry point"; return false; }
+        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather"); GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl lacks an expected entry point"; return false; }
         return true;
     }
 };
+
+enum Op { OP_QUIT = 0, OP_CLEAR, OP_SYNC, OP_PRIMARY, OP_TRACE, OP_GATHER, OP_SPLAT, OP_PATH_TRACE, OP_PRESENT, OP_LOAD_SCENE, OP_SET_PROXY, OP_ASSEMBLE };
+// One posted call: plain data, copied into the ring (pointers must stay valid until the caller has drained: load_scene, set_proxy, resolve do)
+struct Cmd {
+    int op = OP_QUIT;
+    evplp_frame_params fp{};
+    float f[4] = {}; int32_t i[4] = {}; uint32_t u[4] = {};
+    const void *p0 = nullptr, *p1 = nullptr; void *out = nullptr;
+};
+constexpr int kRing = 64;
+constexpr int kSpinBeforeSleep = 200000;     // ~1-2 ms of polling before an idle worker goes to sleep on its condition variable
+
+// sense-reversing barrier of the workers (spins: the waits are microseconds long, in front of a collective)
+struct SpinBarrier {
+    std::atomic<int> count{ 0 }; std::atomic<int> sense{ 0 }; int n = 1;
+    void wait() {
+        const int s = sense.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) { count.store(0, std::memory_order_relaxed); sense.store(s ^ 1, std::memory_order_release); }
+        else { int spins = 0; while (sense.load(std::memory_order_acquire) == s) { if (++spins > 2000) std::this_thread::yield(); } }
+    }
+};
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
+
+struct evplp_group;
+struct Worker {
+    evplp_group *g = nullptr; int rank = 0;
+    std::thread th;
+    Cmd ring[kRing];
+    alignas(64) std::atomic<uint64_t> head{ 0 };      // consumed
+    alignas(64) std::atomic<uint64_t> tail{ 0 };      // posted
+    std::mutex m; std::condition_variable cv; bool sleeping = false;
+    std::atomic<int> status{ 0 };                     // first failing call's status (sticky)
+    char error[512] = "";
+    // host time of this worker (evplp_group_host_stats): inside its rank's enqueue calls / inside exchanges (barriers, copies, collectives)
+    double t_calls = 0.0, t_exchange = 0.0; uint64_t n_cmds = 0;
+};
 
 struct evplp_group {
     int n = 0;
@@ -53,34 +102,184 @@ struct evplp_group {
     float *d_assembled = nullptr;           // rank 0's device: [H][W][3] the frame in image order (evplp_group_resolve)
     size_t strip_floats = 0;                // local_rows * W * 3
     bool split_paths = false; uint32_t per_rank_paths = 0;
+    std::vector<Worker *> workers;
+    SpinBarrier barrier;
+    std::atomic<int> failed{ 0 };           // some rank has failed: collectives are skipped by everybody
     char error[512] = "";
     void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(error, sizeof(error), fmt, ap); va_end(ap); }
 };
 
 static thread_local char g_group_create_error[512] = "";
 
-#define GRP_CHECK(g) do { if (!(g)) return EVPLP_ERR_INVALID; } while (0)
-// Every entry point of a context first looks at the verdict of its last photon splat (context.cpp settle_splat) and may wait for
-// it.  One host thread feeds all ranks, so the ranks whose verdict has already arrived are fed FIRST and the ones that would make
-// the host wait last: no GPU idles behind another rank's wait.  (The ranks are independent contexts; the order of the calls does
-// not change any result.)
-static void feed_order(const evplp_group *g, int *order) {
-    int m = 0; bool late[64];
-    for (int r = 0; r < g->n; r++) { late[r] = evplp::host_would_wait(g->ctx[r]); if (!late[r]) order[m++] = r; }
-    for (int r = 0; r < g->n; r++) if (late[r]) order[m++] = r;
+// ------------------------------------------------------------------------------------------------ the workers
+static void worker_fail(Worker *w, int rc, const char *msg) {
+    int expected = 0;
+    if (w->status.compare_exchange_strong(expected, rc)) { std::snprintf(w->error, sizeof(w->error), "%s", msg ? msg : ""); w->g->failed.store(1, std::memory_order_release); }
 }
-#define GRP_EACH(g, call) do { int order_[64]; feed_order((g), order_); for (int i_ = 0; i_ < (g)->n; i_++) { const int r_ = order_[i_]; evplp_context *c = (g)->ctx[r_]; int rc_ = (call); if (rc_ < 0) { (g)->set_error("rank %d: %s", r_, evplp_last_error(c)); return rc_; } } } while (0)
+// all-gather of equal chunks, this rank's side: it contributes `count` floats at all_send[rank] and receives n * count floats at `recv`
+static void worker_all_gather(Worker *w, float *recv, size_t count, const std::vector<const float *> &all_send) {
+    evplp_group *g = w->g; evplp_context *c = g->ctx[(size_t)w->rank];
+    const float *send = all_send[(size_t)w->rank];
+    if (g->n == 1 && g->virtual_ranks) {       // one rank: its chunk goes to its place in stream order, the host does not wait
+        if (w->status.load(std::memory_order_relaxed) == 0 && recv != send) {
+            hipError_t e = hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) worker_fail(w, EVPLP_ERR_HIP, hipGetErrorString(e));
+        }
+        return;
+    }
+    // everybody arrives, then everybody knows whether somebody has failed: all enter the collective or none
+    g->barrier.wait();
+    if (g->failed.load(std::memory_order_acquire)) return;
+    if (!g->virtual_ranks) {
+        ncclResult_t nr = g->rccl.AllGather(send, recv, count, ncclFloat, g->comms[(size_t)w->rank], c->stream);
+        if (nr != ncclSuccess) worker_fail(w, EVPLP_ERR_HIP, g->rccl.GetErrorString(nr));
+        return;
+    }
+    // virtual ranks share a device: every producer finishes, then plain device copies on the receiver's stream; the producers' buffers
+    // may be overwritten by their next pass only after every receiver has its copy
+    hipError_t e = hipStreamSynchronize(c->stream);
+    g->barrier.wait();
+    for (int q = 0; q < g->n && e == hipSuccess; q++) {
+        float *dst = recv + (size_t)q * count;
+        if (dst != all_send[(size_t)q]) e = hipMemcpyAsync(dst, all_send[(size_t)q], count * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    g->barrier.wait();
+    if (e != hipSuccess) worker_fail(w, EVPLP_ERR_HIP, hipGetErrorString(e));
+}
+
+static void worker_run(Worker *w, const Cmd &cmd) {
+    evplp_group *g = w->g; const int r = w->rank; evplp_context *c = g->ctx[(size_t)r];
+    const bool collective = cmd.op == OP_PRESENT || (cmd.op == OP_TRACE && g->split_paths);
+    int rc = EVPLP_OK;
+    const double t0 = now_ms();
+    if (w->status.load(std::memory_order_relaxed) == 0) {
+        switch (cmd.op) {
+        case OP_CLEAR: rc = evplp_clear_accumulators(c); break;
+        case OP_SYNC: rc = evplp_synchronize(c); break;
+        case OP_PRIMARY: rc = evplp_primary(c, cmd.f, cmd.i[0]); break;
+        case OP_TRACE:
+            if (!g->split_paths) rc = evplp_trace_light_paths(c, cmd.u[0], 0, c->cfg.num_light_paths);
+            else {
+                // in place: rank r's own slice goes to offset r * chunk of its record buffer.  A partial path range never goes to the second
+                // record buffer of overlap_light_tracing (context.cpp only double-buffers whole path sets), so EVPLP_BUF_RECORDS must be the
+                // same buffer before and after the call -- checked, because the exchange below would otherwise gather the wrong buffer.
+                const void *before = c->buf[EVPLP_BUF_RECORDS];
+                rc = evplp_trace_light_paths(c, cmd.u[0], (uint32_t)r * g->per_rank_paths, g->per_rank_paths);
+                if (rc >= 0 && c->buf[EVPLP_BUF_RECORDS] != before) worker_fail(w, EVPLP_ERR_INVALID, "evplp_group_trace_light_paths: a partial path range went into a flipped record buffer");
+            }
+            break;
+        case OP_GATHER: rc = cmd.i[0] == 0 ? evplp_gather_vpl(c, &cmd.fp) : cmd.i[0] == 1 ? evplp_gather_vsl(c, &cmd.fp) : evplp_gather_lvc(c, &cmd.fp); break;
+        case OP_SPLAT: rc = evplp_splat_photons(c, &cmd.fp, cmd.i[0]); break;
+        case OP_PATH_TRACE: rc = evplp_path_trace(c, cmd.f, cmd.u[0], cmd.u[1], cmd.i[0]); break;
+        case OP_PRESENT: rc = evplp::resolve_to_device(c, cmd.f[0], cmd.f[1], cmd.f[2], cmd.i[0], cmd.i[1], cmd.i[2] != 0 || !c->aux_stream); break;
+        case OP_LOAD_SCENE: rc = evplp_load_scene_json(c, (const char *)cmd.p0); break;
+        case OP_SET_PROXY: rc = evplp_set_splat_proxy(c, (const float *)cmd.p0, cmd.i[0], (const int32_t *)cmd.p1, cmd.i[1]); break;
+        case OP_ASSEMBLE: {
+            // rank 0 puts the strips into image order on the device; one copy lands the frame in the caller's buffer (no host-side assembly:
+            // a run that writes every frame resolves every iteration)
+            hipSetDevice(g->device[0]);
+            const size_t frame_floats = (size_t)c->st.W * c->st.H * 3;
+            hipError_t e = hipSuccess;
+            if (!g->d_assembled) e = hipMalloc((void **)&g->d_assembled, sizeof(float) * frame_floats);
+            if (e == hipSuccess) {
+                evplp::launch_assemble_strips(c->st, g->n, g->d_frame[0], g->d_assembled, c->stream);
+                e = hipMemcpyAsync(cmd.out, g->d_assembled, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) worker_fail(w, e == hipErrorOutOfMemory ? EVPLP_ERR_OOM : EVPLP_ERR_HIP, hipGetErrorString(e));
+            break;
+        }
+        default: break;
+        }
+        if (rc < 0) worker_fail(w, rc, evplp_last_error(c));
+    }
+    const double t1 = now_ms();
+    w->t_calls += t1 - t0; w->n_cmds++;
+    if (collective) {          // (reached by every rank, failed or not: the barrier inside decides for all)
+        std::vector<const float *> all((size_t)g->n);
+        if (cmd.op == OP_TRACE) {
+            const size_t chunk = (size_t)g->per_rank_paths * c->cfg.photons_per_path * (sizeof(evplp_record) / sizeof(float));
+            for (int q = 0; q < g->n; q++) all[(size_t)q] = (const float *)g->ctx[(size_t)q]->buf[EVPLP_BUF_RECORDS] + (size_t)q * chunk;
+            worker_all_gather(w, (float *)c->buf[EVPLP_BUF_RECORDS], chunk, all);
+        } else {
+            for (int q = 0; q < g->n; q++) all[(size_t)q] = g->ctx[(size_t)q]->d_rgb;
+            worker_all_gather(w, g->d_frame[(size_t)r], g->strip_floats, all);
+        }
+        w->t_exchange += now_ms() - t1;
+    }
+}
+
+static void worker_main(Worker *w) {
+    hipSetDevice(w->g->device[(size_t)w->rank]);
+    for (;;) {
+        const uint64_t h = w->head.load(std::memory_order_relaxed);
+        int spins = 0;
+        while (w->tail.load(std::memory_order_acquire) == h) {
+            if (++spins < kSpinBeforeSleep) { if ((spins & 63) == 0) std::this_thread::yield(); continue; }
+            std::unique_lock<std::mutex> lk(w->m);
+            w->sleeping = true;
+            w->cv.wait(lk, [&] { return w->tail.load(std::memory_order_acquire) != h; });
+            w->sleeping = false;
+            spins = 0;
+        }
+        const Cmd cmd = w->ring[h % kRing];
+        if (cmd.op == OP_QUIT) { w->head.store(h + 1, std::memory_order_release); return; }
+        worker_run(w, cmd);
+        w->head.store(h + 1, std::memory_order_release);
+    }
+}
+static void post(Worker *w, const Cmd &cmd) {
+    const uint64_t t = w->tail.load(std::memory_order_relaxed);
+    while (t - w->head.load(std::memory_order_acquire) >= (uint64_t)kRing) std::this_thread::yield();      // (the ring is full: the caller is 64 calls ahead)
+    w->ring[t % kRing] = cmd;
+    w->tail.store(t + 1, std::memory_order_seq_cst);
+    std::lock_guard<std::mutex> lk(w->m);                  // (uncontended while the worker polls; pairs with the worker's check before it sleeps)
+    if (w->sleeping) w->cv.notify_one();
+}
+static void drain_one(Worker *w) { int spins = 0; while (w->head.load(std::memory_order_acquire) != w->tail.load(std::memory_order_acquire)) { if (++spins > 1000) std::this_thread::yield(); } }
+static void drain(evplp_group *g) { for (Worker *w : g->workers) drain_one(w); }
+static void quiesce_hook(void *arg) { drain_one((Worker *)arg); }
+// the sticky error of the group, if any: the lowest failing rank's
+static int group_status(evplp_group *g) {
+    for (Worker *w : g->workers) { const int st = w->status.load(std::memory_order_acquire); if (st < 0) { g->set_error("rank %d: %s", w->rank, w->error); return st; } }
+    return EVPLP_OK;
+}
+static int post_all(evplp_group *g, const Cmd &cmd) {
+    if (g->failed.load(std::memory_order_acquire)) { drain(g); return group_status(g); }
+    for (Worker *w : g->workers) post(w, cmd);
+    return EVPLP_OK;
+}
+// calls whose arguments must outlive them, or whose result the caller needs: post, wait until every worker is idle, report
+static int post_and_wait(evplp_group *g, const Cmd &cmd) {
+    int rc = post_all(g, cmd);
+    if (rc < 0) return rc;
+    drain(g);
+    return group_status(g);
+}
+
+#define GRP_CHECK(g) do { if (!(g)) return EVPLP_ERR_INVALID; } while (0)
 
 extern "C" const char *evplp_group_last_error(const evplp_group *g) { return g ? g->error : g_group_create_error; }
 extern "C" int evplp_group_size(const evplp_group *g) { return g ? g->n : EVPLP_ERR_INVALID; }
-extern "C" evplp_context *evplp_group_context(evplp_group *g, int32_t rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[rank] : nullptr; }
+extern "C" evplp_context *evplp_group_context(evplp_group *g, int32_t rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[(size_t)rank] : nullptr; }
+extern "C" int evplp_group_host_stats(evplp_group *g, int32_t rank, double out[3]) {
+    GRP_CHECK(g);
+    if (rank < 0 || rank >= g->n || !out) { g->set_error("evplp_group_host_stats: bad arguments"); return EVPLP_ERR_INVALID; }
+    drain_one(g->workers[(size_t)rank]);
+    out[0] = g->workers[(size_t)rank]->t_calls; out[1] = g->workers[(size_t)rank]->t_exchange; out[2] = (double)g->workers[(size_t)rank]->n_cmds;
+    return EVPLP_OK;
+}
 
 extern "C" void evplp_group_destroy(evplp_group *g) {
     if (!g) return;
-    for (int r = 0; r < (int)g->d_frame.size(); r++) if (g->d_frame[r]) { hipSetDevice(g->device[r]); hipFree(g->d_frame[r]); }
+    for (Worker *w : g->workers) if (w->th.joinable()) { Cmd q; q.op = OP_QUIT; post(w, q); }
+    for (Worker *w : g->workers) { if (w->th.joinable()) w->th.join(); delete w; }
+    g->workers.clear();
+    for (int r = 0; r < (int)g->d_frame.size(); r++) if (g->d_frame[(size_t)r]) { hipSetDevice(g->device[(size_t)r]); hipFree(g->d_frame[(size_t)r]); }
     if (g->d_assembled) { hipSetDevice(g->device[0]); hipFree(g->d_assembled); }
     for (ncclComm_t c : g->comms) if (c && g->rccl.CommDestroy) g->rccl.CommDestroy(c);
-    for (evplp_context *c : g->ctx) evplp_destroy(c);
+    for (evplp_context *c : g->ctx) { c->quiesce = nullptr; evplp_destroy(c); }
     delete g;
 }
 
@@ -93,14 +292,16 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     g->n = gc->n_ranks;
     for (int r = 0; r < g->n; r++) g->device.push_back(gc->devices ? gc->devices[r] : r);
     bool all_same = true, all_distinct = true;
-    for (int r = 0; r < g->n; r++) for (int q = 0; q < r; q++) { if (g->device[r] == g->device[q]) all_distinct = false; else all_same = false; }
+    for (int r = 0; r < g->n; r++) for (int q = 0; q < r; q++) { if (g->device[(size_t)r] == g->device[(size_t)q]) all_distinct = false; else all_same = false; }
     if (g->n > 1 && !all_same && !all_distinct) { delete g; return fail(EVPLP_ERR_INVALID, "evplp_group_create: the ranks' devices must be all distinct (RCCL) or all the same (virtual ranks)"); }
     g->virtual_ranks = g->n > 1 ? all_same : !gc->use_rccl;
     if (gc->use_rccl && g->n > 1 && !all_distinct) { delete g; return fail(EVPLP_ERR_INVALID, "evplp_group_create: RCCL needs one distinct device per rank"); }
-    const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : 8;
+    // strips of 16 rows keep a rank's tile rows in neighbouring pairs: the entry cuts of the gathers then cover groups of 2 x 2 tiles as on
+    // one GPU (8-row strips: 2 x 1 groups, twice as many cuts per pixel); profiles/r05_strip_projection.json has both
+    const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : 16;
     for (int r = 0; r < g->n; r++) {
         evplp_config c = *cfg;
-        c.device = g->device[r]; c.strip_rank = r; c.strip_count = g->n; c.strip_rows = strip_rows;
+        c.device = g->device[(size_t)r]; c.strip_rank = r; c.strip_count = g->n; c.strip_rows = strip_rows;
         evplp_context *h = nullptr;
         int rc = evplp_create(&c, &h);
         if (rc < 0) { int code = fail(rc, "rank %d: %s", r, evplp_last_error(nullptr)); evplp_group_destroy(g); return code; }
@@ -109,8 +310,8 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     g->strip_floats = (size_t)g->ctx[0]->st.local_rows * g->ctx[0]->st.W * 3;
     g->d_frame.assign((size_t)g->n, nullptr);
     for (int r = 0; r < g->n; r++) {
-        hipSetDevice(g->device[r]);
-        hipError_t e = hipMalloc((void **)&g->d_frame[r], sizeof(float) * g->strip_floats * (size_t)g->n);
+        hipSetDevice(g->device[(size_t)r]);
+        hipError_t e = hipMalloc((void **)&g->d_frame[(size_t)r], sizeof(float) * g->strip_floats * (size_t)g->n);
         if (e != hipSuccess) { int code = fail(EVPLP_ERR_OOM, "rank %d: hipMalloc(frame): %s", r, hipGetErrorString(e)); evplp_group_destroy(g); return code; }
     }
     if (!g->virtual_ranks) {
@@ -124,107 +325,70 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     // every rank (identical records, no exchange); large ones are split by path range and shared by one all-gather
     g->split_paths = g->n > 1 && cfg->num_light_paths % (uint32_t)g->n == 0 && cfg->num_light_paths >= 16384;
     g->per_rank_paths = g->split_paths ? cfg->num_light_paths / (uint32_t)g->n : cfg->num_light_paths;
+    g->barrier.n = g->n;
+    for (int r = 0; r < g->n; r++) { Worker *w = new Worker(); w->g = g; w->rank = r; g->workers.push_back(w); }
+    for (Worker *w : g->workers) {
+        w->th = std::thread(worker_main, w);
+        evplp_context *c = g->ctx[(size_t)w->rank];
+        c->worker_tid = w->th.get_id(); c->quiesce_arg = w; c->quiesce = quiesce_hook;
+    }
     *out = g;
     return EVPLP_OK;
 }
 
-// all-gather of equal chunks: rank r contributes `count` floats at send[r] and receives n * count floats at recv[r]
-static int group_all_gather(evplp_group *g, const std::vector<const float *> &send, const std::vector<float *> &recv, size_t count) {
-    if (g->n == 1 && g->virtual_ranks) {       // one rank: its chunk goes to its place in stream order, the host does not wait
-        if (recv[0] != send[0]) { hipError_t e = hipMemcpyAsync(recv[0], send[0], count * sizeof(float), hipMemcpyDeviceToDevice, g->ctx[0]->stream); if (e != hipSuccess) { g->set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; } }
-        return EVPLP_OK;
-    }
-    if (!g->virtual_ranks) {
-        ncclResult_t nr = g->rccl.GroupStart();
-        for (int r = 0; r < g->n && nr == ncclSuccess; r++) nr = g->rccl.AllGather(send[r], recv[r], count, ncclFloat, g->comms[r], g->ctx[r]->stream);
-        ncclResult_t ne = g->rccl.GroupEnd();
-        if (nr == ncclSuccess) nr = ne;
-        if (nr != ncclSuccess) { g->set_error("ncclAllGather: %s", g->rccl.GetErrorString(nr)); return EVPLP_ERR_HIP; }
-        return EVPLP_OK;
-    }
-    // virtual ranks share a device: every producer finishes, then plain device copies on the receivers' streams
-    for (int r = 0; r < g->n; r++) { hipError_t e = hipStreamSynchronize(g->ctx[r]->stream); if (e != hipSuccess) { g->set_error("hipStreamSynchronize: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; } }
-    for (int r = 0; r < g->n; r++)
-        for (int q = 0; q < g->n; q++) {
-            float *dst = recv[r] + (size_t)q * count;
-            if (dst == send[q]) continue;                          // in-place chunk
-            hipError_t e = hipMemcpyAsync(dst, send[q], count * sizeof(float), hipMemcpyDeviceToDevice, g->ctx[r]->stream);
-            if (e != hipSuccess) { g->set_error("hipMemcpyAsync: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
-        }
-    for (int r = 0; r < g->n; r++) hipStreamSynchronize(g->ctx[r]->stream);    // a producer's buffer may be overwritten by its next pass
-    return EVPLP_OK;
-}
-
-extern "C" int evplp_group_load_scene_json(evplp_group *g, const char *json_path) { GRP_CHECK(g); GRP_EACH(g, evplp_load_scene_json(c, json_path)); return EVPLP_OK; }
-extern "C" int evplp_group_clear_accumulators(evplp_group *g) { GRP_CHECK(g); GRP_EACH(g, evplp_clear_accumulators(c)); return EVPLP_OK; }
-extern "C" int evplp_group_synchronize(evplp_group *g) { GRP_CHECK(g); GRP_EACH(g, evplp_synchronize(c)); return EVPLP_OK; }
-extern "C" int evplp_group_primary(evplp_group *g, const float jitter[2], int32_t light_flags) { GRP_CHECK(g); GRP_EACH(g, evplp_primary(c, jitter, light_flags)); return EVPLP_OK; }
-
-extern "C" int evplp_group_trace_light_paths(evplp_group *g, uint32_t rng_seed) {
+extern "C" int evplp_group_load_scene_json(evplp_group *g, const char *json_path) { GRP_CHECK(g); Cmd c; c.op = OP_LOAD_SCENE; c.p0 = json_path; return post_and_wait(g, c); }
+extern "C" int evplp_group_clear_accumulators(evplp_group *g) { GRP_CHECK(g); Cmd c; c.op = OP_CLEAR; return post_all(g, c); }
+extern "C" int evplp_group_synchronize(evplp_group *g) { GRP_CHECK(g); Cmd c; c.op = OP_SYNC; return post_and_wait(g, c); }
+extern "C" int evplp_group_primary(evplp_group *g, const float jitter[2], int32_t light_flags) {
     GRP_CHECK(g);
-    if (!g->split_paths) { GRP_EACH(g, evplp_trace_light_paths(c, rng_seed, 0, c->cfg.num_light_paths)); return EVPLP_OK; }
-    int order[64]; feed_order(g, order);
-    for (int i = 0; i < g->n; i++) {
-        const int r = order[i];
-        // in place: rank r's own slice goes to offset r * chunk of its record buffer.  A partial path range never goes to the second
-        // record buffer of overlap_light_tracing (context.cpp only double-buffers whole path sets), so EVPLP_BUF_RECORDS must be the
-        // same buffer before and after the call -- checked, because the exchange below would otherwise gather the wrong buffer.
-        const void *before = g->ctx[r]->buf[EVPLP_BUF_RECORDS];
-        int rc = evplp_trace_light_paths(g->ctx[r], rng_seed, (uint32_t)r * g->per_rank_paths, g->per_rank_paths);
-        if (rc < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[r])); return rc; }
-        if (g->ctx[r]->buf[EVPLP_BUF_RECORDS] != before) { g->set_error("evplp_group_trace_light_paths: rank %d traced a partial path range into a flipped record buffer", r); return EVPLP_ERR_INVALID; }
-    }
-    const size_t chunk = (size_t)g->per_rank_paths * g->ctx[0]->cfg.photons_per_path * (sizeof(evplp_record) / sizeof(float));
-    std::vector<const float *> send((size_t)g->n); std::vector<float *> recv((size_t)g->n);
-    for (int r = 0; r < g->n; r++) { recv[r] = (float *)g->ctx[r]->buf[EVPLP_BUF_RECORDS]; send[r] = recv[r] + (size_t)r * chunk; }
-    return group_all_gather(g, send, recv, chunk);
+    Cmd c; c.op = OP_PRIMARY; c.f[0] = jitter ? jitter[0] : 0.f; c.f[1] = jitter ? jitter[1] : 0.f; c.i[0] = light_flags;
+    return post_all(g, c);
 }
-
+extern "C" int evplp_group_trace_light_paths(evplp_group *g, uint32_t rng_seed) { GRP_CHECK(g); Cmd c; c.op = OP_TRACE; c.u[0] = rng_seed; return post_all(g, c); }
 extern "C" int evplp_group_gather(evplp_group *g, const evplp_frame_params *fp, int32_t kind) {
     GRP_CHECK(g);
     if (kind < 0 || kind > 2) { g->set_error("evplp_group_gather: kind must be 0 (VPL), 1 (VSL) or 2 (light-path windows)"); return EVPLP_ERR_INVALID; }
-    GRP_EACH(g, kind == 0 ? evplp_gather_vpl(c, fp) : kind == 1 ? evplp_gather_vsl(c, fp) : evplp_gather_lvc(c, fp));
-    return EVPLP_OK;
+    if (!fp) { g->set_error("evplp_group_gather: null frame params"); return EVPLP_ERR_INVALID; }
+    Cmd c; c.op = OP_GATHER; c.fp = *fp; c.i[0] = kind;
+    return post_all(g, c);
 }
-extern "C" int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int32_t clear) { GRP_CHECK(g); GRP_EACH(g, evplp_splat_photons(c, fp, clear)); return EVPLP_OK; }
+extern "C" int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int32_t clear) {
+    GRP_CHECK(g);
+    if (!fp) { g->set_error("evplp_group_splat_photons: null frame params"); return EVPLP_ERR_INVALID; }
+    Cmd c; c.op = OP_SPLAT; c.fp = *fp; c.i[0] = clear;
+    return post_all(g, c);
+}
 extern "C" int evplp_group_set_splat_proxy(evplp_group *g, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris) {
-    GRP_CHECK(g); GRP_EACH(g, evplp_set_splat_proxy(c, vertices, nverts, indices, ntris)); return EVPLP_OK;
+    GRP_CHECK(g);
+    Cmd c; c.op = OP_SET_PROXY; c.p0 = vertices; c.p1 = indices; c.i[0] = nverts; c.i[1] = ntris;
+    return post_and_wait(g, c);
 }
 extern "C" int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate) {
-    GRP_CHECK(g); GRP_EACH(g, evplp_path_trace(c, camera_pos, rng_seed, max_bounces, do_accumulate)); return EVPLP_OK;
+    GRP_CHECK(g);
+    if (!camera_pos) { g->set_error("evplp_group_path_trace: null camera position"); return EVPLP_ERR_INVALID; }
+    Cmd c; c.op = OP_PATH_TRACE; c.f[0] = camera_pos[0]; c.f[1] = camera_pos[1]; c.f[2] = camera_pos[2]; c.u[0] = rng_seed; c.u[1] = max_bounces; c.i[0] = do_accumulate;
+    return post_all(g, c);
 }
 
 // Composite every strip on its GPU and all-gather the strips: every GPU then holds the frame, strip by strip.  This is
 // the per-frame exchange of a run that presents every frame; nothing comes to the host.
-static int group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle) {
-    GRP_EACH(g, evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma, settle || !c->aux_stream));
-    std::vector<const float *> send((size_t)g->n); std::vector<float *> recv((size_t)g->n);
-    for (int r = 0; r < g->n; r++) { send[r] = g->ctx[r]->d_rgb; recv[r] = g->d_frame[r]; }
-    return group_all_gather(g, send, recv, g->strip_floats);
+static Cmd present_cmd(float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle) {
+    Cmd c; c.op = OP_PRESENT; c.f[0] = vs; c.f[1] = ps; c.f[2] = ls; c.i[0] = mask_emitter; c.i[1] = gamma; c.i[2] = settle ? 1 : 0;
+    return c;
 }
 extern "C" int evplp_group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
     GRP_CHECK(g);
-    return group_present(g, vs, ps, ls, mask_emitter, gamma, false);       // (the per-iteration composite: no wait for the splat's verdict)
+    return post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, false));       // (the per-iteration composite: no wait for the splat's verdict)
 }
 
-// evplp_group_present, then the frame in image order on rank 0's device and one copy to the caller.
+// evplp_group_present (settled), then the frame in image order on rank 0's device and one copy to the caller.
 extern "C" int evplp_group_resolve(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
     GRP_CHECK(g);
     if (!out_rgb) { g->set_error("evplp_group_resolve: null output"); return EVPLP_ERR_INVALID; }
-    int rc = group_present(g, vs, ps, ls, mask_emitter, gamma, true);
+    int rc = post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, true));
     if (rc < 0) return rc;
-    // rank 0 puts the strips into image order on the device; one copy lands the frame in the caller's buffer (no host-side assembly:
-    // a run that writes every frame resolves every iteration)
-    evplp_context *c0 = g->ctx[0];
-    hipSetDevice(g->device[0]);
-    const size_t frame_floats = (size_t)c0->st.W * c0->st.H * 3;
-    if (!g->d_assembled) {
-        hipError_t me = hipMalloc((void **)&g->d_assembled, sizeof(float) * frame_floats);
-        if (me != hipSuccess) { g->set_error("evplp_group_resolve: hipMalloc(frame): %s", hipGetErrorString(me)); return EVPLP_ERR_OOM; }
-    }
-    evplp::launch_assemble_strips(c0->st, g->n, g->d_frame[0], g->d_assembled, c0->stream);
-    hipError_t e = hipMemcpyAsync(out_rgb, g->d_assembled, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c0->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
-    if (e != hipSuccess) { g->set_error("frame download: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
-    return EVPLP_OK;
+    Cmd c; c.op = OP_ASSEMBLE; c.out = out_rgb;      // (rank 0's stream: behind its side of the exchange)
+    post(g->workers[0], c);
+    drain(g);
+    return group_status(g);
 }

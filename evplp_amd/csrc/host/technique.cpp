@@ -49,7 +49,7 @@ void check(evplp_group *g, int rc, const char *what) {
 }
 void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int device) {
     evplp_group_config gc; std::memset(&gc, 0, sizeof(gc));
-    gc.n_ranks = 1; gc.strip_rows = 8;
+    gc.n_ranks = 1; gc.strip_rows = 0;      // (0: the group's default, 16-row strips)
     bool virt = false;
     if (json.has("device")) {
         const Json &d = json.at("device");
@@ -358,7 +358,7 @@ private:
             // of the reference's iteration -- and stays on the device
             if (do_finalize) {
                 const float param = frame_mode == 2 ? 1.0f : 1.0f / (float)(num_iterations + 1);
-                check(h, evplp_group_present(h, param, param, 1.0f, 1, 0), "finalize");
+                check(h, evplp_group_present(h, param, param, 1.0f, 1, 1), "finalize");       // (doGammaCorrection = true, :1003)
             }
             num_iterations++;
             if (num_iterations % 20 == 0) {                                                   // :1008-1031

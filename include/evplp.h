@@ -233,7 +233,10 @@ int evplp_scene_metrics(evplp_context *ctx, float *bounding_sphere_radius, float
  *   EVPLP_LIGHT_UNOCCLUDED  cleareveryframe also clears the depth buffer the light pass shares with the deferred pass
  *                           (GL_DEPTH_BUFFER_BIT, :992): the emitter image is then NOT depth-tested against the scene;
  *   EVPLP_LIGHT_SKIP        run.lightRender = false: the light image is not touched at all.
- * The G-buffer itself is always depth-correct. */
+ * The G-buffer itself is always depth-correct.
+ * jitter: any finite NDC translation.  Up to one pixel (|jx| <= 2 / res_x, |jy| <= 2 / res_y; the reference's is at most half a pixel) the
+ * rays start from per-tile-group entry cuts of the tree that are built once per camera; a larger one walks from the root (same result,
+ * ~2x the pass's time). */
 enum evplp_light_flags { EVPLP_LIGHT_CLEAR = 1, EVPLP_LIGHT_UNOCCLUDED = 2, EVPLP_LIGHT_SKIP = 4 };
 int evplp_primary(evplp_context *ctx, const float jitter[2], int32_t light_flags);
 /* [lightTracing]: launch(LightTrace, numLightPaths) (:869-881).  Traces paths
@@ -268,7 +271,11 @@ int evplp_set_splat_proxy(evplp_context *ctx, const float *vertices, int32_t nve
 int evplp_resolve(evplp_context *ctx, float vpl_scale, float photon_scale, float light_scale,
                   int32_t mask_emitter, int32_t gamma, float *out_rgb);
 /* The composite alone (what the reference draws to the screen every iteration, runFinalProgram(param, param, 1, true) :997-1004): the strip's RGB stays in
- * device memory, nothing is copied to the host.  evplp_resolve = this + the download. */
+ * device memory, nothing is copied to the host.  evplp_resolve = this + the download.
+ * With overlap_light_tracing the call does NOT wait for the verdict on the bins of a photon splat that is still in flight (the host stays an
+ * iteration ahead): in the rare iteration whose bins overflowed, the presented frame lacks that one splat pass -- it runs again and is in
+ * the accumulator before the next composite.  Frames that leave the device (evplp_resolve, evplp_download, evplp_group_resolve) always
+ * settle first and are exact. */
 int evplp_present(evplp_context *ctx, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma);
 int evplp_clear_accumulators(evplp_context *ctx);
 
@@ -308,19 +315,22 @@ int evplp_accel_stack_entries(const evplp_context *ctx);
  * Returns the number of words written or a negative status. */
 int evplp_selftest(evplp_context *ctx, int32_t which, uint64_t *out, int32_t capacity);
 
-/* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread drives
- * n_ranks contexts, one per GPU of the node, that own interleaved row strips of the image (see the top of this file); scene and
+/* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread POSTS to
+ * n_ranks contexts -- each driven by a worker thread of its own, bound to its GPU -- that own interleaved row strips of the image (see the top of this file); scene and
  * BVH are replicated; light-path sets of >= 16 384 paths are traced 1/n per rank and shared by an in-place all-gather of the
  * record buffers, smaller ones are traced by every rank; every rank gathers / splats its own rows; evplp_group_resolve
  * composites the strips where they are and all-gathers them, so that every GPU holds the frame.  The collectives are RCCL
  * (ncclAllGather over xGMI; librccl is opened at run time).  Ranks that all share ONE device ("virtual ranks": tests, one-GPU
- * boxes) exchange by device copies instead.  Per-pixel results do not depend on the partition.  Every call enqueues on all
- * ranks and returns; a failing rank's message is in evplp_group_last_error. ---- */
+ * boxes) exchange by device copies instead.  Per-pixel results do not depend on the partition.  A pass call posts its arguments
+ * (copied) to every rank's worker and returns; the workers run their ranks' calls in order.  Errors are sticky: a rank's first failing
+ * call is returned by the next group call -- at the latest by evplp_group_synchronize / evplp_group_resolve, which wait for the
+ * workers -- with the message in evplp_group_last_error.  evplp_* calls made directly on a rank's context (evplp_group_context) wait
+ * until that rank's worker has nothing queued. ---- */
 typedef struct evplp_group evplp_group;
 typedef struct evplp_group_config {
     int32_t n_ranks;          /* contexts = row-strip ranks, 1..64 */
     const int32_t *devices;   /* HIP ordinal of every rank; NULL = 0, 1, .. n_ranks-1.  All distinct (RCCL) or all equal (virtual ranks) */
-    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 8 */
+    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 16 (keeps the gathers' 2 x 2-tile entry-cut groups whole) */
     int32_t use_rccl;         /* 1: a single-rank group goes through RCCL too (otherwise it needs no exchange at all) */
 } evplp_group_config;
 /* cfg: as for evplp_create; device / strip_* are set per rank by the group */
@@ -338,10 +348,14 @@ int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int3
 int evplp_group_set_splat_proxy(evplp_group *g, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris);
 int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
 int evplp_group_synchronize(evplp_group *g);
+/* Host time of rank `rank`'s worker so far, in ms: out[0] inside its rank's pass calls (enqueueing; waits for a splat's verdict included),
+ * out[1] inside exchanges (host barrier + collective / copies), out[2] commands run.  Waits until that worker is idle. */
+int evplp_group_host_stats(evplp_group *g, int32_t rank, double out[3]);
 /* evplp_resolve for the whole frame: out_rgb = HOST pointer, res_y * res_x * 3 floats, y = 0 bottom */
 /* The per-frame exchange alone: composite every rank's strip on its GPU (final.frag:19-35) and all-gather the strips, so that every
  * GPU holds the frame; nothing is copied to the host.  evplp_group_resolve = this + the strips put into image order on rank 0's device
  * (no host-side assembly) + one copy of the W x H x 3 frame to the caller. */
+/* (like evplp_present it does not wait for a pending splat's verdict when the contexts overlap light tracing; evplp_group_resolve does) */
 int evplp_group_present(evplp_group *g, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma);
 int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, float light_scale,
                         int32_t mask_emitter, int32_t gamma, float *out_rgb);

@@ -88,6 +88,22 @@ def test_primary_gbuffer(room, oscene, evplp, builder):
     assert (ref[4][..., 0] > 0).any(), "the light should be visible in this view"
 
 
+def test_primary_with_a_jitter_larger_than_the_cuts_pyramid(room, oscene, evplp):
+    """The eye's entry cuts hold for a jitter of up to one pixel; the ABI takes any float.  A translation of several pixels (here 2.4 and
+    1.6 pixels) must still give the oracle's G-buffer, bit for bit: that call walks from the root (evplp_primary)."""
+    jitter = (0.05, -0.05)
+    assert abs(jitter[0]) > 2.0 / W and abs(jitter[1]) > 2.0 / H
+    with evplp.Context(W, H, NPATHS, NPATHS, P) as c:
+        room.upload(c)
+        for j in (jitter, (0.003, -0.002), jitter):                          # (cuts built by the call in the middle must not leak into the third)
+            c.primary(j)
+            ref = oscene.primary(W, H, j)
+            for b, want in zip((evplp.BUF_GBUF_POSITION, evplp.BUF_GBUF_NORMAL, evplp.BUF_GBUF_DIFFUSE, evplp.BUF_GBUF_PHONG), ref):
+                assert c.download(b)[:H].tobytes() == want.tobytes(), (j, b)
+        with pytest.raises(evplp.EvplpError):
+            c.primary((float("nan"), 0.0))
+
+
 def test_exact_reciprocal_of_the_triangle_predicates(ctx):
     """The triangle predicates divide by n . d with a 7-instruction refinement of v_rcp_f32 instead of the compiler's 11-instruction
     IEEE division.  Checked on all 2^32 float bit patterns on this GPU: the bits differ only for zero / denormal / infinite inputs and
