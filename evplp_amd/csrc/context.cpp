@@ -702,7 +702,10 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
     // statistics need (VPLs per split) * k < 65536.
     int k = 1;
     {
-        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : kDefaultSplitsPerWave;
+        // (a row strip of an n-way partition is a SMALL launch, and small launches want short items: one rank's gather of an eight-way
+        // partition of config #2 takes 9.3 / 12.1 / 17.5 ms for k = 1 / 2 / 4 where an eighth of the one-GPU kernel is 6.2 ms --
+        // profiles/r05_strip_projection.json: projected 5.2x instead of 4.1x at eight ranks.  The result does not depend on k.)
+        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : (c->st.strip_count > 1 ? 1 : kDefaultSplitsPerWave);
         if (c->env_gather_k > 0) k = c->env_gather_k;
         const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
         while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;

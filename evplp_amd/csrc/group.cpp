@@ -296,9 +296,11 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     if (g->n > 1 && !all_same && !all_distinct) { delete g; return fail(EVPLP_ERR_INVALID, "evplp_group_create: the ranks' devices must be all distinct (RCCL) or all the same (virtual ranks)"); }
     g->virtual_ranks = g->n > 1 ? all_same : !gc->use_rccl;
     if (gc->use_rccl && g->n > 1 && !all_distinct) { delete g; return fail(EVPLP_ERR_INVALID, "evplp_group_create: RCCL needs one distinct device per rank"); }
-    // strips of 16 rows keep a rank's tile rows in neighbouring pairs: the entry cuts of the gathers then cover groups of 2 x 2 tiles as on
-    // one GPU (8-row strips: 2 x 1 groups, twice as many cuts per pixel); profiles/r05_strip_projection.json has both
-    const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : 16;
+    // Strips of 16 rows keep a rank's tile rows in neighbouring pairs -- the gathers' entry cuts then cover groups of 2 x 2 tiles as on one
+    // GPU (8-row strips: 2 x 1, twice as many cuts per pixel) -- but interleave the image half as finely.  Single-GPU projection of config
+    // #2 (profiles/r05_strip_projection.json; slowest rank's frame, 8- / 16-row strips): n = 2 28.1 / 27.7 ms, n = 4 15.3 / 15.2, n = 8
+    // 10.3 / 10.6 (balance 0.89 / 0.81): 16 rows up to four ranks, 8 from eight on.
+    const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : (g->n >= 8 ? 8 : 16);
     for (int r = 0; r < g->n; r++) {
         evplp_config c = *cfg;
         c.device = g->device[(size_t)r]; c.strip_rank = r; c.strip_count = g->n; c.strip_rows = strip_rows;

@@ -330,7 +330,7 @@ typedef struct evplp_group evplp_group;
 typedef struct evplp_group_config {
     int32_t n_ranks;          /* contexts = row-strip ranks, 1..64 */
     const int32_t *devices;   /* HIP ordinal of every rank; NULL = 0, 1, .. n_ranks-1.  All distinct (RCCL) or all equal (virtual ranks) */
-    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 16 (keeps the gathers' 2 x 2-tile entry-cut groups whole) */
+    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 16 (keeps the gathers' 2 x 2-tile entry-cut groups whole), 8 from eight ranks on (finer interleave) */
     int32_t use_rccl;         /* 1: a single-rank group goes through RCCL too (otherwise it needs no exchange at all) */
 } evplp_group_config;
 /* cfg: as for evplp_create; device / strip_* are set per rank by the group */
