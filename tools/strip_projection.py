@@ -53,7 +53,7 @@ for name, cfg in CONFIGS.items():
     entry = {"one_gpu": {"passes_ms": base, "frame_ms": base_sum}, "partitions": []}
     print(name, "1 GPU:", {k: round(v, 3) for k, v in base.items()}, "sum %.3f" % base_sum, flush=True)
     for n in (2, 4, 8):
-        for rows in (8, 16):
+        for rows in [int(v) for v in os.environ.get("PROJ_ROWS", "8,16").split(",")]:
             ranks = [run_rank(cfg, n, rows, r) for r in range(n)]
             sums = [sum(x.values()) for x in ranks]
             rec = {"n": n, "strip_rows": rows, "per_rank_passes_ms": ranks, "per_rank_frame_ms": sums, "max_ms": max(sums), "mean_ms": sum(sums) / n,
