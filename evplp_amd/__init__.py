@@ -50,7 +50,7 @@ class Config(C.Structure):
                 ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
                 ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("gather_splits_per_wave", C.c_int32),
                 ("overlap_light_tracing", C.c_int32), ("cut_scratch_bytes", C.c_uint64), ("vsl_mask_bytes", C.c_uint64),
-                ("reserved", C.c_int32 * 2)]
+                ("band_first_row", C.c_int32), ("band_rows", C.c_int32), ("band_capacity_rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Material(C.Structure):
@@ -77,7 +77,11 @@ FOOTPRINTS = {"ideal": FOOTPRINT_IDEAL, "proxy": FOOTPRINT_PROXY}
 
 
 class GroupConfig(C.Structure):
-    _fields_ = [("n_ranks", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("strip_rows", C.c_int32), ("use_rccl", C.c_int32)]
+    _fields_ = [("n_ranks", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("strip_rows", C.c_int32), ("use_rccl", C.c_int32),
+                ("partition", C.c_int32), ("reserved", C.c_int32)]
+
+
+PARTITION_STRIPS, PARTITION_BANDS = 0, 1
 
 
 class PassStats(C.Structure):
@@ -117,6 +121,7 @@ _SIGNATURES = {
     "evplp_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_clear_accumulators": (C.c_int, [_P]),
+    "evplp_set_band": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "evplp_local_rows": (C.c_int, [_P]),
     "evplp_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "evplp_bind_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
@@ -143,6 +148,7 @@ _SIGNATURES = {
     "evplp_group_path_trace": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int32]),
     "evplp_group_synchronize": (C.c_int, [_P]),
     "evplp_group_host_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double * 3)]),
+    "evplp_group_rebalance": (C.c_int, [_P, _P]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_group_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_jitter_sequence": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -225,9 +231,14 @@ class Context:
 
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
-                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0, overlap_light_tracing: bool = False):
+                 bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0, overlap_light_tracing: bool = False,
+                 band=None, band_capacity_rows: int = 0):
+        """band = (first_row, rows): the context owns those contiguous image rows instead of interleaved strips."""
         self._lib = lib()
         cfg = Config()
+        if band is not None:
+            cfg.band_first_row, cfg.band_rows = int(band[0]), int(band[1]); cfg.band_capacity_rows = int(band_capacity_rows)
+            strip_rank, strip_count = 0, 1
         cfg.abi_version = ABI_VERSION; cfg.device = device; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.strip_rank = strip_rank; cfg.strip_count = strip_count; cfg.strip_rows = strip_rows
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths
@@ -393,6 +404,10 @@ class Context:
     def clear_accumulators(self):
         self._check(self._lib.evplp_clear_accumulators(self._h))
 
+    def set_band(self, first_row: int, rows: int):
+        self._check(self._lib.evplp_set_band(self._h, first_row, rows))
+        self.cfg.band_first_row, self.cfg.band_rows = first_row, rows
+
     # -- buffers
     def buffer_info(self, which: int):
         p, n = C.c_void_p(), C.c_size_t()
@@ -441,6 +456,10 @@ class Context:
     def global_rows(self) -> np.ndarray:
         """Global image row of every local row (>= H for padding rows)."""
         from . import strips
+        if self.cfg.band_rows > 0:
+            l = np.arange(self.local_rows)
+            rows = min(self.cfg.band_rows, self.H - self.cfg.band_first_row)
+            return np.where(l < rows, self.cfg.band_first_row + l, self.H + l)
         return strips.global_rows(self.H, self.cfg.strip_rank, self.cfg.strip_count, self.cfg.strip_rows)
 
 
@@ -448,13 +467,15 @@ class Group:
     """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
 
     def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=16,
-                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False):
+                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips"):
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths; cfg.photons_per_path = photons_per_path
         cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic); cfg.overlap_light_tracing = int(overlap_light_tracing)
         gc = GroupConfig(); gc.n_ranks = n_ranks; gc.strip_rows = strip_rows; gc.use_rccl = int(use_rccl)
+        gc.partition = PARTITION_BANDS if partition == "bands" else PARTITION_STRIPS
+        self.partition = partition if n_ranks > 1 else "strips"
         self._devs = (C.c_int32 * n_ranks)(*devices) if devices is not None else None
         gc.devices = C.cast(self._devs, C.POINTER(C.c_int32)) if self._devs is not None else None
         h = C.c_void_p()
@@ -508,6 +529,13 @@ class Group:
     def synchronize(self):
         self._check(self._lib.evplp_group_synchronize(self._h))
 
+    def rebalance(self) -> np.ndarray:
+        """bands partition: move the band boundaries to equal measured cost (clears the accumulators); returns the n + 1 boundaries"""
+        out = np.zeros(self.n + 1, dtype=np.int32)
+        self._check(self._lib.evplp_group_rebalance(self._h, _ptr(out)))
+        self._bands = out.copy()
+        return out
+
     def host_stats(self, r: int) -> dict:
         """host time of rank r's worker thread (ms inside pass calls, ms inside exchanges, commands run)"""
         out = (C.c_double * 3)()
@@ -524,8 +552,16 @@ class Group:
         h = self._lib.evplp_group_context(self._h, r)
         if not h:
             raise EvplpError(ERR_INVALID, "evplp_group_context: bad rank")
-        return Context.borrowed(h, self.W, self.H, strip_rank=r, strip_count=self.n, strip_rows=self.strip_rows,
-                                num_light_paths=self._paths[0], num_vpl_light_paths=self._paths[1], photons_per_path=self._paths[2])
+        c = Context.borrowed(h, self.W, self.H, strip_rank=r, strip_count=self.n, strip_rows=self.strip_rows,
+                             num_light_paths=self._paths[0], num_vpl_light_paths=self._paths[1], photons_per_path=self._paths[2])
+        if self.partition == "bands":
+            b = getattr(self, "_bands", None)
+            if b is None:
+                rows16 = (self.H + 15) // 16 * 16; share = max(16, (rows16 // self.n + 15) // 16 * 16)
+                b = np.minimum(np.arange(self.n + 1) * share, self.H); b[self.n] = self.H
+            c.cfg.strip_rank, c.cfg.strip_count = 0, 1
+            c.cfg.band_first_row = int(b[r]); c.cfg.band_rows = int((b[r + 1] if r + 1 < self.n else (self.H + 15) // 16 * 16) - b[r])
+        return c
 
     def resolve(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
         out = np.empty((self.H, self.W, 3), dtype=np.float32)

@@ -55,6 +55,15 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if (strip_rows <= 0 || (strip_rows % 8) != 0 || cfg->strip_rank < 0 || cfg->strip_rank >= strip_count) {
         snprintf(g_create_error, sizeof(g_create_error), "evplp_create: strip_rows must be a positive multiple of 8 and 0 <= strip_rank < strip_count"); return EVPLP_ERR_INVALID;
     }
+    const bool band_mode = cfg->band_rows > 0;
+    if (band_mode) {
+        const int cap = cfg->band_capacity_rows > 0 ? cfg->band_capacity_rows : cfg->band_rows;
+        if (strip_count != 1 || cfg->band_first_row < 0 || (cfg->band_first_row % 16) != 0 || cfg->band_first_row >= cfg->res_y || cap < cfg->band_rows ||
+            ((cfg->band_rows % 16) != 0 && cfg->band_first_row + cfg->band_rows < cfg->res_y) || cfg->band_first_row + cfg->band_rows > ((cfg->res_y + 15) / 16) * 16) {
+            snprintf(g_create_error, sizeof(g_create_error), "evplp_create: a band starts on a multiple of 16 rows inside the image, is a multiple of 16 rows high unless it ends the image, fits its capacity, and excludes strip_count > 1");
+            return EVPLP_ERR_INVALID;
+        }
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -79,6 +88,12 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     int nblocks = (cfg->res_y + strip_rows - 1) / strip_rows;
     int owned = (nblocks + strip_count - 1) / strip_count;  // padded: equal on every rank (all-gather chunks)
     c->st.local_rows = owned * strip_rows;
+    if (band_mode) {
+        const int cap = cfg->band_capacity_rows > 0 ? cfg->band_capacity_rows : cfg->band_rows;
+        c->st.strip_rows = ((cap + 7) / 8) * 8; c->cfg.strip_rows = c->st.strip_rows;
+        c->st.local_rows = c->st.strip_rows;
+        c->st.band_first = cfg->band_first_row; c->st.band_rows = std::min(cfg->band_rows, cfg->res_y - cfg->band_first_row);
+    }
     // rows of this strip that fall inside the image
     c->rows_in_image = 0;
     for (int l = 0; l < c->st.local_rows; l++) if (c->st.global_row(l) < c->st.H) c->rows_in_image++;
@@ -968,6 +983,24 @@ extern "C" int evplp_resolve(evplp_context *c, float vs, float ps, float ls, int
 extern "C" int evplp_present(evplp_context *c, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
     CTX_CHECK(c);
     return evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma, !c->aux_stream);      // (overlapped contexts keep the host an iteration ahead)
+}
+
+extern "C" int evplp_set_band(evplp_context *c, int32_t first_row, int32_t rows) {
+    CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
+    if (c->st.band_rows <= 0) { c->set_error("evplp_set_band: the context was not created in band mode"); return EVPLP_ERR_INVALID; }
+    if (first_row < 0 || (first_row % 16) != 0 || first_row >= c->st.H || rows <= 0 || rows > c->st.local_rows ||
+        ((rows % 16) != 0 && first_row + rows < c->st.H) || first_row + rows > ((c->st.H + 15) / 16) * 16) {
+        c->set_error("evplp_set_band: rows [%d, %d) are not a band this context can hold (capacity %d rows, multiples of 16)", first_row, first_row + rows, c->st.local_rows); return EVPLP_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); if (c->aux_stream) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    c->st.band_first = first_row; c->st.band_rows = std::min(rows, c->st.H - first_row);
+    c->cfg.band_first_row = first_row; c->cfg.band_rows = rows;
+    c->rows_in_image = 0;
+    for (int l = 0; l < c->st.local_rows; l++) if (c->st.global_row(l) < c->st.H) c->rows_in_image++;
+    c->primary_cuts_valid = false; c->tile_box_valid = false;
+    return evplp_clear_accumulators(c);
 }
 
 extern "C" int evplp_clear_accumulators(evplp_context *c) {

@@ -104,7 +104,11 @@ struct StripDev {
     int32_t W, H;
     int32_t strip_rank, strip_count, strip_rows;
     int32_t local_rows;
+    // band mode (evplp_config.band_rows > 0; strip_count = 1): the context owns the image rows [band_first, band_first + band_rows), stored
+    // from local row 0; local rows beyond the band (padding up to the capacity) lie outside the image
+    int32_t band_first, band_rows;
     __host__ __device__ inline int32_t global_row(int32_t local) const {
+        if (band_rows > 0) return local < band_rows ? band_first + local : H + local;
         int32_t blk = local / strip_rows;
         return (blk * strip_count + strip_rank) * strip_rows + (local - blk * strip_rows);
     }

@@ -102,6 +102,7 @@ struct evplp_group {
     float *d_assembled = nullptr;           // rank 0's device: [H][W][3] the frame in image order (evplp_group_resolve)
     size_t strip_floats = 0;                // local_rows * W * 3
     bool split_paths = false; uint32_t per_rank_paths = 0;
+    bool bands = false; evplp::BandTable band_table{};    // EVPLP_PARTITION_BANDS: first image row of every rank's band (+ H)
     std::vector<Worker *> workers;
     SpinBarrier barrier;
     std::atomic<int> failed{ 0 };           // some rank has failed: collectives are skipped by everybody
@@ -183,7 +184,7 @@ static void worker_run(Worker *w, const Cmd &cmd) {
             hipError_t e = hipSuccess;
             if (!g->d_assembled) e = hipMalloc((void **)&g->d_assembled, sizeof(float) * frame_floats);
             if (e == hipSuccess) {
-                evplp::launch_assemble_strips(c->st, g->n, g->d_frame[0], g->d_assembled, c->stream);
+                evplp::launch_assemble_strips(c->st, g->n, g->bands ? &g->band_table : nullptr, g->d_frame[0], g->d_assembled, c->stream);
                 e = hipMemcpyAsync(cmd.out, g->d_assembled, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -301,9 +302,19 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     // #2 (profiles/r05_strip_projection.json; slowest rank's frame, 8- / 16-row strips): n = 2 28.1 / 27.7 ms, n = 4 15.3 / 15.2, n = 8
     // 10.3 / 10.6 (balance 0.89 / 0.81): 16 rows up to four ranks, 8 from eight on.
     const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : (g->n >= 8 ? 8 : 16);
+    // EVPLP_PARTITION_BANDS: contiguous bands of equal height to begin with (multiples of 16 rows), each with room for twice its share
+    g->bands = gc->partition == EVPLP_PARTITION_BANDS && g->n > 1;
+    const int rows16 = ((cfg->res_y + 15) / 16) * 16, share = std::max(16, ((rows16 / g->n + 15) / 16) * 16), band_cap = std::min(rows16, 2 * share);
+    for (int r = 0; r <= g->n; r++) g->band_table.first[r] = std::min(r * share, cfg->res_y);
+    g->band_table.first[g->n] = cfg->res_y;
+    if (g->bands && g->band_table.first[g->n - 1] >= cfg->res_y) { delete g; return fail(EVPLP_ERR_INVALID, "evplp_group_create: %d bands of at least 16 rows do not fit %d image rows", gc->n_ranks, cfg->res_y); }
     for (int r = 0; r < g->n; r++) {
         evplp_config c = *cfg;
         c.device = g->device[(size_t)r]; c.strip_rank = r; c.strip_count = g->n; c.strip_rows = strip_rows;
+        if (g->bands) {
+            c.strip_rank = 0; c.strip_count = 1; c.strip_rows = 0;
+            c.band_first_row = g->band_table.first[r]; c.band_rows = (r + 1 < g->n ? g->band_table.first[r + 1] : rows16) - g->band_table.first[r]; c.band_capacity_rows = band_cap;
+        }
         evplp_context *h = nullptr;
         int rc = evplp_create(&c, &h);
         if (rc < 0) { int code = fail(rc, "rank %d: %s", r, evplp_last_error(nullptr)); evplp_group_destroy(g); return code; }
@@ -335,6 +346,60 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
         c->worker_tid = w->th.get_id(); c->quiesce_arg = w; c->quiesce = quiesce_hook;
     }
     *out = g;
+    return EVPLP_OK;
+}
+
+// Bands dealt by cost: every rank's device time since the last rebalance, spread evenly over its rows, is a piecewise-constant cost profile of
+// the image; the new boundaries cut it into n parts of equal cost (multiples of 16 rows, at least 16, at most the capacity).  A few rounds of
+// frame + rebalance converge: a band that was expensive gets shorter, and the next round measures its cost at the new height.
+extern "C" int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows) {
+    GRP_CHECK(g);
+    drain(g);
+    int rc = group_status(g); if (rc < 0) return rc;
+    const int H = g->ctx[0]->st.H, n = g->n;
+    if (g->bands) {
+        static const int kPasses[] = { EVPLP_PASS_PRIMARY, EVPLP_PASS_GATHER_VPL, EVPLP_PASS_GATHER_VSL, EVPLP_PASS_GATHER_LVC, EVPLP_PASS_SPLAT, EVPLP_PASS_PATH_TRACE };
+        std::vector<double> cost((size_t)n, 0.0);
+        double total = 0.0;
+        for (int r = 0; r < n; r++) {
+            for (int p : kPasses) {
+                evplp_pass_stats ps;
+                if (g->ctx[(size_t)r]->pass_ran[p] && evplp_pass_stats_get(g->ctx[(size_t)r], p, &ps) == EVPLP_OK) cost[(size_t)r] += ps.ms;
+                g->ctx[(size_t)r]->pass_ran[p] = false;          // (counted once: the next rebalance sees the passes that ran after this one)
+            }
+            total += cost[(size_t)r];
+        }
+        if (total > 0.0) {
+            const int cap = g->ctx[0]->st.local_rows;
+            int first[65]; first[0] = 0; first[n] = H;
+            // cumulative cost at row y: bands in order, constant density within a band
+            auto row_at_cost = [&](double target) {
+                double acc = 0.0;
+                for (int r = 0; r < n; r++) {
+                    const int b0 = g->band_table.first[r], b1 = g->band_table.first[r + 1];
+                    if (acc + cost[(size_t)r] >= target || r == n - 1) return b0 + (cost[(size_t)r] > 0.0 ? (target - acc) / cost[(size_t)r] : 0.0) * (double)(b1 - b0);
+                    acc += cost[(size_t)r];
+                }
+                return (double)H;
+            };
+            for (int r = 1; r < n; r++) {
+                int y = (int)(row_at_cost(total * (double)r / (double)n) / 16.0 + 0.5) * 16;
+                y = std::max(y, first[r - 1] + 16);                               // at least 16 rows
+                y = std::min(y, first[r - 1] + (cap / 16) * 16);                  // at most the capacity
+                y = std::min(y, ((H - 1) / 16) * 16 - (n - 1 - r) * 16);          // room for the bands behind it
+                first[r] = y;
+            }
+            // the bands behind a capped one may be pushed beyond THEIR capacity: walk back from the end
+            for (int r = n - 1; r >= 1; r--) first[r] = std::max(first[r], ((first[r + 1] + 15) / 16) * 16 - (cap / 16) * 16);
+            for (int r = 0; r <= n; r++) g->band_table.first[r] = first[r];
+            for (int r = 0; r < n; r++) {
+                const int rows = (r + 1 < n ? first[r + 1] : ((H + 15) / 16) * 16) - first[r];
+                int rb = evplp_set_band(g->ctx[(size_t)r], first[r], rows);
+                if (rb < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[(size_t)r])); return rb; }
+            }
+        }
+    }
+    if (band_first_rows) for (int r = 0; r <= n; r++) band_first_rows[r] = g->bands ? g->band_table.first[r] : 0;
     return EVPLP_OK;
 }
 

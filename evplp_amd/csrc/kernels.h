@@ -222,7 +222,8 @@ void launch_splat_bin(const SplatArgs &a, hipStream_t s);
 void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hipEvent_t dominant_begin, hipEvent_t dominant_end);
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
-void launch_assemble_strips(const StripDev &st, int nranks, const float *gathered, float *frame, hipStream_t s);
+struct BandTable { int32_t first[65]; };      // first[r] = first image row of rank r's band, first[n] = H
+void launch_assemble_strips(const StripDev &st, int nranks, const BandTable *bands, const float *gathered, float *frame, hipStream_t s);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s);
 
 } // namespace evplp

@@ -111,7 +111,12 @@ typedef struct evplp_config {
      *    Default: a twentieth of the device's memory, at most a quarter of what is free; smaller bounds mean more launches. */
     uint64_t cut_scratch_bytes;
     uint64_t vsl_mask_bytes;
-    int32_t reserved[2];
+    /* Band mode, the other way to give a context a share of the image: with band_rows > 0 (and strip_count <= 1) it owns the CONTIGUOUS image
+     * rows [band_first_row, band_first_row + band_rows), stored from local row 0; band_first_row and band_rows are multiples of 16 (the last
+     * band may end at res_y).  band_capacity_rows >= band_rows sizes its buffers (0 = band_rows): evplp_set_band may later move the band
+     * anywhere within that capacity.  evplp_group's "bands" partition deals such bands by measured cost (evplp_group_rebalance). */
+    int32_t band_first_row, band_rows, band_capacity_rows;
+    int32_t reserved;
 } evplp_config;
 
 /* rt/rtcommon.h:278-308 RtMaterial: three RGBA32F textures (a constant is a 1x1 texture,
@@ -278,6 +283,9 @@ int evplp_resolve(evplp_context *ctx, float vpl_scale, float photon_scale, float
  * settle first and are exact. */
 int evplp_present(evplp_context *ctx, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma);
 int evplp_clear_accumulators(evplp_context *ctx);
+/* Band mode only: move the context's band to the rows [first_row, first_row + rows) (multiples of 16; rows <= band_capacity_rows).  The
+ * accumulators are cleared and the G-buffer is stale: call between runs, not between the iterations of an accumulating run. */
+int evplp_set_band(evplp_context *ctx, int32_t first_row, int32_t rows);
 
 /* ---- buffers / statistics ---- */
 int evplp_local_rows(const evplp_context *ctx);
@@ -332,7 +340,14 @@ typedef struct evplp_group_config {
     const int32_t *devices;   /* HIP ordinal of every rank; NULL = 0, 1, .. n_ranks-1.  All distinct (RCCL) or all equal (virtual ranks) */
     int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 16 (keeps the gathers' 2 x 2-tile entry-cut groups whole), 8 from eight ranks on (finer interleave) */
     int32_t use_rccl;         /* 1: a single-rank group goes through RCCL too (otherwise it needs no exchange at all) */
+    int32_t partition;        /* evplp_group_partition: how the image is dealt to the ranks */
+    int32_t reserved;
 } evplp_group_config;
+/* EVPLP_PARTITION_STRIPS: interleaved blocks of strip_rows rows, block b to rank b % n (balanced by interleaving, at the price of every rank
+ * walking the whole tree for a fraction of the rays).  EVPLP_PARTITION_BANDS: one contiguous band of rows per rank (evplp_config band mode;
+ * strip_rows is ignored) -- equal heights at first, then dealt by measured cost: evplp_group_rebalance moves the band boundaries so that
+ * every rank's last frame would have taken the same time.  Per-pixel results do not depend on either. */
+typedef enum evplp_group_partition { EVPLP_PARTITION_STRIPS = 0, EVPLP_PARTITION_BANDS = 1 } evplp_group_partition;
 /* cfg: as for evplp_create; device / strip_* are set per rank by the group */
 int evplp_group_create(const evplp_config *cfg, const evplp_group_config *gcfg, evplp_group **out);
 void evplp_group_destroy(evplp_group *g);
@@ -348,6 +363,13 @@ int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int3
 int evplp_group_set_splat_proxy(evplp_group *g, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris);
 int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
 int evplp_group_synchronize(evplp_group *g);
+/* EVPLP_PARTITION_BANDS: waits for the ranks, takes every rank's device time of the passes it ran since the last rebalance (HIP events of
+ * primary rays, gathers, photon splat, path tracer), treats it as spread evenly over the rank's rows, and moves the band boundaries (multiples
+ * of 16 rows, within the bands' capacity of twice the equal share) to where every rank would have had the same cost.  The accumulators are
+ * cleared and the G-buffers are stale afterwards: call it after one or two calibration frames, before an accumulating run (the technique
+ * loop does).  band_first_rows: optional, n_ranks + 1 ints, the boundaries it chose.  Returns EVPLP_OK (also for a strips partition or a
+ * single rank: nothing to do). */
+int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows);
 /* Host time of rank `rank`'s worker so far, in ms: out[0] inside its rank's pass calls (enqueueing; waits for a splat's verdict included),
  * out[1] inside exchanges (host barrier + collective / copies), out[2] commands run.  Waits until that worker is idle. */
 int evplp_group_host_stats(evplp_group *g, int32_t rank, double out[3]);

@@ -60,6 +60,57 @@ def test_virtual_ranks_equal_the_single_context(evplp, tmp_path, NL):
         assert img.tobytes() == ref.tobytes(), f"{n} ranks differ from the single context"
 
 
+def test_bands_partition_and_rebalance_equal_the_single_context(evplp, tmp_path):
+    """EVPLP_PARTITION_BANDS: one contiguous band of rows per rank (evplp_config band mode), dealt by measured cost
+    (evplp_group_rebalance).  Any set of bands gives the single context's pixels, bit for bit -- before and after the boundaries move."""
+    Hb = 128
+    jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, Hb, style="hard")
+    sd, _ = scenes.load_obj_scene(jp)
+    NL, NV = 16384, 32
+
+    def render(runner, fp, group):
+        runner.clear_accumulators()
+        for it in range(2):
+            runner.primary((0.002, -0.001)); runner.trace_light_paths(4 + it)
+            if group:
+                runner.gather(fp, 0)
+            else:
+                runner.gather_vpl(fp)
+            runner.splat_photons(fp)
+        return runner.resolve(0.5, 0.5, 1.0)[:Hb]
+    with evplp.Context(W, Hb, NL, NV, P, deterministic=True) as c:
+        c.load_scene_json(jp)
+        bsr, total, _ = c.scene_metrics()
+        fp = frame(evplp, c, sd, bsr, total, NL, NV)
+        ref = render(c, fp, False)
+    assert ref.max() > 0
+    for n in (2, 4):
+        with evplp.Group(W, Hb, NL, NV, P, n, devices=[0] * n, deterministic=True, partition="bands") as g:
+            g.load_scene_json(jp)
+            assert render(g, fp, True).tobytes() == ref.tobytes(), f"{n} equal bands differ from the single context"
+            # the rows a rank's context reports are its band
+            rows = np.concatenate([g.rank(r).global_rows()[g.rank(r).global_rows() < Hb] for r in range(n)])
+            assert np.array_equal(rows, np.arange(Hb))
+            bounds = [g.rebalance() for _ in range(1)][0]
+            assert bounds[0] == 0 and bounds[n] == Hb and (np.diff(bounds) >= 16).all() and (bounds[:-1] % 16 == 0).all()
+            assert render(g, fp, True).tobytes() == ref.tobytes(), f"{n} rebalanced bands {bounds.tolist()} differ from the single context"
+            g.rebalance()
+            assert render(g, fp, True).tobytes() == ref.tobytes()
+    # a band context by hand, moved within its capacity
+    with evplp.Context(W, Hb, NL, NV, P, deterministic=True, band=(32, 48), band_capacity_rows=64) as c:
+        c.load_scene_json(jp)
+        part = render(c, fp, False)
+        ok = c.global_rows() < Hb
+        assert part[ok[:Hb]].tobytes() == ref[32:80].tobytes()
+        c.set_band(64, 64)
+        part = render(c, fp, False)
+        assert part[:64].tobytes() == ref[64:128].tobytes()
+        with pytest.raises(evplp.EvplpError):
+            c.set_band(8, 32)                                       # not a multiple of 16
+        with pytest.raises(evplp.EvplpError):
+            c.set_band(0, 80)                                       # beyond the capacity
+
+
 def test_single_rank_group_through_rccl(evplp, tmp_path):
     """ncclCommInitAll + ncclAllGather with one rank: the RCCL code path itself (communicator, streams, in-place gather)."""
     jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(evplp):
 
 def test_struct_layouts_match_the_header(evplp, tmp_path):
     """The ctypes mirrors against the header itself: a C program prints sizeof / offsetof of what include/evplp.h declares."""
-    assert C.sizeof(evplp.FrameParams) == 72 and C.sizeof(evplp.Config) == 80
+    assert C.sizeof(evplp.FrameParams) == 72 and C.sizeof(evplp.Config) == 88
     assert C.sizeof(evplp.Material) == 40 and C.sizeof(evplp.Camera) == 44 and C.sizeof(evplp.PassStats) == 64
     assert evplp.RECORD_DTYPE.itemsize == 96
     src = tmp_path / "layout.c"
@@ -38,8 +38,8 @@ def test_struct_layouts_match_the_header(evplp, tmp_path):
 int main(void) {
     printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(evplp_config), sizeof(evplp_frame_params), sizeof(evplp_material), sizeof(evplp_camera), sizeof(evplp_pass_stats),
            sizeof(evplp_record), sizeof(evplp_group_config));
-    printf("%zu %zu %zu %zu %zu\\n", offsetof(evplp_config, cut_scratch_bytes), offsetof(evplp_config, vsl_mask_bytes), offsetof(evplp_frame_params, jitter),
-           offsetof(evplp_frame_params, splat_footprint), offsetof(evplp_pass_stats, shaded));
+    printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(evplp_config, cut_scratch_bytes), offsetof(evplp_config, vsl_mask_bytes), offsetof(evplp_frame_params, jitter),
+           offsetof(evplp_frame_params, splat_footprint), offsetof(evplp_pass_stats, shaded), offsetof(evplp_config, band_first_row));
     printf("%d %d\\n", EVPLP_ABI_VERSION, EVPLP_MAX_PROXY_PLANES);
     return 0;
 }
@@ -51,7 +51,7 @@ int main(void) {
     assert sizes == [C.sizeof(evplp.Config), C.sizeof(evplp.FrameParams), C.sizeof(evplp.Material), C.sizeof(evplp.Camera), C.sizeof(evplp.PassStats), 96, C.sizeof(evplp.GroupConfig)]
     offs = [int(x) for x in lines[1].split()]
     assert offs == [evplp.Config.cut_scratch_bytes.offset, evplp.Config.vsl_mask_bytes.offset, evplp.FrameParams.jitter.offset,
-                    evplp.FrameParams.splat_footprint.offset, evplp.PassStats.shaded.offset]
+                    evplp.FrameParams.splat_footprint.offset, evplp.PassStats.shaded.offset, evplp.Config.band_first_row.offset]
     assert [int(x) for x in lines[2].split()] == [evplp.ABI_VERSION, 128]
 
 
