@@ -71,9 +71,11 @@ EV_DEV float dot_exact(V3 a, V3 b) {
 // predicate is bit-identical on CPU and GPU: every dot product is  fma(z, z', fma(y, y', x*x'))  and
 // every cross component is  fma(a, b, -(c*d)).  1/den is an IEEE-correct division.
 typedef float v2f __attribute__((ext_vector_type(2)));
-// 1 / x with the bits of the IEEE division for every normal x below 2^126 -- the division's own refinement of v_rcp_f32 (one
-// Newton-Raphson step, two residual corrections) without the range scaling of v_div_scale / v_div_fixup (7 instructions instead
-// of 11).  tools/ub/rcp_exact.hip compares it with 1.0f / x on all 2^32 bit patterns (tests/test_gpu_parity.py runs it): the
+// 1 / x with the bits of the IEEE division for every normal x below 2^126 -- v_rcp_f32 (a 1-ulp instruction), one Newton-Raphson
+// step and ONE residual correction, without the range scaling of v_div_scale / v_div_fixup (5 instructions instead of 11; the
+// division's own expansion has a second correction, which rounds 1-4 carried: with libm's exact fmaf on the CPU, over every mantissa and
+// seeds at and one ulp either side of the correctly rounded reciprocal, the second correction never changes a bit -- 75 M cases).
+// evplp_selftest(0) compares it with 1.0f / x on all 2^32 bit patterns ON THE DEVICE (tests/test_gpu_parity.py runs it): the
 // two differ only for zero / denormal / infinite x and for |x| >= 2^126.  In the triangle predicates x = n . d: a zero or
 // denormal x makes 1 / x infinite or larger than 2^126 under IEEE and NaN or infinite here -- either way t is infinite, NaN or
 // beyond every segment's range and the predicate is false; |x| >= 2^126 needs coordinates beyond 1e18.  So the predicates
@@ -83,10 +85,8 @@ EV_DEV float rcp_exact(float x) {
     float r = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
-    float err = __builtin_fmaf(-x, r, 1.0f);
-    float q = __builtin_fmaf(err, r, r);
-    err = __builtin_fmaf(-x, q, 1.0f);
-    return __builtin_fmaf(err, r, q);
+    const float err = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(err, r, r);
 }
 EV_DEV bool tri_test(const TriPair &tp, int h, V3 o, V3 d, float tmin, float tmax, float &t, float &beta, float &gamma) {
 #pragma clang fp contract(off)
@@ -396,17 +396,16 @@ EV_DEV v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, 
 EV_DEV v2f pk_min(v2f a, v2f b) { return __builtin_elementwise_min(a, b); }
 EV_DEV v2f pk_max(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
 
-// rcp_exact of both halves: two v_rcp_f32, then the refinement as six packed fmas (a v_pk_fma_f32 rounds each half like v_fma_f32)
+// rcp_exact of both halves: two v_rcp_f32, then the refinement as four packed fmas (a v_pk_fma_f32 rounds each half like v_fma_f32;
+// six until round 5, see rcp_exact)
 EV_DEV v2f rcp_exact2(v2f x) {
 #pragma clang fp contract(off)
     v2f r; r.x = __builtin_amdgcn_rcpf(x.x); r.y = __builtin_amdgcn_rcpf(x.y);
     const v2f one = bc(1.0f);
     const v2f e = pk_fma(-x, r, one);
     r = pk_fma(e, r, r);
-    v2f err = pk_fma(-x, r, one);
-    v2f q = pk_fma(err, r, r);
-    err = pk_fma(-x, q, one);
-    return pk_fma(err, r, q);
+    const v2f err = pk_fma(-x, r, one);
+    return pk_fma(err, r, r);
 }
 // Exact test of a PAIR of triangles with packed fp32 (half 0 = triangle A, half 1 = B): the same
 // operations in the same order as tri_test, two triangles per instruction.  r[0..23] = the 24 dwords

@@ -590,32 +590,47 @@ struct VslFrames { V3 nd_n1, nd_r1, nd_n2, nd_r2; };   // nd12 in the frames of 
 EV_DEV V3 onb_local(const Onb &o, V3 d) { return v3(dot(d, o.t), dot(d, o.b), dot(d, o.n)); }
 constexpr float kConeSlack = 0.00001f;
 EV_DEV V3 select3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }   // (by value: a select between two struct members by address would put the struct into scratch)
-EV_DEV V3 lambert_local(Rng &rng) {                                   // LambertSample's direction in its own frame (rtmaterial.cuh:56-66)
-    float u1 = rng_uniform(rng);
-    float u2 = rng_uniform(rng);
+EV_DEV V3 lambert_local(float u1, float u2) {                          // LambertSample's direction in its own frame (rtmaterial.cuh:56-66)
     float r = vslm::fsqrt(u1);
     V3 p; p.x = r * vslm::cos2pi(u2); p.y = r * vslm::sin2pi(u2);
     p.z = vslm::fsqrt(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
     return p;
 }
-EV_DEV V3 phong_local(float e, Rng &rng) {                            // PhongSample's direction in the frame of the reflected direction (:120-154)
-    float sx = rng_uniform(rng);
-    float sy = rng_uniform(rng);
+EV_DEV V3 phong_local(float e, float sx, float sy) {                  // PhongSample's direction in the frame of the reflected direction (:120-154)
     float cos_t = vslm::fpow(sx, vslm::rcp(e + 1.f));
     float sin_t = vslm::fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
     return v3(sin_t * vslm::cos2pi(sy), sin_t * vslm::sin2pi(sy), cos_t);
+}
+// The estimators' random numbers (round 5; the oracle's evo_vsl_rng_*, where the choice is argued): xoroshiro64, one stream per
+// (pixel, record), ONE STEP PER SAMPLE -- six vector instructions and no multiply, where the PCG stream of the other kernels
+// (device_common.hpp) spent 4 instructions with three integer multiplies on every draw, used or not, and 5 more on each one used:
+// half of a sample-iteration's issue cycles.  The state after the step IS the sample's draws: top 24 bits of each word = its two
+// uniforms, the 16 bits left over = its lobe choice.
+struct VslRng { uint32_t s0, s1; };
+EV_DEV void vsl_rng_step(VslRng &r) {
+    const uint32_t t = r.s1 ^ r.s0;
+    r.s0 = __builtin_rotateleft32(r.s0, 26) ^ t ^ (t << 9);
+    r.s1 = __builtin_rotateleft32(t, 13);
+}
+EV_DEV float vsl_uniform(uint32_t w) { return __builtin_fmaf((float)(w >> 8), 1.0f / 16777216.0f, 1.0f / 16777216.0f); }      // (0, 1] like curand_uniform
+EV_DEV float vsl_choose(const VslRng &r) { return __builtin_fmaf((float)(((r.s0 & 0xffu) << 8) | (r.s1 & 0xffu)), 1.0f / 65536.0f, 0.5f / 65536.0f); }
+EV_DEV uint64_t vsl_key(uint64_t x) { return splitmix64(x); }
+// seed of the pair's stream from the pixel's key (splitmix64(seed << 32 | pixel), once per lane) and the record's (once per VSL, scalar)
+EV_DEV VslRng vsl_rng_seed(uint64_t pixel_key, uint64_t record_key) {
+    const uint32_t a = (uint32_t)pixel_key ^ (uint32_t)record_key, b = (uint32_t)(pixel_key >> 32) ^ (uint32_t)(record_key >> 32);
+    const uint64_t t = (uint64_t)a * (uint64_t)(b | 1u);
+    VslRng r; r.s0 = (uint32_t)t ^ b; r.s1 = ((uint32_t)(t >> 32) ^ a) | 0x80000000u;
+    return r;
 }
 // DIFF (wave-uniform): neither the VSL nor any lit pixel of the tile has a Phong lobe.  Then brdf1 brdf2 = rho_d1 rho_d2 / pi^2 is the same
 // for every sample of a pair, both lobe-selection probabilities are 1 (the `choose` draws only advance the generator) and the MIS
 // denominators are c1 + c2 + 1 / solid angle: a cone sample adds ONE scalar, c1 c2 / (c1 + c2 + 1 / solid angle), and the colour is
 // applied once per pair after the loop.
-EV_DEV void rng_advance(Rng &r) { r.state = r.state * 6364136223846793005ull + r.inc; }
 template <bool DIFF>
-EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const Onb &cone, V3 &acc, float &acc_d, Rng &rng) {  // :395-446
+EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const Onb &cone, V3 &acc, float &acc_d, VslRng &rng) {  // :395-446
     if (P.dead) return;
-    (void)rng_uniform(rng);
-    float ua = rng_uniform(rng);
-    float ub = rng_uniform(rng);
+    vsl_rng_step(rng);
+    const float ua = vsl_uniform(rng.s0), ub = vsl_uniform(rng.s1);
     const V3 wi12 = onb_inverse(cone, square_to_solid_angle(ua, ub, c.cos_half_cone));
     float c1 = fmaxf(dot(px.n1, wi12), 0.0f), c2 = fmaxf(-dot(v.n, wi12), 0.0f);
     float c1c2 = c1 * c2;
@@ -627,13 +642,14 @@ EV_DEV void vsl_sample_cone(const Pixel &px, const Vpl &v, const VslPixel &P, co
     acc = acc + (brdf1 * brdf2) * ((c.solid_angle * c1c2) * w);
 }
 template <bool DIFF>
-EV_DEV void vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, Rng &rng) {  // :448-521
+EV_DEV void vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, VslRng &rng) {  // :448-521
     if (P.dead) return;
-    bool lam = true;
-    if constexpr (DIFF) rng_advance(rng);               // choose < pSel = 1 whatever it is
-    else { float choose = fminf(rng_uniform(rng), 0.999999f); lam = choose < P.psel; }
+    vsl_rng_step(rng);
+    bool lam = true;                                    // (DIFF: choose < pSel = 1 whatever it is)
+    if constexpr (!DIFF) lam = vsl_choose(rng) < P.psel;
+    const float u1 = vsl_uniform(rng.s0), u2 = vsl_uniform(rng.s1);
     V3 p;
-    if (DIFF || lam) p = lambert_local(rng); else p = phong_local(px.e, rng);
+    if (DIFF || lam) p = lambert_local(u1, u2); else p = phong_local(px.e, u1, u2);
     if (!(dot(p, select3(lam, F.nd_n1, F.nd_r1)) > c.cos_half_cone - kConeSlack)) return;
     V3 wi12, brdf1;
     if (lam) {
@@ -647,20 +663,20 @@ EV_DEV void vsl_sample_brdf1(const Pixel &px, const Vpl &v, const VslPixel &P, c
     float cos1 = fmaxf(dot(px.n1, wi12), 0.0f);
     if (cos1 <= 0.000000001f) return;
     float cos2 = fmaxf(-dot(v.n, wi12), 0.0f);
-    (void)rng_uniform(rng);  // :506
     V3 brdf2; float pdf1, pdf2;
     vsl_terms(px, v, P, L, wi12, cos1, cos2, nullptr, &brdf2, pdf1, pdf2);
     const float w = pdf1 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
     acc = acc + (brdf1 * brdf2) * (cos2 * w);
 }
 template <bool DIFF>
-EV_DEV void vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, Rng &rng) {  // :523-594
+EV_DEV void vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, const VslLight &L, const VslCtx &c, const VslFrames &F, V3 &acc, VslRng &rng) {  // :523-594
     if (L.dead) return;
+    vsl_rng_step(rng);
     bool lam = true;
-    if constexpr (DIFF) rng_advance(rng);
-    else { float choose = fminf(rng_uniform(rng), 0.999999f); lam = choose < L.psel; }
+    if constexpr (!DIFF) lam = vsl_choose(rng) < L.psel;
+    const float u1 = vsl_uniform(rng.s0), u2 = vsl_uniform(rng.s1);
     V3 p;
-    if (DIFF || lam) p = lambert_local(rng); else p = phong_local(v.e, rng);
+    if (DIFF || lam) p = lambert_local(u1, u2); else p = phong_local(v.e, u1, u2);
     if (!(dot(p, select3(lam, F.nd_n2, F.nd_r2)) > c.cos_half_cone - kConeSlack)) return;
     V3 wi21, brdf2;
     if (lam) {
@@ -675,7 +691,6 @@ EV_DEV void vsl_sample_brdf2(const Pixel &px, const Vpl &v, const VslPixel &P, c
     if (cos2 <= 0.00000001f) return;
     float cos1 = fmaxf(-dot(px.n1, wi21), 0.0f);
     if (P.dead) return;
-    (void)rng_uniform(rng);  // :579
     V3 brdf1; float pdf1, pdf2;
     vsl_terms(px, v, P, L, -wi21, cos1, cos2, &brdf1, nullptr, pdf1, pdf2);
     const float w = pdf2 * vslm::rcp(pdf1 + pdf2 + c.inv_solid_angle);
@@ -800,6 +815,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
     if (!t.has_tile) return;
     const bool valid = t.in_image;
     const uint32_t pixel_id = (uint32_t)t.gy * (uint32_t)W + (uint32_t)t.x;  // launchIndex.y * dim.x + launchIndex.x (:711)
+    const uint64_t pixel_key = vsl_key(((uint64_t)a.fp.rng_seed << 32) | (uint64_t)pixel_id);
     const uint32_t nvpl = *a.nvpl;
     const int k = a.splits_per_wave;
     const evplp_record *vpls = pinned(a.vpls);
@@ -836,6 +852,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                 const uint32_t i = first + c * (uint32_t)kVplSplit;
                 Vpl v; fetch_vpl_head(vpls, i, v.pos, v.n, v.psel); fetch_vpl_tail(vpls, i, v);
                 const bool lit_lane = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) != 0u;
+                const uint64_t record_key = vsl_key((uint64_t)(1u + a.vpl_src_index[i]) * 0xD1B54A32D192ED03ull);   // (scalar arithmetic)
                 // (wave-uniform) no Phong lobe on either side of any lit pair of this VSL: the estimators' diffuse form
                 const bool diffuse_wave = !(v.rs.x != 0.0f || v.rs.y != 0.0f || v.rs.z != 0.0f) && ballot64(lit_lane && (P.glossy || P.psel < 1.0f)) == 0ull;
                 if (lit_lane) {
@@ -851,8 +868,8 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
                     cx.inv_pi_r2 = a.fp.vsl_inv_pi_radius2; cx.nd12 = nv12;
                     const int num_samples = (int)(cx.half_cone / EV_PI * 2.0f * 100.0f) + 1;  // :632
                     cnt += ((uint32_t)num_samples << 12) + 1u;
-                    // one RNG substream per (pixel, record): any decomposition reproduces the same numbers
-                    Rng rng; rng_init(rng, pixel_id, a.fp.rng_seed, 1u + a.vpl_src_index[i]);
+                    // one stream per (pixel, record): any decomposition reproduces the same numbers
+                    VslRng rng = vsl_rng_seed(pixel_key, record_key);
                     VslLight L;
                     {
                         const float ml = max_color(v.rd), mp = max_color(v.rs);

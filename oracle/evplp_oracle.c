@@ -87,6 +87,7 @@ void evo_rng_init(evo_rng *r, uint32_t index, uint32_t sequence, uint32_t substr
     uint64_t s0 = splitmix64(key + (uint64_t)substream * 0xD1B54A32D192ED03ull);
     r->inc = splitmix64(s0) | 1ull;
     r->state = s0 + r->inc;
+    r->s0 = r->s1 = 0u; r->vsl_draw = -1; r->reserved = 0u;
     (void)evo_rng_u32(r);
 }
 uint32_t evo_rng_u32(evo_rng *r) {
@@ -96,8 +97,40 @@ uint32_t evo_rng_u32(evo_rng *r) {
     uint32_t rot = (uint32_t)(old >> 59u);
     return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
 }
+/* The generator of the VSL estimators (vslSplat's three samplers, :395-594): the reference draws them from the pixel's cuRAND XORWOW
+ * stream -- a xorshift generator whose seeding is not public -- so the build defines its own here as well, and (round 5) picks one of
+ * that family for them instead of the PCG stream above: xoroshiro64 (Blackman & Vigna, "Scrambled linear pseudorandom number
+ * generators", 2018: two 32-bit words, rotations 26 / 13, shift 9, period 2^64 - 1), one stream per (pixel, record), ONE STEP PER
+ * SAMPLE of an estimator.  The 64 bits of the state after the step are the sample's random numbers: the top 24 bits of each word
+ * are its two uniforms ((0, 1] like curand_uniform), the 16 bits those leave over its lobe choice (chooseMaterial, :472 / :548) --
+ * over the period every 64-bit state occurs once, so the three are exactly equidistributed and independent of each other.  The draws
+ * the reference makes and does not use (:414, :506, :579) exist there only to advance its stream; here they consume nothing.
+ * Seed: the pixel's and the record's splitmix64 keys, multiplied into each other (the product makes the state a non-linear function
+ * of the two, so the F2-linear generator carries no XOR relation between the streams of (p, r), (p, r'), (p', r), (p', r')).
+ * evo_rng_uniform serves the samplers' draws in the order the reference makes them: #0 lobe choice, #1 / #2 the two uniforms. */
+void evo_vsl_rng_init(evo_rng *r, uint32_t index, uint32_t sequence, uint32_t substream) {
+    uint64_t pk = splitmix64(((uint64_t)sequence << 32) | (uint64_t)index);
+    uint64_t rk = splitmix64((uint64_t)substream * 0xD1B54A32D192ED03ull);
+    uint32_t a = (uint32_t)pk ^ (uint32_t)rk, b = (uint32_t)(pk >> 32) ^ (uint32_t)(rk >> 32);
+    uint64_t t = (uint64_t)a * (uint64_t)(b | 1u);
+    r->state = r->inc = 0ull;
+    r->s0 = (uint32_t)t ^ b;
+    r->s1 = ((uint32_t)(t >> 32) ^ a) | 0x80000000u;      /* (never the all-zero state) */
+    r->vsl_draw = 3; r->reserved = 0u;
+}
+void evo_vsl_rng_step(evo_rng *r) {
+    uint32_t t = r->s1 ^ r->s0;
+    r->s0 = ((r->s0 << 26) | (r->s0 >> 6)) ^ t ^ (t << 9);
+    r->s1 = (t << 13) | (t >> 19);
+    r->vsl_draw = 0;
+}
 /* curand_uniform: (0,1].  ((x>>8)+1) * 2^-24 is exact in fp32. */
 float evo_rng_uniform(evo_rng *r) {
+    if (r->vsl_draw >= 0) {
+        int k = r->vsl_draw++;
+        if (k == 0) return ((float)(((r->s0 & 0xffu) << 8) | (r->s1 & 0xffu)) + 0.5f) * (1.0f / 65536.0f);   /* (0, 1): 16 bits */
+        return (float)(((k == 1 ? r->s0 : r->s1) >> 8) + 1u) * (1.0f / 16777216.0f);                        /* (a draw past #2 is one the reference does not use) */
+    }
     return (float)((evo_rng_u32(r) >> 8) + 1u) * (1.0f / 16777216.0f);
 }
 
@@ -848,6 +881,7 @@ static v3 vsl_sample_cone(const vsl_ctx *c, float *w, evo_rng *rng) {
     float ml = max_color(c->rd1), mp = max_color(c->rs1);
     if (ml + mp <= 0.000001f) return V3(0, 0, 0);
     float psel = ml / (mp + ml);
+    evo_vsl_rng_step(rng);
     (void)minf(evo_rng_uniform(rng), 0.999999f); /* chooseMaterial: drawn, unused (:414) */
     float a = evo_rng_uniform(rng);
     float b = evo_rng_uniform(rng);
@@ -870,6 +904,7 @@ static v3 vsl_sample_brdf1(const vsl_ctx *c, float *w, evo_rng *rng) {
     float ml = max_color(c->rd1), mp = max_color(c->rs1);
     if (ml + mp <= 0.000001f) return V3(0, 0, 0);
     float psel = ml / (mp + ml);
+    evo_vsl_rng_step(rng);
     float choose = minf(evo_rng_uniform(rng), 0.999999f);
     if (choose < psel) brdf1 = divs(lambert_sample(&wi12, &pdfw, c->n1, c->rd1, rng), psel);
     else brdf1 = divs(phong_sample(&wi12, &pdfw, c->wi10, c->n1, c->rs1, c->e1, rng), 1.0f - psel);
@@ -890,6 +925,7 @@ static v3 vsl_sample_brdf2(const vsl_ctx *c, float *w, evo_rng *rng) {
         float ml = max_color(c->prd), mp = max_color(c->prs);
         if (ml + mp <= 0.000001f) return V3(0, 0, 0);
         float psel = ml / (mp + ml);
+        evo_vsl_rng_step(rng);
         float choose = minf(evo_rng_uniform(rng), 0.999999f);
         if (choose < psel) brdf2 = divs(lambert_sample(&wi21, &pdfw, c->pn, c->prd, rng), psel);
         else brdf2 = divs(phong_sample(&wi21, &pdfw, c->pfd, c->pn, c->prs, c->pe, rng), 1.0f - psel);
@@ -957,7 +993,7 @@ void evo_vsl_splat_pair(const evo_frame_params *fp, const float wi10[3], const f
                         uint32_t rng_index, uint32_t rng_sequence, uint32_t rng_substream, int only, int samples_override, float out[3]) {
     v3 r = V3(0, 0, 0);
     if (visible) {
-        evo_rng rng; evo_rng_init(&rng, rng_index, rng_sequence, rng_substream);
+        evo_rng rng; evo_vsl_rng_init(&rng, rng_index, rng_sequence, rng_substream);
         r = vsl_splat_lit(fp, ld3(wi10), ld3(p1), ld3(n1), ld3(rd), ld3(rs), e, rec, &rng, only, samples_override);
     }
     st3(out, r);
@@ -993,7 +1029,7 @@ void evo_gather_vsl_window(const evo_scene *s, const evo_frame_params *fp, int32
                 const evo_record *rec = &records[i];
                 if (!(rec->flags & EVO_USABLE_VPL)) continue;
                 pairs++;
-                evo_rng rng; evo_rng_init(&rng, pixel_id, fp->rng_seed, 1u + i);
+                evo_rng rng; evo_vsl_rng_init(&rng, pixel_id, fp->rng_seed, 1u + i);
                 result = add(result, vsl_splat(s, fp, wi10, p1, n1, rd, rs, e, rec, &rng));
             }
             float inv = (float)fp->num_vpl_light_paths, acc = (float)fp->do_accumulate;

@@ -22,8 +22,9 @@
  * (normalize, reflect, faceforward, Onb, cosine_sample_hemisphere,
  * intersect_triangle_branchless), CUDA tex2D bilinear filtering.
  * cuRAND XORWOW streams are NOT reproduced (seeding tables are not public): the
- * build defines its own generator (PCG32 XSH-RR seeded by splitmix64, outputs in
- * (0,1] like curand_uniform), shared bit-for-bit by this oracle and the HIP path.
+ * build defines its own generators (PCG32 XSH-RR seeded by splitmix64; for the VSL
+ * estimators xoroshiro64, one step per sample -- outputs in (0,1] like
+ * curand_uniform), shared bit-for-bit by this oracle and the HIP path.
  */
 #ifndef EVPLP_ORACLE_H
 #define EVPLP_ORACLE_H
@@ -109,8 +110,11 @@ int evo_closest(const evo_scene *s, const float o[3], const float d[3], float tm
                 int filter, float *t, float *beta, float *gamma);
 
 /* ---- RNG (build-defined; see header comment) ---- */
-typedef struct evo_rng { uint64_t state, inc; } evo_rng;
+typedef struct evo_rng { uint64_t state, inc; uint32_t s0, s1; int32_t vsl_draw; uint32_t reserved; } evo_rng;
 void evo_rng_init(evo_rng *r, uint32_t index, uint32_t sequence, uint32_t substream);
+/* the VSL estimators' own stream (xoroshiro64, one step per sample; evplp_oracle.c): evo_rng_uniform then serves the draws of the sample */
+void evo_vsl_rng_init(evo_rng *r, uint32_t index, uint32_t sequence, uint32_t substream);
+void evo_vsl_rng_step(evo_rng *r);
 uint32_t evo_rng_u32(evo_rng *r);
 float evo_rng_uniform(evo_rng *r); /* (0,1] like curand_uniform */
 

@@ -38,7 +38,7 @@ class FrameParams(C.Structure):
 
 
 class Rng(C.Structure):
-    _fields_ = [("state", C.c_uint64), ("inc", C.c_uint64)]
+    _fields_ = [("state", C.c_uint64), ("inc", C.c_uint64), ("s0", C.c_uint32), ("s1", C.c_uint32), ("vsl_draw", C.c_int32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -69,6 +69,8 @@ def load():
     l.evo_closest.restype = C.c_int
     l.evo_closest.argtypes = [_P, _P, _P, C.c_float, C.c_float, C.c_int, _P, _P, _P]
     l.evo_rng_init.argtypes = [_P, C.c_uint32, C.c_uint32, C.c_uint32]
+    l.evo_vsl_rng_init.argtypes = [_P, C.c_uint32, C.c_uint32, C.c_uint32]
+    l.evo_vsl_rng_step.argtypes = [_P]
     l.evo_rng_u32.restype = C.c_uint32
     l.evo_rng_u32.argtypes = [_P]
     l.evo_rng_uniform.restype = C.c_float

@@ -105,7 +105,7 @@ def test_primary_with_a_jitter_larger_than_the_cuts_pyramid(room, oscene, evplp)
 
 
 def test_exact_reciprocal_of_the_triangle_predicates(ctx):
-    """The triangle predicates divide by n . d with a 7-instruction refinement of v_rcp_f32 instead of the compiler's 11-instruction
+    """The triangle predicates divide by n . d with a 5-instruction refinement of v_rcp_f32 instead of the compiler's 11-instruction
     IEEE division.  Checked on all 2^32 float bit patterns on this GPU: the bits differ only for zero / denormal / infinite inputs and
     for normal inputs of biased exponent >= 253 (|x| >= 2^126) -- inputs for which the predicate is false under either arithmetic
     (device_common.hpp rcp_exact)."""
