@@ -53,7 +53,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 125.0          # vplSplat, misMode one (lighttracing.cu:282-312)
 FLOP_PER_PAIR_MIS = 195.0      # balance / max / power2
-FLOP_PER_VSL_SAMPLE = 540.0    # 3 estimators x ~180 flop per sample-iteration (+ 11 RNG draws, not counted)
+FLOP_PER_VSL_SAMPLE = 540.0    # 3 estimators x ~180 flop per sample-iteration (+ the sample's random numbers, not counted)
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: FP32 vector peak
 PEAK_HBM_GBS = 8000.0
 
@@ -566,7 +566,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 out["roofline"].update({
                     "flop_per_sample_iteration": FLOP_PER_VSL_SAMPLE, "sample_iterations_per_frame": samples / steps, "lit_pairs_per_frame": shaded / steps,
                     "note": "fp32 VECTOR-ALU bound.  achieved = sample-iterations of the three MIS-combined estimators counted ON THE DEVICE "
-                            "(lighttracing.cu:632-640) x 540 flop (SURVEY 8d: 3 x ~180; the 11 RNG draws per iteration and the BVH walks are "
+                            "(lighttracing.cu:632-640) x 540 flop (SURVEY 8d: 3 x ~180; the three generator steps per iteration and the BVH walks are "
                             "overhead, not counted) / HIP-event kernel time."})
             else:
                 out["roofline"].update({
