@@ -52,7 +52,7 @@ struct Component {
 };
 
 struct Decoder {
-    const uint8_t *p, *end;
+    const uint8_t *p, *end, *base;
     int W = 0, H = 0, ncomp = 0; bool progressive = false;
     int h_max = 1, v_max = 1, mcu_w = 8, mcu_h = 8, mcus_x = 0, mcus_y = 0;
     Component comp[4];
@@ -65,7 +65,7 @@ struct Decoder {
     int eob_run = 0, todo = 0;
     int scan_n = 0, order[4] = { 0, 0, 0, 0 }, ss = 0, se = 63, ah = 0, al = 0;
 
-    Decoder(const uint8_t *d, size_t n) : p(d), end(d + n) {}
+    Decoder(const uint8_t *d, size_t n) : p(d), end(d + n), base(d) {}
 
     int byte() { return p < end ? *p++ : 0; }
     int be16() { int a = byte(); return (a << 8) | byte(); }
@@ -104,6 +104,10 @@ struct Decoder {
         }
         throw std::runtime_error("jpeg: bad Huffman code");
     }
+    // (two's-complement wrap-around, spelled out: corrupted files reach these with values the signed operators leave undefined)
+    static int wrap_add(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+    static int wrap_mul(int a, int b) { return (int)((uint32_t)a * (uint32_t)b); }
+    static int wrap_shl(int a, int n) { return (int)((uint32_t)a << n); }
     // T.81 F.2.2.1 EXTEND
     int receive_extend(int s) {
         if (s == 0) return 0;
@@ -124,8 +128,8 @@ struct Decoder {
         int t = decode_symbol(hdc[c.td]);
         if (t > 15) throw std::runtime_error("jpeg: bad DC category");
         int diff = receive_extend(t);
-        c.dc_pred += diff;
-        d[0] = (int16_t)(c.dc_pred * q[0]);
+        c.dc_pred = wrap_add(c.dc_pred, diff);
+        d[0] = (int16_t)wrap_mul(c.dc_pred, q[0]);
         const HuffTable &ac = hac[c.ta];
         int k = 1;
         do {
@@ -135,7 +139,7 @@ struct Decoder {
                 k += r;
                 if (k > 63) throw std::runtime_error("jpeg: coefficient index out of range");
                 int z = kZigzag[k++];
-                d[z] = (int16_t)(receive_extend(s) * q[z]);
+                d[z] = (int16_t)wrap_mul(receive_extend(s), q[z]);
             }
         } while (k < 64);
     }
@@ -145,8 +149,8 @@ struct Decoder {
             std::memset(d, 0, 64 * sizeof(int16_t));
             int t = decode_symbol(hdc[c.td]);
             if (t > 15) throw std::runtime_error("jpeg: bad DC category");
-            c.dc_pred += receive_extend(t);
-            d[0] = (int16_t)(c.dc_pred << al);
+            c.dc_pred = wrap_add(c.dc_pred, receive_extend(t));
+            d[0] = (int16_t)wrap_shl(c.dc_pred, al);
         } else if (getbit()) d[0] = (int16_t)(d[0] + (int16_t)(1 << al));
     }
     void block_prog_ac(int16_t *d, Component &c) {
@@ -163,7 +167,7 @@ struct Decoder {
                 } else {
                     k += r;
                     if (k > 63) throw std::runtime_error("jpeg: coefficient index out of range");
-                    d[kZigzag[k++]] = (int16_t)(receive_extend(s) << al);
+                    d[kZigzag[k++]] = (int16_t)wrap_shl(receive_extend(s), al);
                 }
             } while (k <= se);
             return;
@@ -197,45 +201,58 @@ struct Decoder {
     }
 
     // ---- inverse DCT into an 8x8 block of a plane
+    // (the arithmetic wraps like the two's-complement machine code of the reference's decoder does: a corrupted file can drive the
+    // 32-bit intermediates over the top, which as signed C++ arithmetic would be undefined behaviour -- found by tools/host_fuzz)
+    struct wi {
+        uint32_t u;
+        wi() : u(0) {}
+        wi(int x) : u((uint32_t)x) {}
+        operator int() const { return (int)u; }
+        friend wi operator+(wi a, wi b) { wi r; r.u = a.u + b.u; return r; }
+        friend wi operator-(wi a, wi b) { wi r; r.u = a.u - b.u; return r; }
+        friend wi operator*(wi a, wi b) { wi r; r.u = a.u * b.u; return r; }
+        wi &operator+=(wi b) { u += b.u; return *this; }
+        wi &operator*=(wi b) { u *= b.u; return *this; }
+    };
     static constexpr int fx(float x) { return (int)((double)x * 4096 + 0.5); }
-    struct Odd { int t0, t1, t2, t3; };
-    static inline void idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int &x0, int &x1, int &x2, int &x3, Odd &o) {
-        int p2 = s2, p3 = s6;
-        int p1 = (p2 + p3) * fx(0.5411961f);
-        int t2 = p1 + p3 * fx(-1.847759065f);
-        int t3 = p1 + p2 * fx(0.765366865f);
-        int t0 = (s0 + s4) * 4096, t1 = (s0 - s4) * 4096;
+    struct Odd { wi t0, t1, t2, t3; };
+    static inline void idct_1d(wi s0, wi s1, wi s2, wi s3, wi s4, wi s5, wi s6, wi s7, wi &x0, wi &x1, wi &x2, wi &x3, Odd &o) {
+        wi p2 = s2, p3 = s6;
+        wi p1 = (p2 + p3) * wi(fx(0.5411961f));
+        wi t2 = p1 + p3 * wi(fx(-1.847759065f));
+        wi t3 = p1 + p2 * wi(fx(0.765366865f));
+        wi t0 = (s0 + s4) * wi(4096), t1 = (s0 - s4) * wi(4096);
         x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;
         t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-        p3 = t0 + t2; int p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-        int p5 = (p3 + p4) * fx(1.175875602f);
-        t0 *= fx(0.298631336f); t1 *= fx(2.053119869f); t2 *= fx(3.072711026f); t3 *= fx(1.501321110f);
-        p1 = p5 + p1 * fx(-0.899976223f); p2 = p5 + p2 * fx(-2.562915447f);
-        p3 *= fx(-1.961570560f); p4 *= fx(-0.390180644f);
+        p3 = t0 + t2; wi p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+        wi p5 = (p3 + p4) * wi(fx(1.175875602f));
+        t0 *= wi(fx(0.298631336f)); t1 *= wi(fx(2.053119869f)); t2 *= wi(fx(3.072711026f)); t3 *= wi(fx(1.501321110f));
+        p1 = p5 + p1 * wi(fx(-0.899976223f)); p2 = p5 + p2 * wi(fx(-2.562915447f));
+        p3 *= wi(fx(-1.961570560f)); p4 *= wi(fx(-0.390180644f));
         o.t3 = t3 + p1 + p4; o.t2 = t2 + p2 + p3; o.t1 = t1 + p2 + p4; o.t0 = t0 + p1 + p3;
     }
     static inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); }
     static void idct(uint8_t *out, int stride, const int16_t *d) {
         int v[64];
         for (int i = 0; i < 8; i++) {
-            int x0, x1, x2, x3; Odd o;
+            wi x0, x1, x2, x3; Odd o;
             idct_1d(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i], x0, x1, x2, x3, o);
-            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-            v[i] = (x0 + o.t3) >> 10; v[56 + i] = (x0 - o.t3) >> 10;
-            v[8 + i] = (x1 + o.t2) >> 10; v[48 + i] = (x1 - o.t2) >> 10;
-            v[16 + i] = (x2 + o.t1) >> 10; v[40 + i] = (x2 - o.t1) >> 10;
-            v[24 + i] = (x3 + o.t0) >> 10; v[32 + i] = (x3 - o.t0) >> 10;
+            x0 += wi(512); x1 += wi(512); x2 += wi(512); x3 += wi(512);
+            v[i] = (int)(x0 + o.t3) >> 10; v[56 + i] = (int)(x0 - o.t3) >> 10;
+            v[8 + i] = (int)(x1 + o.t2) >> 10; v[48 + i] = (int)(x1 - o.t2) >> 10;
+            v[16 + i] = (int)(x2 + o.t1) >> 10; v[40 + i] = (int)(x2 - o.t1) >> 10;
+            v[24 + i] = (int)(x3 + o.t0) >> 10; v[32 + i] = (int)(x3 - o.t0) >> 10;
         }
         for (int i = 0; i < 8; i++) {
             const int *r = v + 8 * i; uint8_t *o8 = out + (size_t)i * stride;
-            int x0, x1, x2, x3; Odd o;
+            wi x0, x1, x2, x3; Odd o;
             idct_1d(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], x0, x1, x2, x3, o);
-            const int bias = 65536 + (128 << 17);
+            const wi bias(65536 + (128 << 17));
             x0 += bias; x1 += bias; x2 += bias; x3 += bias;
-            o8[0] = clamp8((x0 + o.t3) >> 17); o8[7] = clamp8((x0 - o.t3) >> 17);
-            o8[1] = clamp8((x1 + o.t2) >> 17); o8[6] = clamp8((x1 - o.t2) >> 17);
-            o8[2] = clamp8((x2 + o.t1) >> 17); o8[5] = clamp8((x2 - o.t1) >> 17);
-            o8[3] = clamp8((x3 + o.t0) >> 17); o8[4] = clamp8((x3 - o.t0) >> 17);
+            o8[0] = clamp8((int)(x0 + o.t3) >> 17); o8[7] = clamp8((int)(x0 - o.t3) >> 17);
+            o8[1] = clamp8((int)(x1 + o.t2) >> 17); o8[6] = clamp8((int)(x1 - o.t2) >> 17);
+            o8[2] = clamp8((int)(x2 + o.t1) >> 17); o8[5] = clamp8((int)(x2 - o.t1) >> 17);
+            o8[3] = clamp8((int)(x3 + o.t0) >> 17); o8[4] = clamp8((int)(x3 - o.t0) >> 17);
         }
     }
 
@@ -335,6 +352,13 @@ struct Decoder {
         }
         h_max = v_max = 1;
         for (int i = 0; i < ncomp; i++) { if (comp[i].h > h_max) h_max = comp[i].h; if (comp[i].v > v_max) v_max = comp[i].v; }
+        // Two refusals the reference's stb_image v2.16 does not make (found by tools/host_fuzz; later stb versions make the first too):
+        // sampling factors that do not divide the largest one -- its resamplers (and these) then read a component's rows as if they were
+        // as wide as the image, past the end of the plane; and a frame that asks for more memory than any data behind so small a file
+        // could fill (an all-zero block costs two bits; 64 samples per block, three components).
+        for (int i = 0; i < ncomp; i++) if (h_max % comp[i].h != 0 || v_max % comp[i].v != 0) throw std::runtime_error("jpeg: sampling factors that are not integer ratios");
+        if ((uint64_t)W * (uint64_t)H > (1ull << 28) || (uint64_t)W * (uint64_t)H > 4096ull * (uint64_t)(end - base) + (1ull << 20))
+            throw std::runtime_error("jpeg: frame larger than its data can fill");
         mcu_w = 8 * h_max; mcu_h = 8 * v_max;
         mcus_x = (W + mcu_w - 1) / mcu_w; mcus_y = (H + mcu_h - 1) / mcu_h;
         for (int i = 0; i < ncomp; i++) {

@@ -1,6 +1,7 @@
 // zlib (RFC 1950) / DEFLATE (RFC 1951) decompression for the PNG decoder.
 #include "decoders.hpp"
 
+#include <algorithm>
 #include <stdexcept>
 
 namespace evplp {
@@ -81,7 +82,8 @@ std::vector<uint8_t> zlib_inflate(const uint8_t *data, size_t size, size_t size_
     if ((cmf & 15) != 8 || ((cmf << 8) | flg) % 31 != 0) throw std::runtime_error("zlib: bad header");
     if (flg & 32) throw std::runtime_error("zlib: preset dictionary not allowed");
     BitReader br(data + 2, size - 2);
-    std::vector<uint8_t> out; out.reserve(size_hint);
+    // (the hint comes from a header the file wrote itself: never more than a deflate stream of this size can hold, 1032 : 1)
+    std::vector<uint8_t> out; out.reserve(std::min(size_hint, size * 1032 + 64));
     Huffman fixed_lit, fixed_dist; bool have_fixed = false;
     int last;
     do {

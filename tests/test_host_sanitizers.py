@@ -1,0 +1,98 @@
+"""The host-side readers of the asset pipeline under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build; the pool has no GPU
+sanitizers): tools/host_fuzz/host_fuzz.cpp compiled with the decoders, the float-image loaders, the JSON reader and the OBJ / MTL reader,
+run over the committed fixtures and seeded mutations of them.  A reader may refuse a file; it may not touch memory out of bounds, leave
+signed arithmetic undefined, or ask for memory out of proportion to the file.  (Round 5: the first runs found a heap over-read for
+sampling factors that are not integer ratios, signed overflow in the IDCT / dequantisation of corrupted coefficients and two
+allocations sized by a header alone -- fixed in decode_jpeg.cpp / inflate.cpp.)"""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HOST = os.path.join(ROOT, "evplp_amd", "csrc", "host")
+SOURCES = [os.path.join(ROOT, "tools", "host_fuzz", "host_fuzz.cpp")] + [os.path.join(HOST, f) for f in
+                                                                        ("decode_jpeg.cpp", "decode_png.cpp", "inflate.cpp", "images.cpp", "scene_io.cpp")]
+
+OBJ = """# a small scene
+mtllib room.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+v 1 0 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 0 1
+usemtl wall
+f 1/1/1 2/2/1 3/3/1
+f 1/1/1 3/3/1 4/4/1
+usemtl floor
+f 1 2 6 5
+f -1 -2 -3
+g other
+usemtl wall
+f 1//1 2//1 6//1
+"""
+MTL = """newmtl wall
+Kd 0.7 0.6 0.5
+Ks 0.1 0.1 0.1
+Ns 40
+map_Kd tex_a.png
+newmtl floor
+Kd 0.3 0.3 0.3
+Ks 0 0 0
+Ns 0
+map_Ks tex_b.png
+map_Ns tex_a.png
+"""
+SCENE = """{ "camera": { "origin": [0.5, 0.5, 3], "direction": [0.5, 0.5, 0], "up": [0, 1, 0], "fovy": 40, "resolution": [64, 48] },
+  "objects": ["room.obj"], "arealight": { "path": "light.obj", "intensity": [10, 10, 10, 1] },
+  "photonfam": { "numMaxIteration": 3, "renderMode": "vpl", "misMode": "balance", "alpha": 0.7, "numLightPaths": 1000 } }
+"""
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    d = tmp_path_factory.mktemp("host_fuzz")
+    exe = str(d / "host_fuzz")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"), "-o", exe] + SOURCES
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    seeds = d / "seeds"; seeds.mkdir()
+    tex = np.load(os.path.join(HERE, "golden", "textures.npz"))
+    pngs = []
+    for k in tex.files:
+        if k.endswith("__file"):
+            name = k[: -len("__file")]
+            ext = ".jpg" if name.endswith("_jpg") else ".png"
+            (seeds / (name + ext)).write_bytes(tex[k].tobytes())
+            if ext == ".png": pngs.append(tex[k].tobytes())
+    (seeds / "tex_a.png").write_bytes(pngs[0]); (seeds / "tex_b.png").write_bytes(pngs[1])
+    (seeds / "room.obj").write_text(OBJ); (seeds / "room.mtl").write_text(MTL); (seeds / "scene.json").write_text(SCENE)
+    out = np.load(os.path.join(HERE, "golden", "output_surface.npz"))      # the reference's own PFM / HDR bytes of two small images
+    for name in ("a", "b"):
+        (seeds / (name + ".pfm")).write_bytes(out[f"{name}_pfm_bytes"].tobytes())
+        if f"{name}_hdr_bytes" in out.files: (seeds / (name + ".hdr")).write_bytes(out[f"{name}_hdr_bytes"].tobytes())
+    return exe, str(seeds)
+
+
+@pytest.mark.parametrize("rng_seed", [1, 2])
+def test_readers_survive_mutated_files_under_asan_and_ubsan(harness, rng_seed):
+    exe, seeds = harness
+    env = dict(os.environ, ASAN_OPTIONS="max_allocation_size_mb=1024:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, seeds, "400", str(rng_seed)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
+    # every unmutated fixture decodes (iteration 0 of every seed): at least as many successes as image seeds
+    line = r.stdout.strip().splitlines()[-1]
+    decoded = int(line.split("images:")[1].split("decoded")[0])
+    assert decoded >= len([f for f in os.listdir(seeds) if f.endswith((".jpg", ".png"))]), line
