@@ -96,3 +96,27 @@ def test_readers_survive_mutated_files_under_asan_and_ubsan(harness, rng_seed):
     line = r.stdout.strip().splitlines()[-1]
     decoded = int(line.split("images:")[1].split("decoded")[0])
     assert decoded >= len([f for f in os.listdir(seeds) if f.endswith((".jpg", ".png"))]), line
+
+
+def test_jpeg_refusals_found_by_the_harness(tmp_path):
+    """The two refusals decode_jpeg.cpp makes beyond the reference's stb_image v2.16 (round 5): sampling factors that are not integer
+    ratios (its resamplers -- and ours -- would read past the end of a component's plane) and a frame header asking for more pixels
+    than the data behind it can fill.  Through the product's C ABI (evplp_decode_image; no GPU needed)."""
+    sys.path.insert(0, ROOT)
+    import evplp_amd as ev
+    tex = np.load(os.path.join(HERE, "golden", "textures.npz"))
+    name = sorted(k for k in tex.files if k.endswith("_jpg__file") and "420" in k)[0]
+    data = bytearray(tex[name].tobytes())
+    sof = next(i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] in (0xC0, 0xC2))
+    assert data[sof + 9] == 3                                    # three components; component k's sampling byte at sof + 11 + 3 k
+    ok = tmp_path / "ok.jpg"; ok.write_bytes(bytes(data))
+    img, channels = ev.decode_image(str(ok))
+    assert img.shape == tex[name[:-len("__file")] + "__pixels"].shape
+    bad = bytearray(data); bad[sof + 11] = 0x31; bad[sof + 14] = 0x21            # H factors 3, 2, 1: 3 / 2 is not an integer
+    p = tmp_path / "ratio.jpg"; p.write_bytes(bytes(bad))
+    with pytest.raises(ev.EvplpError):
+        ev.decode_image(str(p))
+    big = bytearray(data); big[sof + 5:sof + 9] = b"\xff\xff\xff\xff"           # 65535 x 65535 pixels behind a 1 KB file
+    p = tmp_path / "big.jpg"; p.write_bytes(bytes(big))
+    with pytest.raises(ev.EvplpError):
+        ev.decode_image(str(p))
