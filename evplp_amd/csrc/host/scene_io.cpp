@@ -139,10 +139,12 @@ ObjResult read_obj(HostScene &scene, const std::string &obj_path, bool want_mate
                 if (end == p) break;
                 p = end;
                 if (*p == '/') { p++; if (*p != '/') { ti = std::strtol(p, &end, 10); p = end; } if (*p == '/') { p++; std::strtol(p, &end, 10); p = end; } }
-                int nv = (int)(pos.size() / 3), nt = (int)(tex.size() / 2);
-                int v = vi < 0 ? nv + (int)vi : (int)vi - 1;
-                int t = ti == 0 ? -1 : (ti < 0 ? nt + (int)ti : (int)ti - 1);
-                if (v < 0 || v >= nv) throw std::runtime_error("OBJ face references a missing vertex: " + obj_path);
+                const long nv = (long)(pos.size() / 3), nt = (long)(tex.size() / 2);
+                const long vl = vi < 0 ? nv + vi : vi - 1;
+                long tl = ti == 0 ? -1 : (ti < 0 ? nt + ti : ti - 1);
+                if (vl < 0 || vl >= nv) throw std::runtime_error("OBJ face references a missing vertex: " + obj_path);
+                if (tl < 0 || tl >= nt) tl = -1;                          // (a texture coordinate that does not exist: none, rtcommon.h:701-705)
+                const int v = (int)vl, t = (int)tl;
                 face.emplace_back(v, t);
             }
             MeshData &m = meshes[cur];
