@@ -395,6 +395,18 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
             env.sync_all()
 
     gather_pass = ev.PASS_GATHER_VSL if wl == "vsl" else ev.PASS_GATHER_VPL
+
+    def profile_passes(on):
+        # the two HIP events per pass behind pass_stats()["ms"]: config #4's sub-millisecond iterations run their timed region without them
+        # (as the technique loop of evplp_render_json does for all iterations but its last); the pass times of the line come from the
+        # extra iterations after the timed region, recorded with them
+        if group is not None:
+            group.profile_passes(on)
+        else:
+            for c in ranks:
+                c.profile_passes(on)
+    if wl == "ppm":
+        profile_passes(False)
     for i in range(warmup):
         frame(i)
     sync_all()
@@ -432,6 +444,8 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 read_pass_times()
     sync_all()
     dt = time.perf_counter() - t0
+    if wl == "ppm":
+        profile_passes(True)
     splat_pairs = (sum(c.pass_stats(ev.PASS_SPLAT)["shaded"] for c in ranks) - pairs_before) if wl != "ir" else 0
     extra = min(10, len(jitters) - (warmup + steps))
     if wl == "ppm":

@@ -129,6 +129,8 @@ _SIGNATURES = {
     "evplp_upload": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
     "evplp_pass_stats_get": (C.c_int, [_P, C.c_int32, C.POINTER(PassStats)]),
     "evplp_profile_kernels": (C.c_int, [_P, C.c_int32]),
+    "evplp_profile_passes": (C.c_int, [_P, C.c_int32]),
+    "evplp_group_profile_passes": (C.c_int, [_P, C.c_int32]),
     "evplp_debug_counters": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "evplp_accel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "evplp_accel_builder": (C.c_int, [_P]),
@@ -447,6 +449,11 @@ class Context:
         """Record the events around the photon splat's dominant kernel (pass_stats()["dominant_kernel_ms"]); they sit between its launches."""
         self._check(self._lib.evplp_profile_kernels(self._h, int(on)))
 
+    def profile_passes(self, on: bool = True):
+        """Record the two events per pass that pass_stats()["ms"] needs (default on); off, a loop of sub-millisecond iterations runs
+        without them and pass_stats reports ms = 0 for passes run meanwhile."""
+        self._check(self._lib.evplp_profile_passes(self._h, int(on)))
+
     def debug_counters(self, which: int) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint64)
         n = self._check(self._lib.evplp_debug_counters(self._h, which, _ptr(out), out.size))
@@ -535,6 +542,9 @@ class Group:
         self._check(self._lib.evplp_group_rebalance(self._h, _ptr(out)))
         self._bands = out.copy()
         return out
+
+    def profile_passes(self, on: bool = True):
+        self._check(self._lib.evplp_group_profile_passes(self._h, int(on)))
 
     def host_stats(self, r: int) -> dict:
         """host time of rank r's worker thread (ms inside pass calls, ms inside exchanges, commands run)"""

@@ -28,6 +28,9 @@ struct evplp_context {
     hipEvent_t ev_begin[EVPLP_PASS_COUNT] = {}, ev_end[EVPLP_PASS_COUNT] = {};
     hipEvent_t ev_dom_begin[EVPLP_PASS_COUNT] = {}, ev_dom_end[EVPLP_PASS_COUNT] = {};
     bool pass_ran[EVPLP_PASS_COUNT] = {}, pass_has_dom[EVPLP_PASS_COUNT] = {};
+    // evplp_profile_passes: off = a pass records only the events the library itself waits on (the G-buffer pass's start for the
+    // overlapped light tracing, the record readers', a splat's verdict); its HIP-event time is then not available (pass_timed)
+    bool profile_passes = true, pass_timed[EVPLP_PASS_COUNT] = {};
     // The events around the dominant kernel of the photon splat sit BETWEEN its three dependent launches and hold them apart (18 us of a
     // 227 us pass, round 3): recorded only after evplp_profile_kernels(ctx, 1)
     bool profile_kernels = false;

@@ -272,6 +272,13 @@ extern "C" int evplp_group_host_stats(evplp_group *g, int32_t rank, double out[3
     return EVPLP_OK;
 }
 
+extern "C" int evplp_group_profile_passes(evplp_group *g, int32_t on) {
+    GRP_CHECK(g);
+    drain(g);                                                             // (the flag belongs to the workers' contexts: set between their commands)
+    for (evplp_context *c : g->ctx) c->profile_passes = on != 0;
+    return EVPLP_OK;
+}
+
 extern "C" void evplp_group_destroy(evplp_group *g) {
     if (!g) return;
     for (Worker *w : g->workers) if (w->th.joinable()) { Cmd q; q.op = OP_QUIT; post(w, q); }

@@ -337,8 +337,13 @@ private:
         auto elapsed_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         float prev_timing = 0.f;
         std::vector<float> rgb((size_t)W * H * 3);
+        // The two events per pass behind the stat file's pass times cost a sub-millisecond iteration ~3 % (evplp_profile_passes): a loop
+        // that ends by iteration count records them in its last iteration only; one with a time limit (it waits for every frame anyway) always.
+        const bool always_profile = time_limit_ms < 1e8f;
+        check(h, evplp_group_profile_passes(h, always_profile ? 1 : 0), "profile");
         for (;;) {
             if (num_iterations == num_max_iteration) break;                                   // :938-941
+            if (!always_profile && num_iterations + 1 == num_max_iteration) check(h, evplp_group_profile_passes(h, 1), "profile");
             float jitter[2] = { 0.f, 0.f };
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :946-952
             evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
@@ -380,6 +385,7 @@ private:
         }
         check(h, evplp_group_synchronize(h), "sync");
         float time = elapsed_ms();
+        check(h, evplp_group_profile_passes(h, 1), "profile");
         if (use_stat) {                                                                       // :1109-1119
             Json st = Json::object();
             st.set("time", Json::number(time));

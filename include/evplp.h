@@ -302,6 +302,11 @@ int evplp_pass_stats_get(evplp_context *ctx, int32_t pass, evplp_pass_stats *out
  * hold the launches apart (18 us of a 227 us pass): they are recorded only while this is on (off by default; the gathers' dominant
  * kernels are bracketed always -- their events sit beside 50 ms kernels).  Off: the splat reports dominant_kernel_ms = ms. */
 int evplp_profile_kernels(evplp_context *ctx, int32_t on);
+/* evplp_pass_stats.ms comes from two HIP events around every pass; the command processor retires them between the dispatches, and a
+ * loop of sub-millisecond iterations pays for that (config #4: 18 us of a 0.61 ms iteration).  Off (the default is on): a pass records
+ * only the events the library itself waits on, and evplp_pass_stats_get reports ms = dominant_kernel_ms = 0 for passes run meanwhile
+ * (their counters -- pairs, rays, shaded -- stay valid).  evplp_render_json switches it off for all iterations but the last. */
+int evplp_profile_passes(evplp_context *ctx, int32_t on);
 /* Raw device-side counters of the last run of `pass` (rays, node visits, pairs, aux, then the traversal histogram that
  * only -DEVPLP_TRAVERSAL_STATS=1 diagnostic builds fill).  Returns the number of 64-bit words written. */
 int evplp_debug_counters(evplp_context *ctx, int32_t pass, uint64_t *out, int32_t capacity);
@@ -373,6 +378,8 @@ int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows);
 /* Host time of rank `rank`'s worker so far, in ms: out[0] inside its rank's pass calls (enqueueing; waits for a splat's verdict included),
  * out[1] inside exchanges (host barrier + collective / copies), out[2] commands run.  Waits until that worker is idle. */
 int evplp_group_host_stats(evplp_group *g, int32_t rank, double out[3]);
+/* evplp_profile_passes on every rank's context (waits until the workers are idle) */
+int evplp_group_profile_passes(evplp_group *g, int32_t on);
 /* evplp_resolve for the whole frame: out_rgb = HOST pointer, res_y * res_x * 3 floats, y = 0 bottom */
 /* The per-frame exchange alone: composite every rank's strip on its GPU (final.frag:19-35) and all-gather the strips, so that every
  * GPU holds the frame; nothing is copied to the host.  evplp_group_resolve = this + the strips put into image order on rank 0's device

@@ -571,6 +571,36 @@ def test_overlapped_light_tracing_changes_no_bit(room, evplp):
     assert outs[0] == outs[1]
 
 
+def test_pass_events_can_be_switched_off(room, evplp):
+    """evplp_profile_passes(ctx, 0): the two HIP events per pass are not recorded (a loop of sub-millisecond iterations saves the command
+    processor's time between its dispatches); the passes do the same work -- every accumulator bit, every counter -- and their event
+    time reads 0 until the next pass recorded with events."""
+    outs = []
+    for profiled in (True, False):
+        with evplp.Context(W, H, NPATHS, NPATHS, P, deterministic=True, overlap_light_tracing=True) as c:
+            room.upload(c)
+            c.clear_accumulators()
+            c.profile_passes(profiled)
+            for it in range(3):
+                kw = dict(camera_pos=room.cam_origin, mis_mode=1, pdf_mc=0.35, photon_radius=0.3, num_light_paths=NPATHS, num_vpl_light_paths=NPATHS,
+                          photons_per_path=P, do_accumulate=1, rng_seed=it)
+                c.trace_light_paths(10 + it)
+                c.primary((0.001 * it, -0.002), clear_light=True)
+                c.gather_vpl(evplp.frame_params(**kw))
+                c.splat_photons(evplp.frame_params(**kw))
+                c.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0)
+            st = {p: c.pass_stats(p) for p in (evplp.PASS_PRIMARY, evplp.PASS_LIGHT_TRACE, evplp.PASS_GATHER_VPL, evplp.PASS_SPLAT)}
+            for p, v in st.items():
+                assert (v["ms"] > 0) == profiled, (p, profiled, v["ms"])
+            outs.append((c.download(evplp.BUF_VPL_ACCUM)[:H].tobytes(), c.download(evplp.BUF_PHOTON_ACCUM)[:H].tobytes(),
+                         st[evplp.PASS_GATHER_VPL]["rays"], st[evplp.PASS_SPLAT]["pairs"], c.resolve(1.0, 1.0, 1.0).tobytes()))
+            if not profiled:                      # ... and on again
+                c.profile_passes(True)
+                c.primary((0.0, 0.0))
+                assert c.pass_stats(evplp.PASS_PRIMARY)["ms"] > 0
+    assert outs[0][2] > 0 and outs[0][3] > 0 and outs[0] == outs[1]
+
+
 def test_bins_grow_with_two_passes_in_flight(room, evplp, monkeypatch):
     """overlap_light_tracing keeps up to two photon splats pending.  With two-slot bins every pass overflows and runs again.  In
     deterministic mode a pass never stays pending behind a younger one, so the re-runs keep their place in the stream and the
