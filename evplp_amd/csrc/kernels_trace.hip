@@ -16,11 +16,18 @@ namespace evplp {
 #ifndef EVPLP_PRIMARY_BLOCK_LOG2
 #define EVPLP_PRIMARY_BLOCK_LOG2 2     // 4 x 4 tiles
 #endif
+#if EVPLP_PRIMARY_TIMES      // developer build (tools/primary_times.py): start / end of every tile's wavefront, s_memrealtime ticks (100 MHz)
+__device__ unsigned long long g_primary_times[2 * 65536];
+extern "C" int evplp_debug_primary_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_primary_times), sizeof(unsigned long long) * (size_t)n); }
+#endif
 __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
     // ray set-up and the hit point are written without fused multiply-adds, in the oracle's operation order: together
     // with the exact closest hit the G-buffer POSITIONS are then bit-identical to the CPU restatement, and so is every
     // threshold test downstream that reads them (the photon radius test |X_p - X|^2 <= r^2, frag:152-154)
 #pragma clang fp contract(off)
+#if EVPLP_PRIMARY_TIMES
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x;
     const int tiles_x = (a.st.W + 7) >> 3;
 #if EVPLP_PRIMARY_BLOCKS
@@ -112,6 +119,9 @@ __global__ __launch_bounds__(64) void primary_kernel(PrimaryArgs a) {
             for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
         if (lane == 0) { a.tile_box[2 * tile] = make_float4(lo[0], lo[1], lo[2], 0.f); a.tile_box[2 * tile + 1] = make_float4(hi[0], hi[1], hi[2], 0.f); }
     }
+#if EVPLP_PRIMARY_TIMES
+    if (lane == 0 && tile < 65536) { g_primary_times[2 * tile] = t_start; g_primary_times[2 * tile + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (!in_image) return;
     a.g_pos[p] = pos; a.g_nrm[p] = nrm; a.g_dif[p] = dif; a.g_phg[p] = phg;
     if (!(a.clear_light & EVPLP_LIGHT_SKIP)) {
