@@ -161,6 +161,14 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     }
     if ((e = hipMalloc((void **)&c->d_tile_box, sizeof(float4) * 2 * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_box)", e);
     if ((e = hipMalloc((void **)&c->d_summary, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMalloc(summary)", e);
+    if (const char *env = std::getenv("EVPLP_TILE_MIXED")) c->env_tile_mixed = atoi(env) != 0 ? 1 : 0;
+    if (const char *env = std::getenv("EVPLP_TILE_HEAVY")) c->heavy_threshold = (uint32_t)std::max(atoi(env), 1);
+    c->mixed_trigger = 2u * c->heavy_threshold;
+    if (const char *env = std::getenv("EVPLP_TILE_MIXED_TRIGGER")) c->mixed_trigger = (uint32_t)std::max(atoi(env), 0);
+    c->heavy_cap = (uint32_t)std::min<size_t>(std::max<size_t>((size_t)c->tiles_x * c->tiles_y, 1), 2048);
+    if (const char *env = std::getenv("EVPLP_TILE_HEAVY_CAP")) c->heavy_cap = (uint32_t)std::max(atoi(env), 1);
+    if ((e = hipMalloc((void **)&c->d_heavy_list, sizeof(uint32_t) * c->heavy_cap)) != hipSuccess) return fail("hipMalloc(heavy list)", e);
+    if ((e = hipMalloc((void **)&c->d_tile_flags, std::max<size_t>((size_t)c->tiles_x * c->tiles_y, 1))) != hipSuccess) return fail("hipMalloc(tile flags)", e);
     if ((e = hipMemset(c->d_summary, 0, sizeof(uint32_t) * (kSummaryFinal + kSummaryStride))) != hipSuccess) return fail("hipMemset(summary)", e);
     if ((e = hipMalloc((void **)&c->d_tile_pairs, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_pairs)", e);
     if ((e = hipMalloc((void **)&c->d_tile_frags, sizeof(uint32_t) * std::max<size_t>(ntiles, 1))) != hipSuccess) return fail("hipMalloc(tile_frags)", e);
@@ -199,7 +207,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     free_scene_device(c);
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_cuts); hipFree(c->d_primary_cuts); hipFree(c->d_lt_overflow);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
-    hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary);
+    hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary); hipFree(c->d_heavy_list); hipFree(c->d_tile_flags);
     hipFree(c->d_proxy_slabs); hipFree(c->d_proxy_hm); hipFree(c->d_tile_frags);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if (c->ev_begin[i]) hipEventDestroy(c->ev_begin[i]);
@@ -935,10 +943,15 @@ extern "C" int evplp_splat_photons(evplp_context *c, const evplp_frame_params *f
     a.counters = &c->d_counters[EVPLP_PASS_SPLAT];
     a.proxy_slabs = c->d_proxy_slabs; a.proxy_hm = c->d_proxy_hm; a.proxy_count = c->proxy_count; a.proxy_rin = c->proxy_rin; a.proxy_rout = c->proxy_rout;
     a.tile_frags = c->d_tile_frags; c->last_splat_proxy = fp->splat_footprint == (uint32_t)EVPLP_FOOTPRINT_PROXY;
+    // MIXED tile launch when the previous pass had bins at least twice the heavy threshold (a heuristic, like the choice between the pure
+    // variants it replaces): below that the heavy list stays nearly empty and its bookkeeping costs more than four waves save
+    if (c->env_tile_mixed && c->last_bin_max >= c->mixed_trigger) { a.heavy_list = c->d_heavy_list; a.tile_flags = c->d_tile_flags; a.heavy_cap = c->heavy_cap; a.heavy_threshold = c->heavy_threshold; }
     if ((rc = pass_begin(c, EVPLP_PASS_SPLAT))) return rc;
     if (clear) HIP_TRY(c, hipMemsetAsync(c->buf[EVPLP_BUF_PHOTON_ACCUM], 0, buffer_bytes(c, EVPLP_BUF_PHOTON_ACCUM), c->stream));
     launch_splat_bin(a, c->stream);                                       // (clears the overflow flag, the cursors and the summary)
-    // Tile kernel variant.  One wave per tile is cheapest while bins are short; when some bins are very full (tiles
+    // Tile kernel variant.  (Round 5: when the previous pass had bins of >= mixed_trigger entries the launch is MIXED -- a.heavy_list above,
+    // kernels_splat.hip -- and what follows only decides for deterministic contexts and EVPLP_TILE_MIXED=0.)
+    // One wave per tile is cheapest while bins are short; when some bins are very full (tiles
     // that see a floor at grazing angle collect thousands of photons) those waves set the duration of the launch and
     // four waves per tile win.  Deterministic mode always uses one variant: the fold order is part of the result.
     // Measured (tiles kernel, ms): fullest bin 1405 entries (config #3): 0.31 with one wave, 0.18 with four; fullest bin 365

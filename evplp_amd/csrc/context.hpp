@@ -87,6 +87,8 @@ struct evplp_context {
     // The bin sizes of a splat are known only on the device.  The pass is enqueued completely (fill and tiles kernels do
     // nothing when the bins overflowed); the summary arrives in pinned host memory behind ev_summary and is looked at by the
     // NEXT call on the context (settle_splat): no host round trip, no GPU bubble inside the pass.
+    // MIXED tile launches of the photon splat (kernels.h SplatArgs): heavy list + per-tile flags; EVPLP_TILE_MIXED=0 keeps the pure variants
+    uint32_t *d_heavy_list = nullptr; uint8_t *d_tile_flags = nullptr; uint32_t heavy_cap = 0, heavy_threshold = 256, mixed_trigger = 512; int env_tile_mixed = 1;
     uint32_t *h_summary = nullptr;            // pinned, 4 words per pending pass: [0] bin entries, [1] fullest bin, [2] overflow (slots the fullest bin needed)
     // Up to two passes wait for their verdict (oldest first).  One is the rule: every entry point settles it.  With
     // overlap_light_tracing a second may be in flight: evplp_splat_photons only LOOKS whether the previous one is known yet, and

@@ -131,6 +131,7 @@ struct PathTraceArgs {
 };
 
 constexpr int kSummaryShards = 1024, kSummaryStride = 32, kSummaryFinal = kSummaryShards * kSummaryStride;
+constexpr int kSummaryHeavy = kSummaryFinal + 8;     // tiles on the heavy list of this pass (splat_heavy_kernel)
 // Two-level binning of the photon splat, without contended atomics.  Measured (tools/ub/atomics.hip): returning atomics on
 // scattered addresses retire at 27 G/s chip-wide (64-byte requests at the memory side), atomics on ONE 128-byte line at 88 M/s
 // (11 ns each, whichever words of the line), lines in parallel.  One atomic per (photon, tile) entry on per-tile cursors cost
@@ -185,6 +186,8 @@ struct SplatArgs {
     // EVPLP_FOOTPRINT_PROXY (ProxyDev below): the slabs of the proxy mesh in units of the radius, and the per-tile fragment counts
     const float4 *proxy_slabs; const float *proxy_hm; int32_t proxy_count; float proxy_rin, proxy_rout;
     uint32_t *tile_frags;     // [ntiles] proxy fragments accepted in the tile (statistics, like tile_pairs)
+    // MIXED tile launches (kernels_splat.hip splat_heavy_kernel): tiles with >= heavy_threshold bin entries, at most heavy_cap of them; null = the pure variants
+    uint32_t *heavy_list; uint8_t *tile_flags; uint32_t heavy_cap, heavy_threshold;
 };
 // The proxy mesh of the reference's photon splat as the tile kernel wants it.  A convex mesh is the intersection of its face planes
 // n . x <= h; two faces with opposite normals form a SLAB -h- <= n . x <= h+, and a ray's parameters at the two planes of a slab

@@ -26,6 +26,9 @@
 #include "kernels.h"
 #include <cstring>
 
+#ifndef EVPLP_PROXY_MIXED_WAVES
+#define EVPLP_PROXY_MIXED_WAVES 6
+#endif
 #ifndef EVPLP_PROXY_WAVES
 #define EVPLP_PROXY_WAVES 7
 #endif
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
     for (uint32_t k = blockIdx.x * 256u + tid; k < (uint32_t)(a.tiles_x * a.tiles_y); k += gridDim.x * 256u) a.tile_cursor[k] = 0u;
     if (blockIdx.x == 0u) {
         for (uint32_t k = tid; k < (uint32_t)kSummaryShards; k += 256u) { a.summary[k * kSummaryStride] = 0u; a.summary[k * kSummaryStride + 1] = 0u; }
-        if (tid == 0u) *a.overflow = 0u;
+        if (tid == 0u) { *a.overflow = 0u; a.summary[kSummaryHeavy] = 0u; }
     }
     const uint32_t bw_mask = (1u << a.bucket_w_log2) - 1u, bh_mask = (1u << a.bucket_h_log2) - 1u;
 
@@ -471,8 +474,27 @@ __global__ __launch_bounds__(256) void splat_sort_kernel(const uint32_t *cursor,
 // the second mask of the radius pass and the per-pixel ray ~15 us, the rim lists ~15, the slab loops 40 / 20, and the occupancy the
 // rest -- the kernel follows its occupancy (the ideal kernel padded to six workgroups per CU: 117 / 66 us), which is why the LDS is sized
 // by the launch, the list and the verdicts share 1 KB per wave, and the variant is held to 72 registers.
-template <int WAVES, bool PROXY>   // waves per tile: 1 (four tiles per workgroup) or 4 (one tile per workgroup, for launches with very full bins)
-__global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : EVPLP_PROXY_WAVES) : 8) void splat_tiles_kernel(SplatArgs a) {
+#if EVPLP_TILE_TIMES         // developer build (tools/tile_times.py): start / end clock (100 MHz) and bin entries of every tile (its first wave)
+__device__ unsigned long long g_tile_times[3 * 65536];
+extern "C" int evplp_debug_tile_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_times), sizeof(unsigned long long) * (size_t)n); }
+#endif
+// Which tiles get four waves (MIXED launches of splat_tiles_kernel): a tile whose bin holds at least heavy_threshold entries goes on
+// the heavy list (at most heavy_cap of them; the count sits behind the pass summary, cleared by splat_bin) and is flagged, so that the
+// one-wave workgroup that would have had it leaves it alone.  One thread per tile, between the scatter and the tile kernel.
+__global__ __launch_bounds__(256) void splat_heavy_kernel(SplatArgs a) {
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    if (tile >= (uint32_t)(a.tiles_x * a.tiles_y)) return;
+    bool heavy = min(a.tile_cursor[tile], a.bin_stride) >= a.heavy_threshold;
+    if (heavy) { const uint32_t pos = atomicAdd(&a.summary[kSummaryHeavy], 1u); if (pos < a.heavy_cap) a.heavy_list[pos] = tile; else heavy = false; }
+    a.tile_flags[tile] = heavy ? (uint8_t)1 : (uint8_t)0;
+}
+// WAVES = waves per tile: 1 (four tiles per workgroup), 4 (one tile per workgroup), or 0 = MIXED (round 5): the first heavy_cap
+// workgroups take the tiles of the heavy list with four waves each, the others four light tiles with one wave each.  Per-wave clocks
+// (tools/tile_times.py) showed why neither pure variant is right at config #3: with one wave per tile the 5 % of the tiles whose bins
+// hold 300 - 1 100 entries run for 105 - 118 us while the median tile takes 29 -- the last third of the launch belongs to them alone --
+// and with four waves per tile the other 95 % pay three idle waves each.
+template <int WAVES, bool PROXY>
+__global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : WAVES == 0 ? EVPLP_PROXY_MIXED_WAVES : EVPLP_PROXY_WAVES) : 8) void splat_tiles_kernel(SplatArgs a) {
     // One workgroup = one tile; its four waves share the bin (wave w takes the 64-photon batches w, w + 4, ...) and
     // their per-pixel sums are folded in wave order: the fullest bins (tiles that see a floor at grazing angle) set
     // the duration of the launch.
@@ -496,20 +518,35 @@ __global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : EVPLP_PROXY_WAVES) :
         }
         __syncthreads();
     }
-    const int part = WAVES == 4 ? wave : 0;                       // this wave's share of the bin
-    const int tile = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+#if EVPLP_TILE_TIMES
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr bool MIXED = WAVES == 0;
+    const bool heavy_wg = MIXED && blockIdx.x < a.heavy_cap;      // (workgroup-uniform)
+    const int W = MIXED ? (heavy_wg ? 4 : 1) : WAVES;             // waves of this tile
+    const int part = W == 4 ? wave : 0;                           // this wave's share of the bin
+    int tile = W == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (MIXED && !heavy_wg) tile = ((int)blockIdx.x - (int)a.heavy_cap) * 4 + wave;
     if (blockIdx.x == 0 && wave == 0) {                                   // fold the bin kernel's summary shards
         uint32_t sum = 0u, mx = 0u;
         for (int k = lane; k < kSummaryShards; k += 64) { sum += a.summary[k * kSummaryStride]; mx = max(mx, a.summary[k * kSummaryStride + 1]); }
         for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); }
         if (lane == 0) { a.summary[kSummaryFinal] = sum; a.summary[kSummaryFinal + 1] = mx; a.summary[kSummaryFinal + 2] = *a.overflow; }   // one read-back for the host
     }
-    if (tile >= a.tiles_x * a.tiles_y || *a.overflow != 0u) return;                    // (WAVES == 1 only: whole waves leave, no barrier below)
+    if (MIXED && heavy_wg) {                                      // (the whole workgroup leaves together: no barrier is left behind)
+        if (blockIdx.x >= min(a.summary[kSummaryHeavy], a.heavy_cap)) return;
+        tile = (int)a.heavy_list[blockIdx.x];
+    }
+    if (tile >= a.tiles_x * a.tiles_y || *a.overflow != 0u) return;                    // (one-wave tiles only: whole waves leave, no barrier below)
+    if (MIXED && !heavy_wg && a.tile_flags[tile] != 0) return;                         // (a heavy tile: its own workgroup has it)
     const int tx = tile % a.tiles_x, lty = tile / a.tiles_x;
     const int x = tx * 8 + (lane & 7), ly = lty * 8 + (lane >> 3);
     const bool in_image = x < a.st.W && ly < a.st.local_rows && a.st.global_row(min(ly, a.st.local_rows - 1)) < a.st.H;
     const size_t p = (size_t)min(ly, a.st.local_rows - 1) * a.st.W + min(x, a.st.W - 1);
     const uint32_t b = (uint32_t)tile * a.bin_stride, e = b + min((uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_cursor[tile]), a.bin_stride);
+#if EVPLP_TILE_TIMES
+    if (b >= e && lane == 0 && part == 0 && tile < 65536) { g_tile_times[3 * tile] = t_start; g_tile_times[3 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_tile_times[3 * tile + 2] = 0ull; }
+#endif
     if (b >= e) { if (lane == 0 && part == 0) { a.tile_pairs[tile] = 0u; if (PROXY) a.tile_frags[tile] = 0u; } return; }
 
     // a wave without a batch of its own (most bins hold one or two) only takes part in the fold below
@@ -555,7 +592,7 @@ __global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : EVPLP_PROXY_WAVES) :
     // no specular lobe anywhere in the tile: PhongEval is rho_s * (...) = exactly 0, skip its powf (wave-uniform)
     const bool tile_glossy = __ballot(sps.x != 0.0f || sps.y != 0.0f || sps.z != 0.0f) != 0ull;
 
-    for (uint32_t base = b + 64u * (uint32_t)part; base < e; base += 64u * WAVES) {
+    for (uint32_t base = b + 64u * (uint32_t)part; base < e; base += 64u * (uint32_t)W) {
         uint32_t n = min(64u, e - base);
         if ((uint32_t)lane < n) {
             uint32_t id = a.bin_items[base + lane];
@@ -697,14 +734,14 @@ __global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : EVPLP_PROXY_WAVES) :
         __builtin_amdgcn_wave_barrier();
     }
     for (int off = 32; off > 0; off >>= 1) { pairs += __shfl_down(pairs, off); if (PROXY) frags += __shfl_down(frags, off); }
-    if (WAVES == 4) {
+    if (W == 4) {
         // (.w: lane 0 carries the wave's pairs; lane 1 -- whose own count went into lane 0's -- the wave's proxy fragments)
         const uint32_t frags0 = (uint32_t)__shfl((int)frags, 0);
         if (wave != 0) stage[lane] = make_float4(sum.x, sum.y, sum.z, lane == 0 ? __uint_as_float(pairs) : lane == 1 ? __uint_as_float(frags0) : 0.f);
         __syncthreads();
     }
     if (part == 0) {
-        if (WAVES == 4) for (int w = 1; w < 4; w++) {
+        if (W == 4) for (int w = 1; w < 4; w++) {
             const float4 *other = stage_base + w * stage_rows * 64;
             float4 q = other[lane]; sum = sum + v3(q);
             if (lane == 0) { pairs += __float_as_uint(q.w); if (PROXY) frags += __float_as_uint(other[1].w); }
@@ -716,6 +753,9 @@ __global__ __launch_bounds__(256, PROXY ? (WAVES == 4 ? 6 : EVPLP_PROXY_WAVES) :
             float4 o = a.out[p];
             a.out[p] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w);   // additive blend ONE, ONE (:793)
         }
+#if EVPLP_TILE_TIMES
+        if (lane == 0 && tile < 65536) { g_tile_times[3 * tile] = t_start; g_tile_times[3 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_tile_times[3 * tile + 2] = (unsigned long long)(e - b); }
+#endif
         if (lane == 0) {
             a.tile_pairs[tile] = pairs;
             if (PROXY) a.tile_frags[tile] = frags;
@@ -750,6 +790,13 @@ void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hip
     const bool proxy = a.fp.splat_footprint == (uint32_t)EVPLP_FOOTPRINT_PROXY;
     // dynamic LDS of the tile kernel (its layout is at the top of splat_tiles_kernel)
     const size_t lds_bytes = sizeof(float4) * (size_t)(4 * (a.fp.mis_mode == 5u ? 4 : 3) * 64) + (proxy ? sizeof(float4) * (size_t)(4 * 64 + a.proxy_count) + sizeof(float) * (size_t)a.proxy_count : 0);
+    if (a.heavy_list && !a.deterministic) {          // MIXED: heavy tiles with four waves (the first heavy_cap workgroups), the others with one
+        hipLaunchKernelGGL(splat_heavy_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, a);
+        const uint32_t grid = a.heavy_cap + (ntiles + 3) / 4;
+        if (proxy) hipLaunchKernelGGL((splat_tiles_kernel<0, true>), dim3(grid), dim3(256), lds_bytes, s, a); else hipLaunchKernelGGL((splat_tiles_kernel<0, false>), dim3(grid), dim3(256), lds_bytes, s, a);
+        if (dom_end) hipEventRecord(dom_end, s);
+        return;
+    }
     if (split_tiles) { if (proxy) hipLaunchKernelGGL((splat_tiles_kernel<4, true>), dim3(ntiles), dim3(256), lds_bytes, s, a); else hipLaunchKernelGGL((splat_tiles_kernel<4, false>), dim3(ntiles), dim3(256), lds_bytes, s, a); }
     else { if (proxy) hipLaunchKernelGGL((splat_tiles_kernel<1, true>), dim3((ntiles + 3) / 4), dim3(256), lds_bytes, s, a); else hipLaunchKernelGGL((splat_tiles_kernel<1, false>), dim3((ntiles + 3) / 4), dim3(256), lds_bytes, s, a); }
     if (dom_end) hipEventRecord(dom_end, s);

@@ -400,6 +400,32 @@ def test_photon_splat_proxy_one_wave_per_tile(room, oscene, evplp, inputs):
             assert_image_close(got[..., :3], proxy[..., :3], what="proxy splat, one wave per tile")
 
 
+def test_photon_splat_mixed_tile_launch(room, oscene, evplp, inputs, monkeypatch):
+    """The MIXED launch of the tile kernel (tiles whose bins hold many entries get a workgroup of four waves, the others one wave; chosen
+    when the previous pass had full bins): forced here with a heavy threshold of 4 entries, so that this small frame has tiles of both
+    kinds -- same pairs and fragments as the oracle, the same image up to the order of the sums; and again with a heavy list of two
+    entries, which overflows (the tiles that do not fit stay one-wave tiles)."""
+    gbuf, records = inputs
+    radius = 0.35
+    kw = dict(camera_pos=oscene.sd.cam_origin, mis_mode=1, pdf_mc=1.0 / math.pi / radius ** 2, photon_radius=radius, num_light_paths=NPATHS,
+              num_vpl_light_paths=NPATHS, photons_per_path=P, jitter=(0.003, -0.002))
+    monkeypatch.setenv("EVPLP_TILE_HEAVY", "4"); monkeypatch.setenv("EVPLP_TILE_MIXED_TRIGGER", "0")
+    for cap in ("2048", "2"):
+        monkeypatch.setenv("EVPLP_TILE_HEAVY_CAP", cap)
+        with evplp.Context(W, H, NPATHS, NPATHS, P) as c:
+            room.upload(c)
+            c.primary((0.003, -0.002)); upload_inputs(c, evplp, gbuf, records)
+            for _ in range(2):
+                got, st, ideal, proxy, ost = _splat_both_ways(c, evplp, oscene, gbuf, records, kw, None)
+                assert st["nodes"] >> 32 >= 4 and (st["nodes"] & 0xffffffff) > 50, "no bin reaches the heavy threshold: the test does not exercise the four-wave workgroups"
+                assert st["pairs"] == int(ost[0]) and st["rays"] == int(ost[3])
+                assert_image_close(got[..., :3], proxy[..., :3], what="proxy splat, mixed launch")
+                c.splat_photons(evplp.frame_params(**kw), clear=True)                  # ... and the plain radius rule through the same launch
+                st_i = c.pass_stats(evplp.PASS_SPLAT)
+                assert st_i["pairs"] == int(ost[0])
+                assert_image_close(c.download(evplp.BUF_PHOTON_ACCUM)[:H][..., :3], ideal[..., :3], what="ideal splat, mixed launch")
+
+
 def test_splat_proxy_mesh_is_validated(ctx, evplp):
     """A mesh whose fragment count is not the entry / exit rule of a convex body is refused, with the reason."""
     v, t = oa.icosphere42()

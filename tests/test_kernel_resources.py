@@ -34,8 +34,11 @@ def kernel_table(src):
      {"gather_vpl_kernelILb1": 64, "gather_vpl_kernelILb0": 64, "gather_vsl_walk_kernelILb1": 64, "gather_vsl_walk_kernelILb0": 64, "gather_vsl_shade_kernel": 128}),
     ("kernels_cut.hip", ["gather_cut_kernel", "primary_cut_kernel"], {"gather_cut_kernel": 64}),
     # (the proxy-footprint variants of the tile kernel, ILb1, are held to seven / six waves per SIMD below)
-    ("kernels_splat.hip", ["splat_bin_kernel", "splat_scatter_kernel", "splat_tiles_kernelILi1ELb0", "splat_tiles_kernelILi4ELb0", "splat_tiles_kernelILi4ELb1", "resolve_kernel"],
-     {"splat_tiles_kernelILi1ELb0": 64, "splat_tiles_kernelILi4ELb0": 64, "splat_tiles_kernelILi1ELb1": 72, "splat_tiles_kernelILi4ELb1": 80}),
+    # (ILi0E: the MIXED launch -- heavy tiles with four waves, the others with one; its proxy variant runs at six waves like the four-wave one)
+    ("kernels_splat.hip", ["splat_bin_kernel", "splat_scatter_kernel", "splat_heavy_kernel", "splat_tiles_kernelILi1ELb0", "splat_tiles_kernelILi4ELb0", "splat_tiles_kernelILi0ELb0",
+                           "splat_tiles_kernelILi4ELb1", "splat_tiles_kernelILi0ELb1", "resolve_kernel"],
+     {"splat_tiles_kernelILi1ELb0": 64, "splat_tiles_kernelILi4ELb0": 64, "splat_tiles_kernelILi0ELb0": 64, "splat_tiles_kernelILi1ELb1": 72, "splat_tiles_kernelILi4ELb1": 80,
+      "splat_tiles_kernelILi0ELb1": 80}),
     ("kernels_pt.hip", ["path_trace_kernel"], {}),
     ("kernels_trace.hip", ["light_trace_kernel", "primary_kernel"], {"light_trace_kernel": 128, "primary_kernel": 64}),
 ])
