@@ -164,8 +164,15 @@ EV_DEV void store_record(evplp_record *r, V3 pos, uint32_t flags, V3 n, float ps
 #ifndef EVPLP_LT_SPEC
 #define EVPLP_LT_SPEC 1          // speculative while-while: leaves a lane may postpone (closest_lane4 SPEC); 300 000 paths: 0.433 / 0.423 / 0.440 ms for 0 / 1 / 2
 #endif
+#if EVPLP_LT_TIMES           // developer build (tools/lt_times.py): start / end clock (100 MHz) of every wavefront
+__device__ unsigned long long g_lt_times[2 * 16384];
+extern "C" int evplp_debug_lt_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lt_times), sizeof(unsigned long long) * (size_t)n); }
+#endif
 __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTraceArgs a) {
     extern __shared__ int32_t lds_stack[];   // [bvh_depth + 2][64 lanes]
+#if EVPLP_LT_TIMES
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x;
     const uint32_t local = blockIdx.x * 64u + lane;
     if (local >= a.path_count) return;
@@ -229,6 +236,9 @@ __global__ __launch_bounds__(64, EVPLP_LT_WAVES) void light_trace_kernel(LightTr
         next_pos = hit_pos; next_dir = dir;
     }
     for (uint32_t i = filled; i < P; i++) store_record(&rec[i], zero, 0u, zero, 0.f, zero, zero, zero, zero, 0.f);
+#if EVPLP_LT_TIMES
+    if (lane == 0 && blockIdx.x < 16384u) { g_lt_times[2 * blockIdx.x] = t_start; g_lt_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // Stable compaction of the usable VPL records (flags & IsUsableVpl, rt/lighttracing.cu:372) of
