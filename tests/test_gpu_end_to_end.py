@@ -620,3 +620,36 @@ def test_api_misuse_is_reported(evplp):
         with pytest.raises(evplp.EvplpError) as e:
             c.load_scene_json("/nonexistent/scene.json")                              # the message names the file
         assert e.value.status == evplp.ERR_IO and "/nonexistent/scene.json" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_contexts_and_groups_give_their_memory_back(evplp, tmp_path):
+    """evplp_destroy / evplp_group_destroy free what the passes allocated on the way (second record and G-buffer sets of the overlapped
+    loop, cut scratch, VSL masks, bins, heavy list, the group's frame buffers): device memory in use after five rounds of create /
+    render / destroy is what it was after the first."""
+    import torch
+    jp = evplp.synth_scene(str(tmp_path), "living", 3000, 5, 96, 64, style="textured")
+
+    def one_round():
+        with evplp.Context(96, 64, 256, 256, 4, overlap_light_tracing=True) as c:
+            c.load_scene_json(jp)
+            cam = c.camera(); bsr, total, _ = c.scene_metrics()
+            for it in range(3):
+                kw = dict(camera_pos=list(cam.origin), mis_mode=1, pdf_mc=0.3, clamping_value=1.0 / total, photon_radius=0.05 * bsr, vsl_radius=0.05 * bsr,
+                          vsl_inv_pi_radius2=1.0 / (math.pi * (0.05 * bsr) ** 2), num_light_paths=256, num_vpl_light_paths=256, photons_per_path=4, do_accumulate=1, rng_seed=it)
+                c.trace_light_paths(it); c.primary((0.001, 0.001))
+                c.gather_vpl(evplp.frame_params(**kw)); c.gather_vsl(evplp.frame_params(**kw))
+                c.splat_photons(evplp.frame_params(**kw, splat_footprint="proxy")); c.present(1.0, 1.0, 1.0)
+            c.resolve(1.0, 1.0, 1.0)
+        with evplp.Group(96, 64, 256, 256, 4, 2, devices=[0, 0]) as g:
+            g.load_scene_json(jp)
+            kw = dict(camera_pos=[0, 0, 0], mis_mode=1, pdf_mc=0.3, photon_radius=0.1, num_light_paths=256, num_vpl_light_paths=256, photons_per_path=4, do_accumulate=1)
+            g.primary((0.0, 0.0)); g.trace_light_paths(1); g.gather(evplp.frame_params(**kw), 0); g.splat_photons(evplp.frame_params(**kw)); g.resolve(1.0, 1.0, 1.0)
+    series = []
+    for _ in range(8):
+        one_round()
+        torch.cuda.synchronize()
+        series.append(torch.cuda.mem_get_info(0)[0])
+    # (the runtime's own pools may still grow once or twice in steps of 2^n MB; a leak of the library's grows every round)
+    steps = [a - b for a, b in zip(series[:-1], series[1:])]
+    assert sum(1 for d in steps[2:] if d > 0) <= 1 and series[2] - series[-1] <= 32 << 20, (series, steps)
