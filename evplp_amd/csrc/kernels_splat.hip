@@ -225,11 +225,14 @@ __global__ __launch_bounds__(256) void splat_tile_box_kernel(SplatArgs a) {
 __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
     __shared__ float4 s_rec[257 * kRecF4];
     __shared__ uint32_t s_pair[kSegCap];
-    __shared__ uint32_t s_cnt[kMaxBuckets];
-    __shared__ uint32_t s_off[kMaxBuckets];
+    // bucket counters and offsets: sized by the launch (num_buckets rounded up to 4: 128 at 1024^2, 254 -> 256 at 1080p) -- as two static
+    // kMaxBuckets arrays they were 8 of the kernel's 37 KB and the fifth workgroup of a CU did not fit (round 5)
+    extern __shared__ uint32_t s_bucket_lds[];
+    const uint32_t nb4 = ((uint32_t)a.num_buckets + 3u) & ~3u;
+    uint32_t *const s_cnt = s_bucket_lds, *const s_off = s_bucket_lds + nb4;
     __shared__ uint32_t s_n, s_nbig, s_wsum[4];
     const uint32_t tid = threadIdx.x, group = blockIdx.x, wg_base = group * (uint32_t)kBinGroup;
-    for (uint32_t b = tid; b < (uint32_t)kMaxBuckets; b += 256u) s_cnt[b] = 0u;
+    for (uint32_t b = tid; b < nb4; b += 256u) s_cnt[b] = 0u;
     if (tid == 0u) { s_n = 0u; s_nbig = 0u; }
     // this launch also clears what the NEXT two use: the tiles' bin cursors, the pass summary, the overflow flag
     for (uint32_t k = blockIdx.x * 256u + tid; k < (uint32_t)(a.tiles_x * a.tiles_y); k += gridDim.x * 256u) a.tile_cursor[k] = 0u;
@@ -295,15 +298,18 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
     }
     // counting sort of the entries by bucket: exclusive scan of the bucket counts (4 buckets per thread) ...
     const uint32_t b0 = tid * 4u;
-    const uint32_t c0_ = s_cnt[b0], c1_ = s_cnt[b0 + 1u], c2_ = s_cnt[b0 + 2u], c3_ = s_cnt[b0 + 3u], tsum = c0_ + c1_ + c2_ + c3_;
+    const bool mine = b0 < nb4;                        // (this thread's four buckets exist)
+    const uint32_t c0_ = mine ? s_cnt[b0] : 0u, c1_ = mine ? s_cnt[b0 + 1u] : 0u, c2_ = mine ? s_cnt[b0 + 2u] : 0u, c3_ = mine ? s_cnt[b0 + 3u] : 0u, tsum = c0_ + c1_ + c2_ + c3_;
     uint32_t x = tsum;
     for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off); if ((int)(tid & 63u) >= off) x += y; }
     if ((tid & 63u) == 63u) s_wsum[tid >> 6] = x;
     __syncthreads();
     uint32_t excl = x - tsum;
     for (uint32_t w = 0; w < (tid >> 6); w++) excl += s_wsum[w];
-    s_off[b0] = excl; s_off[b0 + 1u] = excl + c0_; s_off[b0 + 2u] = excl + c0_ + c1_; s_off[b0 + 3u] = excl + c0_ + c1_ + c2_;
-    s_cnt[b0] = 0u; s_cnt[b0 + 1u] = 0u; s_cnt[b0 + 2u] = 0u; s_cnt[b0 + 3u] = 0u;       // now: entries placed per bucket
+    if (mine) {
+        s_off[b0] = excl; s_off[b0 + 1u] = excl + c0_; s_off[b0 + 2u] = excl + c0_ + c1_; s_off[b0 + 3u] = excl + c0_ + c1_ + c2_;
+        s_cnt[b0] = 0u; s_cnt[b0 + 1u] = 0u; s_cnt[b0 + 2u] = 0u; s_cnt[b0 + 3u] = 0u;       // now: entries placed per bucket
+    }
     __syncthreads();
     const uint32_t n_raw = min(s_n, (uint32_t)kSegCap), n = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // slots used, entries
     uint16_t *off_row = a.seg_off + (size_t)group * (a.num_buckets + 1);
@@ -778,7 +784,7 @@ void launch_splat_bin(const SplatArgs &a, hipStream_t s) {
     const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
     if (!a.boxes_valid) hipLaunchKernelGGL(splat_tile_box_kernel, dim3((ntiles + 15) / 16), dim3(256), 0, s, a);   // (else: written by primary_kernel)
     uint32_t *items = a.deterministic ? a.bin_items_tmp : a.bin_items;
-    hipLaunchKernelGGL(splat_bin_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(splat_bin_kernel, dim3((uint32_t)a.num_bin_groups), dim3(256), sizeof(uint32_t) * 2u * (size_t)(((uint32_t)a.num_buckets + 3u) & ~3u), s, a);
     const uint32_t per = 256u * kScatterG, slices = ((uint32_t)a.num_bin_groups + per - 1u) / per, big_rows = ((uint32_t)a.num_bin_groups + slices - 1u) / slices;
     hipLaunchKernelGGL(splat_scatter_kernel, dim3(slices, (uint32_t)a.num_buckets + big_rows), dim3(256), 0, s, a, items);
 }
