@@ -219,12 +219,19 @@ EV_DEV void fetch_vpl_tail(const evplp_record *vpls, uint32_t i, Vpl &v) {
     v.rd = v3(f_of(rb[8]), f_of(rb[9]), f_of(rb[10])); v.rs = v3(f_of(rb[12]), f_of(rb[13]), f_of(rb[14])); v.e = f_of(rb[15]);
 }
 
+#if EVPLP_GATHER_TIMES       // developer build (tools/gather_times.py): start / end clock (100 MHz) of every 16th item's wavefront
+__device__ unsigned long long g_gather_times[2 * 131072];
+extern "C" int evplp_debug_gather_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gather_times), sizeof(unsigned long long) * (size_t)n); }
+#endif
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
 template <bool CUT>
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
 __attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
 #endif
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
+#if EVPLP_GATHER_TIMES
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     // dynamic LDS: [192] the view directions, then one [192] block per level of the k-split fold (log2 k + 1 of them).  Sized by k
     // because LDS is what limits occupancy next: 7 single-wavefront workgroups per SIMD fit while a workgroup stays within
     // 5120 bytes (the allocation granule of this part is 1280 bytes: 5376 bytes measured 6 % slower, one wave per SIMD fewer)
@@ -384,6 +391,9 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
 #if EVPLP_XCD_TIMES
     // (developer probe, tools/xcd_balance.py: when did the last item of every XCD end?  s_memrealtime ticks at 100 MHz)
     if (lane == 0) atomicMax(&a.counters->hist[16 + (blockIdx.x & 7u)], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+#if EVPLP_GATHER_TIMES
+    if (lane == 0 && (blockIdx.x & 15u) == 0u && (blockIdx.x >> 4) < 131072u) { g_gather_times[2 * (blockIdx.x >> 4)] = t_start; g_gather_times[2 * (blockIdx.x >> 4) + 1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     // per-lane statistics ride in the unused fourth component: shadow rays | unoccluded pairs << 16 (both < 65536 per item)
     int lane_out = lane, blk_out = (int)blockIdx.x;
