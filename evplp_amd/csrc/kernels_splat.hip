@@ -326,7 +326,15 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(SplatArgs a) {
 // Scatter kernel (kernels.h "Two-level binning"): workgroup (slice, bucket).  Also the pass summary: total entries and the
 // fullest bin, one atomic per workgroup on one of 1024 shard lines.
 EV_DEV void splat_big_group(const SplatArgs &a, uint32_t *items, uint32_t group);
+#if EVPLP_SCATTER_TIMES      // developer build (tools/tile_times.py --scatter): start / end clock of every workgroup, and its entries
+__device__ unsigned long long g_scatter_times[3 * 65536];
+extern "C" int evplp_debug_scatter_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scatter_times), sizeof(unsigned long long) * (size_t)n); }
+#endif
 __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_t *items) {
+#if EVPLP_SCATTER_TIMES
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    struct Stamp { unsigned long long t0; uint32_t id; uint32_t *n; __device__ ~Stamp() { if (threadIdx.x == 0 && id < 65536u) { g_scatter_times[3 * id] = t0; g_scatter_times[3 * id + 1] = __builtin_amdgcn_s_memrealtime(); g_scatter_times[3 * id + 2] = n ? *n : 0xffffffffull; } } };
+#endif
     if (blockIdx.y >= (uint32_t)a.num_buckets) {                           // the rows beyond the buckets: photons with large rectangles
         splat_big_group(a, items, (blockIdx.y - (uint32_t)a.num_buckets) * gridDim.x + blockIdx.x);
         return;
@@ -334,6 +342,9 @@ __global__ __launch_bounds__(256) void splat_scatter_kernel(SplatArgs a, uint32_
     constexpr int kTilesMax = 1 << kMaxBucketTilesLog2;
     constexpr uint32_t kNG = 256u * kScatterG;                            // bin-groups of a slice
     __shared__ uint32_t s_cnt[kTilesMax], s_base[kTilesMax], s_max, s_total;
+#if EVPLP_SCATTER_TIMES
+    Stamp stamp{ t_start, blockIdx.y * gridDim.x + blockIdx.x, &s_total };
+#endif
     __shared__ uint32_t s_start[kNG + 1];                                 // first entry of every group's run in the workgroup's entry numbering
     __shared__ uint16_t s_beg[kNG];                                       // ... and where that run starts in the group's segment
     const uint32_t ntile = 1u << (a.bucket_w_log2 + a.bucket_h_log2);   // tiles of a bucket
