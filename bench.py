@@ -67,6 +67,11 @@ P = 4                                   # numMaxBounces 3 -> 4 record slots per 
 STRIP_ROWS = 16                         # two tile rows per strip block: a rank's entry-cut groups stay 2 x 2 tiles (8-row strips: 2 x 1, twice the cuts per pixel)
 
 
+def strip_rows_for(a):
+    """--strip-rows, or the library's own default (evplp_group_create): 16-row blocks"""
+    return a.strip_rows if a.strip_rows > 0 else STRIP_ROWS
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +89,11 @@ def parse():
     ap.add_argument("--front-end", default="auto", choices=["auto", "ranks", "group"],
                     help="N > 1: `group` = one process driving evplp_group, the library's own multi-GPU entry (auto: whenever this process sees N devices); "
                          "`ranks` = one process per GPU over torch.distributed (auto: fewer devices than ranks, or EVPLP_BENCH_BACKEND=gloo)")
+    ap.add_argument("--strip-rows", type=int, default=0, help="N > 1: height of a row block (multiple of 8); 0 = 16")
+    ap.add_argument("--deal", default="cost", choices=["cost", "roundRobin"],
+                    help="N > 1: row blocks dealt by the cost a calibration frame clocks (evplp_group_rebalance / evplp_deal_blocks; the default where the "
+                         "workload has a gather) or block b to rank b %% N")
+    ap.add_argument("--exchange-every", type=int, default=1, help="N > 1: the composited strips are all-gathered every k-th frame (0 = never inside the timed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (configs #3-#5, other scene, 16384-slot variant, GPU path tracer, render_json)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="path-tracer iterations of the CPU baseline sample (0 = auto, ~12 s)")
@@ -284,17 +294,24 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     builder = {"sah": ev.BVH_SAH, "sbvh": ev.BVH_SBVH, "lbvh": ev.BVH_LBVH, "gpu": ev.BVH_LBVH_GPU}[a.bvh]
     nrec = n_light * P
     group = None
+    SR = strip_rows_for(a)
+    # room for a deal by cost: 150 % of the equal share of blocks (what evplp_group_create gives its ranks)
+    nblocks = (H + SR - 1) // SR
+    cap_blocks = min(nblocks, (-(-nblocks // max(a.gpus, 1)) * 150 + 99) // 100)
+    deal_by_cost = a.deal == "cost" and a.gpus > 1 and wl in ("ir", "evplp", "vsl")
+    owner = [None]                          # the dealt table (owner rank of every image block), once it exists
+    block_cost = [None]                     # ... and the clocked costs it was dealt from (a rank stores its blocks most expensive first)
     if env.group_front_end:
         # one process, the native multi-GPU entry: a.gpus ranks on distinct devices (RCCL) or, when the box has fewer, all on device 0
         devices = list(range(a.gpus)) if env.ndev >= a.gpus else [0] * a.gpus
-        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=STRIP_ROWS, bvh_builder=builder, overlap_light_tracing=True)
+        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=SR, bvh_builder=builder, overlap_light_tracing=True)
         group.load_scene_json(json_path)
         ranks = [group.rank(r) for r in range(a.gpus)]
         ctx = ranks[0]
         n_ranks = a.gpus
     else:
-        ctx = ev.Context(W, H, n_light, n_vpl, P, device=env.device_index, strip_rank=rank, strip_count=world, strip_rows=STRIP_ROWS,
-                         bvh_builder=builder, overlap_light_tracing=True)
+        ctx = ev.Context(W, H, n_light, n_vpl, P, device=env.device_index, strip_rank=rank, strip_count=world, strip_rows=SR,
+                         bvh_builder=builder, overlap_light_tracing=True, strip_capacity_rows=cap_blocks * SR if world > 1 else 0)
         ctx.load_scene_json(json_path)
         ctx.set_stream(env.stream.cuda_stream)
         ranks = [ctx]
@@ -333,8 +350,9 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     footprint = [a.footprint]
     last_jitter = [(0.0, 0.0)]      # (the G-buffer on the device belongs to this jitter: the proxy rule's eye rays go through it)
 
-    def frame(it):
+    def frame(it, advance=True):
         jitter = (float(jitters[it][0]), float(jitters[it][1]))
+        exchange = a.exchange_every > 0 and (it + 1) % a.exchange_every == 0
         last_jitter[0] = jitter
         fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode=mis, pdf_mc=sched["pdf_mc"], clamping_value=sched["clamp"],
                              photon_radius=sched["radius"], vsl_radius=sched["vsl_radius"], vsl_inv_pi_radius2=sched["vsl_inv"],
@@ -352,7 +370,7 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                 group.gather(fp, 1)
             if wl != "ir":
                 group.splat_photons(fp)
-            group.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True)      # runFinalProgram(param, param, 1, true), rtcomphoton.h:997-1004
+            group.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True, exchange=exchange)      # runFinalProgram(param, param, 1, true), rtcomphoton.h:997-1004
         else:
             def light_paths():
                 if split_paths:
@@ -378,12 +396,12 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                     print("HIST", it, ctx.debug_counters(ev.PASS_SPLAT)[4:4 + 28].tolist(), flush=True)
             # the frame ends with the composite (rtcomphoton.h:997-1004), as the group front end's present() does
             ctx.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True)
-            if use_dist:
+            if use_dist and exchange:
                 if wl != "ppm":
                     env.all_gather(full, strip)
                 if wl != "ir":
                     env.all_gather(pfull, pstrip)
-        if progressive:   # rtcomphoton.h:1033-1063 after numIterations++
+        if progressive and advance:   # rtcomphoton.h:1033-1063 after numIterations++
             r, c, p, vr, vi = ev.progressive_step(it + 1, 0.7, clamp_start, n_vpl, n_light, sched["radius"], sched["clamp"], sched["pdf_mc"],
                                                   wl == "vsl", sched["vsl_radius"], sched["vsl_inv"])
             sched.update(radius=r, clamp=c, pdf_mc=p, vsl_radius=vr, vsl_inv=vi)
@@ -405,6 +423,20 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
         else:
             for c in ranks:
                 c.profile_passes(on)
+    if deal_by_cost:
+        # one calibration frame with the self-clocking gather kernels, then the deal (the accumulators are cleared; the schedule does not move)
+        if group is not None:
+            group.calibrate(True); frame(0, advance=False); group.rebalance()
+            owner[0] = group.block_owners()
+            ranks = [group.rank(r) for r in range(a.gpus)]; ctx = ranks[0]
+        elif use_dist:
+            from evplp_amd import strips as _strips
+            ctx.calibrate_blocks(True); frame(0, advance=False); env.sync_all()
+            cost = torch.from_numpy(ctx.block_costs().astype(np.int64)).to(dev)
+            cost = env.all_reduce(cost, dist.ReduceOp.SUM).cpu().numpy().astype(np.uint64)
+            owner[0] = ev.deal_blocks(cost, world, cap_blocks)              # (every process computes the same table)
+            block_cost[0] = cost
+            ctx.set_blocks(_strips.blocks_of_rank(owner[0], rank, cost)); ctx.calibrate_blocks(False)
     if wl == "ppm":
         profile_passes(False)
     for i in range(warmup):
@@ -501,14 +533,17 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
             def assemble(t):
                 t = t.cpu().numpy().reshape(n_ranks if use_dist else 1, ctx.local_rows, W, 4)
                 img = np.zeros((H, W, 4), np.float32)
+                from evplp_amd import strips as _strips
                 for r in range(t.shape[0]):
-                    l = np.arange(ctx.local_rows); blk = l // STRIP_ROWS
-                    gr = (blk * t.shape[0] + r) * STRIP_ROWS + (l - blk * STRIP_ROWS)
+                    blocks = _strips.blocks_of_rank(owner[0], r, block_cost[0]) if owner[0] is not None else np.arange(r, nblocks, t.shape[0])
+                    gr = _strips.rows_of_blocks(H, blocks, SR, ctx.local_rows) if t.shape[0] > 1 else np.arange(ctx.local_rows)
                     ok = gr < H
                     img[gr[ok]] = t[r][ok]
                 return img
-            if use_dist and wl == "ppm":
+            if use_dist and (wl == "ppm" or a.exchange_every != 1):
                 env.all_gather(full, strip)
+                if wl != "ir":
+                    env.all_gather(pfull, pstrip)
             if use_dist and wl == "ir":
                 pfull = torch.zeros(world * pstrip.numel(), dtype=torch.float32, device=dev); env.all_gather(pfull, pstrip)
             torch.cuda.synchronize(dev)
@@ -531,7 +566,8 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
                        "scene": f"procedural conference stand-in, style {scene} ({'curved / thin furniture, rotated clutter, ~2400 small occluders' if scene == 'hard' else 'tessellated boxes'}), "
                                 f"{a.tris} target triangles, seed 1234 (reference meshes are LFS stubs)",
                        "resolution": [W, H], "num_light_paths": n_light, "num_vpl_light_paths": n_vpl, "photons_per_path": P, "mis_mode": mis,
-                       "usable_vpl_records": int(usable), "partition": f"{n_ranks} x interleaved {STRIP_ROWS}-row strips",
+                       "usable_vpl_records": int(usable), "partition": f"{n_ranks} x interleaved {SR}-row strips" + ((", blocks dealt by clocked cost: " + str(np.bincount(owner[0], minlength=n_ranks).tolist()) + " blocks per rank") if owner[0] is not None else ""),
+                       "exchange_every": a.exchange_every,
                        "front_end": "evplp_group (one process, C ABI)" if group is not None else ("one process per rank, torch.distributed " + env.backend if use_dist else "one context"),
                        "physical_gpus": physical,
                        "path_definition": "gather: (pixel, usable VPL record) pair that passes the cosine test = 1 shadow ray; splat: (photon, covered pixel) pair",
@@ -746,7 +782,7 @@ def group_under_launcher(a):
     if rank == 0:
         try:
             import evplp_amd as ev
-            g = ev.Group(64, 64, 64, 64, P, a.gpus, devices=list(range(a.gpus)), strip_rows=STRIP_ROWS)      # opens RCCL on the N devices
+            g = ev.Group(64, 64, 64, 64, P, a.gpus, devices=list(range(a.gpus)), strip_rows=strip_rows_for(a))      # opens RCCL on the N devices
             g.close()
         except Exception as e:      # noqa: BLE001 -- any failure means "use the other front end"
             sys.stderr.write(f"bench.py: evplp_group on {a.gpus} devices failed ({e}); falling back to --front-end ranks\n")

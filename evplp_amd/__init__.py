@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVPLP_LIB") or os.path.join(_HERE, "lib", "libevplp_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # evplp_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_OOM = 0, -1, -2, -3, -4, -5, -6
@@ -50,7 +50,7 @@ class Config(C.Structure):
                 ("num_light_paths", C.c_uint32), ("num_vpl_light_paths", C.c_uint32), ("photons_per_path", C.c_uint32),
                 ("bvh_builder", C.c_int32), ("deterministic", C.c_int32), ("gather_splits_per_wave", C.c_int32),
                 ("overlap_light_tracing", C.c_int32), ("cut_scratch_bytes", C.c_uint64), ("vsl_mask_bytes", C.c_uint64),
-                ("band_first_row", C.c_int32), ("band_rows", C.c_int32), ("band_capacity_rows", C.c_int32), ("reserved", C.c_int32)]
+                ("band_first_row", C.c_int32), ("band_rows", C.c_int32), ("band_capacity_rows", C.c_int32), ("strip_capacity_rows", C.c_int32)]
 
 
 class Material(C.Structure):
@@ -78,7 +78,7 @@ FOOTPRINTS = {"ideal": FOOTPRINT_IDEAL, "proxy": FOOTPRINT_PROXY}
 
 class GroupConfig(C.Structure):
     _fields_ = [("n_ranks", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("strip_rows", C.c_int32), ("use_rccl", C.c_int32),
-                ("partition", C.c_int32), ("reserved", C.c_int32)]
+                ("partition", C.c_int32), ("strip_capacity_pct", C.c_int32)]
 
 
 PARTITION_STRIPS, PARTITION_BANDS = 0, 1
@@ -122,6 +122,12 @@ _SIGNATURES = {
     "evplp_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
     "evplp_clear_accumulators": (C.c_int, [_P]),
     "evplp_set_band": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "evplp_set_blocks": (C.c_int, [_P, _P, C.c_int32]),
+    "evplp_get_blocks": (C.c_int, [_P, _P, C.c_int32]),
+    "evplp_calibrate_blocks": (C.c_int, [_P, C.c_int32]),
+    "evplp_block_costs": (C.c_int, [_P, _P, C.c_int32]),
+    "evplp_deal_blocks": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "evplp_rank_blocks": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
     "evplp_local_rows": (C.c_int, [_P]),
     "evplp_buffer_info": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "evplp_bind_buffer": (C.c_int, [_P, C.c_int32, _P, C.c_size_t]),
@@ -151,8 +157,11 @@ _SIGNATURES = {
     "evplp_group_synchronize": (C.c_int, [_P]),
     "evplp_group_host_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double * 3)]),
     "evplp_group_rebalance": (C.c_int, [_P, _P]),
+    "evplp_group_calibrate": (C.c_int, [_P, C.c_int32]),
+    "evplp_group_block_owners": (C.c_int, [_P, _P, C.c_int32]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_group_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
+    "evplp_group_present_ex": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32]),
     "evplp_jitter_sequence": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "evplp_json_query": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
     "evplp_progressive_step": (None, [C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
@@ -234,7 +243,7 @@ class Context:
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
                  bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0, overlap_light_tracing: bool = False,
-                 band=None, band_capacity_rows: int = 0):
+                 band=None, band_capacity_rows: int = 0, strip_capacity_rows: int = 0):
         """band = (first_row, rows): the context owns those contiguous image rows instead of interleaved strips."""
         self._lib = lib()
         cfg = Config()
@@ -246,7 +255,7 @@ class Context:
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths
         cfg.photons_per_path = photons_per_path; cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
         cfg.gather_splits_per_wave = gather_splits_per_wave
-        cfg.overlap_light_tracing = int(overlap_light_tracing)
+        cfg.overlap_light_tracing = int(overlap_light_tracing); cfg.strip_capacity_rows = int(strip_capacity_rows)
         self.cfg = cfg
         h = C.c_void_p()
         rc = self._lib.evplp_create(C.byref(cfg), C.byref(h))
@@ -406,6 +415,30 @@ class Context:
     def clear_accumulators(self):
         self._check(self._lib.evplp_clear_accumulators(self._h))
 
+    def set_blocks(self, image_blocks=None):
+        """row-strip context: own these image blocks (in this local order) instead of the blocks b % strip_count == strip_rank; None = back to that"""
+        if image_blocks is None:
+            self._check(self._lib.evplp_set_blocks(self._h, None, 0)); return
+        b = np.ascontiguousarray(image_blocks, dtype=np.int32)
+        self._check(self._lib.evplp_set_blocks(self._h, _ptr(b), b.size))
+
+    def blocks(self) -> np.ndarray:
+        """the image blocks this context owns, in local order"""
+        n = self._check(self._lib.evplp_get_blocks(self._h, None, 0))
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.evplp_get_blocks(self._h, _ptr(out), n))
+        return out
+
+    def calibrate_blocks(self, on: bool = True):
+        self._check(self._lib.evplp_calibrate_blocks(self._h, int(on)))
+
+    def block_costs(self) -> np.ndarray:
+        """clock ticks the gathers' wavefronts spent in every IMAGE block since calibrate_blocks(True) (0 for other ranks' blocks)"""
+        sr = self.cfg.strip_rows if self.cfg.strip_count > 1 else (self.H + 7) // 8 * 8
+        out = np.zeros((self.H + sr - 1) // sr, dtype=np.uint64)
+        self._check(self._lib.evplp_block_costs(self._h, _ptr(out), out.size))
+        return out
+
     def set_band(self, first_row: int, rows: int):
         self._check(self._lib.evplp_set_band(self._h, first_row, rows))
         self.cfg.band_first_row, self.cfg.band_rows = first_row, rows
@@ -467,21 +500,45 @@ class Context:
             l = np.arange(self.local_rows)
             rows = min(self.cfg.band_rows, self.H - self.cfg.band_first_row)
             return np.where(l < rows, self.cfg.band_first_row + l, self.H + l)
-        return strips.global_rows(self.H, self.cfg.strip_rank, self.cfg.strip_count, self.cfg.strip_rows)
+        if self.cfg.strip_count <= 1:
+            return strips.global_rows(self.H, self.cfg.strip_rank, self.cfg.strip_count, self.cfg.strip_rows)
+        return strips.rows_of_blocks(self.H, self.blocks(), self.cfg.strip_rows, self.local_rows)      # (the library's table: dealt or round-robin)
+
+
+def deal_blocks(costs, n_ranks: int, capacity_blocks: int) -> np.ndarray:
+    """evplp_deal_blocks: owner rank of every image block for these per-block costs (host only, deterministic)"""
+    c = np.ascontiguousarray(costs, dtype=np.uint64)
+    owner = np.zeros(c.size, dtype=np.int32)
+    rc = lib().evplp_deal_blocks(_ptr(c), c.size, n_ranks, capacity_blocks, _ptr(owner))
+    if rc < 0:
+        raise EvplpError(rc, "evplp_deal_blocks: the blocks do not fit the ranks' capacity")
+    return owner
+
+
+def rank_blocks(costs, owner, rank: int) -> np.ndarray:
+    """evplp_rank_blocks: the blocks a deal gives `rank`, in the order it stores and launches them (most expensive first; costs=None: image order)"""
+    o = np.ascontiguousarray(owner, dtype=np.int32)
+    c = None if costs is None else np.ascontiguousarray(costs, dtype=np.uint64)
+    out = np.zeros(o.size, dtype=np.int32)
+    n = lib().evplp_rank_blocks(_ptr(c), _ptr(o), o.size, rank, _ptr(out), out.size)
+    if n < 0:
+        raise EvplpError(n, "evplp_rank_blocks")
+    return out[:n]
 
 
 class Group:
     """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
 
-    def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=16,
-                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips"):
+    def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=0,
+                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips", strip_capacity_pct=0):
+        """strip_rows = 0: the library's choice (16 rows)"""
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths; cfg.photons_per_path = photons_per_path
         cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic); cfg.overlap_light_tracing = int(overlap_light_tracing)
         gc = GroupConfig(); gc.n_ranks = n_ranks; gc.strip_rows = strip_rows; gc.use_rccl = int(use_rccl)
-        gc.partition = PARTITION_BANDS if partition == "bands" else PARTITION_STRIPS
+        gc.partition = PARTITION_BANDS if partition == "bands" else PARTITION_STRIPS; gc.strip_capacity_pct = int(strip_capacity_pct)
         self.partition = partition if n_ranks > 1 else "strips"
         self._devs = (C.c_int32 * n_ranks)(*devices) if devices is not None else None
         gc.devices = C.cast(self._devs, C.POINTER(C.c_int32)) if self._devs is not None else None
@@ -490,7 +547,7 @@ class Group:
         if rc != OK:
             raise EvplpError(rc, self._lib.evplp_group_last_error(None).decode())
         self._h = h; self.W, self.H, self.n = res_x, res_y, n_ranks
-        self.strip_rows = strip_rows
+        self.strip_rows = strip_rows if strip_rows > 0 else 16
         self._paths = (num_light_paths, num_vpl_light_paths, photons_per_path)
 
     def _check(self, rc):
@@ -537,10 +594,21 @@ class Group:
         self._check(self._lib.evplp_group_synchronize(self._h))
 
     def rebalance(self) -> np.ndarray:
-        """bands partition: move the band boundaries to equal measured cost (clears the accumulators); returns the n + 1 boundaries"""
+        """bands partition: move the band boundaries to equal measured cost (clears the accumulators); returns the n + 1 boundaries.
+        strips partition: deal the blocks by the cost clocked since calibrate() (block_owners() has the result)"""
         out = np.zeros(self.n + 1, dtype=np.int32)
         self._check(self._lib.evplp_group_rebalance(self._h, _ptr(out)))
         self._bands = out.copy()
+        return out
+
+    def calibrate(self, on: bool = True):
+        """strips partition: the gathers clock their blocks until rebalance() deals them by cost"""
+        self._check(self._lib.evplp_group_calibrate(self._h, int(on)))
+
+    def block_owners(self) -> np.ndarray:
+        n = self._check(self._lib.evplp_group_block_owners(self._h, None, 0))
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.evplp_group_block_owners(self._h, _ptr(out), n))
         return out
 
     def profile_passes(self, on: bool = True):
@@ -552,9 +620,9 @@ class Group:
         self._check(self._lib.evplp_group_host_stats(self._h, r, C.byref(out)))
         return {"calls_ms": out[0], "exchange_ms": out[1], "commands": int(out[2])}
 
-    def present(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False):
-        """composite + all-gather of the strips on the devices (the per-frame exchange); nothing comes to the host"""
-        self._check(self._lib.evplp_group_present(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma)))
+    def present(self, vpl_scale=1.0, photon_scale=1.0, light_scale=1.0, mask_emitter=False, gamma=False, exchange=True):
+        """composite + all-gather of the strips on the devices (the per-frame exchange); nothing comes to the host.  exchange=False: the composite alone"""
+        self._check(self._lib.evplp_group_present_ex(self._h, vpl_scale, photon_scale, light_scale, int(mask_emitter), int(gamma), int(exchange)))
 
     def rank(self, r: int) -> "Context":
         """rank r's context (borrowed): pass statistics, buffers"""

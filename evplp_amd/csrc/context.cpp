@@ -47,6 +47,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if (cfg->gather_splits_per_wave < 0 || cfg->gather_splits_per_wave > 32 || (cfg->gather_splits_per_wave & (cfg->gather_splits_per_wave - 1)) != 0) {
         snprintf(g_create_error, sizeof(g_create_error), "evplp_create: gather_splits_per_wave must be 0 (automatic) or a power of two <= 32"); return EVPLP_ERR_INVALID;
     }
+    if (cfg->strip_capacity_rows < 0) { snprintf(g_create_error, sizeof(g_create_error), "evplp_create: strip_capacity_rows is negative"); return EVPLP_ERR_INVALID; }
     if (cfg->num_vpl_light_paths > cfg->num_light_paths) {
         snprintf(g_create_error, sizeof(g_create_error), "evplp_create: num_vpl_light_paths > num_light_paths (VPLs are the first paths of the same set, lighttracing.cu:368)"); return EVPLP_ERR_INVALID;
     }
@@ -79,6 +80,7 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     if (const char *env = std::getenv("EVPLP_BVH_BUILDER"))
         c->env_bvh_builder = !std::strcmp(env, "sbvh") ? EVPLP_BVH_SBVH : !std::strcmp(env, "lbvh") ? EVPLP_BVH_LBVH : !std::strcmp(env, "gpu") ? EVPLP_BVH_LBVH_GPU : EVPLP_BVH_SAH;
     if (const char *env = std::getenv("EVPLP_CUTS")) c->env_cuts = atoi(env) != 0 ? 1 : 0;
+    if (const char *env = std::getenv("EVPLP_ITEM_DEAL")) c->env_item_deal = atoi(env) != 0 ? 1 : 0;
     if (const char *env = std::getenv("EVPLP_CUT_BYTES")) c->env_cut_bytes = (size_t)strtoull(env, nullptr, 10);      // (tests: forces the band path)
     if (const char *env = std::getenv("EVPLP_GATHER_K")) { int v = atoi(env); if (v >= 1 && v <= 32 && (v & (v - 1)) == 0) c->env_gather_k = v; }
     if (const char *env = std::getenv("EVPLP_TILE_BLOCK_LOG2")) c->env_tile_block_log2 = std::max(0, atoi(env));
@@ -87,7 +89,10 @@ extern "C" int evplp_create(const evplp_config *cfg, evplp_context **out) {
     c->st.strip_rank = cfg->strip_rank; c->st.strip_count = strip_count; c->st.strip_rows = strip_rows;
     int nblocks = (cfg->res_y + strip_rows - 1) / strip_rows;
     int owned = (nblocks + strip_count - 1) / strip_count;  // padded: equal on every rank (all-gather chunks)
+    // strip_capacity_rows: room for more blocks than the equal share (a deal by cost gives a rank of cheap blocks more of them: evplp_set_blocks)
+    if (strip_count > 1 && cfg->strip_capacity_rows > owned * strip_rows) owned = std::min((cfg->strip_capacity_rows + strip_rows - 1) / strip_rows, nblocks);
     c->st.local_rows = owned * strip_rows;
+    c->st.cap_blocks = owned; c->image_blocks = nblocks;
     if (band_mode) {
         const int cap = cfg->band_capacity_rows > 0 ? cfg->band_capacity_rows : cfg->band_rows;
         c->st.strip_rows = ((cap + 7) / 8) * 8; c->cfg.strip_rows = c->st.strip_rows;
@@ -208,7 +213,7 @@ extern "C" void evplp_destroy(evplp_context *c) {
     hipFree(c->d_vpls); hipFree(c->d_vpl_src); hipFree(c->d_scalars); hipFree(c->d_counters); hipFree(c->d_rgb); hipFree(c->d_partial); hipFree(c->d_vsl_masks); hipFree(c->d_cuts); hipFree(c->d_primary_cuts); hipFree(c->d_lt_overflow);
     hipFree(c->d_tile_cursor); hipFree(c->d_bin_items); hipFree(c->d_bin_items_tmp); hipFree(c->d_seg); hipFree(c->d_seg_off); hipFree(c->d_big_list); hipFree(c->d_big_count);
     hipFree(c->d_compact); hipFree(c->d_tile_box); hipFree(c->d_tile_pairs); hipFree(c->d_summary); hipFree(c->d_heavy_list); hipFree(c->d_tile_flags);
-    hipFree(c->d_proxy_slabs); hipFree(c->d_proxy_hm); hipFree(c->d_tile_frags);
+    hipFree(c->d_proxy_slabs); hipFree(c->d_proxy_hm); hipFree(c->d_tile_frags); hipFree(c->d_blocks); hipFree(c->d_block_cost);
     for (int i = 0; i < EVPLP_PASS_COUNT; i++) {
         if (c->ev_begin[i]) hipEventDestroy(c->ev_begin[i]);
         if (c->ev_end[i]) hipEventDestroy(c->ev_end[i]);
@@ -688,6 +693,10 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.partial_stride = (size_t)c->st.W * c->st.local_rows;
     a.counters = &c->d_counters[pass];
     a.splits_per_wave = 1;
+    a.block_cost = c->calibrate ? c->d_block_cost : nullptr;
+    // tiles to XCDs while an XCD's share is >= 1024 tiles (its sum of tile costs then averages out: 1.9 % spread at 1024 x 1024), items over all
+    // XCDs below that (a strip of an n-way partition, small images); EVPLP_ITEM_DEAL=0 / 1 forces either (developer A/B)
+    a.item_deal = c->env_item_deal >= 0 ? c->env_item_deal : ((size_t)c->tiles_x * c->tiles_y < 8192 ? 1 : 0);
     // tile blocks: as many tile rows as a row strip keeps adjacent, at most 8
     int sh = 8;
     if (c->st.strip_count > 1) { sh = 1; while (sh * 2 <= std::min(8, c->st.strip_rows / 8) && (c->st.strip_rows / 8) % (sh * 2) == 0) sh *= 2; }
@@ -1001,6 +1010,10 @@ extern "C" int evplp_present(evplp_context *c, float vs, float ps, float ls, int
     return evplp::resolve_to_device(c, vs, ps, ls, mask_emitter, gamma, !c->aux_stream);      // (overlapped contexts keep the host an iteration ahead)
 }
 
+static void count_rows_in_image(evplp_context *c) {
+    c->rows_in_image = 0;
+    for (int l = 0; l < c->st.local_rows; l++) if (c->st.global_row(l) < c->st.H) c->rows_in_image++;
+}
 extern "C" int evplp_set_band(evplp_context *c, int32_t first_row, int32_t rows) {
     CTX_CHECK(c);
     { int rc_ = settle_splat(c); if (rc_) return rc_; }
@@ -1013,10 +1026,79 @@ extern "C" int evplp_set_band(evplp_context *c, int32_t first_row, int32_t rows)
     HIP_TRY(c, hipStreamSynchronize(c->stream)); if (c->aux_stream) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
     c->st.band_first = first_row; c->st.band_rows = std::min(rows, c->st.H - first_row);
     c->cfg.band_first_row = first_row; c->cfg.band_rows = rows;
-    c->rows_in_image = 0;
-    for (int l = 0; l < c->st.local_rows; l++) if (c->st.global_row(l) < c->st.H) c->rows_in_image++;
+    count_rows_in_image(c);
     c->primary_cuts_valid = false; c->tile_box_valid = false;
     return evplp_clear_accumulators(c);
+}
+
+// ---- dealt blocks (include/evplp.h): the owned-block table of a row-strip context, and the per-block cost the deal is made from
+extern "C" int evplp_set_blocks(evplp_context *c, const int32_t *image_blocks, int32_t count) {
+    CTX_CHECK(c);
+    { int rc_ = settle_splat(c); if (rc_) return rc_; }
+    if (c->st.strip_count <= 1 || c->st.band_rows > 0) { c->set_error("evplp_set_blocks: the context is not a row-strip context (strip_count > 1)"); return EVPLP_ERR_INVALID; }
+    const int cap = c->st.cap_blocks, nb = c->image_blocks;
+    if (image_blocks && (count < 0 || count > cap)) { c->set_error("evplp_set_blocks: %d blocks do not fit the context's %d (strip_capacity_rows)", count, cap); return EVPLP_ERR_INVALID; }
+    std::vector<int32_t> table;
+    if (image_blocks) {
+        table.assign((size_t)cap + nb, -1);
+        for (int l = 0; l < cap; l++) table[(size_t)l] = nb + l;                   // holds nothing: rows >= H
+        for (int l = 0; l < count; l++) {
+            const int b = image_blocks[l];
+            if (b < 0 || b >= nb || table[(size_t)cap + b] >= 0) { c->set_error("evplp_set_blocks: block %d is outside the image's %d blocks or listed twice", b, nb); return EVPLP_ERR_INVALID; }
+            table[(size_t)l] = b; table[(size_t)cap + b] = l;
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); if (c->aux_stream) HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    if (image_blocks) {
+        if (!c->d_blocks) HIP_TRY(c, hipMalloc((void **)&c->d_blocks, sizeof(int32_t) * ((size_t)cap + nb)));
+        HIP_TRY(c, hipMemcpy(c->d_blocks, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+        c->blocks_host.swap(table);
+        c->st.blocks = c->d_blocks; c->st.blocks_host = c->blocks_host.data();
+    } else { c->st.blocks = nullptr; c->st.blocks_host = nullptr; c->blocks_host.clear(); }       // back to block b -> rank b % strip_count
+    count_rows_in_image(c);
+    c->primary_cuts_valid = false; c->tile_box_valid = false;
+    return evplp_clear_accumulators(c);
+}
+extern "C" int evplp_get_blocks(evplp_context *c, int32_t *image_blocks, int32_t capacity) {
+    CTX_CHECK(c);
+    int n = 0;
+    const int cap = c->st.band_rows > 0 ? 0 : c->st.local_rows / c->st.strip_rows;
+    for (int l = 0; l < cap; l++) {
+        const int b = c->st.global_block(l);
+        if (b >= c->image_blocks) continue;
+        if (image_blocks && n < capacity) image_blocks[n] = b;
+        n++;
+    }
+    return n;
+}
+extern "C" int evplp_calibrate_blocks(evplp_context *c, int32_t on) {
+    CTX_CHECK(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const size_t bytes = sizeof(unsigned long long) * (size_t)std::max(c->st.local_rows / std::max(c->st.strip_rows, 1), 1);
+    if (on) {
+        if (!c->d_block_cost) HIP_TRY(c, hipMalloc((void **)&c->d_block_cost, bytes));
+        HIP_TRY(c, hipMemsetAsync(c->d_block_cost, 0, bytes, c->stream));
+    }
+    c->calibrate = on != 0;
+    return EVPLP_OK;
+}
+extern "C" int evplp_block_costs(evplp_context *c, uint64_t *cost_per_image_block, int32_t capacity) {
+    CTX_CHECK(c);
+    if (!cost_per_image_block || capacity < c->image_blocks) { c->set_error("evplp_block_costs: the output needs room for %d blocks", c->image_blocks); return EVPLP_ERR_INVALID; }
+    if (!c->d_block_cost) { c->set_error("evplp_block_costs: no calibration has run (evplp_calibrate_blocks)"); return EVPLP_ERR_INVALID; }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int cap = c->st.local_rows / c->st.strip_rows;
+    std::vector<unsigned long long> local((size_t)cap);
+    HIP_TRY(c, hipMemcpyAsync(local.data(), c->d_block_cost, sizeof(unsigned long long) * local.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->image_blocks; b++) cost_per_image_block[b] = 0;
+    int n = 0;
+    for (int l = 0; l < cap; l++) {
+        const int b = c->st.band_rows > 0 ? 0 : c->st.global_block(l);
+        if (b < c->image_blocks) { cost_per_image_block[b] += local[(size_t)l]; n++; }
+    }
+    return n;
 }
 
 extern "C" int evplp_clear_accumulators(evplp_context *c) {

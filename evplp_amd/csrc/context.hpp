@@ -24,6 +24,10 @@ struct evplp_context {
     evplp_config cfg{};
     evplp::StripDev st{};
     int32_t rows_in_image = 0;
+    // dealt blocks (evplp_set_blocks): the table behind st.blocks / st.blocks_host, [cap_blocks] local -> image block, then [image blocks] image -> local block
+    std::vector<int32_t> blocks_host; int32_t *d_blocks = nullptr; int32_t image_blocks = 0;
+    // evplp_calibrate_blocks: while on, the gathers run their self-clocking variants and add every item's resident time to its local block's counter
+    bool calibrate = false; unsigned long long *d_block_cost = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev_begin[EVPLP_PASS_COUNT] = {}, ev_end[EVPLP_PASS_COUNT] = {};
     hipEvent_t ev_dom_begin[EVPLP_PASS_COUNT] = {}, ev_dom_end[EVPLP_PASS_COUNT] = {};
@@ -101,6 +105,7 @@ struct evplp_context {
     // Test / developer overrides, read ONCE by evplp_create (never in a pass): EVPLP_BVH_BUILDER (every suite under every builder),
     // EVPLP_BIN_STRIDE (forces the photon-bin overflow path), EVPLP_GATHER_K, EVPLP_TILE_BLOCK_LOG2.  -1 / 0 = not set.
     int32_t env_bvh_builder = -1, env_gather_k = 0, env_tile_block_log2 = -1, env_cuts = -1;      // env_cuts: EVPLP_CUTS=0 walks from the root
+    int32_t env_item_deal = -1;                // EVPLP_ITEM_DEAL: 0 tiles dealt to XCDs, 1 a tile's items over all XCDs (default: by launch size)
     int32_t env_split_min = 0;                 // EVPLP_SPLIT_MIN: fullest bin from which the splat's tile kernel runs four waves per tile
     size_t env_cut_bytes = 0;                  // EVPLP_CUT_BYTES: test override of evplp_config.cut_scratch_bytes
 

@@ -100,6 +100,9 @@ struct SceneDev {
 };
 
 // Strip geometry shared by all per-pixel kernels.
+#ifndef EVPLP_BLOCK_TABLE
+#define EVPLP_BLOCK_TABLE 1      // developer knob (A/B builds): 0 compiles the owned-block table out of the kernels (round-robin deal only)
+#endif
 struct StripDev {
     int32_t W, H;
     int32_t strip_rank, strip_count, strip_rows;
@@ -107,10 +110,35 @@ struct StripDev {
     // band mode (evplp_config.band_rows > 0; strip_count = 1): the context owns the image rows [band_first, band_first + band_rows), stored
     // from local row 0; local rows beyond the band (padding up to the capacity) lie outside the image
     int32_t band_first, band_rows;
+    // DEALT blocks (evplp_set_blocks; strip_count > 1): the owned-block table replaces "block b belongs to rank b % strip_count".
+    //   blocks[l], l < cap_blocks = local_rows / strip_rows: the image block stored in local block l; a local block that holds nothing carries an
+    //     index >= the image's block count, i.e. rows >= H: outside the image, as the padding rows of the round-robin deal are;
+    //   blocks[cap_blocks + b], b < image blocks: the local block that holds image block b, or -1 (another rank's).
+    // nullptr = the round-robin deal.  Two copies of the same table: `blocks` in device memory, `blocks_host` for the host side of global_row.
+    const int32_t *blocks, *blocks_host;
+    int32_t cap_blocks, pad_st;
+    __host__ __device__ inline int32_t global_block(int32_t local_blk) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int32_t *t = EVPLP_BLOCK_TABLE ? blocks : nullptr;
+#else
+        const int32_t *t = blocks_host;
+#endif
+        return t ? t[local_blk] : local_blk * strip_count + strip_rank;
+    }
     __host__ __device__ inline int32_t global_row(int32_t local) const {
         if (band_rows > 0) return local < band_rows ? band_first + local : H + local;
         int32_t blk = local / strip_rows;
-        return (blk * strip_count + strip_rank) * strip_rows + (local - blk * strip_rows);
+        return global_block(blk) * strip_rows + (local - blk * strip_rows);
+    }
+    // the local block that holds image block b, or -1 (strip_count > 1 only)
+    __host__ __device__ inline int32_t local_block(int32_t b) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int32_t *t = EVPLP_BLOCK_TABLE ? blocks : nullptr;
+#else
+        const int32_t *t = blocks_host;
+#endif
+        if (t) return t[cap_blocks + b];
+        return b % strip_count == strip_rank ? b / strip_count : -1;
     }
 };
 

@@ -66,13 +66,21 @@ struct Cmd {
 constexpr int kRing = 64;
 constexpr int kSpinBeforeSleep = 200000;     // ~1-2 ms of polling before an idle worker goes to sleep on its condition variable
 
-// sense-reversing barrier of the workers (spins: the waits are microseconds long, in front of a collective)
+// sense-reversing barrier of the workers (spins: the waits are microseconds long, in front of a collective).  wait(flag) returns ONE
+// verdict for all parties of a generation: the last arriver reads `flag` once, in front of flipping the sense, and everybody leaves with
+// what it read -- a rank that fails right behind the barrier cannot make its peers disagree about whether the collective is entered.
 struct SpinBarrier {
-    std::atomic<int> count{ 0 }; std::atomic<int> sense{ 0 }; int n = 1;
-    void wait() {
+    std::atomic<int> count{ 0 }; std::atomic<int> sense{ 0 }; std::atomic<int> verdict{ 0 }; int n = 1;
+    int wait(const std::atomic<int> *flag = nullptr) {
         const int s = sense.load(std::memory_order_acquire);
-        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) { count.store(0, std::memory_order_relaxed); sense.store(s ^ 1, std::memory_order_release); }
-        else { int spins = 0; while (sense.load(std::memory_order_acquire) == s) { if (++spins > 2000) std::this_thread::yield(); } }
+        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+            count.store(0, std::memory_order_relaxed);
+            verdict.store(flag ? flag->load(std::memory_order_acquire) : 0, std::memory_order_relaxed);
+            sense.store(s ^ 1, std::memory_order_release);
+        } else { int spins = 0; while (sense.load(std::memory_order_acquire) == s) { if (++spins > 2000) std::this_thread::yield(); } }
+        // (the verdict of THIS generation: the next one's last arriver cannot overwrite it before every party of this one has arrived there,
+        // i.e. has returned from here)
+        return verdict.load(std::memory_order_relaxed);
     }
 };
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -103,6 +111,11 @@ struct evplp_group {
     size_t strip_floats = 0;                // local_rows * W * 3
     bool split_paths = false; uint32_t per_rank_paths = 0;
     bool bands = false; evplp::BandTable band_table{};    // EVPLP_PARTITION_BANDS: first image row of every rank's band (+ H)
+    // EVPLP_PARTITION_STRIPS: the blocks as dealt (evplp_group_rebalance); empty = block b belongs to rank b % n
+    std::vector<int32_t> owner;             // [image blocks] rank
+    uint32_t *d_owner = nullptr;            // rank 0's device: [image blocks] rank << 16 | local block (assemble_strips_kernel)
+    int strip_rows = 16, image_blocks = 0, cap_blocks = 0;
+    size_t strip_floats_cap = 0;            // d_frame's chunk size (the capacity); strip_floats <= it is what an exchange moves
     std::vector<Worker *> workers;
     SpinBarrier barrier;
     std::atomic<int> failed{ 0 };           // some rank has failed: collectives are skipped by everybody
@@ -128,9 +141,10 @@ static void worker_all_gather(Worker *w, float *recv, size_t count, const std::v
         }
         return;
     }
-    // everybody arrives, then everybody knows whether somebody has failed: all enter the collective or none
-    g->barrier.wait();
-    if (g->failed.load(std::memory_order_acquire)) return;
+    // everybody arrives, then everybody gets the SAME answer to "has somebody failed": all enter the collective or none (the barrier's last
+    // arriver reads the flag once for all; a rank that reads it for itself could see a failure its peers, already past the barrier, raised
+    // in their NEXT command and skip a collective they have entered)
+    if (g->barrier.wait(&g->failed) != 0) return;
     if (!g->virtual_ranks) {
         ncclResult_t nr = g->rccl.AllGather(send, recv, count, ncclFloat, g->comms[(size_t)w->rank], c->stream);
         if (nr != ncclSuccess) worker_fail(w, EVPLP_ERR_HIP, g->rccl.GetErrorString(nr));
@@ -151,7 +165,7 @@ static void worker_all_gather(Worker *w, float *recv, size_t count, const std::v
 
 static void worker_run(Worker *w, const Cmd &cmd) {
     evplp_group *g = w->g; const int r = w->rank; evplp_context *c = g->ctx[(size_t)r];
-    const bool collective = cmd.op == OP_PRESENT || (cmd.op == OP_TRACE && g->split_paths);
+    const bool collective = (cmd.op == OP_PRESENT && cmd.i[3] != 0) || (cmd.op == OP_TRACE && g->split_paths);
     int rc = EVPLP_OK;
     const double t0 = now_ms();
     if (w->status.load(std::memory_order_relaxed) == 0) {
@@ -184,7 +198,7 @@ static void worker_run(Worker *w, const Cmd &cmd) {
             hipError_t e = hipSuccess;
             if (!g->d_assembled) e = hipMalloc((void **)&g->d_assembled, sizeof(float) * frame_floats);
             if (e == hipSuccess) {
-                evplp::launch_assemble_strips(c->st, g->n, g->bands ? &g->band_table : nullptr, g->d_frame[0], g->d_assembled, c->stream);
+                evplp::launch_assemble_strips(c->st, g->n, g->bands ? &g->band_table : nullptr, g->owner.empty() ? nullptr : g->d_owner, (int)(g->strip_floats / ((size_t)c->st.W * 3)), g->d_frame[0], g->d_assembled, c->stream);
                 e = hipMemcpyAsync(cmd.out, g->d_assembled, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -260,6 +274,19 @@ static int post_and_wait(evplp_group *g, const Cmd &cmd) {
 }
 
 #define GRP_CHECK(g) do { if (!(g)) return EVPLP_ERR_INVALID; } while (0)
+// What a pass call can refuse without touching a device is refused HERE, on the caller's thread, at once -- as the plain context does -- and
+// leaves the group usable; only failures of the device side are sticky.  (The configuration is the same on every rank and never changes.)
+static int check_frame_params(evplp_group *g, const evplp_frame_params *fp, const char *name, bool splat) {
+    const evplp_config &cf = g->ctx[0]->cfg;
+    if (fp->photons_per_path != cf.photons_per_path || fp->num_light_paths != cf.num_light_paths || fp->num_vpl_light_paths > cf.num_vpl_light_paths) {
+        g->set_error("%s: frame params disagree with the configuration (paths / photons per path)", name); return EVPLP_ERR_INVALID;
+    }
+    if (fp->mis_mode > 5u) { g->set_error("%s: mis_mode %u out of range", name, fp->mis_mode); return EVPLP_ERR_INVALID; }
+    if (!splat && fp->num_vpl_light_paths == 0) { g->set_error("%s: num_vpl_light_paths is 0 (the reference disables the pass, rtcomphoton.h:200-203)", name); return EVPLP_ERR_INVALID; }
+    if (splat && !(fp->photon_radius > 0.0f)) { g->set_error("%s: photon_radius must be > 0", name); return EVPLP_ERR_INVALID; }
+    if (splat && fp->splat_footprint > (uint32_t)EVPLP_FOOTPRINT_PROXY) { g->set_error("%s: splat_footprint %u out of range", name, fp->splat_footprint); return EVPLP_ERR_INVALID; }
+    return EVPLP_OK;
+}
 
 extern "C" const char *evplp_group_last_error(const evplp_group *g) { return g ? g->error : g_group_create_error; }
 extern "C" int evplp_group_size(const evplp_group *g) { return g ? g->n : EVPLP_ERR_INVALID; }
@@ -285,7 +312,7 @@ extern "C" void evplp_group_destroy(evplp_group *g) {
     for (Worker *w : g->workers) { if (w->th.joinable()) w->th.join(); delete w; }
     g->workers.clear();
     for (int r = 0; r < (int)g->d_frame.size(); r++) if (g->d_frame[(size_t)r]) { hipSetDevice(g->device[(size_t)r]); hipFree(g->d_frame[(size_t)r]); }
-    if (g->d_assembled) { hipSetDevice(g->device[0]); hipFree(g->d_assembled); }
+    if (g->d_assembled || g->d_owner) { hipSetDevice(g->device[0]); hipFree(g->d_assembled); hipFree(g->d_owner); }
     for (ncclComm_t c : g->comms) if (c && g->rccl.CommDestroy) g->rccl.CommDestroy(c);
     for (evplp_context *c : g->ctx) { c->quiesce = nullptr; evplp_destroy(c); }
     delete g;
@@ -305,10 +332,11 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     g->virtual_ranks = g->n > 1 ? all_same : !gc->use_rccl;
     if (gc->use_rccl && g->n > 1 && !all_distinct) { delete g; return fail(EVPLP_ERR_INVALID, "evplp_group_create: RCCL needs one distinct device per rank"); }
     // Strips of 16 rows keep a rank's tile rows in neighbouring pairs -- the gathers' entry cuts then cover groups of 2 x 2 tiles as on one
-    // GPU (8-row strips: 2 x 1, twice as many cuts per pixel) -- but interleave the image half as finely.  Single-GPU projection of config
-    // #2 (profiles/r05_strip_projection.json; slowest rank's frame, 8- / 16-row strips): n = 2 28.1 / 27.7 ms, n = 4 15.3 / 15.2, n = 8
-    // 10.3 / 10.6 (balance 0.89 / 0.81): 16 rows up to four ranks, 8 from eight on.
-    const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : (g->n >= 8 ? 8 : 16);
+    // GPU (8-row strips: 2 x 1, twice as many cuts per pixel) -- but interleave the image half as finely.  Round 5 took 8 rows from eight
+    // ranks on for that; with the blocks dealt by cost and launched most expensive first (evplp_group_rebalance) the finer interleave buys
+    // nothing any more and the cheaper cuts win at every rank count (single-GPU projection of config #2, profiles/r06_strip_projection.json:
+    // n = 8, 8- / 16-row blocks: slowest rank 8.49 / 8.06 ms; n = 4: 14.97 / 14.60).
+    const int strip_rows = gc->strip_rows > 0 ? gc->strip_rows : 16;
     // EVPLP_PARTITION_BANDS: contiguous bands of equal height to begin with (multiples of 16 rows), each with room for twice its share
     g->bands = gc->partition == EVPLP_PARTITION_BANDS && g->n > 1;
     const int rows16 = ((cfg->res_y + 15) / 16) * 16, share = std::max(16, ((rows16 / g->n + 15) / 16) * 16), band_cap = std::min(rows16, 2 * share);
@@ -318,6 +346,10 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     for (int r = 0; r < g->n; r++) {
         evplp_config c = *cfg;
         c.device = g->device[(size_t)r]; c.strip_rank = r; c.strip_count = g->n; c.strip_rows = strip_rows;
+        {   // room for a deal by cost: strip_capacity_pct of the equal share of blocks, rounded up (0 = 150 %)
+            const int nb = (cfg->res_y + strip_rows - 1) / strip_rows, share = (nb + g->n - 1) / g->n, pct = gc->strip_capacity_pct > 0 ? std::max(gc->strip_capacity_pct, 100) : 150;
+            c.strip_capacity_rows = g->n > 1 ? std::min(nb, (share * pct + 99) / 100) * strip_rows : 0;
+        }
         if (g->bands) {
             c.strip_rank = 0; c.strip_count = 1; c.strip_rows = 0;
             c.band_first_row = g->band_table.first[r]; c.band_rows = (r + 1 < g->n ? g->band_table.first[r + 1] : rows16) - g->band_table.first[r]; c.band_capacity_rows = band_cap;
@@ -327,11 +359,16 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
         if (rc < 0) { int code = fail(rc, "rank %d: %s", r, evplp_last_error(nullptr)); evplp_group_destroy(g); return code; }
         g->ctx.push_back(h);
     }
-    g->strip_floats = (size_t)g->ctx[0]->st.local_rows * g->ctx[0]->st.W * 3;
+    g->strip_rows = g->ctx[0]->st.strip_rows; g->image_blocks = g->ctx[0]->image_blocks; g->cap_blocks = g->ctx[0]->st.cap_blocks;
+    g->strip_floats_cap = (size_t)g->ctx[0]->st.local_rows * g->ctx[0]->st.W * 3;
+    // an exchange moves the rows in use: the equal share under the round-robin deal (the capacity beyond it holds nothing), the fullest rank's
+    // blocks after a deal by cost
+    g->strip_floats = g->bands || g->n == 1 ? g->strip_floats_cap
+                                            : (size_t)((g->image_blocks + g->n - 1) / g->n) * (size_t)g->strip_rows * g->ctx[0]->st.W * 3;
     g->d_frame.assign((size_t)g->n, nullptr);
     for (int r = 0; r < g->n; r++) {
         hipSetDevice(g->device[(size_t)r]);
-        hipError_t e = hipMalloc((void **)&g->d_frame[(size_t)r], sizeof(float) * g->strip_floats * (size_t)g->n);
+        hipError_t e = hipMalloc((void **)&g->d_frame[(size_t)r], sizeof(float) * g->strip_floats_cap * (size_t)g->n);
         if (e != hipSuccess) { int code = fail(EVPLP_ERR_OOM, "rank %d: hipMalloc(frame): %s", r, hipGetErrorString(e)); evplp_group_destroy(g); return code; }
     }
     if (!g->virtual_ranks) {
@@ -364,6 +401,47 @@ extern "C" int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows) {
     drain(g);
     int rc = group_status(g); if (rc < 0) return rc;
     const int H = g->ctx[0]->st.H, n = g->n;
+    if (!g->bands && n > 1) {
+        // ---- EVPLP_PARTITION_STRIPS: deal the blocks by the cost the gathers clocked (evplp_group_calibrate)
+        const int nb = g->image_blocks;
+        std::vector<uint64_t> cost((size_t)nb, 0), mine((size_t)nb);
+        uint64_t total = 0;
+        for (int r = 0; r < n; r++) {
+            int rb = evplp_block_costs(g->ctx[(size_t)r], mine.data(), nb);
+            if (rb < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[(size_t)r])); return rb; }
+            for (int b = 0; b < nb; b++) { cost[(size_t)b] += mine[(size_t)b]; total += mine[(size_t)b]; }
+        }
+        if (total == 0) { g->set_error("evplp_group_rebalance: no block cost was clocked (evplp_group_calibrate, then a frame with a gather)"); return EVPLP_ERR_INVALID; }
+        std::vector<int32_t> owner((size_t)nb);
+        rc = evplp_deal_blocks(cost.data(), nb, n, g->cap_blocks, owner.data());
+        if (rc < 0) { g->set_error("evplp_group_rebalance: %d blocks do not fit %d ranks of %d", nb, n, g->cap_blocks); return rc; }
+        // every rank's blocks, the most expensive first (evplp_rank_blocks: the launch order); all tables are built before any is set
+        std::vector<std::vector<int32_t>> lists((size_t)n);
+        std::vector<uint32_t> packed((size_t)nb);
+        size_t most = 0;
+        for (int r = 0; r < n; r++) {
+            auto &l = lists[(size_t)r];
+            l.resize((size_t)nb);
+            l.resize((size_t)evplp_rank_blocks(cost.data(), owner.data(), nb, r, l.data(), nb));
+            for (size_t i = 0; i < l.size(); i++) packed[(size_t)l[i]] = ((uint32_t)r << 16) | (uint32_t)i;
+            most = std::max(most, l.size());
+        }
+        hipSetDevice(g->device[0]);
+        if (!g->d_owner && hipMalloc((void **)&g->d_owner, sizeof(uint32_t) * (size_t)nb) != hipSuccess) { (void)hipGetLastError(); g->set_error("evplp_group_rebalance: hipMalloc(owner table)"); return EVPLP_ERR_OOM; }
+        if (hipMemcpy(g->d_owner, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); g->set_error("evplp_group_rebalance: hipMemcpy(owner table)"); return EVPLP_ERR_HIP; }
+        for (int r = 0; r < n; r++) {
+            int rb = evplp_set_blocks(g->ctx[(size_t)r], lists[(size_t)r].data(), (int32_t)lists[(size_t)r].size());
+            if (rb >= 0) rb = evplp_calibrate_blocks(g->ctx[(size_t)r], 0);
+            if (rb < 0) {      // (cannot happen with a table evplp_deal_blocks made for this capacity; if it does, everybody returns to the default deal)
+                g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[(size_t)r]));
+                for (int q = 0; q < n; q++) evplp_set_blocks(g->ctx[(size_t)q], nullptr, 0);
+                g->owner.clear(); g->strip_floats = (size_t)((nb + n - 1) / n) * (size_t)g->strip_rows * g->ctx[0]->st.W * 3;
+                return rb;
+            }
+        }
+        g->owner.swap(owner);
+        g->strip_floats = most * (size_t)g->strip_rows * g->ctx[0]->st.W * 3;
+    }
     if (g->bands) {
         static const int kPasses[] = { EVPLP_PASS_PRIMARY, EVPLP_PASS_GATHER_VPL, EVPLP_PASS_GATHER_VSL, EVPLP_PASS_GATHER_LVC, EVPLP_PASS_SPLAT, EVPLP_PASS_PATH_TRACE };
         std::vector<double> cost((size_t)n, 0.0);
@@ -376,7 +454,8 @@ extern "C" int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows) {
             }
             total += cost[(size_t)r];
         }
-        if (total > 0.0) {
+        if (!(total > 0.0)) { g->set_error("evplp_group_rebalance: no pass was timed since the last rebalance (evplp_group_profile_passes is off, or no frame ran)"); return EVPLP_ERR_INVALID; }
+        {
             const int cap = g->ctx[0]->st.local_rows;
             int first[65]; first[0] = 0; first[n] = H;
             // cumulative cost at row y: bands in order, constant density within a band
@@ -398,16 +477,37 @@ extern "C" int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows) {
             }
             // the bands behind a capped one may be pushed beyond THEIR capacity: walk back from the end
             for (int r = n - 1; r >= 1; r--) first[r] = std::max(first[r], ((first[r + 1] + 15) / 16) * 16 - (cap / 16) * 16);
-            for (int r = 0; r <= n; r++) g->band_table.first[r] = first[r];
             for (int r = 0; r < n; r++) {
                 const int rows = (r + 1 < n ? first[r + 1] : ((H + 15) / 16) * 16) - first[r];
                 int rb = evplp_set_band(g->ctx[(size_t)r], first[r], rows);
-                if (rb < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[(size_t)r])); return rb; }
+                if (rb < 0) {      // the group's table follows the contexts: the ranks already moved go back to where the table says they are
+                    g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[(size_t)r]));
+                    for (int q = 0; q < r; q++) evplp_set_band(g->ctx[(size_t)q], g->band_table.first[q], (q + 1 < n ? g->band_table.first[q + 1] : ((H + 15) / 16) * 16) - g->band_table.first[q]);
+                    return rb;
+                }
             }
+            for (int r = 0; r <= n; r++) g->band_table.first[r] = first[r];
         }
     }
     if (band_first_rows) for (int r = 0; r <= n; r++) band_first_rows[r] = g->bands ? g->band_table.first[r] : 0;
     return EVPLP_OK;
+}
+
+extern "C" int evplp_group_calibrate(evplp_group *g, int32_t on) {
+    GRP_CHECK(g);
+    drain(g);
+    int rc = group_status(g); if (rc < 0) return rc;
+    for (int r = 0; r < g->n; r++) {
+        int rb = evplp_calibrate_blocks(g->ctx[(size_t)r], on);
+        if (rb < 0) { g->set_error("rank %d: %s", r, evplp_last_error(g->ctx[(size_t)r])); return rb; }
+    }
+    return EVPLP_OK;
+}
+extern "C" int evplp_group_block_owners(evplp_group *g, int32_t *owner_rank, int32_t capacity) {
+    GRP_CHECK(g);
+    if (g->bands) { g->set_error("evplp_group_block_owners: the group deals bands, not blocks"); return EVPLP_ERR_INVALID; }
+    for (int b = 0; b < g->image_blocks && owner_rank && b < capacity; b++) owner_rank[b] = g->owner.empty() ? b % g->n : g->owner[(size_t)b];
+    return g->image_blocks;
 }
 
 extern "C" int evplp_group_load_scene_json(evplp_group *g, const char *json_path) { GRP_CHECK(g); Cmd c; c.op = OP_LOAD_SCENE; c.p0 = json_path; return post_and_wait(g, c); }
@@ -423,12 +523,14 @@ extern "C" int evplp_group_gather(evplp_group *g, const evplp_frame_params *fp, 
     GRP_CHECK(g);
     if (kind < 0 || kind > 2) { g->set_error("evplp_group_gather: kind must be 0 (VPL), 1 (VSL) or 2 (light-path windows)"); return EVPLP_ERR_INVALID; }
     if (!fp) { g->set_error("evplp_group_gather: null frame params"); return EVPLP_ERR_INVALID; }
+    { int rc = check_frame_params(g, fp, "evplp_group_gather", false); if (rc < 0) return rc; }
     Cmd c; c.op = OP_GATHER; c.fp = *fp; c.i[0] = kind;
     return post_all(g, c);
 }
 extern "C" int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int32_t clear) {
     GRP_CHECK(g);
     if (!fp) { g->set_error("evplp_group_splat_photons: null frame params"); return EVPLP_ERR_INVALID; }
+    { int rc = check_frame_params(g, fp, "evplp_group_splat_photons", true); if (rc < 0) return rc; }
     Cmd c; c.op = OP_SPLAT; c.fp = *fp; c.i[0] = clear;
     return post_all(g, c);
 }
@@ -446,20 +548,26 @@ extern "C" int evplp_group_path_trace(evplp_group *g, const float camera_pos[3],
 
 // Composite every strip on its GPU and all-gather the strips: every GPU then holds the frame, strip by strip.  This is
 // the per-frame exchange of a run that presents every frame; nothing comes to the host.
-static Cmd present_cmd(float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle) {
-    Cmd c; c.op = OP_PRESENT; c.f[0] = vs; c.f[1] = ps; c.f[2] = ls; c.i[0] = mask_emitter; c.i[1] = gamma; c.i[2] = settle ? 1 : 0;
+static Cmd present_cmd(float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, bool settle, bool exchange) {
+    Cmd c; c.op = OP_PRESENT; c.f[0] = vs; c.f[1] = ps; c.f[2] = ls; c.i[0] = mask_emitter; c.i[1] = gamma; c.i[2] = settle ? 1 : 0; c.i[3] = exchange ? 1 : 0;
     return c;
 }
 extern "C" int evplp_group_present(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma) {
     GRP_CHECK(g);
-    return post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, false));       // (the per-iteration composite: no wait for the splat's verdict)
+    return post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, false, true));       // (the per-iteration composite: no wait for the splat's verdict)
+}
+// exchange = 0: every rank composites its strip where it is and nobody waits for anybody -- no host barrier, no collective: the iteration of
+// a loop whose frame is looked at only now and then (a sub-millisecond iteration pays for the exchange otherwise: DESIGN section 5)
+extern "C" int evplp_group_present_ex(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, int32_t exchange) {
+    GRP_CHECK(g);
+    return post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, false, exchange != 0));
 }
 
 // evplp_group_present (settled), then the frame in image order on rank 0's device and one copy to the caller.
 extern "C" int evplp_group_resolve(evplp_group *g, float vs, float ps, float ls, int32_t mask_emitter, int32_t gamma, float *out_rgb) {
     GRP_CHECK(g);
     if (!out_rgb) { g->set_error("evplp_group_resolve: null output"); return EVPLP_ERR_INVALID; }
-    int rc = post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, true));
+    int rc = post_all(g, present_cmd(vs, ps, ls, mask_emitter, gamma, true, true));
     if (rc < 0) return rc;
     Cmd c; c.op = OP_ASSEMBLE; c.out = out_rgb;      // (rank 0's stream: behind its side of the exchange)
     post(g->workers[0], c);

@@ -47,6 +47,25 @@ struct Grp {   // RAII for the C handle
 void check(evplp_group *g, int rc, const char *what) {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + evplp_group_last_error(g));
 }
+// What the `device` block says about the RUN (the rest of it configures the group, create_group):
+//   "deal": "cost" | "roundRobin" -- row blocks dealt by the cost a calibration frame clocks (evplp_group_calibrate / _rebalance), or block b to
+//           rank b % N.  Default: by cost when the run has more than one rank, a VPL / VSL gather, and at least four iterations (the
+//           calibration frame is one more); results do not depend on it.
+//   "exchangeEvery": k -- the strips are all-gathered (every GPU holds the frame) in every k-th iteration's composite; 0 = never inside the
+//           loop.  Default 1: what the reference's per-iteration runFinalProgram to the window amounts to (rtcomphoton.h:997-1004).  The
+//           frames that are WRITTEN (:1079-1102, 1124-1132) always exchange.  Results do not depend on it.
+struct RunOptions { int deal = -1; int exchange_every = 1; };       // deal: -1 default, 0 round robin, 1 by cost
+RunOptions run_options(const Json &json) {
+    RunOptions o;
+    if (!json.has("device")) return o;
+    const Json &d = json.at("device");
+    if (d.has("deal")) {
+        const std::string v = d.at("deal").as_string("device.deal");
+        if (v == "cost") o.deal = 1; else if (v == "roundRobin") o.deal = 0; else throw JsonError("device.deal: \"cost\" or \"roundRobin\"");
+    }
+    if (d.has("exchangeEvery")) { o.exchange_every = (int)d.at("exchangeEvery").as_int("device.exchangeEvery"); if (o.exchange_every < 0) throw JsonError("device.exchangeEvery: must be >= 0"); }
+    return o;
+}
 void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int device) {
     evplp_group_config gc; std::memset(&gc, 0, sizeof(gc));
     gc.n_ranks = 1; gc.strip_rows = 0;      // (0: the group's default, 16-row strips)
@@ -57,6 +76,7 @@ void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int devic
         if (d.has("virtual")) virt = d.at("virtual").as_bool("device.virtual");
         if (d.has("stripRows")) gc.strip_rows = (int)d.at("stripRows").as_int("device.stripRows");
         if (d.has("rccl")) gc.use_rccl = d.at("rccl").as_bool("device.rccl") ? 1 : 0;
+        if (d.has("stripCapacityPct")) gc.strip_capacity_pct = (int)d.at("stripCapacityPct").as_int("device.stripCapacityPct");
     }
     if (gc.n_ranks < 1 || gc.n_ranks > 64) throw JsonError("device.gpus: must be 1..64");
     std::vector<int32_t> devs((size_t)gc.n_ranks);
@@ -293,6 +313,7 @@ public:
         if (json.has("deterministic")) cfg.deterministic = json.at("deterministic").as_bool("deterministic") ? 1 : 0;   // build-only key
         cfg.overlap_light_tracing = 1;      // the loop below calls primary, then light tracing: they overlap
         Grp grp; create_group(grp, cfg, json, device);
+        run_opts = run_options(json);
         upload_scene_group(grp.g, scene);
         splat_footprint = setup_splat_footprint(grp.g, json, out_dir);                                          // :677
         float bsr = 0.f, total_area = 0.f, light_area = 0.f;
@@ -334,6 +355,19 @@ private:
         check(h, evplp_group_clear_accumulators(h), "clear");
         int num_iterations = 0;
         auto t0 = std::chrono::steady_clock::now();
+        // Row blocks dealt by cost (RunOptions above): one frame of the first iteration's light paths and gather with the self-clocking
+        // kernels, un-jittered, then the deal.  Nothing of it reaches the images: the rebalance clears the accumulators, the loop below traces
+        // the same light paths again, the jitter sequence and the progressive state have not moved.  Its time is part of the run's.
+        const bool can_deal = evplp_group_size(h) > 1 && do_vpl_splat && !lvc && do_deferred && do_light_tracing;
+        if (can_deal && (run_opts.deal == 1 || (run_opts.deal < 0 && num_max_iteration >= 4))) {
+            float j0[2] = { 0.f, 0.f };
+            evplp_frame_params fp = params(scene, rng_offset, j0);
+            check(h, evplp_group_calibrate(h, 1), "calibrate");
+            check(h, evplp_group_primary(h, j0, EVPLP_LIGHT_SKIP), "primary (calibration)");
+            check(h, evplp_group_trace_light_paths(h, rng_offset), "light tracing (calibration)");
+            check(h, evplp_group_gather(h, &fp, force_vsl ? 1 : 0), "gather (calibration)");
+            check(h, evplp_group_rebalance(h, nullptr), "rebalance");
+        }
         auto elapsed_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         float prev_timing = 0.f;
         std::vector<float> rgb((size_t)W * H * 3);
@@ -363,7 +397,8 @@ private:
             // of the reference's iteration -- and stays on the device
             if (do_finalize) {
                 const float param = frame_mode == 2 ? 1.0f : 1.0f / (float)(num_iterations + 1);
-                check(h, evplp_group_present(h, param, param, 1.0f, 1, 1), "finalize");       // (doGammaCorrection = true, :1003)
+                const bool exchange = run_opts.exchange_every > 0 && (num_iterations + 1) % run_opts.exchange_every == 0;
+                check(h, evplp_group_present_ex(h, param, param, 1.0f, 1, 1, exchange ? 1 : 0), "finalize");       // (doGammaCorrection = true, :1003)
             }
             num_iterations++;
             if (num_iterations % 20 == 0) {                                                   // :1008-1031
@@ -430,6 +465,7 @@ private:
     bool force_vsl = false; float vsl_radius = 0.f, vsl_inv_pi_radius2 = 0.f;
     bool lvc = false;
     uint32_t splat_footprint = EVPLP_FOOTPRINT_PROXY;
+    RunOptions run_opts;
     int bvh_builder = EVPLP_BVH_SAH;   // measured 9% faster frames than the Morton LBVH on the conference stand-in; "bvhBuilder": "lbvh" selects the LBVH
 };
 

@@ -84,7 +84,11 @@ struct GatherArgs {
     // a launch covers the rows [band_first, band_first + band_rows) of tile BLOCKS only (band_rows = 0: all of them): the entry cuts of a
     // large configuration are built and consumed band by band so that their scratch stays bounded (config #5: 137 GB for all at once).
     // cut_group_row_first: the first row of tile groups that has slots in `cuts`
-    int32_t band_first, band_rows, cut_group_row_first, pad2;
+    int32_t band_first, band_rows, cut_group_row_first;
+    int32_t item_deal;                // 1: a tile's items go to all XCDs (small launches: strips); 0: tiles are dealt to XCDs (kernels_gather.hip item_index)
+    // calibration launches only (evplp_calibrate_blocks; the kernels' COST variants): the 100 MHz clock ticks every item was resident, added to
+    // its local block's counter -- what evplp_group_rebalance deals the blocks by
+    unsigned long long *block_cost;
 };
 // Entry cuts.  A frustum around ALL segments between one VPL and the pixels of a group of 2 x 2 tiles (the box of their end points
 // + four planes through the VPL) descends the tree breadth-first, dropping every subtree it cannot reach, until the surviving cut
@@ -226,7 +230,7 @@ void launch_splat_tiles(const SplatArgs &a, bool split_tiles, hipStream_t s, hip
 void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, const float4 *light,
                     float vs, float ps, float ls, int mask_emitter, int gamma, float *out_rgb, hipStream_t s);
 struct BandTable { int32_t first[65]; };      // first[r] = first image row of rank r's band, first[n] = H
-void launch_assemble_strips(const StripDev &st, int nranks, const BandTable *bands, const float *gathered, float *frame, hipStream_t s);
+void launch_assemble_strips(const StripDev &st, int nranks, const BandTable *bands, const uint32_t *owner, int chunk_rows, const float *gathered, float *frame, hipStream_t s);
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s);
 
 } // namespace evplp

@@ -122,7 +122,7 @@ struct Item { int x, ly, gy, group; bool in_image, has_tile; uint32_t p; };   //
 #define EVPLP_XCD_TIMES 0
 #endif
 #ifndef EVPLP_XCD_ROTATE
-#define EVPLP_XCD_ROTATE 1
+#define EVPLP_XCD_ROTATE 2
 #endif
 struct ItemIx { int tx, ty, sg, tile_l, blk; };      // tile, group of splits within the launch, tile index in launch order, tile block
 template <bool RANGE = false>
@@ -132,16 +132,24 @@ EV_DEV ItemIx item_index(const GatherArgs &a, int b) {
     const bool grp = EVPLP_GROUP_ORDER == 1 && a.cuts != nullptr;
     const int gwl = grp ? a.cut_gw_log2 : 0, ghl = grp ? a.cut_gh_log2 : 0, gl = gwl + ghl;
     const int xcd = b & 7, j = b >> 3;
-    const int q = j & ((1 << gl) - 1), r = j >> gl;            // tile within its cut group (fastest), then the group of splits, then the unit
+    const int q = j & ((1 << gl) - 1);                         // tile within its cut group (fastest), then the group of splits, then the unit
+    // (round 6) a.item_deal: the groups of ONE tile are consecutive workgroups and so go to all eight XCDs -- no tile owns an L2, but every XCD
+    // gets an eighth of every tile.  With tiles dealt to XCDs (the default for whole images: a tile's items share its G-buffer lines and tree
+    // neighbourhood in one L2, 0.7 % faster at 1024 x 1024) an XCD's share is a sum over (tiles / 8) tile costs, and those vary tenfold: over
+    // the 2 048 tiles of an eight-way partition's strip the XCDs finish 10-22 % of the launch apart (tools/xcd_balance.py --strip-count 8).
+    const int r = a.item_deal ? b : j >> gl;
     const int unit_j = r / groups;
-    const int unit = unit_j * 8 + xcd;                         // cut group (or tile) in block order
+    const int unit = a.item_deal ? unit_j : unit_j * 8 + xcd;  // cut group (or tile) in block order
     const int shl = a.block_h_log2, bwl = 3 - gwl, bhl = shl - ghl, nbx = (tiles_x + 7) >> 3;   // block = 8 x (1 << shl) tiles
     const int l = unit & ((1 << (bwl + bhl)) - 1);
     ItemIx ix;
     ix.blk = a.band_first * nbx + (unit >> (bwl + bhl));       // (a launch may cover a band of block rows only)
     // (EVPLP_XCD_ROTATE: the column of a block a given XCD takes rotates with the row and the block -- with XCD = column every XCD owned
     // 8-pixel-wide vertical stripes of the image, and the stripes' costs differ systematically: tools/xcd_balance.py)
-    const int rot = EVPLP_XCD_ROTATE ? (l >> bwl) + ix.blk : 0;
+    // (round 6: ... with the block's ROW counted in tile rows.  "+ blk" alone repeats with the blocks of a row -- 16 at 1024 pixels, a multiple of
+    // 8 -- so that a row strip, whose blocks are one or two tile rows high, kept the stripes: EVPLP_XCD_ROTATE=1 is that formula.  Whole images
+    // -- blocks of 8 tile rows -- are dealt exactly as before.)
+    const int rot = EVPLP_XCD_ROTATE == 0 ? 0 : EVPLP_XCD_ROTATE == 1 ? (l >> bwl) + ix.blk : (l >> bwl) + (ix.blk % nbx) + ((ix.blk / nbx) << bhl);
     const int ux = ((ix.blk % nbx) << bwl) | ((l + rot) & ((1 << bwl) - 1)), uy = ((ix.blk / nbx) << bhl) | (l >> bwl);
     ix.tx = (ux << gwl) | (q & ((1 << gwl) - 1)); ix.ty = (uy << ghl) | (q >> gwl);
     ix.sg = r - unit_j * groups;
@@ -160,6 +168,9 @@ EV_DEV Item item_setup(const GatherArgs &a, int lane, int b) {
     t.x = ix.tx * 8 + (lane & 7); t.ly = ix.ty * 8 + (lane >> 3);
     const int cly = max(min(t.ly, st.local_rows - 1), 0);
     t.gy = st.global_row(cly);
+    // (a tile whose first row lies outside the image -- a local block that holds nothing under a dealt block table, the padding blocks of the
+    // round-robin deal, the rows behind a band -- has no pixel in it: rows ascend within a tile)
+    t.has_tile = t.has_tile && __builtin_amdgcn_readfirstlane(t.gy) < st.H;
     t.in_image = t.has_tile && t.x < st.W && t.ly < st.local_rows && t.gy < st.H;
     t.p = (uint32_t)cly * (uint32_t)st.W + (uint32_t)min(t.x, st.W - 1);
     return t;
@@ -224,11 +235,19 @@ __device__ unsigned long long g_gather_times[2 * 131072];
 extern "C" int evplp_debug_gather_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gather_times), sizeof(unsigned long long) * (size_t)n); }
 #endif
 // One item = (tile, group of splits_per_wave consecutive splits): lane = pixel.
-template <bool CUT>
+// COST (calibration launches, evplp_calibrate_blocks): the item adds the clock ticks it was resident to its local block's counter
+EV_DEV void item_cost_add(const GatherArgs &a, int ty, unsigned long long t0, int waves) {
+    const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+    // (kernels of different residency add up as launch time does: ticks x 8 / waves per SIMD)
+    if (threadIdx.x == 0) atomicAdd(&a.block_cost[(ty * 8) / a.st.strip_rows], dt * 8ull / (unsigned long long)waves);
+}
+template <bool CUT, bool COST = false>
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
 __attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
 #endif
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(GatherArgs a) {
+    unsigned long long t_cost = 0ull;
+    if constexpr (COST) t_cost = __builtin_amdgcn_s_memrealtime();
 #if EVPLP_GATHER_TIMES
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -401,6 +420,7 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vpl_kernel(Gath
     const bool in_image = (rays >> 31) != 0u;           // (parked in the counter's top bit at the start: one register fewer across the walks)
     rays &= 0xffffu;
     if (in_image) a.partial[(size_t)item_index(a, blk_out).sg * a.partial_stride + item_texel(a, lane_out, blk_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(rays | (shaded << 16)));
+    if constexpr (COST) item_cost_add(a, item_index(a, blk_out).ty, t_cost, EVPLP_GATHER_WAVES);
 }
 
 // out = (balanced-tree sum of the per-group partials) / numVplLightPaths + doAccumulate * out   (lighttracing.cu:378);
@@ -728,11 +748,13 @@ EV_DEV size_t vsl_mask_base(const GatherArgs &a, int tile_in_launch_order, int g
 }
 EV_DEV int launch_tile(const GatherArgs &a) { return item_index<true>(a, (int)blockIdx.x).tile_l; }      // the tile's index in launch order
 
-template <bool CUT>
+template <bool CUT, bool COST = false>
 #if EVPLP_WALK_ASM && !EVPLP_TRAVERSAL_STATS
 __attribute__((amdgpu_num_vgpr(52)))      // v[52:63] belong to the hand-written node visit (device_common.hpp)
 #endif
 __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel(GatherArgs a) {
+    unsigned long long t_cost = 0ull;
+    if constexpr (COST) t_cost = __builtin_amdgcn_s_memrealtime();
     __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
     const Item t = item_setup<true>(a, lane, (int)blockIdx.x);
@@ -814,9 +836,13 @@ __global__ __launch_bounds__(64, EVPLP_GATHER_WAVES) void gather_vsl_walk_kernel
     // 64 lanes x 4095 VSLs -- it does not fit the 16-bit field the VPL gather's per-pixel statistics word has for it)
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0 && rays != 0u) atomicAdd(&a.counters->shard_rays[blockIdx.x & (kCounterShards - 1)], (unsigned long long)rays);
+    if constexpr (COST) item_cost_add(a, item_index<true>(a, (int)blockIdx.x).ty, t_cost, EVPLP_GATHER_WAVES);
 }
 
+template <bool COST = false>
 __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(GatherArgs a) {
+    unsigned long long t_cost = 0ull;
+    if constexpr (COST) t_cost = __builtin_amdgcn_s_memrealtime();
     extern __shared__ float s_lvl[];                   // one [192] block per level of the k-split fold
     __shared__ unsigned long long s_lit[kVslChunk];
     const int lane = threadIdx.x;
@@ -942,6 +968,7 @@ __global__ __launch_bounds__(64, EVPLP_VSL_WAVES) void gather_vsl_shade_kernel(G
     asm volatile("" : "+v"(lane_out), "+s"(blk_out));   // (the store address is formed here, not carried through the estimators)
     const int group_out = a.group_first + item_index<true>(a, blk_out).sg;
     if (valid) a.partial[(size_t)group_out * a.partial_stride + item_texel<true>(a, lane_out, blk_out)] = make_float4(total.x, total.y, total.z, __uint_as_float(nlit << 16));
+    if constexpr (COST) item_cost_add(a, item_index<true>(a, blk_out).ty, t_cost, EVPLP_VSL_WAVES);
 }
 
 int gather_launch_tiles(const GatherArgs &a) {                    // tiles of a launch: whole blocks of 8 x (1 << block_h_log2)
@@ -961,14 +988,25 @@ static size_t fold_lds_bytes(const GatherArgs &a, int extra_floats) {
     int levels = 1; while ((1 << (levels - 1)) < a.splits_per_wave) levels++;       // log2 k + 1
     return (size_t)(levels * 192 + extra_floats) * sizeof(float);
 }
+// (a.block_cost set: the calibration variants of the same kernels -- same results, every item also clocks itself)
 void launch_gather_vpl_items(const GatherArgs &a, hipStream_t s) {
-    if (a.cuts) hipLaunchKernelGGL(gather_vpl_kernel<true>, gather_grid(a), dim3(64), fold_lds_bytes(a, kGatherPxFloats), s, a);
-    else hipLaunchKernelGGL(gather_vpl_kernel<false>, gather_grid(a), dim3(64), fold_lds_bytes(a, kGatherPxFloats), s, a);
+    const size_t lds = fold_lds_bytes(a, kGatherPxFloats);
+    if (a.block_cost) {
+        if (a.cuts) hipLaunchKernelGGL((gather_vpl_kernel<true, true>), gather_grid(a), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((gather_vpl_kernel<false, true>), gather_grid(a), dim3(64), lds, s, a);
+    } else if (a.cuts) hipLaunchKernelGGL((gather_vpl_kernel<true>), gather_grid(a), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((gather_vpl_kernel<false>), gather_grid(a), dim3(64), lds, s, a);
 }
 void launch_gather_vsl(const GatherArgs &a, hipStream_t s) {
-    if (a.cuts) hipLaunchKernelGGL(gather_vsl_walk_kernel<true>, gather_grid(a), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(gather_vsl_walk_kernel<false>, gather_grid(a), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(gather_vsl_shade_kernel, gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
+    if (a.block_cost) {
+        if (a.cuts) hipLaunchKernelGGL((gather_vsl_walk_kernel<true, true>), gather_grid(a), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((gather_vsl_walk_kernel<false, true>), gather_grid(a), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((gather_vsl_shade_kernel<true>), gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
+        return;
+    }
+    if (a.cuts) hipLaunchKernelGGL((gather_vsl_walk_kernel<true>), gather_grid(a), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((gather_vsl_walk_kernel<false>), gather_grid(a), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((gather_vsl_shade_kernel<false>), gather_grid(a), dim3(64), fold_lds_bytes(a, 0), s, a);
 }
 
 } // namespace evplp

@@ -118,9 +118,8 @@ EV_DEV bool box_within(float4 blo, float4 bhi, V3 c, float reach2) {
 EV_DEV int local_tile_row(const SplatArgs &a, int ty) {                  // -1: row strip of another GPU
     if (a.st.band_rows > 0) { const int l = ty * 8 - a.st.band_first; return (l >= 0 && l < a.st.band_rows) ? (l >> 3) : -1; }
     if (a.st.strip_count == 1) return ty;
-    const int tiles_per_block = a.st.strip_rows >> 3, blk = ty / tiles_per_block;
-    if (blk % a.st.strip_count != a.st.strip_rank) return -1;
-    return (blk / a.st.strip_count) * tiles_per_block + (ty - blk * tiles_per_block);
+    const int tiles_per_block = a.st.strip_rows >> 3, blk = ty / tiles_per_block, lb = a.st.local_block(blk);      // (ty is an image tile row: blk < image blocks)
+    return lb < 0 ? -1 : lb * tiles_per_block + (ty - blk * tiles_per_block);
 }
 
 // compact photon: [0] pos.xyz, cpn   [1] w12.xyz, d2   [2] wflux.xyz, alive   [3] brdf2.xyz (misMode 5 only)
@@ -858,23 +857,28 @@ void launch_resolve(const StripDev &st, const float4 *vpl, const float4 *pm, con
     size_t n = (size_t)st.W * st.local_rows;
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, vpl, pm, light, vs, ps, ls, mask_emitter, gamma, out_rgb);
 }
-// De-interleave of the all-gathered row strips (evplp_group_resolve): gathered = [n ranks][local_rows][W][3], rank r's local row l
+// De-interleave of the all-gathered row strips (evplp_group_resolve): gathered = [n ranks][chunk_rows][W][3] (the rows an exchange moves: <= local_rows), rank r's local row l
 // is image row StripDev{rank r}.global_row(l); frame = [H][W][3].  One thread per float of the frame.
 // bands: rank r owns the rows [bands.first[r], bands.first[r + 1]) (evplp_group with contiguous bands); null = interleaved strips
-__global__ __launch_bounds__(256) void assemble_strips_kernel(StripDev st, int nranks, BandTable bands, int use_bands, const float *gathered, float *frame) {
+// owner: the dealt blocks of the group (evplp_group_rebalance), owner[b] = rank << 16 | local block of image block b; null = round-robin
+__global__ __launch_bounds__(256) void assemble_strips_kernel(StripDev st, int nranks, BandTable bands, int use_bands, const uint32_t *owner, int chunk_rows, const float *gathered, float *frame) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t row_floats = (size_t)st.W * 3, n = row_floats * (size_t)st.H;
     if (i >= n) return;
     const int y = (int)(i / row_floats); const size_t x = i - (size_t)y * row_floats;
     int r, l;
     if (use_bands) { r = 0; while (r + 1 < nranks && y >= bands.first[r + 1]) r++; l = y - bands.first[r]; }
-    else { const int blk = y / st.strip_rows; r = blk % nranks; l = (blk / nranks) * st.strip_rows + (y - blk * st.strip_rows); }
-    frame[i] = gathered[((size_t)r * st.local_rows + l) * row_floats + x];
+    else {
+        const int blk = y / st.strip_rows; int lb;
+        if (owner) { const uint32_t o = owner[blk]; r = (int)(o >> 16); lb = (int)(o & 0xffffu); } else { r = blk % nranks; lb = blk / nranks; }
+        l = lb * st.strip_rows + (y - blk * st.strip_rows);
+    }
+    frame[i] = gathered[((size_t)r * chunk_rows + l) * row_floats + x];
 }
-void launch_assemble_strips(const StripDev &st, int nranks, const BandTable *bands, const float *gathered, float *frame, hipStream_t s) {
+void launch_assemble_strips(const StripDev &st, int nranks, const BandTable *bands, const uint32_t *owner, int chunk_rows, const float *gathered, float *frame, hipStream_t s) {
     const size_t n = (size_t)st.W * 3 * st.H;
     BandTable none; std::memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(assemble_strips_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, nranks, bands ? *bands : none, bands ? 1 : 0, gathered, frame);
+    hipLaunchKernelGGL(assemble_strips_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, nranks, bands ? *bands : none, bands ? 1 : 0, owner, chunk_rows, gathered, frame);
 }
 void launch_fill_zero(void *p, size_t bytes, hipStream_t s) { hipMemsetAsync(p, 0, bytes, s); }
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EVPLP_ABI_VERSION 3
+#define EVPLP_ABI_VERSION 4
 
 typedef enum evplp_status {
     EVPLP_OK = 0,
@@ -116,7 +116,9 @@ typedef struct evplp_config {
      * band may end at res_y).  band_capacity_rows >= band_rows sizes its buffers (0 = band_rows): evplp_set_band may later move the band
      * anywhere within that capacity.  evplp_group's "bands" partition deals such bands by measured cost (evplp_group_rebalance). */
     int32_t band_first_row, band_rows, band_capacity_rows;
-    int32_t reserved;
+    /* Row strips (strip_count > 1): rows of strip storage, a multiple of strip_rows; 0 = the equal share, ceil(blocks / strip_count) blocks.
+     * More than that leaves room for a deal by cost (evplp_set_blocks), which gives a rank of cheap blocks more of them. */
+    int32_t strip_capacity_rows;
 } evplp_config;
 
 /* rt/rtcommon.h:278-308 RtMaterial: three RGBA32F textures (a constant is a 1x1 texture,
@@ -287,6 +289,28 @@ int evplp_clear_accumulators(evplp_context *ctx);
  * accumulators are cleared and the G-buffer is stale: call between runs, not between the iterations of an accumulating run. */
 int evplp_set_band(evplp_context *ctx, int32_t first_row, int32_t rows);
 
+/* Row-strip contexts (strip_count > 1): which blocks of strip_rows image rows this context owns.  By default block b belongs to rank
+ * b % strip_count.  evplp_set_blocks replaces that by a table: local block l holds image block image_blocks[l], l < count <= the context's
+ * capacity (evplp_config.strip_capacity_rows / strip_rows); image_blocks = NULL restores the default.  Every kernel, statistic and buffer
+ * layout follows the table; per-pixel results do not depend on it.  As with evplp_set_band the accumulators are cleared and the G-buffer is
+ * stale afterwards: call between runs.  evplp_get_blocks returns the number of blocks owned (and up to `capacity` of them, in local order). */
+int evplp_set_blocks(evplp_context *ctx, const int32_t *image_blocks, int32_t count);
+int evplp_get_blocks(evplp_context *ctx, int32_t *image_blocks, int32_t capacity);
+/* What a deal by cost is made from.  While calibration is on, the VPL / VSL gathers run self-clocking variants of their kernels (same
+ * results; every wavefront adds the time it was resident to its block's counter; +1 % of the kernel); switching it on clears the counters.
+ * evplp_block_costs: the counters by IMAGE block (cost_per_image_block[b], b < ceil(res_y / strip_rows), 0 for blocks of other ranks), in
+ * 100 MHz clock ticks normalised to eight wavefronts per SIMD; returns the number of blocks this context owns. */
+int evplp_calibrate_blocks(evplp_context *ctx, int32_t on);
+int evplp_block_costs(evplp_context *ctx, uint64_t *cost_per_image_block, int32_t capacity);
+/* The deal itself (host only, no GPU): longest-processing-time-first -- blocks in order of falling cost, each to the rank with the least
+ * cost so far that still has room (at most capacity_blocks per rank) -- ties by block index, so that every process of a multi-process run
+ * computes the same table from the same costs.  owner_rank: nblocks ints.  Returns 0, or EVPLP_ERR_INVALID when nranks * capacity_blocks
+ * < nblocks. */
+int evplp_deal_blocks(const uint64_t *cost_per_image_block, int32_t nblocks, int32_t nranks, int32_t capacity_blocks, int32_t *owner_rank);
+/* The blocks a deal gives `rank`, in the order the rank stores (and launches) them: the most expensive first -- a strip's gather is a small
+ * launch and its longest items must not start late in it (cost = NULL: image order).  Returns their number; out_blocks may be NULL. */
+int evplp_rank_blocks(const uint64_t *cost_per_image_block, const int32_t *owner_rank, int32_t nblocks, int32_t rank, int32_t *out_blocks, int32_t capacity);
+
 /* ---- buffers / statistics ---- */
 int evplp_local_rows(const evplp_context *ctx);
 /* device_ptr and bytes may each be null.  Taking the device pointer of EVPLP_BUF_GBUF_POSITION (or binding memory to it)
@@ -343,10 +367,10 @@ typedef struct evplp_group evplp_group;
 typedef struct evplp_group_config {
     int32_t n_ranks;          /* contexts = row-strip ranks, 1..64 */
     const int32_t *devices;   /* HIP ordinal of every rank; NULL = 0, 1, .. n_ranks-1.  All distinct (RCCL) or all equal (virtual ranks) */
-    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 16 (keeps the gathers' 2 x 2-tile entry-cut groups whole), 8 from eight ranks on (finer interleave) */
+    int32_t strip_rows;       /* height of a row block, multiple of 8; 0 = 16 (keeps the gathers' 2 x 2-tile entry-cut groups whole) */
     int32_t use_rccl;         /* 1: a single-rank group goes through RCCL too (otherwise it needs no exchange at all) */
     int32_t partition;        /* evplp_group_partition: how the image is dealt to the ranks */
-    int32_t reserved;
+    int32_t strip_capacity_pct; /* EVPLP_PARTITION_STRIPS: a rank's strip storage in percent of the equal share; 0 = 150 (room for evplp_group_rebalance's deal by cost), 100 = none */
 } evplp_group_config;
 /* EVPLP_PARTITION_STRIPS: interleaved blocks of strip_rows rows, block b to rank b % n (balanced by interleaving, at the price of every rank
  * walking the whole tree for a fraction of the rays).  EVPLP_PARTITION_BANDS: one contiguous band of rows per rank (evplp_config band mode;
@@ -368,12 +392,21 @@ int evplp_group_splat_photons(evplp_group *g, const evplp_frame_params *fp, int3
 int evplp_group_set_splat_proxy(evplp_group *g, const float *vertices, int32_t nverts, const int32_t *indices, int32_t ntris);
 int evplp_group_path_trace(evplp_group *g, const float camera_pos[3], uint32_t rng_seed, uint32_t max_bounces, int32_t do_accumulate);
 int evplp_group_synchronize(evplp_group *g);
-/* EVPLP_PARTITION_BANDS: waits for the ranks, takes every rank's device time of the passes it ran since the last rebalance (HIP events of
+/* Calibration for evplp_group_rebalance under EVPLP_PARTITION_STRIPS: evplp_calibrate_blocks on every rank (waits for the workers). */
+int evplp_group_calibrate(evplp_group *g, int32_t on);
+/* The owner of every image block (nblocks = ceil(res_y / strip_rows) ints, rank numbers); returns nblocks. */
+int evplp_group_block_owners(evplp_group *g, int32_t *owner_rank, int32_t capacity);
+/* EVPLP_PARTITION_STRIPS: waits for the ranks, collects the per-block costs their gathers clocked since evplp_group_calibrate(g, 1), deals
+ * the blocks by cost (evplp_deal_blocks, capacity = strip_capacity_pct of the equal share), gives every rank its table (evplp_set_blocks)
+ * and switches the calibration off.  The all-gather of the strips then moves max-blocks-per-rank x strip_rows rows per rank.  Returns
+ * EVPLP_ERR_INVALID when no cost was clocked (no calibration, or no gather ran).  As below, accumulators are cleared: calibrate on a frame
+ * in front of an accumulating run (the technique loop does when "device": {"deal": "cost"}).
+ * EVPLP_PARTITION_BANDS: waits for the ranks, takes every rank's device time of the passes it ran since the last rebalance (HIP events of
  * primary rays, gathers, photon splat, path tracer), treats it as spread evenly over the rank's rows, and moves the band boundaries (multiples
  * of 16 rows, within the bands' capacity of twice the equal share) to where every rank would have had the same cost.  The accumulators are
  * cleared and the G-buffers are stale afterwards: call it after one or two calibration frames, before an accumulating run (the technique
- * loop does).  band_first_rows: optional, n_ranks + 1 ints, the boundaries it chose.  Returns EVPLP_OK (also for a strips partition or a
- * single rank: nothing to do). */
+ * loop does).  band_first_rows: optional, n_ranks + 1 ints, the boundaries it chose (zeros for strips).  A single rank: nothing to do,
+ * EVPLP_OK.  Bands without a timed pass since the last rebalance (evplp_profile_passes off): EVPLP_ERR_INVALID, nothing changes. */
 int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows);
 /* Host time of rank `rank`'s worker so far, in ms: out[0] inside its rank's pass calls (enqueueing; waits for a splat's verdict included),
  * out[1] inside exchanges (host barrier + collective / copies), out[2] commands run.  Waits until that worker is idle. */
@@ -386,6 +419,10 @@ int evplp_group_profile_passes(evplp_group *g, int32_t on);
  * (no host-side assembly) + one copy of the W x H x 3 frame to the caller. */
 /* (like evplp_present it does not wait for a pending splat's verdict when the contexts overlap light tracing; evplp_group_resolve does) */
 int evplp_group_present(evplp_group *g, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma);
+/* exchange = 0: the composite alone, every rank for itself -- no host barrier, no collective (the reference needs the assembled frame only when
+ * it is shown or written: rtcomphoton.h:997-1004, 1079-1102, 1124-1132); exchange != 0 = evplp_group_present.  The technique loop:
+ * "device": {"exchangeEvery": k}. */
+int evplp_group_present_ex(evplp_group *g, float vpl_scale, float photon_scale, float light_scale, int32_t mask_emitter, int32_t gamma, int32_t exchange);
 int evplp_group_resolve(evplp_group *g, float vpl_scale, float photon_scale, float light_scale,
                         int32_t mask_emitter, int32_t gamma, float *out_rgb);
 
@@ -441,8 +478,11 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
  * scene JSON, load OBJ/MTL, run the `photonfam` technique, write the three images + stat file.
  * json_overrides: optional JSON object text merged over the technique block (may be NULL).
  * Build-only keys of a technique block: "bvhBuilder": "sah" | "sbvh" | "lbvh" | "gpu" (evplp_bvh_builder); "deterministic": bool (photon bins accumulated in record
- * order); "device": {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool} -- run on an evplp_group of N row-strip ranks
- * (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a single rank goes through RCCL too). */
+ * order); "device": {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool, "deal": "cost" | "roundRobin", "exchangeEvery": k,
+ * "stripCapacityPct": p} -- run on an evplp_group of N row-strip ranks (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a
+ * single rank goes through RCCL too; "deal": row blocks dealt by the cost a calibration frame clocks -- the default from two ranks and four
+ * iterations on -- or block b to rank b % N; "exchangeEvery": the strips are all-gathered in every k-th iteration's composite, 0 = only for
+ * the frames that are written, default 1). */
 int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap);
 
 #ifdef __cplusplus

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(evplp):
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in include/evplp.h but not exported: {missing}"
     assert declared == set(evplp._SIGNATURES), declared ^ set(evplp._SIGNATURES)
-    assert lib.evplp_abi_version() == 3 == evplp.ABI_VERSION
+    assert lib.evplp_abi_version() == 4 == evplp.ABI_VERSION
 
 
 def test_struct_layouts_match_the_header(evplp, tmp_path):
@@ -204,3 +204,60 @@ def test_lfs_pointer_meshes_are_reported_as_such(evplp):
         pytest.skip("reference scenes not present here")
     rc, msg = _render(evplp, f)
     assert rc == evplp.ERR_IO and "Git-LFS pointer" in msg
+
+
+def test_deal_blocks_balances_and_is_deterministic(evplp):
+    """evplp_deal_blocks (host only): every block gets exactly one owner, nobody exceeds the capacity, the fullest rank is never fuller than under
+    the round-robin deal, close to the mean when the blocks allow it, and the same costs always give the same table (every process of a
+    multi-process run computes it for itself)."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    for n, nb, capf in [(2, 8, 1.5), (4, 64, 1.5), (8, 64, 1.5), (8, 128, 1.5), (8, 64, 1.0), (3, 7, 2.0), (64, 64, 1.0)]:
+        # a costly belt in the middle of the image (the furnished room's chairs and table), a cheap floor and ceiling, noise
+        y = (np.arange(nb) + 0.5) / nb
+        cost = (1000 * (1.0 + 8.0 * np.exp(-((y - 0.48) / 0.06) ** 2)) * rng.uniform(0.8, 1.2, nb)).astype(np.uint64)
+        share = -(-nb // n); cap = min(nb, int(np.ceil(share * capf)))
+        owner = evplp.deal_blocks(cost, n, cap)
+        assert owner.shape == (nb,) and owner.min() >= 0 and owner.max() < n
+        counts = np.bincount(owner, minlength=n)
+        assert counts.max() <= cap and counts.sum() == nb
+        loads = np.array([cost[owner == r].sum() for r in range(n)], dtype=np.float64)
+        rr = np.array([cost[np.arange(nb) % n == r].sum() for r in range(n)], dtype=np.float64)
+        assert loads.max() <= rr.max()
+        if nb >= 8 * n and capf > 1.0:
+            assert loads.mean() / loads.max() > 0.97, (n, nb, loads.tolist())
+        assert evplp.deal_blocks(cost, n, cap).tolist() == owner.tolist()
+    # all costs equal: still a valid deal within the capacity
+    owner = evplp.deal_blocks(np.full(10, 5, np.uint64), 4, 3)
+    assert np.bincount(owner, minlength=4).max() <= 3
+    with pytest.raises(evplp.EvplpError):
+        evplp.deal_blocks(np.ones(9, np.uint64), 2, 4)                 # 9 blocks do not fit 2 x 4
+
+
+def test_block_tables_reassemble(evplp):
+    """strips.rows_of_blocks / assemble_blocks (what bench.py's rank processes use after a deal by cost) mirror StripDev::global_row with a table."""
+    import numpy as np
+    from evplp_amd import strips
+    H, W, SR = 100, 5, 16                                              # 7 blocks, the last one short
+    owner = np.array([2, 0, 0, 1, 2, 0, 1])
+    frame = np.arange(H * W * 3, dtype=np.float32).reshape(H, W, 3)
+    chunk = 3 * SR
+    gathered = np.full((3, chunk, W, 3), -1.0, np.float32)
+    for r in range(3):
+        blocks = strips.blocks_of_rank(owner, r)
+        rows = strips.rows_of_blocks(H, blocks, SR, chunk)
+        assert (rows < H).sum() == sum(min(SR, H - b * SR) for b in blocks)
+        ok = rows < H
+        gathered[r][ok] = frame[rows[ok]]
+    assert np.array_equal(strips.assemble_blocks(gathered, H, owner, SR), frame)
+    # a rank's storage order: most expensive first, ties by index -- the C function and its Python mirror agree
+    cost = np.array([5, 9, 9, 1, 7, 2, 2], np.uint64)
+    for r in range(3):
+        assert strips.blocks_of_rank(owner, r, cost).tolist() == evplp.rank_blocks(cost, owner, r).tolist()
+        assert strips.blocks_of_rank(owner, r).tolist() == evplp.rank_blocks(None, owner, r).tolist()
+    assert strips.blocks_of_rank(owner, 0, cost).tolist() == [1, 2, 5]
+    # the round-robin deal through the same functions equals strips.global_rows
+    for r in range(3):
+        rr = strips.rows_of_blocks(H, np.arange(r, 7, 3), SR, strips.local_rows(H, 3, SR))
+        g = strips.global_rows(H, r, 3, SR)
+        assert np.array_equal(rr[rr < H], g[g < H])

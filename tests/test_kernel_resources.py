@@ -30,7 +30,9 @@ def kernel_table(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("src, zero_scratch, budgets", [
-    ("kernels_gather.hip", ["gather_vpl_kernelILb1", "gather_vpl_kernelILb0", "gather_vsl_walk_kernelILb1", "gather_vsl_walk_kernelILb0", "gather_vsl_shade_kernel", "gather_reduce_kernel"],
+    # (second template argument Lb0: the product kernels; Lb1 = the self-clocking calibration variants, evplp_calibrate_blocks, run for one frame
+    # before a deal by cost -- held to their register budgets, not to zero scratch: the VPL one parks its start clock in 8 bytes of it)
+    ("kernels_gather.hip", ["gather_vpl_kernelILb1ELb0", "gather_vpl_kernelILb0ELb0", "gather_vsl_walk_kernelILb1ELb0", "gather_vsl_walk_kernelILb0ELb0", "gather_vsl_shade_kernelILb0", "gather_reduce_kernel"],
      {"gather_vpl_kernelILb1": 64, "gather_vpl_kernelILb0": 64, "gather_vsl_walk_kernelILb1": 64, "gather_vsl_walk_kernelILb0": 64, "gather_vsl_shade_kernel": 128}),
     ("kernels_cut.hip", ["gather_cut_kernel", "primary_cut_kernel"], {"gather_cut_kernel": 64}),
     # (the proxy-footprint variants of the tile kernel, ILb1, are held to seven / six waves per SIMD below)

@@ -23,7 +23,7 @@ def _frame_params(oa, room):
                 num_vpl_light_paths=NPATHS, photons_per_path=P, rng_seed=4, jitter=(0.002, 0.001))
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, deal="roundRobin"):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,6 +45,26 @@ def _worker(rank, world, port, out_path):
     # 2. this rank's strips (rows it owns), compact local buffers
     rows = strips.global_rows(H, rank, world, STRIP)
     lr = strips.local_rows(H, world, STRIP)
+    owner = None
+    if deal == "cost":
+        # the deal by cost as bench.py's rank processes make it: every rank has clocked ITS blocks (here: a stand-in cost, the lit pixels of
+        # the block's rows), the per-block costs are summed over the ranks, and every process computes the same table from them with the
+        # library's own evplp_deal_blocks (host only); capacity = 150 % of the equal share
+        import evplp_amd
+        nblocks = (H + STRIP - 1) // STRIP
+        g0 = osc.primary(W, H, kw["jitter"])
+        mine = np.zeros(nblocks, np.int64)
+        for r in rows[rows < H]:
+            mine[int(r) // STRIP] += 1 + 37 * int((g0[0][int(r), :, 3] != 0).sum()) * (1 + (int(r) // STRIP) % 3)
+        cost_t = torch.from_numpy(mine)
+        dist.all_reduce(cost_t)
+        cap = min(nblocks, ((nblocks + world - 1) // world * 150 + 99) // 100)
+        block_cost = cost_t.numpy().astype(np.uint64)
+        owner = evplp_amd.deal_blocks(block_cost, world, cap)
+        my_blocks = strips.blocks_of_rank(owner, rank, block_cost)            # (most expensive first: the order a rank stores and launches them)
+        assert my_blocks.tolist() == evplp_amd.rank_blocks(block_cost, owner, rank).tolist()
+        lr = int(max((owner == q).sum() for q in range(world))) * STRIP          # equal chunks: the fullest rank's rows
+        rows = strips.rows_of_blocks(H, my_blocks, STRIP, lr)
     g = osc.primary(W, H, kw["jitter"])            # replicated G-buffer (cheap here); only own rows are used below
     vpl_full = np.zeros((H, W, 4), np.float32); pm_full = np.zeros((H, W, 4), np.float32)
     for r in rows[rows < H]:
@@ -56,21 +76,24 @@ def _worker(rank, world, port, out_path):
     # 3. framebuffer all-gather (equal, padded chunks) + de-interleave
     gathered = torch.zeros(world * local.size, dtype=torch.float32)        # flat, like bench.py
     dist.all_gather_into_tensor(gathered, torch.from_numpy(local).reshape(-1))
-    frame = strips.assemble(gathered.numpy().reshape((world,) + local.shape), H, world, STRIP)
+    if owner is None:
+        frame = strips.assemble(gathered.numpy().reshape((world,) + local.shape), H, world, STRIP)
+    else:
+        frame = strips.assemble_blocks(gathered.numpy().reshape((world,) + local.shape), H, owner, STRIP, block_cost)
     if rank == 0:
         np.save(out_path, frame)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_two_rank_strips_equal_single_process(world, tmp_path):
+@pytest.mark.parametrize("world, deal", [(2, "roundRobin"), (2, "cost")])
+def test_two_rank_strips_equal_single_process(world, deal, tmp_path):
     sys.path.insert(0, HERE)
     import oracle_api as oa
     import scenes
     out = str(tmp_path / "frame.npy")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if deal == "cost" else 0)
+    mp.spawn(_worker, args=(world, port, out, deal), nprocs=world, join=True)
     frame = np.load(out)
     # single-process reference of the same frame
     room = scenes.box_room(seed=5, n_boxes=3, tess=1, aspect=W / H)

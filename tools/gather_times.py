@@ -7,8 +7,10 @@ os.environ["EVPLP_LIB"] = os.path.join(ROOT, "evplp_amd", "lib", "libevplp_hip_g
 sys.path.insert(0, ROOT)
 import evplp_amd as ev
 style = sys.argv[1] if len(sys.argv) > 1 else "hard"
+# optional: strip_count strip_rank strip_rows (one rank of an n-way partition, alone on the GPU)
+SC, SRK, SRW = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1, 0, 16)
 jp = ev.synth_scene("/tmp/evplp_gt_" + style, "conf", 331000, 1234, 1024, 1024, style=style)
-with ev.Context(1024, 1024, 1024, 1024, 4) as c:
+with ev.Context(1024, 1024, 1024, 1024, 4, strip_count=SC, strip_rank=SRK, strip_rows=SRW) as c:
     c.load_scene_json(jp)
     cam = c.camera()
     fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=1024, num_vpl_light_paths=1024, photons_per_path=4, do_accumulate=0)
@@ -22,7 +24,7 @@ t = np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).astype(np.float64) / 100.0
 t = t[t[:, 1] > 0]
 t -= t[:, 0].min()
 life = t[:, 1] - t[:, 0]; end = t[:, 1].max()
-print(f"{style}: gather {st['dominant_kernel_ms']:.2f} ms by events; sampled items {len(t)} (every 16th); first start -> last end {end / 1e3:.2f} ms")
+print(f"{style} strips {SC}/{SRK}/{SRW}: gather {st['dominant_kernel_ms']:.2f} ms by events; sampled items {len(t)} (every 16th); first start -> last end {end / 1e3:.2f} ms")
 print("item lifetime us: mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f" % (life.mean(), np.median(life), np.percentile(life, 90), np.percentile(life, 99), life.max()))
 for q in range(20):
     mid = (q + 0.5) * end / 20

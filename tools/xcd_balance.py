@@ -15,9 +15,12 @@ ap.add_argument("--scene", default="hard")
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--paths", type=int, default=1024)
 ap.add_argument("--vsl", action="store_true", help="the VSL gather (estimator kernel: first row, walk kernel: second row)")
+ap.add_argument("--strip-count", type=int, default=1)
+ap.add_argument("--strip-rank", type=int, default=0)
+ap.add_argument("--strip-rows", type=int, default=16)
 a = ap.parse_args()
 jp = ev.synth_scene("/tmp/evplp_xcd_%s" % a.scene, "conf", 331000, 1234, a.res, a.res, style=a.scene)
-c = ev.Context(a.res, a.res, a.paths, a.paths, 4)
+c = ev.Context(a.res, a.res, a.paths, a.paths, 4, strip_rank=a.strip_rank, strip_count=a.strip_count, strip_rows=a.strip_rows)
 c.load_scene_json(jp)
 cam = c.camera()
 import math
