@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--deal", default="cost", choices=["cost", "roundRobin"],
                     help="N > 1: row blocks dealt by the cost a calibration frame clocks (evplp_group_rebalance / evplp_deal_blocks; the default where the "
                          "workload has a gather) or block b to rank b %% N")
+    ap.add_argument("--split-light-paths", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: every rank traces 1/N of the light paths + in-place all-gather of the records (on), all of them (off), or what evplp_group_split_model expects to be faster (auto)")
     ap.add_argument("--exchange-every", type=int, default=1, help="N > 1: the composited strips are all-gathered every k-th frame (0 = never inside the timed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (configs #3-#5, other scene, 16384-slot variant, GPU path tracer, render_json)")
@@ -299,12 +301,13 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     nblocks = (H + SR - 1) // SR
     cap_blocks = min(nblocks, (-(-nblocks // max(a.gpus, 1)) * 150 + 99) // 100)
     deal_by_cost = a.deal == "cost" and a.gpus > 1 and wl in ("ir", "evplp", "vsl")
+    SPLIT = {"auto": 0, "on": 1, "off": -1}[a.split_light_paths]
     owner = [None]                          # the dealt table (owner rank of every image block), once it exists
     block_cost = [None]                     # ... and the clocked costs it was dealt from (a rank stores its blocks most expensive first)
     if env.group_front_end:
         # one process, the native multi-GPU entry: a.gpus ranks on distinct devices (RCCL) or, when the box has fewer, all on device 0
         devices = list(range(a.gpus)) if env.ndev >= a.gpus else [0] * a.gpus
-        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=SR, bvh_builder=builder, overlap_light_tracing=True)
+        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=SR, bvh_builder=builder, overlap_light_tracing=True, split_light_paths=SPLIT)
         group.load_scene_json(json_path)
         ranks = [group.rank(r) for r in range(a.gpus)]
         ctx = ranks[0]
@@ -332,9 +335,9 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
         ctx.bind_buffer(ev.BUF_PHOTON_ACCUM, pstrip.data_ptr(), pstrip.numel() * 4)
         full = torch.zeros(world * strip.numel(), dtype=torch.float32, device=dev) if use_dist else strip
         pfull = torch.zeros(world * pstrip.numel(), dtype=torch.float32, device=dev) if (use_dist and wl != "ir") else pstrip
-        # a light-tracing launch is latency-bound (0.26 ms for 1024 paths, 0.25 ms for 128): small path counts are traced
-        # redundantly by every rank (identical records, no exchange); large ones are split and all-gathered
-        split_paths = use_dist and n_light % world == 0 and (n_light >= 16384 or env.force_dist)
+        # a light-tracing launch is latency-bound (0.26 ms for 1024 paths, 0.25 ms for 128): the paths are traced redundantly by every rank
+        # (identical records, no exchange) unless the library's cost model expects a share + the exchange to be faster (--split-light-paths)
+        split_paths = use_dist and n_light % world == 0 and (SPLIT > 0 or (SPLIT == 0 and ev.split_model(n_light, P, world)[0]) or env.force_dist)
         per_rank = n_light // world if split_paths else n_light
         chunk = records.numel() // world
         # in place, as evplp_group does it: rank r traced its paths into slice r of its own record buffer

@@ -78,7 +78,7 @@ FOOTPRINTS = {"ideal": FOOTPRINT_IDEAL, "proxy": FOOTPRINT_PROXY}
 
 class GroupConfig(C.Structure):
     _fields_ = [("n_ranks", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("strip_rows", C.c_int32), ("use_rccl", C.c_int32),
-                ("partition", C.c_int32), ("strip_capacity_pct", C.c_int32)]
+                ("partition", C.c_int32), ("strip_capacity_pct", C.c_int32), ("split_light_paths", C.c_int32), ("reserved", C.c_int32)]
 
 
 PARTITION_STRIPS, PARTITION_BANDS = 0, 1
@@ -158,6 +158,7 @@ _SIGNATURES = {
     "evplp_group_host_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double * 3)]),
     "evplp_group_rebalance": (C.c_int, [_P, _P]),
     "evplp_group_calibrate": (C.c_int, [_P, C.c_int32]),
+    "evplp_group_split_model": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_double * 2)]),
     "evplp_group_block_owners": (C.c_int, [_P, _P, C.c_int32]),
     "evplp_group_resolve": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P]),
     "evplp_group_present": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
@@ -515,6 +516,13 @@ def deal_blocks(costs, n_ranks: int, capacity_blocks: int) -> np.ndarray:
     return owner
 
 
+def split_model(num_light_paths: int, photons_per_path: int, n_ranks: int):
+    """evplp_group_split_model: (split expected to be faster?, ms with every rank tracing all paths, ms with a share + the record exchange)"""
+    out = (C.c_double * 2)()
+    rc = lib().evplp_group_split_model(num_light_paths, photons_per_path, n_ranks, C.byref(out))
+    return bool(rc == 1), out[0], out[1]
+
+
 def rank_blocks(costs, owner, rank: int) -> np.ndarray:
     """evplp_rank_blocks: the blocks a deal gives `rank`, in the order it stores and launches them (most expensive first; costs=None: image order)"""
     o = np.ascontiguousarray(owner, dtype=np.int32)
@@ -530,7 +538,7 @@ class Group:
     """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
 
     def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=0,
-                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips", strip_capacity_pct=0):
+                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips", strip_capacity_pct=0, split_light_paths=0):
         """strip_rows = 0: the library's choice (16 rows)"""
         self._lib = lib()
         cfg = Config()
@@ -538,7 +546,7 @@ class Group:
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths; cfg.photons_per_path = photons_per_path
         cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic); cfg.overlap_light_tracing = int(overlap_light_tracing)
         gc = GroupConfig(); gc.n_ranks = n_ranks; gc.strip_rows = strip_rows; gc.use_rccl = int(use_rccl)
-        gc.partition = PARTITION_BANDS if partition == "bands" else PARTITION_STRIPS; gc.strip_capacity_pct = int(strip_capacity_pct)
+        gc.partition = PARTITION_BANDS if partition == "bands" else PARTITION_STRIPS; gc.strip_capacity_pct = int(strip_capacity_pct); gc.split_light_paths = int(split_light_paths)
         self.partition = partition if n_ranks > 1 else "strips"
         self._devs = (C.c_int32 * n_ranks)(*devices) if devices is not None else None
         gc.devices = C.cast(self._devs, C.POINTER(C.c_int32)) if self._devs is not None else None

@@ -380,7 +380,10 @@ extern "C" int evplp_group_create(const evplp_config *cfg, const evplp_group_con
     }
     // a light-tracing launch is latency-bound (0.26 ms for 1024 paths, 0.25 ms for 128): small path counts are traced redundantly by
     // every rank (identical records, no exchange); large ones are split by path range and shared by one all-gather
-    g->split_paths = g->n > 1 && cfg->num_light_paths % (uint32_t)g->n == 0 && cfg->num_light_paths >= 16384;
+    // (round 6: until round 5 the rule was "sets of >= 16 384 paths are split".  Config #4 at four ranks: 75 000 paths take 0.24 ms where 300 000
+    // take 0.46, and the exchange moves 28.8 MB over every link -- more than the 0.22 ms the split saves at any plausible xGMI rate.)
+    g->split_paths = g->n > 1 && cfg->num_light_paths % (uint32_t)g->n == 0 &&
+                     (gc->split_light_paths > 0 || (gc->split_light_paths == 0 && evplp_group_split_model(cfg->num_light_paths, cfg->photons_per_path, g->n, nullptr) == 1));
     g->per_rank_paths = g->split_paths ? cfg->num_light_paths / (uint32_t)g->n : cfg->num_light_paths;
     g->barrier.n = g->n;
     for (int r = 0; r < g->n; r++) { Worker *w = new Worker(); w->g = g; w->rank = r; g->workers.push_back(w); }
@@ -493,6 +496,15 @@ extern "C" int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows) {
     return EVPLP_OK;
 }
 
+extern "C" int evplp_group_split_model(uint32_t num_light_paths, uint32_t photons_per_path, int32_t n_ranks, double out_ms[2]) {
+    if (n_ranks < 1) return EVPLP_ERR_INVALID;
+    auto trace_ms = [](double paths) { return 0.20 + 1.2e-6 * std::max(0.0, paths - 131072.0); };
+    const double all = trace_ms((double)num_light_paths);
+    const double chunk_bytes = (double)num_light_paths * photons_per_path * sizeof(evplp_record) / n_ranks;
+    const double shared = trace_ms((double)num_light_paths / n_ranks) + (n_ranks > 1 ? 0.02 + chunk_bytes / 48.0e9 * 1.0e3 : 0.0);
+    if (out_ms) { out_ms[0] = all; out_ms[1] = shared; }
+    return n_ranks > 1 && shared < all ? 1 : 0;
+}
 extern "C" int evplp_group_calibrate(evplp_group *g, int32_t on) {
     GRP_CHECK(g);
     drain(g);

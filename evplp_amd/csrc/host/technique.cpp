@@ -77,6 +77,7 @@ void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int devic
         if (d.has("stripRows")) gc.strip_rows = (int)d.at("stripRows").as_int("device.stripRows");
         if (d.has("rccl")) gc.use_rccl = d.at("rccl").as_bool("device.rccl") ? 1 : 0;
         if (d.has("stripCapacityPct")) gc.strip_capacity_pct = (int)d.at("stripCapacityPct").as_int("device.stripCapacityPct");
+        if (d.has("splitLightPaths")) gc.split_light_paths = d.at("splitLightPaths").as_bool("device.splitLightPaths") ? 1 : -1;   // (absent: the library's cost model)
     }
     if (gc.n_ranks < 1 || gc.n_ranks > 64) throw JsonError("device.gpus: must be 1..64");
     std::vector<int32_t> devs((size_t)gc.n_ranks);

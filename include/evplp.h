@@ -354,8 +354,8 @@ int evplp_selftest(evplp_context *ctx, int32_t which, uint64_t *out, int32_t cap
 
 /* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread POSTS to
  * n_ranks contexts -- each driven by a worker thread of its own, bound to its GPU -- that own interleaved row strips of the image (see the top of this file); scene and
- * BVH are replicated; light-path sets of >= 16 384 paths are traced 1/n per rank and shared by an in-place all-gather of the
- * record buffers, smaller ones are traced by every rank; every rank gathers / splats its own rows; evplp_group_resolve
+ * BVH are replicated; light paths are traced by every rank in full (same seed, identical records, no exchange) or 1/n per rank and shared by
+ * an in-place all-gather of the record buffers (evplp_group_config.split_light_paths); every rank gathers / splats its own rows; evplp_group_resolve
  * composites the strips where they are and all-gathers them, so that every GPU holds the frame.  The collectives are RCCL
  * (ncclAllGather over xGMI; librccl is opened at run time).  Ranks that all share ONE device ("virtual ranks": tests, one-GPU
  * boxes) exchange by device copies instead.  Per-pixel results do not depend on the partition.  A pass call posts its arguments
@@ -371,7 +371,18 @@ typedef struct evplp_group_config {
     int32_t use_rccl;         /* 1: a single-rank group goes through RCCL too (otherwise it needs no exchange at all) */
     int32_t partition;        /* evplp_group_partition: how the image is dealt to the ranks */
     int32_t strip_capacity_pct; /* EVPLP_PARTITION_STRIPS: a rank's strip storage in percent of the equal share; 0 = 150 (room for evplp_group_rebalance's deal by cost), 100 = none */
+    /* Light tracing on n ranks: 1 = every rank traces 1/n of the paths and the record buffers are all-gathered in place (num_light_paths must be
+     * a multiple of n_ranks, else as -1); -1 = every rank traces ALL paths with the same seed (identical records, no exchange); 0 = whichever
+     * the library's cost model expects to be faster (evplp_group_split_model: a light-tracing launch has a latency floor, so a share of the
+     * paths is not n times faster to trace, while the exchange moves num_light_paths x photons_per_path x 96 / n bytes over every xGMI link). */
+    int32_t split_light_paths;
+    int32_t reserved;
 } evplp_group_config;
+/* The model behind split_light_paths = 0 (host only): light tracing of N paths takes 0.20 ms + 1.2 us per 1 000 paths beyond 131 072 (two
+ * wavefronts per SIMD; tools/lt_scale.py on one MI355X); an in-place all-gather of chunks of B bytes takes 0.02 ms + B / 48 GB/s (every chunk
+ * crosses one xGMI link; 48 GB/s is an ASSUMED effective rate -- no second device was ever available to this build).  Returns 1 when
+ * splitting is expected to save time, 0 when not; out_ms (optional): [0] all paths on every rank, [1] a share + the exchange. */
+int evplp_group_split_model(uint32_t num_light_paths, uint32_t photons_per_path, int32_t n_ranks, double out_ms[2]);
 /* EVPLP_PARTITION_STRIPS: interleaved blocks of strip_rows rows, block b to rank b % n (balanced by interleaving, at the price of every rank
  * walking the whole tree for a fraction of the rays).  EVPLP_PARTITION_BANDS: one contiguous band of rows per rank (evplp_config band mode;
  * strip_rows is ignored) -- equal heights at first, then dealt by measured cost: evplp_group_rebalance moves the band boundaries so that

@@ -34,7 +34,7 @@ def test_virtual_ranks_equal_the_single_context(evplp, tmp_path, NL):
     images = {}
     for n in (1, 2, 4):
         # (the 4-rank group also runs light tracing on its second stream, beside the G-buffer pass)
-        with evplp.Group(W, H, NL, NV, P, n, devices=[0] * n, deterministic=True, overlap_light_tracing=(n == 4)) as g:
+        with evplp.Group(W, H, NL, NV, P, n, devices=[0] * n, deterministic=True, overlap_light_tracing=(n == 4), split_light_paths=1 if NL >= 16384 else -1) as g:
             g.load_scene_json(jp)
             c0 = evplp.lib().evplp_group_context(g._h, 0)
             import ctypes as C
@@ -86,7 +86,7 @@ def test_bands_partition_and_rebalance_equal_the_single_context(evplp, tmp_path)
         ref = render(c, fp, False)
     assert ref.max() > 0
     for n in (2, 4):
-        with evplp.Group(W, Hb, NL, NV, P, n, devices=[0] * n, deterministic=True, partition="bands") as g:
+        with evplp.Group(W, Hb, NL, NV, P, n, devices=[0] * n, deterministic=True, partition="bands", split_light_paths=1) as g:
             g.load_scene_json(jp)
             assert render(g, fp, True).tobytes() == ref.tobytes(), f"{n} equal bands differ from the single context"
             # the rows a rank's context reports are its band
@@ -169,7 +169,7 @@ def test_dealt_blocks_and_the_cost_rebalance_equal_the_single_context(evplp, tmp
                 assert img[ok].tobytes() == ref[rows[ok]].tobytes()
     # (2) the group: calibrate, rebalance, render again
     for n in (2, 4):
-        with evplp.Group(W, Hb, NL, NV, P, n, devices=[0] * n, deterministic=True) as g:
+        with evplp.Group(W, Hb, NL, NV, P, n, devices=[0] * n, deterministic=True, split_light_paths=1) as g:
             g.load_scene_json(jp)
             assert g.block_owners().tolist() == [b % n for b in range(8)]
             with pytest.raises(evplp.EvplpError) as e:
@@ -198,7 +198,7 @@ def test_a_rank_that_fails_behind_a_collective_does_not_hang_the_group(evplp, tm
     destroying the group must not hang.  Argument errors, on the other hand, are refused at once on the caller's thread and leave the group usable."""
     jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H)
     NL, NV = 16384, 32
-    with evplp.Group(W, H, NL, NV, P, 2, devices=[0, 0], deterministic=True) as g:
+    with evplp.Group(W, H, NL, NV, P, 2, devices=[0, 0], deterministic=True, split_light_paths=1) as g:
         g.load_scene_json(jp)
         fp = evplp.frame_params(camera_pos=(15.56, -4.79, 4.37), mis_mode="one", num_light_paths=NL, num_vpl_light_paths=NV, photons_per_path=P, photon_radius=0.1)
         bad = evplp.frame_params(camera_pos=(15.56, -4.79, 4.37), mis_mode="one", num_light_paths=NL, num_vpl_light_paths=NV, photons_per_path=P, photon_radius=0.0)
@@ -225,7 +225,7 @@ def test_a_rank_that_fails_behind_a_collective_does_not_hang_the_group(evplp, tm
 def test_single_rank_group_through_rccl(evplp, tmp_path):
     """ncclCommInitAll + ncclAllGather with one rank: the RCCL code path itself (communicator, streams, in-place gather)."""
     jp = evplp.synth_scene(str(tmp_path), "room", 3000, 9, W, H)
-    with evplp.Group(W, H, 16384, 32, P, 1, use_rccl=True, deterministic=True) as g:
+    with evplp.Group(W, H, 16384, 32, P, 1, use_rccl=True, deterministic=True, split_light_paths=1) as g:
         g.load_scene_json(jp)
         fp = evplp.frame_params(camera_pos=(15.56, -4.79, 4.37), mis_mode="one", num_light_paths=16384, num_vpl_light_paths=32, photons_per_path=P)
         g.primary(); g.trace_light_paths(1); g.gather(fp, 0)
@@ -240,17 +240,23 @@ def test_single_rank_group_through_rccl(evplp, tmp_path):
 def test_render_json_on_a_group_of_virtual_ranks(evplp, tmp_path):
     """The technique loop on 4 strip ranks (JSON `device` block) writes the same files as on one."""
     outs = {}
-    for n in (1, 4):
-        d = tmp_path / f"n{n}"; d.mkdir()
+    # (round 6) ... and so does every way of running the group: blocks dealt by the cost a calibration frame clocks, the strips exchanged only
+    # for the frames that are written (exchangeEvery 0) or every second iteration, light paths split over the ranks + record all-gather
+    variants = {"1": dict(gpus=1), "4": dict(gpus=4, virtual=True),
+                "4 dealt, no exchange in the loop, split paths": dict(gpus=4, virtual=True, deal="cost", exchangeEvery=0, splitLightPaths=True),
+                "4 round robin, exchange every 2nd": dict(gpus=4, virtual=True, deal="roundRobin", exchangeEvery=2, splitLightPaths=False, stripRows=8)}
+    for k, (name, dev) in enumerate(variants.items()):
+        d = tmp_path / f"v{k}"; d.mkdir()
         jp = evplp.synth_scene(str(d), "room", 3000, 3, 80, 56, style="hard")
         root = json.load(open(jp))
         root["photonfam"].update(numMaxIteration=3, numLightPaths=2000, numVplLightPaths=40, radiusPercentage=0.05, misMode="balance", DoProgressive=True,
-                                 deterministic=True, device=dict(gpus=n, virtual=True), combinedFilename="c.pfm", weightedPhotonFilename="pm.pfm",
+                                 deterministic=True, device=dev, combinedFilename="c.pfm", weightedPhotonFilename="pm.pfm",
                                  weightedVplFilename="vpl.pfm", statFilename="s.json", run=dict(photonSplat=True))
         json.dump(root, open(jp, "w"))
         evplp.render_json(jp)
-        outs[n] = [open(d / f, "rb").read() for f in ("c.pfm", "pm.pfm", "vpl.pfm")]
-    assert outs[1] == outs[4]
+        outs[name] = [open(d / f, "rb").read() for f in ("c.pfm", "pm.pfm", "vpl.pfm")]
+    for name in variants:
+        assert outs[name] == outs["1"], name
 
 
 def test_group_errors_are_reported(evplp):

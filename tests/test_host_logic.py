@@ -261,3 +261,14 @@ def test_block_tables_reassemble(evplp):
         rr = strips.rows_of_blocks(H, np.arange(r, 7, 3), SR, strips.local_rows(H, 3, SR))
         g = strips.global_rows(H, r, 3, SR)
         assert np.array_equal(rr[rr < H], g[g < H])
+
+
+def test_split_model_prefers_redundant_light_tracing_where_the_exchange_costs_more(evplp):
+    """evplp_group_split_model (host only): config #4's 300 000 paths on four ranks and config #3's 500 000 on eight are traced in full by every
+    rank (the record exchange would cost more than the shorter launch saves); a set of many millions is split."""
+    for nl, n in ((1024, 8), (300000, 4), (500000, 8)):
+        split, all_ms, shared_ms = evplp.split_model(nl, 4, n)
+        assert not split and all_ms <= shared_ms
+    split, all_ms, shared_ms = evplp.split_model(64_000_000, 4, 8)
+    assert split and shared_ms < all_ms
+    assert evplp.split_model(300000, 4, 1)[0] is False

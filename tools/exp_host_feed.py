@@ -3,7 +3,9 @@ What it measures: how long the CALLER's thread is busy per iteration (wall time 
 between) against the time an iteration takes until it is done on the GPU.  Virtual ranks share one device, so the GPU time per
 iteration is the sum of all strips' work, NOT what n devices would take: the number that carries over to n GPUs is the host's
 time per iteration, which must stay well below a rank's GPU time per iteration (0.15-0.6 ms at config #4).
-usage: python tools/exp_host_feed.py [label]"""
+(round 6) EXCHANGE_EVERY=k in the environment: the strips are all-gathered in every k-th iteration's composite only (0 = never in the loop;
+evplp_group_present_ex, the technique loop's "device": {"exchangeEvery": k}) -- the other iterations composite locally, no host barrier.
+usage: [EXCHANGE_EVERY=k] python tools/exp_host_feed.py [label]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,8 +13,9 @@ import evplp_amd as ev
 
 W, H, NL, P = 1920, 1080, 300000, 4
 label = sys.argv[1] if len(sys.argv) > 1 else ""
+EX = int(os.environ.get("EXCHANGE_EVERY", "1"))
 jp = ev.synth_scene("/tmp/evplp_host_t", "conf", 331000, 1234, W, H, style="hard")
-print(f"# {label}: config #4 (1920 x 1080, 300 000 light paths, photon splat, composite + all-gather of the strips per iteration), evplp_group, virtual ranks on device 0")
+print(f"# {label}: config #4 (1920 x 1080, 300 000 light paths, photon splat, composite per iteration, all-gather of the strips every {EX} iteration(s) (0 = never)), evplp_group, virtual ranks on device 0")
 for n in (1, 4, 8):
     with ev.Group(W, H, NL, 0, P, n, devices=[0] * n, strip_rows=16, overlap_light_tracing=True) as g:
         g.load_scene_json(jp)
@@ -22,7 +25,7 @@ for n in (1, 4, 8):
                              do_accumulate=1, splat_footprint="proxy")
 
         def iteration(it):
-            g.trace_light_paths(it); g.primary((0.0, 0.0)); g.splat_photons(fp); g.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True)
+            g.trace_light_paths(it); g.primary((0.0, 0.0)); g.splat_photons(fp); g.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True, exchange=EX > 0 and (it + 1) % EX == 0)
         for it in range(10):
             iteration(it)
         g.synchronize()

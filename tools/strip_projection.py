@@ -23,6 +23,7 @@ ap.add_argument("--rows", default="8,16")
 ap.add_argument("--n", default="")
 ap.add_argument("--deals", default="roundRobin,cost")
 ap.add_argument("--capacity-pct", type=int, default=150)
+ap.add_argument("--split-light-paths", default="auto", choices=["auto", "on", "off"], help="as evplp_group_config.split_light_paths (auto: evplp_group_split_model)")
 args = ap.parse_args()
 P = 4
 CONFIGS = {
@@ -59,7 +60,8 @@ def run_rank(cfg, n, rows, r, blocks=None, calibrate=False, cap_rows=0):
         kw = dict(camera_pos=list(cam.origin), mis_mode=cfg["mis"], pdf_mc=(nv / nl) / math.pi / radius ** 2, clamping_value=1.0 / total, photon_radius=radius,
                   vsl_radius=vsl_r, vsl_inv_pi_radius2=1.0 / (math.pi * vsl_r * vsl_r),
                   num_light_paths=nl, num_vpl_light_paths=nvp, photons_per_path=P, do_accumulate=1, splat_footprint="proxy")
-        split = n > 1 and nl % n == 0 and nl >= 16384          # evplp_group's rule: large path sets are traced 1 / n per rank and all-gathered
+        # evplp_group's rule: every rank traces all paths, or -- where its cost model expects that to be faster, or on request -- 1 / n of them + all-gather
+        split = n > 1 and nl % n == 0 and (args.split_light_paths == "on" or (args.split_light_paths == "auto" and ev.split_model(nl, P, n)[0]))
         acc = {k: [] for k, _ in PASSES}
         if calibrate:
             c.calibrate_blocks(True)
@@ -107,7 +109,7 @@ def partition_record(n, rows, deal, ranks, base_sum, owner=None):
 
 
 result = {"what": "single-GPU projection of the row-strip partition (every rank's strip run alone on one MI355X; per-pass HIP-event times); NOT a scaling measurement: "
-                  "no exchange, no second device was involved", "scene": "furnished conference stand-in, 331 k triangles", "capacity_pct": args.capacity_pct, "configs": {}}
+                  "no exchange, no second device was involved", "scene": "furnished conference stand-in, 331 k triangles", "capacity_pct": args.capacity_pct, "split_light_paths": args.split_light_paths, "configs": {}}
 for name in args.configs.split(","):
     cfg = CONFIGS[name]
     base, _ = run_rank(cfg, 1, 16, 0)
