@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <random>
 #include <string>
 #include <vector>
@@ -309,6 +310,127 @@ int main(int argc, char **argv) {
         auto pq = [&](double q) { return hist[(size_t)(q * (hist.size() - 1))]; };
         std::printf("frustum walk: %.2f node visits / packet, %.2f candidate leaves / packet (%.3f of the packets have none; percentiles 50/75/90/95/99/max %d %d %d %d %d %d); wave phase: %.2f leaf boxes tested, %.2f entered, %.2f triangle pairs / packet\n",
                     fvis / n, cands / n, none / n, pq(.5), pq(.75), pq(.9), pq(.95), pq(.99), hist.back(), tested / n, entered / n, prs / n);
+        return 0;
+    }
+
+    if (mode == 4) {
+        // (round 6) COHERENT RE-BINNING: lane <-> pixel is free (per-pixel sums, fixed VPL order), so the 256 pixels of a group of 2 x 2 tiles can
+        // be dealt to its four wavefronts by WORLD position instead of by screen quadrant: a tile that straddles a depth discontinuity (chair in
+        // front of floor) makes a fat bundle of segments for every VPL.  Same group cut for both (it bounds all 256 pixels; budget pc, breadth
+        // first, bounds from the union box: the device's), then the four walks.  pa = clustering: 0 k-d (median split of the largest extent, twice),
+        // 1 sorted by distance from the eye (argv eye = the first VPL-independent guess: centroid of all tile points is NOT the eye, so the key is
+        // the distance to `EYE=x,y,z`), 2 k-d over position + 0.5 x normal (six dimensions).  Prints both totals and, per decile of the screen
+        // tiles' box diagonal relative to the group's smallest, where the cost sits.
+        const int clustering = pa, budget = pc ? pc : 8, flags = 3;
+        const int tiles_x = (int)std::lround(std::sqrt((double)ntiles));
+        if (tiles_x * tiles_x != ntiles) { std::fprintf(stderr, "mode 4 needs the full tile grid\n"); return 1; }
+        float eye[3] = { 0, 0, 0 }; if (getenv("EYE")) std::sscanf(getenv("EYE"), "%f,%f,%f", &eye[0], &eye[1], &eye[2]);
+        const int GX = tiles_x / 2;
+        std::vector<std::vector<float>> rebinned((size_t)GX * GX);       // per group: 4 x 64 x 7 floats, built on first use
+        auto build_rebinned = [&](int gx, int gy) {
+            std::vector<float> &R = rebinned[(size_t)gy * GX + gx];
+            if (!R.empty()) return;
+            struct Px { float v[7]; };
+            std::vector<Px> px;
+            for (int j = 0; j < 4; j++) { const int ti = (gy * 2 + j / 2) * tiles_x + gx * 2 + j % 2; const float *T = &tiles[(size_t)ti * 64 * 7]; for (int l = 0; l < 64; l++) { Px q; std::memcpy(q.v, T + l * 7, 28); px.push_back(q); } }
+            auto key_dim = [&](const Px &q, int dim) { return dim < 3 ? q.v[dim] : 0.5f * q.v[4 + dim - 3]; };
+            std::function<void(int, int, int)> split = [&](int lo, int hi, int levels) {
+                if (levels == 0) return;
+                if (clustering == 1) {
+                    auto dist = [&](const Px &q) { float s = 0; for (int k = 0; k < 3; k++) s += (q.v[k] - eye[k]) * (q.v[k] - eye[k]); return q.v[3] != 0.f ? s : 3e38f; };
+                    std::sort(px.begin() + lo, px.begin() + hi, [&](const Px &a, const Px &b) { return dist(a) < dist(b); });
+                    return;                                          // one sort, chunks of 64
+                }
+                const int dims = clustering == 2 ? 6 : 3;
+                int best = 0; float best_e = -1.f;
+                for (int dim = 0; dim < dims; dim++) { float mn = 3e38f, mx = -3e38f; for (int i = lo; i < hi; i++) if (px[(size_t)i].v[3] != 0.f) { mn = std::min(mn, key_dim(px[(size_t)i], dim)); mx = std::max(mx, key_dim(px[(size_t)i], dim)); } if (mx - mn > best_e) { best_e = mx - mn; best = dim; } }
+                // (pixels outside the scene -- w = 0 -- sort to the end: they are dead lanes wherever they sit)
+                std::sort(px.begin() + lo, px.begin() + hi, [&](const Px &a, const Px &b) { const float ka = a.v[3] != 0.f ? key_dim(a, best) : 3e38f, kb = b.v[3] != 0.f ? key_dim(b, best) : 3e38f; return ka < kb; });
+                const int mid = (lo + hi) / 2;
+                split(lo, mid, levels - 1); split(mid, hi, levels - 1);
+            };
+            split(0, 256, 2);
+            R.resize(4 * 64 * 7);
+            for (int i = 0; i < 256; i++) std::memcpy(&R[(size_t)i * 7], px[(size_t)i].v, 28);
+        };
+        struct Acc { double walks = 0, nodes = 0, pairs = 0, lanes = 0, groups = 0, cutsz = 0; double cost() const { return 15.0 * nodes + 46.0 * pairs; } };
+        Acc A[2]; Acc D[2][10];
+        auto eval_group = [&](const float *const T4[4], const float *vpl, Acc &acc, Acc *dec) {
+            Packet PK[4];
+            Frustum F; F.begin({ vpl[0], vpl[1], vpl[2] }, { vpl[3], vpl[4], vpl[5] });
+            int live = 0;
+            for (int j = 0; j < 4; j++) { PK[j].setup(T4[j], vpl); if (PK[j].nalive) { live++; F.centre(PK[j], T4[j]); } }
+            if (!live) return false;
+            F.axes();
+            {   // bounds from the eight corners of the union box of all valid pixels (the device's)
+                float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f }; int nv = 0;
+                for (int j = 0; j < 4; j++) for (int l = 0; l < 64; l++) if (T4[j][l * 7 + 3] != 0.f) { nv++; for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], T4[j][l * 7 + k]); hi[k] = std::max(hi[k], T4[j][l * 7 + k]); } }
+                Packet C; C.vp = F.vp; C.vn = F.vn; for (int l = 0; l < 64; l++) C.alive[l] = false;
+                for (int q = 0; q < 8; q++) { const V pq = { (q & 1) ? hi[0] : lo[0], (q & 2) ? hi[1] : lo[1], (q & 4) ? hi[2] : lo[2] }; C.alive[q] = true; C.pp[q] = pq; C.d[q] = pq - F.vp; }
+                if (nv) F.bound(C);
+            }
+            F.finish();
+            std::vector<Box> cut; { Box r; std::memset(&r, 0, sizeof r); r.ref = 0; for (int k = 0; k < 3; k++) r.h[k] = 1e30f; cut.push_back(r); }
+            size_t leaves_in_row = 0;
+            while (!cut.empty() && leaves_in_row < cut.size()) {
+                const Box e = cut.front();
+                if (e.ref < 0) { cut.erase(cut.begin()); cut.push_back(e); leaves_in_row++; continue; }
+                const BvhNode &n = bb.nodes[e.ref];
+                Box kids[2]; int nk = 0;
+                for (int ch = 0; ch < 2; ch++) { const Box b = child_box(n, ch); if (b.ref == kNoChild || F.outside(b, flags)) continue; kids[nk++] = b; }
+                if ((int)cut.size() - 1 + nk > budget) break;
+                cut.erase(cut.begin()); for (int k = 0; k < nk; k++) cut.push_back(kids[k]);
+                leaves_in_row = 0;
+            }
+            const bool is_root = cut.size() == 1 && cut[0].ref == 0 && cut[0].h[0] > 1e29f;
+            std::sort(cut.begin(), cut.end(), [&](const Box &a, const Box &b) {
+                auto dist = [&](const Box &q) { const float vp[3] = { F.vp.x, F.vp.y, F.vp.z }; float s2 = 0; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(vp[k] - q.c[k]) - q.h[k], 0.f); s2 += e * e; } return s2; };
+                return dist(a) > dist(b); });
+            acc.groups++; acc.cutsz += (double)cut.size();
+            for (int j = 0; j < 4; j++) if (PK[j].nalive) {
+                acc.walks++; acc.lanes += PK[j].nalive; if (dec) { dec->walks++; dec->lanes += PK[j].nalive; }
+                if (cut.empty()) continue;
+                const std::vector<BvhNode> init = pair_up(cut);
+                const WalkOut o = walk(PK[j], is_root ? nullptr : &init, false);
+                acc.nodes += o.nodes; acc.pairs += o.pairs; if (dec) { dec->nodes += o.nodes; dec->pairs += o.pairs; }
+            }
+            return true;
+        };
+        // decile of a group by how much deeper it is than a flat patch: diagonal of the group's position box / the smallest of its tiles' diagonals
+        auto group_spread = [&](int gx, int gy) {
+            float glo[3] = { 1e30f, 1e30f, 1e30f }, ghi[3] = { -1e30f, -1e30f, -1e30f }, dmin = 1e30f;
+            for (int j = 0; j < 4; j++) {
+                const int ti = (gy * 2 + j / 2) * tiles_x + gx * 2 + j % 2; const float *T = &tiles[(size_t)ti * 64 * 7];
+                float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+                for (int l = 0; l < 64; l++) if (T[l * 7 + 3] != 0.f) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], T[l * 7 + k]); hi[k] = std::max(hi[k], T[l * 7 + k]); glo[k] = std::min(glo[k], T[l * 7 + k]); ghi[k] = std::max(ghi[k], T[l * 7 + k]); }
+                if (lo[0] <= hi[0]) dmin = std::min(dmin, std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2])));
+            }
+            const float dg = std::sqrt((ghi[0] - glo[0]) * (ghi[0] - glo[0]) + (ghi[1] - glo[1]) * (ghi[1] - glo[1]) + (ghi[2] - glo[2]) * (ghi[2] - glo[2]));
+            return dg / std::max(dmin, 1e-6f);
+        };
+        // the groups' spread deciles first (all groups)
+        std::vector<float> spread((size_t)GX * GX); for (int gy = 0; gy < GX; gy++) for (int gx = 0; gx < GX; gx++) spread[(size_t)gy * GX + gx] = group_spread(gx, gy);
+        std::vector<float> sorted_spread = spread; std::sort(sorted_spread.begin(), sorted_spread.end());
+        auto decile = [&](float v) { int d = (int)(std::lower_bound(sorted_spread.begin(), sorted_spread.end(), v) - sorted_spread.begin()) * 10 / (int)sorted_spread.size(); return std::min(d, 9); };
+        while (A[0].walks < nwalks) {
+            const int gx = (int)(rng() % (unsigned)GX), gy = (int)(rng() % (unsigned)GX), vi = (int)(rng() % (unsigned)nvpl);
+            const float *vpl = &vpls[(size_t)vi * 6];
+            const float *S4[4]; for (int j = 0; j < 4; j++) S4[j] = &tiles[(size_t)((gy * 2 + j / 2) * tiles_x + gx * 2 + j % 2) * 64 * 7];
+            const int dc = decile(spread[(size_t)gy * GX + gx]);
+            if (!eval_group(S4, vpl, A[0], &D[0][dc])) continue;
+            build_rebinned(gx, gy);
+            const std::vector<float> &R = rebinned[(size_t)gy * GX + gx];
+            const float *R4[4] = { &R[0], &R[64 * 7], &R[128 * 7], &R[192 * 7] };
+            eval_group(R4, vpl, A[1], &D[1][dc]);
+        }
+        const char *nm[2] = { "screen quadrants", "re-binned" };
+        for (int v = 0; v < 2; v++)
+            std::printf("%-17s: %.0f (group, VPL) samples, %.0f walks (%.3f per sample), %.1f lanes alive per walk; per walk %.2f visits %.2f pairs est VALU %.0f;  per SAMPLE est VALU %.0f;  per live (pixel, VPL) pair %.2f\n",
+                        nm[v], A[v].groups, A[v].walks, A[v].walks / A[v].groups, A[v].lanes / A[v].walks, A[v].nodes / A[v].walks, A[v].pairs / A[v].walks, A[v].cost() / A[v].walks, A[v].cost() / A[v].groups, A[v].cost() / A[v].lanes);
+        std::printf("re-binned / screen: est VALU per live pair %.4f (the kill criterion: < 0.92), walks %.4f\n", (A[1].cost() / A[1].lanes) / (A[0].cost() / A[0].lanes), A[1].walks / A[0].walks);
+        std::printf("by decile of the group's depth spread (group box diagonal / smallest tile box diagonal): share of the screen-quadrant cost, re-binned / screen cost\n");
+        for (int dcl = 0; dcl < 10; dcl++) std::printf("   decile %d (spread <= %.2f): share %.3f  ratio %.3f  walks ratio %.3f\n", dcl, sorted_spread[std::min((size_t)((dcl + 1) * sorted_spread.size() / 10), sorted_spread.size() - 1)],
+                                                        D[0][dcl].cost() / A[0].cost(), D[1][dcl].cost() / std::max(D[0][dcl].cost(), 1.0), D[1][dcl].walks / std::max(D[0][dcl].walks, 1.0));
         return 0;
     }
 
