@@ -96,6 +96,8 @@ def parse():
     ap.add_argument("--split-light-paths", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: every rank traces 1/N of the light paths + in-place all-gather of the records (on), all of them (off), or what evplp_group_split_model expects to be faster (auto)")
     ap.add_argument("--exchange-every", type=int, default=1, help="N > 1: the composited strips are all-gathered every k-th frame (0 = never inside the timed loop)")
+    ap.add_argument("--scratch-gb", type=float, default=0.0, help="evplp_config.cut_scratch_bytes in GB (0 = the library's default of 8 GB; config #5 needs 68 GB for one band)")
+    ap.add_argument("--mask-gb", type=float, default=0.0, help="evplp_config.vsl_mask_bytes in GB (0 = the library's default of 2 GB; config #5 needs 8.6 GB for one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (configs #3-#5, other scene, 16384-slot variant, GPU path tracer, render_json)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="path-tracer iterations of the CPU baseline sample (0 = auto, ~12 s)")
@@ -307,14 +309,16 @@ def run_workload(env, wl, steps, warmup, scene, primary=True):
     if env.group_front_end:
         # one process, the native multi-GPU entry: a.gpus ranks on distinct devices (RCCL) or, when the box has fewer, all on device 0
         devices = list(range(a.gpus)) if env.ndev >= a.gpus else [0] * a.gpus
-        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=SR, bvh_builder=builder, overlap_light_tracing=True, split_light_paths=SPLIT)
+        group = ev.Group(W, H, n_light, n_vpl, P, a.gpus, devices=devices, strip_rows=SR, bvh_builder=builder, overlap_light_tracing=True, split_light_paths=SPLIT,
+                         cut_scratch_bytes=int(a.scratch_gb * 2 ** 30), vsl_mask_bytes=int(a.mask_gb * 2 ** 30))
         group.load_scene_json(json_path)
         ranks = [group.rank(r) for r in range(a.gpus)]
         ctx = ranks[0]
         n_ranks = a.gpus
     else:
         ctx = ev.Context(W, H, n_light, n_vpl, P, device=env.device_index, strip_rank=rank, strip_count=world, strip_rows=SR,
-                         bvh_builder=builder, overlap_light_tracing=True, strip_capacity_rows=cap_blocks * SR if world > 1 else 0)
+                         bvh_builder=builder, overlap_light_tracing=True, strip_capacity_rows=cap_blocks * SR if world > 1 else 0,
+                         cut_scratch_bytes=int(a.scratch_gb * 2 ** 30), vsl_mask_bytes=int(a.mask_gb * 2 ** 30))
         ctx.load_scene_json(json_path)
         ctx.set_stream(env.stream.cuda_stream)
         ranks = [ctx]

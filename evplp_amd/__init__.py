@@ -244,7 +244,7 @@ class Context:
     def __init__(self, res_x: int, res_y: int, num_light_paths: int, num_vpl_light_paths: int, photons_per_path: int,
                  device: int = 0, strip_rank: int = 0, strip_count: int = 1, strip_rows: int = 16,
                  bvh_builder: int = BVH_SAH, deterministic: bool = False, gather_splits_per_wave: int = 0, overlap_light_tracing: bool = False,
-                 band=None, band_capacity_rows: int = 0, strip_capacity_rows: int = 0):
+                 band=None, band_capacity_rows: int = 0, strip_capacity_rows: int = 0, cut_scratch_bytes: int = 0, vsl_mask_bytes: int = 0):
         """band = (first_row, rows): the context owns those contiguous image rows instead of interleaved strips."""
         self._lib = lib()
         cfg = Config()
@@ -257,6 +257,7 @@ class Context:
         cfg.photons_per_path = photons_per_path; cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic)
         cfg.gather_splits_per_wave = gather_splits_per_wave
         cfg.overlap_light_tracing = int(overlap_light_tracing); cfg.strip_capacity_rows = int(strip_capacity_rows)
+        cfg.cut_scratch_bytes = int(cut_scratch_bytes); cfg.vsl_mask_bytes = int(vsl_mask_bytes)
         self.cfg = cfg
         h = C.c_void_p()
         rc = self._lib.evplp_create(C.byref(cfg), C.byref(h))
@@ -538,13 +539,14 @@ class Group:
     """evplp_group: n row-strip ranks driven by one thread (RCCL across distinct GPUs, device copies for virtual ranks)."""
 
     def __init__(self, res_x, res_y, num_light_paths, num_vpl_light_paths, photons_per_path, n_ranks, devices=None, strip_rows=0,
-                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips", strip_capacity_pct=0, split_light_paths=0):
+                 use_rccl=False, deterministic=False, bvh_builder=BVH_SAH, overlap_light_tracing=False, partition="strips", strip_capacity_pct=0, split_light_paths=0, cut_scratch_bytes=0, vsl_mask_bytes=0):
         """strip_rows = 0: the library's choice (16 rows)"""
         self._lib = lib()
         cfg = Config()
         cfg.abi_version = ABI_VERSION; cfg.res_x = res_x; cfg.res_y = res_y
         cfg.num_light_paths = num_light_paths; cfg.num_vpl_light_paths = num_vpl_light_paths; cfg.photons_per_path = photons_per_path
         cfg.bvh_builder = bvh_builder; cfg.deterministic = int(deterministic); cfg.overlap_light_tracing = int(overlap_light_tracing)
+        cfg.cut_scratch_bytes = int(cut_scratch_bytes); cfg.vsl_mask_bytes = int(vsl_mask_bytes)
         gc = GroupConfig(); gc.n_ranks = n_ranks; gc.strip_rows = strip_rows; gc.use_rccl = int(use_rccl)
         gc.partition = PARTITION_BANDS if partition == "bands" else PARTITION_STRIPS; gc.strip_capacity_pct = int(strip_capacity_pct); gc.split_light_paths = int(split_light_paths)
         self.partition = partition if n_ranks > 1 else "strips"

@@ -13,6 +13,8 @@
 using namespace evplp;
 
 static thread_local char g_create_error[512] = "";
+// default bounds of the gathers' two large scratch buffers (evplp_config.cut_scratch_bytes / vsl_mask_bytes = 0; include/evplp.h has the table)
+constexpr size_t kDefaultCutScratchBytes = (size_t)8 << 30, kDefaultVslMaskBytes = (size_t)2 << 30;
 
 void evplp_context::set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt);
@@ -764,16 +766,13 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         ca.groups_x = (c->tiles_x + (1 << ca.gw_log2) - 1) >> ca.gw_log2;
         ca.vpls = c->d_vpls; ca.nvpl = &c->d_scalars[0]; ca.vpl_stride = (uint32_t)nvpl_slots_of(c);
         const size_t per_block_row = (size_t)(sh >> ca.gh_log2) * ca.groups_x * ca.vpl_stride * (size_t)kCutSlotBytes;
-        // The bound of the scratch: evplp_config.cut_scratch_bytes, or -- looked up ONCE per context, at its first gather -- a quarter of the
-        // device's memory (72 GB of 288) but no more than half of what is free then (config #5's 68 GB fit one band: 1.397 -> 1.371 s per
-        // iteration against six bands of 12 GB).  EVPLP_CUT_BYTES: test override (forces the band path).
+        // The bound of the scratch: evplp_config.cut_scratch_bytes, or 8 GB (round 6; until round 5 a quarter of the device's memory -- 72 GB of
+        // 288 -- which let config #5's 68 GB of slots sit in one band -- 0.7 % faster than the nine it takes now, 1 167 against 1 174 ms -- and took a quarter of the GPU from whoever else
+        // lives on it: a library embedded in a host application asks for that much only when told to).  Configurations within the bound --
+        // config #2 / #3: 4.3 GB -- allocate what they need; larger ones are gathered band by band.  EVPLP_CUT_BYTES: test override.
         if (c->cut_cap == 0) {
             c->cut_cap = c->env_cut_bytes ? c->env_cut_bytes : (size_t)c->cfg.cut_scratch_bytes;
-            if (c->cut_cap == 0) {
-                size_t mem_free = 0, mem_total = 0;
-                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)48 << 30; }
-                c->cut_cap = std::max<size_t>(std::min(mem_total / 4, mem_free / 2), (size_t)1 << 30);
-            }
+            if (c->cut_cap == 0) c->cut_cap = kDefaultCutScratchBytes;
         }
         band_rows = (int)std::min<size_t>((size_t)nby, c->cut_cap / std::max<size_t>(per_block_row, 1));
         if (band_rows < 1) { use_cuts = false; band_rows = nby; }            // (the bound does not hold one row of tile blocks: walks from the root)
@@ -802,16 +801,12 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         const size_t tiles = (size_t)gather_launch_tiles(a), per_item = (size_t)k * (size_t)a.masks_per_split * sizeof(unsigned long long);
         vsl_groups = kVplSplit / k;
         vsl_per_launch = vsl_groups;
-        // the bound of the mask buffer: evplp_config.vsl_mask_bytes, or -- once per context -- a twentieth of the device's memory (14 GB of 288:
-        // config #5's 8.6 GB in one launch), at most a quarter of what is free then
+        // the bound of the mask buffer: evplp_config.vsl_mask_bytes, or 2 GB (round 6; until round 5 a twentieth of the device's memory, which
+        // held config #5's 8.6 GB in one launch)
         if (c->mask_cap == 0) {
             c->mask_cap = (size_t)c->cfg.vsl_mask_bytes;
             if (const char *me = std::getenv("EVPLP_MASK_BYTES")) c->mask_cap = (size_t)strtoull(me, nullptr, 10);      // (developer switch)
-            if (c->mask_cap == 0) {
-                size_t mem_free = 0, mem_total = 0;
-                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)20 << 30; }
-                c->mask_cap = std::max<size_t>(std::min(mem_total / 20, mem_free / 4), (size_t)1 << 28);
-            }
+            if (c->mask_cap == 0) c->mask_cap = kDefaultVslMaskBytes;
         }
         const size_t mask_cap = c->mask_cap;
         while (vsl_per_launch > 1 && tiles * (size_t)vsl_per_launch * per_item > mask_cap) vsl_per_launch = (vsl_per_launch + 1) / 2;

@@ -313,6 +313,11 @@ public:
         cfg.photons_per_path = (uint32_t)photons_per_path; cfg.bvh_builder = bvh_builder;
         if (json.has("deterministic")) cfg.deterministic = json.at("deterministic").as_bool("deterministic") ? 1 : 0;   // build-only key
         cfg.overlap_light_tracing = 1;      // the loop below calls primary, then light tracing: they overlap
+        if (json.has("device")) {           // build-only: the bounds of the gathers' scratch buffers (evplp_config; defaults 8 GB / 2 GB)
+            const Json &d = json.at("device");
+            if (d.has("cutScratchGB")) cfg.cut_scratch_bytes = (uint64_t)(std::max(d.at("cutScratchGB").as_float("device.cutScratchGB"), 0.0f) * 1073741824.0);
+            if (d.has("vslMaskGB")) cfg.vsl_mask_bytes = (uint64_t)(std::max(d.at("vslMaskGB").as_float("device.vslMaskGB"), 0.0f) * 1073741824.0);
+        }
         Grp grp; create_group(grp, cfg, json, device);
         run_opts = run_options(json);
         upload_scene_group(grp.g, scene);

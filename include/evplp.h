@@ -103,12 +103,22 @@ typedef struct evplp_config {
                                   *    set none is ever left pending behind a younger one (bitwise reproducible accumulation). */
     /* Upper bounds of the two large scratch buffers of the gathers, in bytes; 0 = the library's default.  Both are allocated on the first
      * gather that needs them, grow to what the configuration asks for within the bound, and live until evplp_destroy.
-     *  cut_scratch_bytes: the entry cuts of the VPL / VSL gathers, 256 bytes per (group of 2 x 2 tiles, VPL record slot): 4.3 GB at
-     *    config #2, 68 GB at config #5.  Default: a quarter of the device's memory, at most half of what is free at the first gather.
-     *    A configuration that needs more is gathered in bands of tile rows (same results); a bound too small for one row of tile
-     *    blocks, or an allocation that fails, makes the walks start at the root (same results, slower).
+     *  cut_scratch_bytes: the entry cuts of the VPL / VSL gathers, 256 bytes per (group of 2 x 2 tiles, VPL record slot).  Default 8 GB.
+     *    A configuration that needs more is gathered in bands of tile rows (same results, every band's launches have a tail of their own:
+     *    config #5 in nine bands and five launches instead of one and one: 1 174 against 1 167 ms per iteration, 0.7 %); a bound too small for one row of tile blocks, or an allocation that fails,
+     *    makes the walks start at the root (same results, ~40 % slower).
      *  vsl_mask_bytes: the lit-lane masks between the two kernels of the VSL gather (8 bytes per (tile, VSL slot) of a launch).
-     *    Default: a twentieth of the device's memory, at most a quarter of what is free; smaller bounds mean more launches. */
+     *    Default 2 GB; smaller bounds mean more launches.
+     * What one context allocates on one GPU (whole image; a rank of an n-way group: ~1/n of the per-pixel rows, x 1.5 with the deal's capacity):
+     *                                  config #2 (ir)   #3 (evplp)        #4 (ppm)        #5 (vsl)
+     *   G-buffer, accumulators, RGB     0.16 GB          0.16 GB           0.30 GB         0.62 GB      (9 planes x 16 B + 12 B per pixel)
+     *   records (x 2 when overlapped)   0.4 MB           192 (384) MB      115 (230) MB    115 (230) MB
+     *   gather partial sums             1.07 GB          1.07 GB           -               8.6 GB       (64 / 128 groups x 16 B per pixel)
+     *   entry cuts (bounded, above)     4.3 GB           4.3 GB            -               8 GB of 68   (in nine bands)
+     *   VSL masks (bounded, above)      -                -                 -               2 GB of 8.6  (in five launches)
+     *   photon bins + compact photons   -                0.5 GB            0.4 GB          0.5 GB
+     *   scene (331 k triangles)         0.1 GB everywhere (nodes, leaf blocks in two layouts, attributes; textures on top)
+     * A caller that has the device to itself sets cut_scratch_bytes = 72 GB, vsl_mask_bytes = 14 GB for config #5 (one band, one launch). */
     uint64_t cut_scratch_bytes;
     uint64_t vsl_mask_bytes;
     /* Band mode, the other way to give a context a share of the image: with band_rows > 0 (and strip_count <= 1) it owns the CONTIGUOUS image
@@ -490,10 +500,11 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
  * json_overrides: optional JSON object text merged over the technique block (may be NULL).
  * Build-only keys of a technique block: "bvhBuilder": "sah" | "sbvh" | "lbvh" | "gpu" (evplp_bvh_builder); "deterministic": bool (photon bins accumulated in record
  * order); "device": {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool, "deal": "cost" | "roundRobin", "exchangeEvery": k,
- * "stripCapacityPct": p} -- run on an evplp_group of N row-strip ranks (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a
+ * "stripCapacityPct": p, "splitLightPaths": bool, "cutScratchGB": g, "vslMaskGB": g} -- run on an evplp_group of N row-strip ranks (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a
  * single rank goes through RCCL too; "deal": row blocks dealt by the cost a calibration frame clocks -- the default from two ranks and four
  * iterations on -- or block b to rank b % N; "exchangeEvery": the strips are all-gathered in every k-th iteration's composite, 0 = only for
- * the frames that are written, default 1). */
+ * the frames that are written, default 1; "splitLightPaths": evplp_group_config.split_light_paths, absent = the cost model; "cutScratchGB" /
+ * "vslMaskGB": evplp_config.cut_scratch_bytes / vsl_mask_bytes). */
 int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap);
 
 #ifdef __cplusplus
