@@ -142,6 +142,7 @@ _SIGNATURES = {
     "evplp_accel_builder": (C.c_int, [_P]),
     "evplp_accel_stack_entries": (C.c_int, [_P]),
     "evplp_selftest": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
+    "evplp_debug_ev_math": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "evplp_group_create": (C.c_int, [C.POINTER(Config), _P, C.POINTER(_P)]),
     "evplp_group_destroy": (None, [_P]),
     "evplp_group_last_error": (C.c_char_p, [_P]),
@@ -365,6 +366,13 @@ class Context:
         return out[:n]
 
     # -- passes
+    def ev_math(self, which: int, x, y=None):
+        """ev_math.h on the device: which 0 -> (sin x, cos x), 1 -> x ** y (evplp_debug_ev_math)"""
+        x = _f32(x).reshape(-1); y = None if y is None else _f32(y).reshape(-1)
+        o0 = np.empty_like(x); o1 = np.empty_like(x)
+        self._check(self._lib.evplp_debug_ev_math(self._h, which, _ptr(x), _ptr(y), x.size, _ptr(o0), _ptr(o1)))
+        return (o0, o1) if which == 0 else o0
+
     def set_stream(self, stream_ptr: int):
         self._check(self._lib.evplp_set_stream(self._h, C.c_void_p(stream_ptr)))
 

@@ -2,6 +2,7 @@
 // run on rather than assumed.
 #include "device_common.hpp"
 #include "context.hpp"
+#include "ev_math.h"
 
 namespace evplp {
 
@@ -47,7 +48,38 @@ __global__ __launch_bounds__(256) void selftest_pow_kernel(unsigned long long *o
     }
 }
 
+// evplp_debug_ev_math: ev_math.h's functions AS THE DEVICE COMPUTES THEM, on the caller's inputs.  The light-tracing records are compared with
+// the oracle's byte for byte, and the oracle #includes the same header: that comparison vouches for the walk and the draw order, not for
+// these functions -- unless the header really gives the same bits on both machines, which is what tests/test_gpu_parity.py checks with this
+// entry point (device results against the oracle's gcc build of the header, dense grids over the callers' input ranges).
+__global__ __launch_bounds__(256) void ev_math_kernel(int which, const float *x, const float *y, uint32_t n, float *o0, float *o1) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) { float s, c; evm_sincosf(x[i], &s, &c); o0[i] = s; o1[i] = c; }
+    else o0[i] = evm_powf(x[i], y[i]);
+}
+
 } // namespace evplp
+
+extern "C" int evplp_debug_ev_math(evplp_context *c, int32_t which, const float *x, const float *y, int32_t n, float *out0, float *out1) {
+    if (!c || !x || !out0 || n <= 0 || which < 0 || which > 1 || (which == 0 && !out1) || (which == 1 && !y)) { if (c) c->set_error("evplp_debug_ev_math: bad arguments"); return EVPLP_ERR_INVALID; }
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return EVPLP_ERR_HIP;
+    float *d = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)n;
+    if (hipMalloc((void **)&d, 4 * bytes) != hipSuccess) { (void)hipGetLastError(); c->set_error("evplp_debug_ev_math: out of memory"); return EVPLP_ERR_OOM; }
+    float *dx = d, *dy = d + n, *d0 = d + 2 * (size_t)n, *d1 = d + 3 * (size_t)n;
+    hipError_t e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && which == 1) e = hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(evplp::ev_math_kernel, dim3(((uint32_t)n + 255u) / 256u), dim3(256), 0, c->stream, which, dx, dy, (uint32_t)n, d0, d1);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && which == 0) e = hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { c->set_error("evplp_debug_ev_math: %s", hipGetErrorString(e)); return EVPLP_ERR_HIP; }
+    return EVPLP_OK;
+}
 
 extern "C" int evplp_selftest(evplp_context *c, int32_t which, uint64_t *out, int32_t capacity) {
     if (!c || !out || capacity < 6 || which < 0 || which > 1) { if (c) c->set_error("evplp_selftest: bad arguments"); return EVPLP_ERR_INVALID; }

@@ -361,6 +361,10 @@ int evplp_accel_stack_entries(const evplp_context *ctx);
  * where the lobe is >= 1e-4 of its peak, in units of 1e-12.
  * Returns the number of words written or a negative status. */
 int evplp_selftest(evplp_context *ctx, int32_t which, uint64_t *out, int32_t capacity);
+/* The direction-sampling functions of light tracing (csrc/ev_math.h: evm_sincosf, evm_powf) as the DEVICE computes them, on host arrays of n
+ * inputs: which = 0: out0 = sin(x), out1 = cos(x); which = 1: out0 = x^y.  For tests: the header is shared with the CPU oracle by #include,
+ * so the byte-equality of the light-path records says nothing about these functions unless they give the same bits on both machines. */
+int evplp_debug_ev_math(evplp_context *ctx, int32_t which, const float *x, const float *y, int32_t n, float *out0, float *out1);
 
 /* ---- multi-GPU group (SURVEY 8b "Threading", 8e; the reference has one device, main.cpp:111-115).  One caller thread POSTS to
  * n_ranks contexts -- each driven by a worker thread of its own, bound to its GPU -- that own interleaved row strips of the image (see the top of this file); scene and

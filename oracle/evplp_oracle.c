@@ -539,6 +539,9 @@ static inline v3 phong_sample(v3 *out, float *pdfw, v3 in, v3 normal, v3 rho_s, 
 float evo_tri_area(const float v9[9]) { return tri_area(v9); }
 void evo_math_sincos(float x, float *s, float *c) { evm_sincosf(x, s, c); }
 float evo_math_pow(float x, float y) { return evm_powf(x, y); }
+/* ... over arrays (tests/test_gpu_parity.py: the device's results of the same header against these, bit for bit) */
+void evo_math_sincos_array(const float *x, int n, float *s, float *c) { for (int i = 0; i < n; i++) evm_sincosf(x[i], &s[i], &c[i]); }
+void evo_math_pow_array(const float *x, const float *y, int n, float *out) { for (int i = 0; i < n; i++) out[i] = evm_powf(x[i], y[i]); }
 float evo_phong_eval_f(const float out[3], const float in[3], const float n[3], float e) { return phong_eval_f(ld3(out), ld3(in), ld3(n), e); }
 float evo_lambert_pdf_a(const float n1[3], const float n2[3], const float v12[3]) { return lambert_pdf_a(ld3(n1), ld3(n2), ld3(v12)); }
 float evo_phong_pdf_a(const float n1[3], const float n2[3], const float v12[3], const float in[3], const float rs[3], float e) {

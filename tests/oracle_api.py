@@ -78,6 +78,8 @@ def load():
     l.evo_tri_area.restype = C.c_float
     l.evo_tri_area.argtypes = [_P]
     l.evo_math_sincos.argtypes = [C.c_float, _P, _P]
+    l.evo_math_sincos_array.argtypes = [_P, C.c_int, _P, _P]
+    l.evo_math_pow_array.argtypes = [_P, _P, C.c_int, _P]
     l.evo_math_pow.restype = C.c_float
     l.evo_math_pow.argtypes = [C.c_float, C.c_float]
     l.evo_phong_eval_f.restype = C.c_float

@@ -134,7 +134,10 @@ def test_config3_evplp_hard_scene_rows(evplp, hard_scene):
         c.splat_photons(evplp.frame_params(**kw, splat_footprint="proxy"), clear=True)
         pmx = c.download(evplp.BUF_PHOTON_ACCUM)[ok]
         stx = c.pass_stats(evplp.PASS_SPLAT)
-    # 2 M record slots, every byte as the oracle traces them
+    # 2 M record slots, every byte as the oracle traces them.  (What that vouches for: the walk, the closest hits, the draw order and the
+    # record arithmetic.  The sampled directions' sin / cos / pow come from csrc/ev_math.h, which the oracle #includes -- equal by
+    # construction; that the header gives the same bits on the device as under gcc is its own test, test_gpu_parity.py::
+    # test_direction_sampling_functions_give_the_oracles_bits_on_the_device.)
     assert rec.tobytes() == osc.trace_light_paths(3, N, P).tobytes()
     okw = dict(kw); okw["mis_mode"] = 1
     ovpl = np.zeros((H, W, 4), np.float32); opm = np.zeros((H, W, 4), np.float32); opmx = np.zeros((H, W, 4), np.float32); opairs = 0; ofrags = 0

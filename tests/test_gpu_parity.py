@@ -123,6 +123,39 @@ def test_hardware_power_function_of_the_phong_lobes(ctx):
     assert len(err) == 6 and (err > 0).all() and err.max() <= 2e-6, err
 
 
+def test_direction_sampling_functions_give_the_oracles_bits_on_the_device(ctx, oracle):
+    """What the byte-equality of the light-path records does NOT prove by itself: the oracle #includes the product's csrc/ev_math.h, so the
+    sampled directions' sin / cos / pow agree by construction IF that header computes the same bits under gcc on the host and under clang on
+    the GPU (it uses only + - * / fma, rint and integer operations, contraction off).  Here that is evidenced on the part: evm_sincosf and
+    evm_powf run on the device (evplp_debug_ev_math) over dense grids of the callers' input ranges -- phi = 2 pi u for 2^22 values of u in
+    (0, 1] and the same number of random ones, negative and large arguments; x^y for u^(1 / (e + 1)) and cos^e with Phong exponents from 0
+    to 10 000 -- and every result is compared bit for bit with the oracle's gcc build of the same header."""
+    lib = oracle
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    u = np.concatenate([(np.arange(1, n + 1, dtype=np.float64) / n).astype(np.float32), rng.random(n, dtype=np.float32)])
+    phi = (np.float32(2.0) * np.float32(3.14159265358979323846)) * u
+    xs = np.concatenate([phi, -phi[: n // 4], rng.uniform(-8000.0, 8000.0, n // 4).astype(np.float32), np.array([0.0, 1e-30, 8191.0], np.float32)])
+    s_dev, c_dev = ctx.ev_math(0, xs)
+    s_ref = np.empty_like(xs); c_ref = np.empty_like(xs)
+    lib.evo_math_sincos_array(xs.ctypes.data, xs.size, s_ref.ctypes.data, c_ref.ctypes.data)
+    assert s_dev.tobytes() == s_ref.tobytes() and c_dev.tobytes() == c_ref.tobytes(), (int((s_dev.view(np.uint32) != s_ref.view(np.uint32)).sum()), int((c_dev.view(np.uint32) != c_ref.view(np.uint32)).sum()))
+    assert np.abs(s_dev[:n].astype(np.float64) - np.sin(phi[:n].astype(np.float64))).max() < 5e-7      # (and they ARE sines)
+    es = np.array([0.0, 0.5, 1.0, 5.0, 20.0, 100.0, 1000.0, 10000.0], np.float32)
+    m = 1 << 19
+    xp, yp = [], []
+    for e in es:
+        x = np.concatenate([(np.arange(1, m + 1, dtype=np.float64) / m).astype(np.float32), rng.random(m, dtype=np.float32)])
+        xp += [x, x]; yp += [np.full(x.size, np.float32(1.0) / (e + np.float32(1.0)), np.float32), np.full(x.size, e, np.float32)]   # sample_phong: u^(1 / (e + 1)); its pdf: cos^e
+    xp = np.concatenate(xp + [np.array([0.0, 1.0, 0.25, 1e-38, 0.3], np.float32)]); yp = np.concatenate(yp + [np.array([2.0, 77.0, 0.5, 3.0, 0.0], np.float32)])
+    p_dev = ctx.ev_math(1, xp, yp)
+    p_ref = np.empty_like(xp)
+    lib.evo_math_pow_array(xp.ctypes.data, yp.ctypes.data, xp.size, p_ref.ctypes.data)
+    assert p_dev.tobytes() == p_ref.tobytes(), int((p_dev.view(np.uint32) != p_ref.view(np.uint32)).sum())
+    ok = p_ref > 1e-30
+    assert np.abs(p_dev[ok].astype(np.float64) / np.power(xp[ok].astype(np.float64), yp[ok].astype(np.float64)) - 1.0).max() < 2e-7
+
+
 def test_light_image_flags(room, oscene, evplp):
     """rtcomphoton.h:985-995: run.lightRender = false leaves the light image alone; cleareveryframe clears the depth buffer the
     light pass shares with the deferred pass, so the emitter is drawn without a depth test."""
@@ -151,7 +184,9 @@ def test_light_tracing_records(ctx, oscene, evplp):
     used = ref["flags"] != 0
     assert used.sum() > NPATHS
     # the feeders are compiled without contraction and sample directions with the shared ev_math.h: every field of every
-    # record is the oracle's, bit for bit
+    # record is the oracle's, bit for bit.  (The oracle #includes that header, so for sin / cos / pow of the sampled directions this
+    # equality holds by construction -- it vouches for the walk and the draw order; the header's own bits on the device are checked by
+    # test_direction_sampling_functions_give_the_oracles_bits_on_the_device below.)
     assert got.tobytes() == ref.tobytes()
     # a sliced trace (multi-GPU: each rank a range of paths) writes the same records
     ctx.upload(evplp.BUF_RECORDS, np.zeros_like(got))
