@@ -430,7 +430,7 @@ int evplp_group_block_owners(evplp_group *g, int32_t *owner_rank, int32_t capaci
  * primary rays, gathers, photon splat, path tracer), treats it as spread evenly over the rank's rows, and moves the band boundaries (multiples
  * of 16 rows, within the bands' capacity of twice the equal share) to where every rank would have had the same cost.  The accumulators are
  * cleared and the G-buffers are stale afterwards: call it after one or two calibration frames, before an accumulating run (the technique
- * loop does).  band_first_rows: optional, n_ranks + 1 ints, the boundaries it chose (zeros for strips).  A single rank: nothing to do,
+ * loops always run on strips: the bands are an option of this API, not of evplp_render_json).  band_first_rows: optional, n_ranks + 1 ints, the boundaries it chose (zeros for strips).  A single rank: nothing to do,
  * EVPLP_OK.  Bands without a timed pass since the last rebalance (evplp_profile_passes off): EVPLP_ERR_INVALID, nothing changes. */
 int evplp_group_rebalance(evplp_group *g, int32_t *band_first_rows);
 /* Host time of rank `rank`'s worker so far, in ms: out[0] inside its rank's pass calls (enqueueing; waits for a splat's verdict included),

@@ -154,6 +154,69 @@ def test_vsl_rng_known_answers_and_statistics(oracle):
     assert ps.min() > 1e-4 and ps.max() < 1.0 - 1e-4, (ps.min(), ps.max())
 
 
+def test_vsl_rng_three_way_dependence_is_confined_to_the_low_bits(oracle):
+    """ADVICE (round 5): the estimators read the RAW xoroshiro64 state -- no * / ** scrambler -- so consecutive samples are linear images of each
+    other: s1' = rotl(s0 ^ s1, 13) exactly.  In terms of the 24-bit uniforms (ua, ub) = (s0 >> 8, s1 >> 8): the top 11 bits of the NEXT ub
+    are the LOW 11 bits of ua XOR ub -- a three-way relation no pairwise test sees.  This test states it as a known answer, and then shows
+    what the estimators need: at the resolution an integrand can see (the top bits), triples of consecutive draws are jointly uniform
+    (three-dimensional chi-square, 32^3 cells), and smooth functions of (ua_n, ub_n, ub_n+1) / (ua_n, ub_n, ua_n+1) average to the
+    product of their means within four standard errors.  The low bits of a uniform place a sample within 2^-13 of where its high bits put
+    it; what they decide downstream is the NEXT sample's position, as a hash of bits the current sample's geometry does not depend on."""
+    from scipy import stats
+    U = np.uint64
+    M32 = U(0xFFFFFFFF)
+
+    def sm(x):
+        with np.errstate(over="ignore"):
+            x = x + U(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> U(30))) * U(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> U(27))) * U(0x94D049BB133111EB)
+            return x ^ (x >> U(31))
+    rotl = lambda x, k: ((x << U(k)) | (x >> U(32 - k))) & M32
+
+    def seed(pix, sub, seq=1):
+        with np.errstate(over="ignore"):
+            pk, rk = sm((U(seq) << U(32)) | pix.astype(U)), sm(sub.astype(U) * U(0xD1B54A32D192ED03))
+        a, b = (pk ^ rk) & M32, ((pk >> U(32)) ^ (rk >> U(32))) & M32
+        t = a * (b | U(1))
+        return (t & M32) ^ b, ((t >> U(32)) ^ a) | U(0x80000000)
+
+    def step(s0, s1):
+        t = s1 ^ s0
+        return rotl(s0, 26) ^ t ^ ((t << U(9)) & M32), rotl(t, 13)
+    s0, s1 = seed(np.arange(768)[:, None], np.arange(1, 769)[None, :])
+    s0, s1 = np.ascontiguousarray(np.broadcast_to(s0, (768, 768))).ravel(), np.ascontiguousarray(np.broadcast_to(s1, (768, 768))).ravel()
+    assert (int(s0[5 * 768 + 8]), int(s1[5 * 768 + 8])) != (0, 0)
+    # the vectorised restatement is the oracle's generator
+    r = oa.Rng(); oracle.evo_vsl_rng_init(C.byref(r), 5, 1, 9); oracle.evo_vsl_rng_step(C.byref(r))
+    t0, t1 = step(s0[5 * 768 + 8:5 * 768 + 9], s1[5 * 768 + 8:5 * 768 + 9])
+    assert (r.s0, r.s1) == (int(t0[0]), int(t1[0]))
+    ps, zs = [], []
+    uni = lambda w: ((w >> U(8)).astype(np.float64) + 1.0) / 16777216.0
+    s0, s1 = step(s0, s1)
+    for _ in range(6):
+        n0, n1 = step(s0, s1)
+        ia, ib, ib2 = s0 >> U(8), s1 >> U(8), n1 >> U(8)
+        # the known answer: top 11 bits of the next ub = low 11 bits of (ua ^ ub)
+        assert np.array_equal(ib2 >> U(13), (ia ^ ib) & U(0x7FF))
+        a, b, a2, b2 = uni(s0), uni(s1), uni(n0), uni(n1)
+        for x, y, z in ((a, b, b2), (a, b, a2), (b, a2, b2)):
+            cell = ((x * 32).astype(np.int64).clip(0, 31) * 32 + (y * 32).astype(np.int64).clip(0, 31)) * 32 + (z * 32).astype(np.int64).clip(0, 31)
+            h = np.bincount(cell, minlength=32 ** 3)
+            e = x.size / 32 ** 3
+            ps.append(stats.chi2.sf(((h - e) ** 2 / e).sum(), 32 ** 3 - 1))
+            # smooth three-way statistics: E[f(x) g(y) h(z)] against E f E g E h (independent uniforms: cos(2 pi k u) has mean 0, variance 1/2)
+            for kx, ky, kz in ((1, 1, 1), (1, 2, 3), (3, 1, 2), (5, 7, 11)):
+                v = np.cos(2 * np.pi * kx * x) * np.cos(2 * np.pi * ky * y) * np.cos(2 * np.pi * kz * z)
+                zs.append(v.mean() / (np.sqrt(0.125) / np.sqrt(v.size)))
+            v = (x - 0.5) * (y - 0.5) * (z - 0.5)
+            zs.append(v.mean() / ((1.0 / 12.0) ** 1.5 / np.sqrt(v.size)))
+        s0, s1 = n0, n1
+    ps, zs = np.array(ps), np.array(zs)
+    assert ps.min() > 1e-4 and ps.max() < 1.0 - 1e-4, (ps.min(), ps.max())          # 18 three-dimensional tests on fixed inputs: a known answer
+    assert np.abs(zs).max() < 4.5, np.abs(zs).max()                                 # 90 z-scores
+
+
 def test_bvh_matches_brute_force(room_scene, oracle):
     room, s = room_scene
     rng = np.random.RandomState(4)
