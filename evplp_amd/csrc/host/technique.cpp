@@ -54,7 +54,15 @@ void check(evplp_group *g, int rc, const char *what) {
 //   "exchangeEvery": k -- the strips are all-gathered (every GPU holds the frame) in every k-th iteration's composite; 0 = never inside the
 //           loop.  Default 1: what the reference's per-iteration runFinalProgram to the window amounts to (rtcomphoton.h:997-1004).  The
 //           frames that are WRITTEN (:1079-1102, 1124-1132) always exchange.  Results do not depend on it.
-struct RunOptions { int deal = -1; int exchange_every = 1; };       // deal: -1 default, 0 round robin, 1 by cost
+//   "partition": "strips" | "iterations" -- what the N GPUs share out.  "strips" (default): the image, as above.  "iterations" (round 6; the
+//           photonfam techniques in accumulate mode): the ITERATIONS of the progressive run -- GPU g renders iterations g, g + N, g + 2N, ... of
+//           the whole image on a context of its own (each has its own seed, jitter and radius: rtcomphoton.h:936-1063 makes an iteration
+//           depend on its number only), nothing is exchanged while the loop runs, and the accumulators are summed -- in rank order, on the
+//           host -- whenever a frame is written.  N times the iterations per second with no replicated work and nothing to balance; a single
+//           iteration is no faster, every GPU holds whole-image buffers, and the sums are associated differently from one GPU's (images agree
+//           to fp32 round-off, ~1e-7, not bit for bit).  What config #4 wants: its iteration is two latency-bound walks that row strips cannot
+//           shorten.
+struct RunOptions { int deal = -1; int exchange_every = 1; bool shard_iterations = false; };       // deal: -1 default, 0 round robin, 1 by cost
 RunOptions run_options(const Json &json) {
     RunOptions o;
     if (!json.has("device")) return o;
@@ -63,10 +71,15 @@ RunOptions run_options(const Json &json) {
         const std::string v = d.at("deal").as_string("device.deal");
         if (v == "cost") o.deal = 1; else if (v == "roundRobin") o.deal = 0; else throw JsonError("device.deal: \"cost\" or \"roundRobin\"");
     }
+    if (d.has("partition")) {
+        const std::string v = d.at("partition").as_string("device.partition");
+        if (v == "iterations") o.shard_iterations = true; else if (v != "strips") throw JsonError("device.partition: \"strips\" or \"iterations\"");
+    }
     if (d.has("exchangeEvery")) { o.exchange_every = (int)d.at("exchangeEvery").as_int("device.exchangeEvery"); if (o.exchange_every < 0) throw JsonError("device.exchangeEvery: must be >= 0"); }
     return o;
 }
-void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int device) {
+// shard >= 0: the group of ONE rank that renders the iterations of shard `shard` ("partition": "iterations"): device + shard, or `device` when virtual
+void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int device, int shard = -1) {
     evplp_group_config gc; std::memset(&gc, 0, sizeof(gc));
     gc.n_ranks = 1; gc.strip_rows = 0;      // (0: the group's default, 16-row strips)
     bool virt = false;
@@ -80,11 +93,18 @@ void create_group(Grp &grp, const evplp_config &cfg, const Json &json, int devic
         if (d.has("splitLightPaths")) gc.split_light_paths = d.at("splitLightPaths").as_bool("device.splitLightPaths") ? 1 : -1;   // (absent: the library's cost model)
     }
     if (gc.n_ranks < 1 || gc.n_ranks > 64) throw JsonError("device.gpus: must be 1..64");
+    if (shard >= 0) { device = virt ? device : device + shard; gc.n_ranks = 1; }
     std::vector<int32_t> devs((size_t)gc.n_ranks);
     for (int r = 0; r < gc.n_ranks; r++) devs[(size_t)r] = virt ? device : device + r;
     gc.devices = devs.data();
     int rc = evplp_group_create(&cfg, &gc, &grp.g);
     if (rc < 0) throw std::runtime_error(std::string("evplp_group_create: ") + evplp_group_last_error(nullptr));
+}
+int device_gpus(const Json &json) {
+    if (!json.has("device") || !json.at("device").has("gpus")) return 1;
+    const int n = (int)json.at("device").at("gpus").as_int("device.gpus");
+    if (n < 1 || n > 64) throw JsonError("device.gpus: must be 1..64");
+    return n;
 }
 void upload_scene_group(evplp_group *g, const HostScene &scene) {
     for (int r = 0; r < evplp_group_size(g); r++) {
@@ -318,10 +338,22 @@ public:
             if (d.has("cutScratchGB")) cfg.cut_scratch_bytes = (uint64_t)(std::max(d.at("cutScratchGB").as_float("device.cutScratchGB"), 0.0f) * 1073741824.0);
             if (d.has("vslMaskGB")) cfg.vsl_mask_bytes = (uint64_t)(std::max(d.at("vslMaskGB").as_float("device.vslMaskGB"), 0.0f) * 1073741824.0);
         }
-        Grp grp; create_group(grp, cfg, json, device);
         run_opts = run_options(json);
-        upload_scene_group(grp.g, scene);
-        splat_footprint = setup_splat_footprint(grp.g, json, out_dir);                                          // :677
+        const int gpus = device_gpus(json);
+        if (run_opts.shard_iterations && (frame_mode != 1 || gpus < 2)) {
+            if (gpus >= 2) std::printf("note: device.partition \"iterations\" needs frameMode \"accumulate\"; running on row strips\n");
+            run_opts.shard_iterations = false;
+        }
+        // one group of N strip ranks -- or N groups of one whole-image rank each, one per shard of the iterations
+        std::vector<Grp> grps((size_t)(run_opts.shard_iterations ? gpus : 1));
+        std::vector<evplp_group *> hs;
+        for (size_t k = 0; k < grps.size(); k++) {
+            create_group(grps[k], cfg, json, device, run_opts.shard_iterations ? (int)k : -1);
+            upload_scene_group(grps[k].g, scene);
+            splat_footprint = setup_splat_footprint(grps[k].g, json, out_dir);                                  // :677
+            hs.push_back(grps[k].g);
+        }
+        Grp &grp = grps[0];
         float bsr = 0.f, total_area = 0.f, light_area = 0.f;
         { evplp_context *h0 = evplp_group_context(grp.g, 0);
           if (evplp_scene_metrics(h0, &bsr, &total_area, &light_area) < 0) throw std::runtime_error(std::string("scene metrics: ") + evplp_last_error(h0)); }
@@ -338,7 +370,7 @@ public:
             if (vsl_radius <= 0.008f) { vsl_radius = std::max(vsl_radius, 0.008f); std::printf("warning : vslRadius is too small. clamped vslRadius\n"); }
             vsl_inv_pi_radius2 = kInvPi / (vsl_radius * vsl_radius);
         }
-        run(grp.g, scene, res_x, res_y);
+        run(hs, scene, res_x, res_y);
     }
 
 private:
@@ -356,15 +388,19 @@ private:
     }
 
     // rtcomphoton.h:883-1133
-    void run(evplp_group *h, const HostScene &scene, int W, int H) {
+    // hs: ONE group (of one or more strip ranks), or one single-rank group per shard of the iterations (RunOptions::shard_iterations)
+    void run(const std::vector<evplp_group *> &hs, const HostScene &scene, int W, int H) {
         JitterSampler sampler(rng_offset);
-        check(h, evplp_group_clear_accumulators(h), "clear");
+        evplp_group *h = hs[0];
+        const int S = (int)hs.size();
+        auto all = [&](int (*fn)(evplp_group *), const char *what) { for (evplp_group *q : hs) check(q, fn(q), what); };
+        all(evplp_group_clear_accumulators, "clear");
         int num_iterations = 0;
         auto t0 = std::chrono::steady_clock::now();
         // Row blocks dealt by cost (RunOptions above): one frame of the first iteration's light paths and gather with the self-clocking
         // kernels, un-jittered, then the deal.  Nothing of it reaches the images: the rebalance clears the accumulators, the loop below traces
         // the same light paths again, the jitter sequence and the progressive state have not moved.  Its time is part of the run's.
-        const bool can_deal = evplp_group_size(h) > 1 && do_vpl_splat && !lvc && do_deferred && do_light_tracing;
+        const bool can_deal = S == 1 && evplp_group_size(h) > 1 && do_vpl_splat && !lvc && do_deferred && do_light_tracing;
         if (can_deal && (run_opts.deal == 1 || (run_opts.deal < 0 && num_max_iteration >= 4))) {
             float j0[2] = { 0.f, 0.f };
             evplp_frame_params fp = params(scene, rng_offset, j0);
@@ -380,10 +416,11 @@ private:
         // The two events per pass behind the stat file's pass times cost a sub-millisecond iteration ~3 % (evplp_profile_passes): a loop
         // that ends by iteration count records them in its last iteration only; one with a time limit (it waits for every frame anyway) always.
         const bool always_profile = time_limit_ms < 1e8f;
-        check(h, evplp_group_profile_passes(h, always_profile ? 1 : 0), "profile");
+        for (evplp_group *q : hs) check(q, evplp_group_profile_passes(q, always_profile ? 1 : 0), "profile");
         for (;;) {
             if (num_iterations == num_max_iteration) break;                                   // :938-941
-            if (!always_profile && num_iterations + 1 == num_max_iteration) check(h, evplp_group_profile_passes(h, 1), "profile");
+            h = hs[(size_t)(num_iterations % S)];                                             // (this iteration's shard; S = 1: the one group)
+            if (!always_profile && num_iterations + S >= num_max_iteration) check(h, evplp_group_profile_passes(h, 1), "profile");   // (every shard's last iteration)
             float jitter[2] = { 0.f, 0.f };
             if (use_jitter) sampler.next_jitter(W, H, jitter);                                // :946-952
             evplp_frame_params fp = params(scene, (uint32_t)num_iterations + rng_offset, jitter);
@@ -402,13 +439,13 @@ private:
             // [finalize] runFinalProgram(param, param, 1, true) to the window (:997-1004): headless, the composite still runs -- it is part
             // of the reference's iteration -- and stays on the device
             if (do_finalize) {
-                const float param = frame_mode == 2 ? 1.0f : 1.0f / (float)(num_iterations + 1);
+                const float param = frame_mode == 2 ? 1.0f : 1.0f / (float)(num_iterations / S + 1);      // (a shard's own frame: over ITS iterations so far)
                 const bool exchange = run_opts.exchange_every > 0 && (num_iterations + 1) % run_opts.exchange_every == 0;
                 check(h, evplp_group_present_ex(h, param, param, 1.0f, 1, 1, exchange ? 1 : 0), "finalize");       // (doGammaCorrection = true, :1003)
             }
             num_iterations++;
             if (num_iterations % 20 == 0) {                                                   // :1008-1031
-                check(h, evplp_group_synchronize(h), "sync");
+                all(evplp_group_synchronize, "sync");
                 float cur = elapsed_ms();
                 std::printf("numIter: %d | raduis: %g | clamping: %g | timing: %g\n", num_iterations, photon_radius, clamping_value, cur - prev_timing);
                 if (target_rendering_time != -1.f) {
@@ -420,13 +457,14 @@ private:
             if (do_progressive)                                                               // :1033-1063
                 evplp_progressive_step(num_iterations, alpha_progressive, clamping_start, (uint32_t)num_vpl_light_paths, (uint32_t)num_light_paths,
                                        &photon_radius, &clamping_value, &pdf_mc, force_vsl ? 1 : 0, &vsl_radius, &vsl_inv_pi_radius2);
-            if (write_every_frame) dump_frame(h, W, H, num_iterations, rgb);                  // :1079-1102
-            if (time_limit_ms < 1e8f) check(h, evplp_group_synchronize(h), "sync");           // a wall-clock limit needs finished frames
+            if (write_every_frame) dump_frame(hs, W, H, num_iterations, rgb);                 // :1079-1102
+            if (time_limit_ms < 1e8f) all(evplp_group_synchronize, "sync");                   // a wall-clock limit needs finished frames
             if (elapsed_ms() >= time_limit_ms) break;                                         // :1065
         }
-        check(h, evplp_group_synchronize(h), "sync");
+        all(evplp_group_synchronize, "sync");
         float time = elapsed_ms();
-        check(h, evplp_group_profile_passes(h, 1), "profile");
+        for (evplp_group *q : hs) check(q, evplp_group_profile_passes(q, 1), "profile");
+        h = hs[0];
         if (use_stat) {                                                                       // :1109-1119
             Json st = Json::object();
             st.set("time", Json::number(time));
@@ -438,6 +476,7 @@ private:
         }
         float param = frame_mode == 2 ? 1.0f : 1.0f / (float)std::max(num_iterations, 1);     // :1122
         // :1124-1132: three composites, un-masked sums, FlipY, Save
+        ShardSum sum(hs);                                    // (S > 1: shard 0's accumulators now hold the sum over the shards)
         auto compose = [&](float vs, float ps, float ls) {
             check(h, evplp_group_resolve(h, vs, ps, ls, 0, 0, rgb.data()), "resolve");
             return flip_y(rgb, W, H);
@@ -450,8 +489,40 @@ private:
         if (save_image(weighted_photon_filename.c_str(), W, H, pm.data()) != EVPLP_OK) throw std::runtime_error("cannot write " + weighted_photon_filename);
     }
 
-    void dump_frame(evplp_group *h, int W, int H, int iter, std::vector<float> &rgb) {
+    // Iterations sharded over several contexts: a written frame needs the SUM of the shards' VPL and photon accumulators.  They are brought to
+    // the host, added in shard order (a fixed association: the same run gives the same bits again) and put into shard 0's buffers, whose own
+    // contents come back when this object goes (the run may go on accumulating).  The emitter image is the same on every shard: the light
+    // mesh is drawn through the un-jittered matrix (rtcomphoton.h:720-727), every iteration writes the same pixels.
+    struct ShardSum {
+        const std::vector<evplp_group *> &hs; std::vector<std::vector<float>> own;
+        explicit ShardSum(const std::vector<evplp_group *> &shards) : hs(shards) {
+            if (hs.size() < 2) return;
+            static const int kPlanes[2] = { EVPLP_BUF_VPL_ACCUM, EVPLP_BUF_PHOTON_ACCUM };
+            for (evplp_group *q : hs) check(q, evplp_group_synchronize(q), "sync");
+            for (int k = 0; k < 2; k++) {
+                evplp_context *c0 = evplp_group_context(hs[0], 0);
+                size_t bytes = 0;
+                if (evplp_buffer_info(c0, kPlanes[k], nullptr, &bytes) < 0) throw std::runtime_error(std::string("accumulator size: ") + evplp_last_error(c0));
+                std::vector<float> acc(bytes / sizeof(float)), part(bytes / sizeof(float));
+                if (evplp_download(c0, kPlanes[k], acc.data(), bytes) < 0) throw std::runtime_error(std::string("accumulator download: ") + evplp_last_error(c0));
+                own.push_back(acc);
+                for (size_t r = 1; r < hs.size(); r++) {
+                    evplp_context *c = evplp_group_context(hs[r], 0);
+                    if (evplp_download(c, kPlanes[k], part.data(), bytes) < 0) throw std::runtime_error(std::string("accumulator download: ") + evplp_last_error(c));
+                    for (size_t i = 0; i < acc.size(); i++) acc[i] += part[i];
+                }
+                if (evplp_upload(c0, kPlanes[k], acc.data(), bytes) < 0) throw std::runtime_error(std::string("accumulator upload: ") + evplp_last_error(c0));
+            }
+        }
+        ~ShardSum() {
+            static const int kPlanes[2] = { EVPLP_BUF_VPL_ACCUM, EVPLP_BUF_PHOTON_ACCUM };
+            for (size_t k = 0; k < own.size(); k++) evplp_upload(evplp_group_context(hs[0], 0), kPlanes[k], own[k].data(), own[k].size() * sizeof(float));
+        }
+    };
+    void dump_frame(const std::vector<evplp_group *> &hs, int W, int H, int iter, std::vector<float> &rgb) {
         float param = frame_mode == 2 ? 1.0f : 1.0f / (float)iter;                            // :1088
+        ShardSum sum(hs);
+        evplp_group *h = hs[0];
         check(h, evplp_group_resolve(h, param, param, 1.0f, 0, 0, rgb.data()), "resolve");
         std::vector<float> top = flip_y(rgb, W, H);
         size_t i = weighted_photon_filename.find_last_of('.');                                // :1097-1101

@@ -508,7 +508,11 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
  * single rank goes through RCCL too; "deal": row blocks dealt by the cost a calibration frame clocks -- the default from two ranks and four
  * iterations on -- or block b to rank b % N; "exchangeEvery": the strips are all-gathered in every k-th iteration's composite, 0 = only for
  * the frames that are written, default 1; "splitLightPaths": evplp_group_config.split_light_paths, absent = the cost model; "cutScratchGB" /
- * "vslMaskGB": evplp_config.cut_scratch_bytes / vsl_mask_bytes). */
+ * "vslMaskGB": evplp_config.cut_scratch_bytes / vsl_mask_bytes).
+ * "device": {"gpus": N, "partition": "iterations"} (photonfam / lvcphotonfam, frameMode accumulate): the N GPUs share out the ITERATIONS of the
+ * progressive run instead of the image -- GPU g renders iterations g, g + N, ... of the whole frame on a context of its own, nothing is
+ * exchanged inside the loop, the accumulators are summed (rank order, on the host) when a frame is written.  N times the iterations per second
+ * with no replicated work; images agree with one GPU's to fp32 round-off (the sums are associated differently), not bit for bit. */
 int evplp_render_json(const char *json_path, const char *json_overrides, int32_t device, char *err, size_t err_cap);
 
 #ifdef __cplusplus

@@ -259,6 +259,35 @@ def test_render_json_on_a_group_of_virtual_ranks(evplp, tmp_path):
         assert outs[name] == outs["1"], name
 
 
+def test_render_json_with_the_iterations_shared_out(evplp, tmp_path):
+    """"device": {"gpus": N, "partition": "iterations"}: every GPU renders every N-th iteration of the whole frame on a context of its own and the
+    accumulators are summed when a frame is written.  The result is the one-GPU run's up to the association of the sums (fp32 round-off: 1e-6
+    relative L2, a few ulps per pixel), is reproducible bit for bit, and the per-iteration dumps (writeEveryFrame) follow the same rule."""
+    outs = {}
+    variants = {"1": dict(gpus=1), "3 shards": dict(gpus=3, virtual=True, partition="iterations"), "3 shards again": dict(gpus=3, virtual=True, partition="iterations"),
+                "2 shards": dict(gpus=2, virtual=True, partition="iterations")}
+    for k, (name, dev) in enumerate(variants.items()):
+        d = tmp_path / f"v{k}"; d.mkdir()
+        jp = evplp.synth_scene(str(d), "room", 3000, 3, 80, 56, style="hard")
+        root = json.load(open(jp))
+        root["photonfam"].update(numMaxIteration=7, numLightPaths=2000, numVplLightPaths=40, radiusPercentage=0.05, misMode="balance", DoProgressive=True,
+                                 deterministic=True, device=dev, combinedFilename="c.pfm", weightedPhotonFilename="pm.pfm", writeEveryFrame=True,
+                                 weightedVplFilename="vpl.pfm", statFilename="s.json", run=dict(photonSplat=True))
+        json.dump(root, open(jp, "w"))
+        evplp.render_json(jp)
+        outs[name] = {f: evplp.load_pfm(str(d / f)) for f in ("c.pfm", "pm.pfm", "vpl.pfm", "pm_3.pfm", "pm_7.pfm")}
+        assert json.load(open(d / "s.json"))["numIterations"] == 7
+    for f, ref in outs["1"].items():
+        assert ref.max() > 0, f
+        for name in ("3 shards", "2 shards"):
+            img = outs[name][f]
+            rel = np.linalg.norm(img.astype(np.float64) - ref) / np.linalg.norm(ref)
+            assert rel < 1e-6, (name, f, rel)
+            assert np.abs(img - ref).max() <= 4e-6 * max(float(ref.max()), 1.0), (name, f)
+        assert outs["3 shards"][f].tobytes() == outs["3 shards again"][f].tobytes(), f
+    assert any(outs["3 shards"][f].tobytes() != outs["1"][f].tobytes() for f in outs["1"]) or True      # (equal bits would be a coincidence, not a requirement)
+
+
 def test_group_errors_are_reported(evplp):
     with pytest.raises(evplp.EvplpError) as e:
         evplp.Group(16, 16, 4, 4, 2, 2, devices=[0, 0], use_rccl=True)

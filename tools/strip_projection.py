@@ -23,6 +23,7 @@ ap.add_argument("--rows", default="8,16")
 ap.add_argument("--n", default="")
 ap.add_argument("--deals", default="roundRobin,cost")
 ap.add_argument("--capacity-pct", type=int, default=150)
+ap.add_argument("--rounds", type=int, default=1, help="calibrate + deal this many times (every round clocks the blocks under the previous round's deal)")
 ap.add_argument("--split-light-paths", default="auto", choices=["auto", "on", "off"], help="as evplp_group_config.split_light_paths (auto: evplp_group_split_model)")
 args = ap.parse_args()
 P = 4
@@ -132,6 +133,9 @@ for name in args.configs.split(","):
                 cal = dict(cfg); cal["frames"] = 2
                 cost = sum(run_rank(cal, n, rows, r, calibrate=True, cap_rows=cap * rows)[1] for r in range(n))
                 owner = ev.deal_blocks(cost, n, cap)
+                for _ in range(args.rounds - 1):      # again, under the deal just made
+                    cost = sum(run_rank(cal, n, rows, r, blocks=strips.blocks_of_rank(owner, r, cost), calibrate=True, cap_rows=cap * rows)[1] for r in range(n))
+                    owner = ev.deal_blocks(cost, n, cap)
                 dealt = [run_rank(cfg, n, rows, r, blocks=strips.blocks_of_rank(owner, r, cost), cap_rows=cap * rows)[0] for r in range(n)]
                 rec = partition_record(n, rows, "cost", dealt, base_sum, owner)
                 rec["block_cost_ticks"] = [int(v) for v in cost]
