@@ -30,10 +30,13 @@ N GPUs, two front ends (--front-end auto picks `group` whenever the process sees
         `python bench.py --gpus N --front-end ranks` starts the N rank processes itself (before anything touches a GPU) and relays
         rank 0's JSON line.  EVPLP_BENCH_BACKEND=gloo stages the collectives through the host and lets the ranks share GPUs (rank r
         uses device r mod #devices): the N > 1 logic with the real kernels on a one-GPU box.
-Either way the image is cut into interleaved 16-row strips (rank r owns row blocks b with b % N == r); the scene and the BVH are
-replicated; large light-path sets are traced 1/N per rank and shared by an all-gather of the record buffer, small ones are traced
-redundantly; each rank gathers / splats its own pixels; the framebuffer strips are all-gathered every frame.  Total work is
-fixed ("scaling": "strong").
+Either way the image is cut into interleaved blocks of 16 rows; the scene and the BVH are replicated; the light paths are traced by
+every rank (same seed, identical records) unless the library's cost model expects 1/N per rank + an all-gather of the record buffer to be
+faster (--split-light-paths); each rank gathers / splats its own pixels; the framebuffer strips are all-gathered every frame
+(--exchange-every k: every k-th).  (round 6) --deal cost (the default where the workload has a gather): one calibration frame in front
+of the warm-up in which the gathers clock their blocks, then the blocks are dealt by cost -- evplp_group_rebalance, or, with one process
+per GPU, evplp_block_costs + an all-reduce of the per-block costs + evplp_deal_blocks in every process -- and every rank launches its most
+expensive blocks first; --deal roundRobin: block b to rank b % N.  Total work is fixed ("scaling": "strong").
 
 Path = one evaluated light-transport sample: gather -> one (pixel, usable VPL record) pair
 that passes the cosine test and traces its shadow ray; splat -> one (photon, covered pixel) pair.
