@@ -127,58 +127,3 @@ extern "C" double evplp_image_rel_mse(int32_t npix, const float *a, const float 
     return result / (float)npix;
 }
 
-// The deal of row blocks by cost (include/evplp.h; SURVEY 8e "row strips are load-imbalanced").  Longest-processing-time-first, then
-// pairwise improvement between the fullest rank and every other one (move a block, or swap two) until the largest load stops falling.
-// Deterministic: ties go to the lower block index / lower rank, so every process of a multi-process run arrives at the same table.
-extern "C" int evplp_deal_blocks(const uint64_t *cost, int32_t nblocks, int32_t nranks, int32_t cap, int32_t *owner) {
-    if (!cost || !owner || nblocks < 0 || nranks < 1 || cap < 0 || (int64_t)nranks * cap < nblocks) return EVPLP_ERR_INVALID;
-    std::vector<int32_t> order((size_t)nblocks);
-    for (int b = 0; b < nblocks; b++) order[(size_t)b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
-    std::vector<uint64_t> load((size_t)nranks, 0); std::vector<int32_t> count((size_t)nranks, 0);
-    for (int32_t b : order) {
-        int best = -1;
-        for (int r = 0; r < nranks; r++) if (count[(size_t)r] < cap && (best < 0 || load[(size_t)r] < load[(size_t)best])) best = r;
-        owner[b] = best; load[(size_t)best] += cost[b]; count[(size_t)best]++;
-    }
-    for (int pass = 0; pass < 4 * nblocks + 16; pass++) {
-        int hi = 0;
-        for (int r = 1; r < nranks; r++) if (load[(size_t)r] > load[(size_t)hi]) hi = r;
-        // the best single move or swap between `hi` and another rank: the one that leaves the smaller of the pair's two new maxima
-        uint64_t best_max = load[(size_t)hi]; int best_a = -1, best_b = -1, best_r = -1;
-        for (int a = 0; a < nblocks; a++) {
-            if (owner[a] != hi) continue;
-            for (int r = 0; r < nranks; r++) {
-                if (r == hi) continue;
-                if (count[(size_t)r] < cap) {       // move a -> r
-                    const uint64_t m = std::max(load[(size_t)hi] - cost[a], load[(size_t)r] + cost[a]);
-                    if (m < best_max) { best_max = m; best_a = a; best_b = -1; best_r = r; }
-                }
-            }
-            for (int b = 0; b < nblocks; b++) {   // swap a <-> b
-                const int r = owner[b];
-                if (r == hi || cost[b] >= cost[a]) continue;
-                const uint64_t m = std::max(load[(size_t)hi] - cost[a] + cost[b], load[(size_t)r] + cost[a] - cost[b]);
-                if (m < best_max) { best_max = m; best_a = a; best_b = b; best_r = r; }
-            }
-        }
-        if (best_a < 0) break;
-        owner[best_a] = best_r; load[(size_t)hi] -= cost[best_a]; load[(size_t)best_r] += cost[best_a];
-        if (best_b >= 0) { owner[best_b] = hi; load[(size_t)hi] += cost[best_b]; load[(size_t)best_r] -= cost[best_b]; }
-        else { count[(size_t)hi]--; count[(size_t)best_r]++; }
-    }
-    return EVPLP_OK;
-}
-
-// The order in which a rank STORES the blocks a deal gave it -- and therefore the order in which its kernels launch them: the most expensive
-// first.  A strip's gather is a small launch (6-10 ms at eight ranks) whose longest items -- the tiles on depth discontinuities, 2.7-4 ms each
-// against a median of 0.1 ms -- sit in the middle of the image: launched in image order they start 4 ms in and the GPU drains for 1-1.5 ms
-// behind them (tools/gather_times.py); launched first they are done long before the cheap blocks run out.  Ties by block index.
-extern "C" int evplp_rank_blocks(const uint64_t *cost, const int32_t *owner, int32_t nblocks, int32_t rank, int32_t *out_blocks, int32_t capacity) {
-    if (!owner || nblocks < 0) return EVPLP_ERR_INVALID;
-    std::vector<int32_t> mine;
-    for (int b = 0; b < nblocks; b++) if (owner[b] == rank) mine.push_back(b);
-    if (cost) std::stable_sort(mine.begin(), mine.end(), [&](int32_t x, int32_t y) { return cost[x] > cost[y]; });
-    for (size_t i = 0; i < mine.size() && out_blocks && (int32_t)i < capacity; i++) out_blocks[i] = mine[i];
-    return (int)mine.size();
-}

@@ -99,6 +99,22 @@ def test_readers_survive_mutated_files_under_asan_and_ubsan(harness, rng_seed):
     assert decoded >= len([f for f in os.listdir(seeds) if f.endswith((".jpg", ".png"))]), line
 
 
+def test_block_deal_under_asan_and_ubsan(tmp_path):
+    """evplp_deal_blocks / evplp_rank_blocks (csrc/host/deal.cpp; round 6) on 6 000 random cost tables -- equal costs, zeros, costs up to 2^64,
+    no blocks, capacities that just fit and that do not -- under ASan + UBSan, every deal checked for its invariants (one owner per block, nobody
+    over capacity, never worse than round robin by its own measure, a rank's blocks listed in falling cost)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "deal_fuzz")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+           os.path.join(ROOT, "tools", "host_fuzz", "deal_fuzz.cpp"), os.path.join(HOST, "deal.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for seed in ("5", "77"):
+        r = subprocess.run([exe, "3000", seed], capture_output=True, text=True, timeout=600, env=dict(os.environ, UBSAN_OPTIONS="print_stacktrace=1"))
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_jpeg_refusals_found_by_the_harness(tmp_path):
     """The two refusals decode_jpeg.cpp makes beyond the reference's stb_image v2.16 (round 5): sampling factors that are not integer
     ratios (its resamplers -- and ours -- would read past the end of a component's plane) and a frame header asking for more pixels
