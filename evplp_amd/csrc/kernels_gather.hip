@@ -505,7 +505,10 @@ __global__ __launch_bounds__(64, EVPLP_LVC_WAVES) void gather_lvc_kernel(GatherA
     int32_t *stack = lds_stack + lane;
 
     Rng rng; rng_init(rng, (uint32_t)y * (uint32_t)a.st.W + (uint32_t)x, a.fp.rng_seed, 0x4c564300u);   // :369-370
-    const uint32_t offset = (uint32_t)(fminf(rng_uniform(rng), 0.999999f) * (float)a.fp.num_light_paths);  // :372
+#ifndef EVPLP_LVC_NO_OFFSET
+#define EVPLP_LVC_NO_OFFSET 0     // developer probe (tools/quick_bench.py --lvc, round 6): every pixel's window starts at path 0, so that the lanes of a wave walk towards the SAME record at the same time -- the per-lane walk on the packet walk's own ray population
+#endif
+    const uint32_t offset = EVPLP_LVC_NO_OFFSET ? 0u : (uint32_t)(fminf(rng_uniform(rng), 0.999999f) * (float)a.fp.num_light_paths);  // :372
     V3 result = v3(0.f, 0.f, 0.f);
     unsigned long long rays = 0, pairs = 0;
     for (uint32_t i = 0; i < a.fp.num_vpl_light_paths; i++) {

@@ -313,6 +313,112 @@ int main(int argc, char **argv) {
         return 0;
     }
 
+    if (mode == 5) {
+        // (round 6) PACKET OR PER-LANE?  The packet walk visits the UNION of what its 64 segments touch; the walks that cost the most (tiles on
+        // silhouettes: per-wave clocks show items 30 x the median) may be expensive because that union is large while every single segment
+        // touches little -- the case in which a per-lane walk (one ray per lane, lockstep: the wave pays the LONGEST lane) would be cheaper.
+        // For random (group of 2 x 2 tiles, VPL) samples with the device's group cut: per tile walk the packet's visits U and pairs, and, for
+        // every lane alive at the start, the visits / triangle tests of that segment walking alone from the same cut (any-hit: stops at its
+        // first hit).  Printed by class of U: the share of the packet cost, the mean and max single-segment visits, and what a hybrid
+        // "packet up to T visits, then per-lane for the lanes still alive" would cost with a per-lane node visit priced at pa (default 40)
+        // and a per-lane triangle test at pb (default 30) vector instructions per wave step.
+        const int CN = pa ? pa : 40, CT = pb ? pb : 30, budget = pc ? pc : 8, flags = 3;
+        const int tiles_x = (int)std::lround(std::sqrt((double)ntiles)), GX = tiles_x / 2;
+        struct Cls { double n = 0, pk_cost = 0, U = 0, mean_v = 0, max_v = 0, max_t = 0, lane_cost = 0, alive0 = 0, alive1 = 0; };
+        const int NC = 8; const unsigned edges[NC] = { 8, 16, 32, 64, 128, 256, 512, 0xffffffffu };
+        Cls C[NC];
+        const int thresholds[6] = { 32, 64, 96, 128, 192, 256 };
+        double hybrid[6] = {}, total_pk = 0, walks = 0;
+        // a single segment from the cut: visits and triangle tests until its first hit
+        auto lane_walk = [&](const Packet &P0, int l, const std::vector<Box> &cut, bool is_root, unsigned &visits, unsigned &tris) {
+            visits = tris = 0;
+            const V o = P0.vp, d = P0.d[l];
+            auto enters = [&](const float *c, const float *h) {
+                float ax = c[0] * P0.ivx[l] + P0.nox[l], ay = c[1] * P0.ivy[l] + P0.noy[l], az = c[2] * P0.ivz[l] + P0.noz[l];
+                float bx = h[0] * std::fabs(P0.ivx[l]), by = h[1] * std::fabs(P0.ivy[l]), bz = h[2] * std::fabs(P0.ivz[l]);
+                float tn = clamp01(std::max(std::max(ax - bx, ay - by), az - bz)), tf = clamp01(std::min(std::min(ax + bx, ay + by), az + bz));
+                return tn < tf;
+            };
+            std::vector<int32_t> st;
+            if (is_root) st.push_back(0);
+            else for (size_t k = cut.size(); k-- > 0;) { visits += (k & 1) == 0 ? 1 : 0; if (enters(cut[k].c, cut[k].h)) st.push_back(cut[k].ref); }   // (two cut entries per synthetic node)
+            while (!st.empty()) {
+                const int32_t cur = st.back(); st.pop_back();
+                if (cur < 0) {
+                    if (cur == kNoChild) continue;
+                    const uint32_t id = (uint32_t)~cur, block = id >> 2, cnt = (id & 3u) + 1u;
+                    for (uint32_t k = 0; k < cnt; k++) { tris++; if (tri_hit(bb.tri_flat[block * 4 + k], o, d, kTmin, kTmax)) return true; }
+                    continue;
+                }
+                const BvhNode &n = bb.nodes[cur]; visits++;
+                float c0[3], h0[3], c1[3], h1[3];
+                for (int k = 0; k < 3; k++) { c0[k] = n.ctr[k][0]; h0[k] = n.hal[k][0]; c1[k] = n.ctr[k][1]; h1[k] = n.hal[k][1]; }
+                if (n.c1 != kNoChild && enters(c1, h1)) st.push_back(n.c1);
+                if (n.c0 != kNoChild && enters(c0, h0)) st.push_back(n.c0);
+            }
+            return false;
+        };
+        while (walks < nwalks) {
+            const int gx = (int)(rng() % (unsigned)GX), gy = (int)(rng() % (unsigned)GX), vi = (int)(rng() % (unsigned)nvpl);
+            const float *vpl = &vpls[(size_t)vi * 6];
+            const float *T4[4]; for (int j = 0; j < 4; j++) T4[j] = &tiles[(size_t)((gy * 2 + j / 2) * tiles_x + gx * 2 + j % 2) * 64 * 7];
+            Packet PK[4];
+            Frustum F; F.begin({ vpl[0], vpl[1], vpl[2] }, { vpl[3], vpl[4], vpl[5] });
+            int live = 0;
+            for (int j = 0; j < 4; j++) { PK[j].setup(T4[j], vpl); if (PK[j].nalive) { live++; F.centre(PK[j], T4[j]); } }
+            if (!live) continue;
+            F.axes();
+            {
+                float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f }; int nv = 0;
+                for (int j = 0; j < 4; j++) for (int l = 0; l < 64; l++) if (T4[j][l * 7 + 3] != 0.f) { nv++; for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], T4[j][l * 7 + k]); hi[k] = std::max(hi[k], T4[j][l * 7 + k]); } }
+                Packet Cc; Cc.vp = F.vp; Cc.vn = F.vn; for (int l = 0; l < 64; l++) Cc.alive[l] = false;
+                for (int q = 0; q < 8; q++) { const V pq = { (q & 1) ? hi[0] : lo[0], (q & 2) ? hi[1] : lo[1], (q & 4) ? hi[2] : lo[2] }; Cc.alive[q] = true; Cc.pp[q] = pq; Cc.d[q] = pq - F.vp; }
+                if (nv) F.bound(Cc);
+            }
+            F.finish();
+            std::vector<Box> cut; { Box r; std::memset(&r, 0, sizeof r); r.ref = 0; for (int k = 0; k < 3; k++) r.h[k] = 1e30f; cut.push_back(r); }
+            size_t leaves_in_row = 0;
+            while (!cut.empty() && leaves_in_row < cut.size()) {
+                const Box e = cut.front();
+                if (e.ref < 0) { cut.erase(cut.begin()); cut.push_back(e); leaves_in_row++; continue; }
+                const BvhNode &n = bb.nodes[e.ref];
+                Box kids[2]; int nk = 0;
+                for (int ch = 0; ch < 2; ch++) { const Box b = child_box(n, ch); if (b.ref == kNoChild || F.outside(b, flags)) continue; kids[nk++] = b; }
+                if ((int)cut.size() - 1 + nk > budget) break;
+                cut.erase(cut.begin()); for (int k = 0; k < nk; k++) cut.push_back(kids[k]);
+                leaves_in_row = 0;
+            }
+            const bool is_root = cut.size() == 1 && cut[0].ref == 0 && cut[0].h[0] > 1e29f;
+            std::sort(cut.begin(), cut.end(), [&](const Box &a, const Box &b) {
+                auto dist = [&](const Box &q) { const float vp[3] = { F.vp.x, F.vp.y, F.vp.z }; float s2 = 0; for (int k = 0; k < 3; k++) { float e = std::max(std::fabs(vp[k] - q.c[k]) - q.h[k], 0.f); s2 += e * e; } return s2; };
+                return dist(a) > dist(b); });
+            for (int j = 0; j < 4; j++) if (PK[j].nalive) {
+                walks++;
+                if (cut.empty()) { C[0].n++; C[0].alive0 += PK[j].nalive; C[0].alive1 += PK[j].nalive; continue; }
+                const Packet P0 = PK[j];                     // (the packet walk kills lanes: the single-segment walks need the untouched copy)
+                // single segments first
+                unsigned mv = 0, mt = 0; double sv = 0; int na = 0;
+                for (int l = 0; l < 64; l++) if (P0.alive[l]) { unsigned v, t; lane_walk(P0, l, cut, is_root, v, t); mv = std::max(mv, v); mt = std::max(mt, t); sv += v; na++; }
+                const std::vector<BvhNode> init = pair_up(cut);
+                const WalkOut o = walk(PK[j], is_root ? nullptr : &init, false);
+                const double pk = 15.0 * o.nodes + 46.0 * o.pairs, ln = (double)CN * mv + (double)CT * mt;
+                int c = 0; while (o.nodes > edges[c]) c++;
+                C[c].n++; C[c].pk_cost += pk; C[c].U += o.nodes; C[c].mean_v += sv / std::max(na, 1); C[c].max_v += mv; C[c].max_t += mt; C[c].lane_cost += ln; C[c].alive0 += o.alive0; C[c].alive1 += o.alive1;
+                total_pk += pk;
+                // hybrid: the packet walk as it is while it stays within T visits; beyond, T visits' worth of packet work is lost and the lanes
+                // walk alone (upper bound: all lanes that were alive at the START walk alone, from the cut)
+                for (int q = 0; q < 6; q++) hybrid[q] += o.nodes <= (unsigned)thresholds[q] ? pk : std::min(pk, 15.0 * thresholds[q] + 46.0 * o.pairs * thresholds[q] / std::max(o.nodes, 1u) + ln);
+            }
+        }
+        std::printf("per-lane prices: node visit %d, triangle test %d vector instructions per wave step; %0.f walks\n", CN, CT, walks);
+        std::printf("  packet visits U  | walks   | share of packet cost | mean U | single segment: mean visits, longest lane's visits, longest lane's triangle tests | per-lane cost / packet cost | lanes alive start -> end\n");
+        for (int c = 0; c < NC; c++) if (C[c].n > 0)
+            std::printf("  U <= %-10u | %.4f | %.3f | %.1f | %.1f  %.1f  %.1f | %.2f | %.1f -> %.1f\n", edges[c], C[c].n / walks, C[c].pk_cost / std::max(total_pk, 1.0), C[c].U / C[c].n,
+                        C[c].mean_v / C[c].n, C[c].max_v / C[c].n, C[c].max_t / C[c].n, C[c].lane_cost / std::max(C[c].pk_cost, 1.0), C[c].alive0 / C[c].n, C[c].alive1 / C[c].n);
+        for (int q = 0; q < 6; q++) std::printf("hybrid, switch after %3d packet visits: %.3f of the packet-only cost\n", thresholds[q], hybrid[q] / std::max(total_pk, 1.0));
+        return 0;
+    }
+
     if (mode == 4) {
         // (round 6) COHERENT RE-BINNING: lane <-> pixel is free (per-pixel sums, fixed VPL order), so the 256 pixels of a group of 2 x 2 tiles can
         // be dealt to its four wavefronts by WORLD position instead of by screen quadrant: a tile that straddles a depth discontinuity (chair in
