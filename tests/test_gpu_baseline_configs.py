@@ -287,3 +287,47 @@ def test_config5_progressive_vsl_and_photons_2048(evplp, tmp_path_factory):
     assert np.isfinite(full).all() and np.isfinite(pmf).all() and full.min() >= 0 and pmf.min() >= 0 and full[..., :3].max() > 0
     for rank, (rows, img) in first_iteration.items():
         assert full[rows].tobytes() == img.tobytes(), rank       # a strip partition changes no bit of the VSL gather
+
+
+@pytest.mark.parametrize("name, W, H, n_ranks, n_light, n_vpl, kind", [
+    ("config #3 on eight dealt ranks", 1024, 1024, 8, 500000, 1024, 0),
+    ("config #4 on four ranks", 1920, 1080, 4, 300000, 0, -1),
+])
+def test_multi_gpu_configs_at_full_size_equal_one_context(evplp, tmp_path, name, W, H, n_ranks, n_light, n_vpl, kind):
+    """The partitioned path at the BASELINE sizes (round 6): config #3's frame on EIGHT row-strip ranks whose blocks were dealt by the cost a
+    calibration frame clocked (evplp_group_calibrate / _rebalance: uneven tables, most expensive block first), and two iterations of config
+    #4 on FOUR ranks (no gather: round-robin blocks; strips exchanged only for the frame that is read) -- virtual ranks, i.e. the real
+    kernels and the real group on the one GPU -- give the single context's frame, bit for bit."""
+    jp = evplp.synth_scene(str(tmp_path), "conference_synth", 331000, 1234, W, H, style="hard")
+
+    def render(runner, group):
+        bsr, total, _ = (runner.rank(0) if group else runner).scene_metrics()
+        cam = (runner.rank(0) if group else runner).camera()
+        radius = 0.003 * bsr
+        kw = dict(camera_pos=list(cam.origin), mis_mode="balance" if n_vpl else "one", pdf_mc=(n_vpl / n_light) / math.pi / radius ** 2, clamping_value=1.0 / total,
+                  photon_radius=radius, num_light_paths=n_light, num_vpl_light_paths=n_vpl, photons_per_path=P, do_accumulate=1, splat_footprint="proxy")
+        if group and kind >= 0:
+            runner.calibrate(True)
+            runner.primary((0.0, 0.0)); runner.trace_light_paths(0); runner.gather(evplp.frame_params(**kw), kind)
+            runner.rebalance()
+            owner = runner.block_owners()
+            assert len(set(owner.tolist())) == n_ranks and not np.array_equal(owner, np.arange(owner.size) % n_ranks), "the deal by cost left the round-robin table"
+        runner.clear_accumulators()
+        for it in range(2):
+            jitter = tuple(float(v) for v in evplp.jitter_sequence(0, it + 1, W, H)[it])
+            fp = evplp.frame_params(**kw, jitter=jitter, rng_seed=it)
+            runner.primary(jitter); runner.trace_light_paths(it)
+            if kind >= 0:
+                (runner.gather(fp, kind) if group else runner.gather_vpl(fp))
+            runner.splat_photons(fp)
+            if group:
+                runner.present(1.0 / (it + 1), 1.0 / (it + 1), 1.0, mask_emitter=True, gamma=True, exchange=False)
+        return runner.resolve(0.5, 0.5, 1.0)[:H]
+    with evplp.Context(W, H, n_light, n_vpl, P, deterministic=True, overlap_light_tracing=True) as c:
+        c.load_scene_json(jp)
+        ref = render(c, False)
+    assert ref.max() > 0
+    with evplp.Group(W, H, n_light, n_vpl, P, n_ranks, devices=[0] * n_ranks, deterministic=True, overlap_light_tracing=True) as g:
+        g.load_scene_json(jp)
+        img = render(g, True)
+    assert img.tobytes() == ref.tobytes(), name
