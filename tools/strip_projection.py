@@ -23,6 +23,7 @@ ap.add_argument("--rows", default="8,16")
 ap.add_argument("--n", default="")
 ap.add_argument("--deals", default="roundRobin,cost")
 ap.add_argument("--capacity-pct", type=int, default=150)
+ap.add_argument("--wall", action="store_true", help="also time every rank's FRAMES by the wall clock with light tracing overlapped (as the technique loop and bench.py run them): frame_wall_ms")
 ap.add_argument("--rounds", type=int, default=1, help="calibrate + deal this many times (every round clocks the blocks under the previous round's deal)")
 ap.add_argument("--split-light-paths", default="auto", choices=["auto", "on", "off"], help="as evplp_group_config.split_light_paths (auto: evplp_group_split_model)")
 args = ap.parse_args()
@@ -97,13 +98,46 @@ def run_rank(cfg, n, rows, r, blocks=None, calibrate=False, cap_rows=0):
                     acc[k].append(v)
         out = {k: sum(v) / len(v) for k, v in acc.items()}
         cost = c.block_costs() if (calibrate and cfg["gather"]) else None
-        return out, cost
+    if args.wall and not calibrate:
+        # the same rank again as the loops run it: light tracing on its second stream beside the G-buffer pass, no per-pass waits; wall clock over 6 frames
+        import time
+        with ev.Context(W, H, nl, nv, P, strip_rank=r, strip_count=n, strip_rows=rows, strip_capacity_rows=cap_rows if n > 1 else 0, overlap_light_tracing=True) as c:
+            c.load_scene_json(scene(W, H))
+            if blocks is not None:
+                c.set_blocks(blocks)
+
+            def frame(it):
+                jitter = tuple(float(v) for v in ev.jitter_sequence(0, it + 1, W, H)[it])
+                fp = ev.frame_params(**kw, jitter=jitter, rng_seed=it)
+                if cfg["gather"]:
+                    c.primary(jitter); c.trace_light_paths(it, r * (nl // n), nl // n) if split else c.trace_light_paths(it)
+                else:
+                    (c.trace_light_paths(it, r * (nl // n), nl // n) if split else c.trace_light_paths(it)); c.primary(jitter)
+                if cfg["gather"] == "vpl":
+                    c.gather_vpl(fp)
+                elif cfg["gather"] == "vsl":
+                    c.gather_vsl(fp)
+                if cfg["splat"]:
+                    c.splat_photons(fp)
+                c.present(1.0, 1.0, 1.0, mask_emitter=True, gamma=True)
+            nfr = 3 if cfg["gather"] == "vsl" else 6
+            for it in range(2):
+                frame(it)
+            c.synchronize(); t0 = time.perf_counter()
+            for it in range(nfr):
+                frame(2 + it)
+            c.synchronize()
+            out["frame_wall"] = (time.perf_counter() - t0) / nfr * 1e3
+    return out, cost
 
 
-def partition_record(n, rows, deal, ranks, base_sum, owner=None):
+def partition_record(n, rows, deal, ranks, base_sum, owner=None, base_wall=None):
+    walls = [x.pop("frame_wall") for x in ranks] if all("frame_wall" in x for x in ranks) else None
     sums = [sum(x.values()) for x in ranks]
     rec = {"n": n, "strip_rows": rows, "deal": deal, "per_rank_passes_ms": ranks, "per_rank_frame_ms": sums, "max_ms": max(sums), "mean_ms": sum(sums) / n,
            "sum_ms": sum(sums), "balance": (sum(sums) / n) / max(sums), "projected_speedup_without_exchange": base_sum / max(sums)}
+    if walls is not None and base_wall:
+        rec["per_rank_frame_wall_ms"] = walls; rec["projected_speedup_wall_without_exchange"] = base_wall / max(walls); rec["balance_wall"] = (sum(walls) / n) / max(walls)
     if owner is not None:
         rec["blocks_per_rank"] = np.bincount(owner, minlength=n).tolist(); rec["owner"] = [int(v) for v in owner]
     return rec
@@ -114,9 +148,10 @@ result = {"what": "single-GPU projection of the row-strip partition (every rank'
 for name in args.configs.split(","):
     cfg = CONFIGS[name]
     base, _ = run_rank(cfg, 1, 16, 0)
+    base_wall = base.pop("frame_wall", None)
     base_sum = sum(base.values())
-    entry = {"resolution": [cfg["W"], cfg["H"]], "one_gpu": {"passes_ms": base, "frame_ms": base_sum}, "partitions": []}
-    print(name, "1 GPU:", {k: round(v, 3) for k, v in base.items()}, "sum %.3f" % base_sum, flush=True)
+    entry = {"resolution": [cfg["W"], cfg["H"]], "one_gpu": {"passes_ms": base, "frame_ms": base_sum, "frame_wall_ms": base_wall}, "partitions": []}
+    print(name, "1 GPU:", {k: round(v, 3) for k, v in base.items()}, "sum %.3f" % base_sum, ("wall %.3f" % base_wall) if base_wall else "", flush=True)
     for n in ([int(v) for v in args.n.split(",")] if args.n else cfg["n"]):
         for rows in [int(v) for v in args.rows.split(",")]:
             nb = (cfg["H"] + rows - 1) // rows
@@ -124,10 +159,10 @@ for name in args.configs.split(","):
             want_cost = "cost" in args.deals and cfg["gather"] is not None
             if "roundRobin" in args.deals:
                 rr = [run_rank(cfg, n, rows, r, cap_rows=cap * rows) for r in range(n)]
-                rec = partition_record(n, rows, "roundRobin", [x[0] for x in rr], base_sum)
+                rec = partition_record(n, rows, "roundRobin", [x[0] for x in rr], base_sum, base_wall=base_wall)
                 entry["partitions"].append(rec)
                 print(f"  {name} n={n} rows={rows} roundRobin: per-rank ms {[round(s, 2) for s in rec['per_rank_frame_ms']]} max {rec['max_ms']:.2f} sum {rec['sum_ms']:.1f} "
-                      f"balance {rec['balance']:.3f} projected x{rec['projected_speedup_without_exchange']:.2f}", flush=True)
+                      f"balance {rec['balance']:.3f} projected x{rec['projected_speedup_without_exchange']:.2f}" + (f" | wall: max {max(rec['per_rank_frame_wall_ms']):.2f} ms x{rec['projected_speedup_wall_without_exchange']:.2f}" if 'per_rank_frame_wall_ms' in rec else ""), flush=True)
             if want_cost:
                 # the calibration frame of every rank under the round-robin deal (self-clocking kernels; its pass times are not used)
                 cal = dict(cfg); cal["frames"] = 2
@@ -137,11 +172,11 @@ for name in args.configs.split(","):
                     cost = sum(run_rank(cal, n, rows, r, blocks=strips.blocks_of_rank(owner, r, cost), calibrate=True, cap_rows=cap * rows)[1] for r in range(n))
                     owner = ev.deal_blocks(cost, n, cap)
                 dealt = [run_rank(cfg, n, rows, r, blocks=strips.blocks_of_rank(owner, r, cost), cap_rows=cap * rows)[0] for r in range(n)]
-                rec = partition_record(n, rows, "cost", dealt, base_sum, owner)
+                rec = partition_record(n, rows, "cost", dealt, base_sum, owner, base_wall=base_wall)
                 rec["block_cost_ticks"] = [int(v) for v in cost]
                 entry["partitions"].append(rec)
                 print(f"  {name} n={n} rows={rows} cost      : per-rank ms {[round(s, 2) for s in rec['per_rank_frame_ms']]} max {rec['max_ms']:.2f} sum {rec['sum_ms']:.1f} "
-                      f"balance {rec['balance']:.3f} projected x{rec['projected_speedup_without_exchange']:.2f} blocks {rec['blocks_per_rank']}", flush=True)
+                      f"balance {rec['balance']:.3f} projected x{rec['projected_speedup_without_exchange']:.2f} blocks {rec['blocks_per_rank']}" + (f" | wall: max {max(rec['per_rank_frame_wall_ms']):.2f} ms x{rec['projected_speedup_wall_without_exchange']:.2f}" if 'per_rank_frame_wall_ms' in rec else ""), flush=True)
     result["configs"][name] = entry
     json.dump(result, open(args.out, "w"), indent=1)
 print("wrote", args.out)
