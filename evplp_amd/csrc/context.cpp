@@ -685,6 +685,7 @@ extern "C" int evplp_trace_light_paths(evplp_context *c, uint32_t rng_seed, uint
     return EVPLP_OK;
 }
 
+static bool small_gather_launch(const evplp_context *c) { return (size_t)c->tiles_x * (size_t)((c->rows_in_image + 7) / 8) <= 8192; }
 static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, GatherArgs &a, int pass) {
     std::memset(&a, 0, sizeof(a));
     a.sc = c->sc; a.st = c->st; a.fp = *fp; a.pdf_mc2 = fp->pdf_mc * fp->pdf_mc;
@@ -696,9 +697,11 @@ static int fill_gather_args(evplp_context *c, const evplp_frame_params *fp, Gath
     a.counters = &c->d_counters[pass];
     a.splits_per_wave = 1;
     a.block_cost = c->calibrate ? c->d_block_cost : nullptr;
+    // (small_gather_launch: at most 8 192 OWNED tiles -- half a 1024 x 1024 image, a rank of a two-way partition; the capacity rows a dealt
+    // partition keeps in reserve hold nothing and leave at once)
     // tiles to XCDs while an XCD's share is >= 1024 tiles (its sum of tile costs then averages out: 1.9 % spread at 1024 x 1024), items over all
     // XCDs below that (a strip of an n-way partition, small images); EVPLP_ITEM_DEAL=0 / 1 forces either (developer A/B)
-    a.item_deal = c->env_item_deal >= 0 ? c->env_item_deal : ((size_t)c->tiles_x * c->tiles_y < 8192 ? 1 : 0);
+    a.item_deal = c->env_item_deal >= 0 ? c->env_item_deal : (small_gather_launch(c) ? 1 : 0);
     // tile blocks: as many tile rows as a row strip keeps adjacent, at most 8
     int sh = 8;
     if (c->st.strip_count > 1) { sh = 1; while (sh * 2 <= std::min(8, c->st.strip_rows / 8) && (c->st.strip_rows / 8) % (sh * 2) == 0) sh *= 2; }
@@ -742,7 +745,11 @@ static int run_gather(evplp_context *c, const evplp_frame_params *fp, bool vsl) 
         // (a row strip of an n-way partition is a SMALL launch, and small launches want short items: one rank's gather of an eight-way
         // partition of config #2 takes 9.3 / 12.1 / 17.5 ms for k = 1 / 2 / 4 where an eighth of the one-GPU kernel is 6.2 ms --
         // profiles/r05_strip_projection.json: projected 5.2x instead of 4.1x at eight ranks.  The result does not depend on k.)
-        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : (c->st.strip_count > 1 ? 1 : kDefaultSplitsPerWave);
+        // (round 6: keyed on the size of the launch -- at most 8 192 owned tiles, the threshold of item_deal -- instead of on strip_count > 1, which
+        // missed the bands of EVPLP_PARTITION_BANDS; at eight dealt ranks k = 2 projects x5.1 where k = 1 projects x6.5: an item twice as long
+        // is a tail twice as long)
+        const bool small_launch = small_gather_launch(c);
+        k = c->cfg.gather_splits_per_wave > 0 ? c->cfg.gather_splits_per_wave : (small_launch ? 1 : kDefaultSplitsPerWave);
         if (c->env_gather_k > 0) k = c->env_gather_k;
         const size_t max_vpls = std::max<size_t>((size_t)c->cfg.num_vpl_light_paths * c->cfg.photons_per_path, 1);
         while (k > 1 && (max_vpls / kVplSplit + 1) * (size_t)k >= 65536) k >>= 1;
