@@ -10,8 +10,12 @@ style = sys.argv[1] if len(sys.argv) > 1 else "hard"
 # optional: strip_count strip_rank strip_rows (one rank of an n-way partition, alone on the GPU)
 SC, SRK, SRW = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1, 0, 16)
 jp = ev.synth_scene("/tmp/evplp_gt_" + style, "conf", 331000, 1234, 1024, 1024, style=style)
-with ev.Context(1024, 1024, 1024, 1024, 4, strip_count=SC, strip_rank=SRK, strip_rows=SRW) as c:
+# BLOCKS=b0,b1,...: the rank's block table (evplp_set_blocks), e.g. what tools/strip_projection.py printed as "owner" for a deal by cost
+BLOCKS = [int(v) for v in os.environ["BLOCKS"].split(",")] if os.environ.get("BLOCKS") else None
+with ev.Context(1024, 1024, 1024, 1024, 4, strip_count=SC, strip_rank=SRK, strip_rows=SRW, strip_capacity_rows=(len(BLOCKS) * SRW if BLOCKS else 0)) as c:
     c.load_scene_json(jp)
+    if BLOCKS:
+        c.set_blocks(BLOCKS)
     cam = c.camera()
     fp = ev.frame_params(camera_pos=list(cam.origin), mis_mode="one", num_light_paths=1024, num_vpl_light_paths=1024, photons_per_path=4, do_accumulate=0)
     for it in range(3):
