@@ -73,6 +73,10 @@ def test_create_rejects_bad_configs(evplp):
     cfg.abi_version = evplp.ABI_VERSION; cfg.res_x = cfg.res_y = 8; cfg.num_light_paths = 4; cfg.num_vpl_light_paths = 8; cfg.photons_per_path = 4
     assert evplp.lib().evplp_create(C.byref(cfg), C.byref(h)) == evplp.ERR_INVALID
     assert b"num_vpl_light_paths" in evplp.lib().evplp_last_error(None)
+    cfg.num_vpl_light_paths = 4; cfg.strip_capacity_rows = -16
+    assert evplp.lib().evplp_create(C.byref(cfg), C.byref(h)) == evplp.ERR_INVALID
+    assert b"strip_capacity_rows" in evplp.lib().evplp_last_error(None)
+    cfg.strip_capacity_rows = 0
     assert evplp.lib().evplp_create(None, C.byref(h)) == evplp.ERR_INVALID
 
 
