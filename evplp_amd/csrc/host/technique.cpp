@@ -52,8 +52,10 @@ void check(evplp_group *g, int rc, const char *what) {
 //           rank b % N.  Default: by cost when the run has more than one rank, a VPL / VSL gather, and at least four iterations (the
 //           calibration frame is one more); results do not depend on it.
 //   "exchangeEvery": k -- the strips are all-gathered (every GPU holds the frame) in every k-th iteration's composite; 0 = never inside the
-//           loop.  Default 1: what the reference's per-iteration runFinalProgram to the window amounts to (rtcomphoton.h:997-1004).  The
-//           frames that are WRITTEN (:1079-1102, 1124-1132) always exchange.  Results do not depend on it.
+//           loop.  Default 0: this loop is headless -- nothing looks at the assembled frame between the frames that are WRITTEN
+//           (rtcomphoton.h:1079-1102, 1124-1132), and those always exchange; 1 is what the reference's per-iteration runFinalProgram to
+//           the window amounts to (:997-1004): a host barrier and an all-gather per iteration, which a sub-millisecond iteration feels
+//           (profiles/r06_host_feed.txt).  Every rank still composites its strip every iteration.  Results do not depend on it.
 //   "partition": "strips" | "iterations" -- what the N GPUs share out.  "strips" (default): the image, as above.  "iterations" (round 6; the
 //           photonfam techniques in accumulate mode): the ITERATIONS of the progressive run -- GPU g renders iterations g, g + N, g + 2N, ... of
 //           the whole image on a context of its own (each has its own seed, jitter and radius: rtcomphoton.h:936-1063 makes an iteration
@@ -62,7 +64,7 @@ void check(evplp_group *g, int rc, const char *what) {
 //           iteration is no faster, every GPU holds whole-image buffers, and the sums are associated differently from one GPU's (images agree
 //           to fp32 round-off, ~1e-7, not bit for bit).  What config #4 wants: its iteration is two latency-bound walks that row strips cannot
 //           shorten.
-struct RunOptions { int deal = -1; int exchange_every = 1; bool shard_iterations = false; };       // deal: -1 default, 0 round robin, 1 by cost
+struct RunOptions { int deal = -1; int exchange_every = 0; bool shard_iterations = false; };       // deal: -1 default, 0 round robin, 1 by cost
 RunOptions run_options(const Json &json) {
     RunOptions o;
     if (!json.has("device")) return o;

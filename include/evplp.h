@@ -507,7 +507,7 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
  * "stripCapacityPct": p, "splitLightPaths": bool, "cutScratchGB": g, "vslMaskGB": g} -- run on an evplp_group of N row-strip ranks (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a
  * single rank goes through RCCL too; "deal": row blocks dealt by the cost a calibration frame clocks -- the default from two ranks and four
  * iterations on -- or block b to rank b % N; "exchangeEvery": the strips are all-gathered in every k-th iteration's composite, 0 = only for
- * the frames that are written, default 1; "splitLightPaths": evplp_group_config.split_light_paths, absent = the cost model; "cutScratchGB" /
+ * the frames that are written -- the default: the loop is headless; 1 = the reference's per-iteration draw; "splitLightPaths": evplp_group_config.split_light_paths, absent = the cost model; "cutScratchGB" /
  * "vslMaskGB": evplp_config.cut_scratch_bytes / vsl_mask_bytes).
  * "device": {"gpus": N, "partition": "iterations"} (photonfam / lvcphotonfam, frameMode accumulate): the N GPUs share out the ITERATIONS of the
  * progressive run instead of the image -- GPU g renders iterations g, g + N, ... of the whole frame on a context of its own, nothing is

@@ -242,7 +242,7 @@ def test_render_json_on_a_group_of_virtual_ranks(evplp, tmp_path):
     outs = {}
     # (round 6) ... and so does every way of running the group: blocks dealt by the cost a calibration frame clocks, the strips exchanged only
     # for the frames that are written (exchangeEvery 0) or every second iteration, light paths split over the ranks + record all-gather
-    variants = {"1": dict(gpus=1), "4": dict(gpus=4, virtual=True),
+    variants = {"1": dict(gpus=1), "4": dict(gpus=4, virtual=True), "4, strips exchanged every iteration": dict(gpus=4, virtual=True, exchangeEvery=1),
                 "4 dealt, no exchange in the loop, split paths": dict(gpus=4, virtual=True, deal="cost", exchangeEvery=0, splitLightPaths=True),
                 "4 round robin, exchange every 2nd": dict(gpus=4, virtual=True, deal="roundRobin", exchangeEvery=2, splitLightPaths=False, stripRows=8)}
     for k, (name, dev) in enumerate(variants.items()):
