@@ -11,6 +11,60 @@
 
 namespace evplp {
 
+// Corner triples (indices into `face`) of a triangulation of the polygon face[0 .. n): a fan when every corner is convex in the polygon's own
+// plane (or the polygon is degenerate), ear clipping otherwise.  Orientation is kept.
+static void triangulate_polygon(const std::vector<float> &pos, const std::vector<std::pair<int, int>> &face, std::vector<int> &out) {
+    const int n = (int)face.size();
+    out.clear();
+    if (n < 3) return;
+    auto fan = [&]() { out.clear(); for (int k = 1; k + 1 < n; k++) { out.push_back(0); out.push_back(k); out.push_back(k + 1); } };
+    if (n == 3) { fan(); return; }
+    auto P = [&](int k, int c) { return (double)pos[(size_t)3 * (size_t)face[(size_t)k].first + (size_t)c]; };
+    double nx = 0, ny = 0, nz = 0;                      // Newell normal
+    for (int k = 0; k < n; k++) {
+        const int j = (k + 1) % n;
+        nx += (P(k, 1) - P(j, 1)) * (P(k, 2) + P(j, 2)); ny += (P(k, 2) - P(j, 2)) * (P(k, 0) + P(j, 0)); nz += (P(k, 0) - P(j, 0)) * (P(k, 1) + P(j, 1));
+    }
+    const double ax = std::fabs(nx), ay = std::fabs(ny), az = std::fabs(nz);
+    if (!(ax + ay + az > 0.0)) { fan(); return; }       // degenerate (or NaN): nothing to decide
+    // drop the dominant axis; keep the winding counter-clockwise in the projection
+    const int drop = ax >= ay && ax >= az ? 0 : ay >= az ? 1 : 2, ua = (drop + 1) % 3, va = (drop + 2) % 3;
+    const double sgn = (drop == 0 ? nx : drop == 1 ? ny : nz) > 0 ? 1.0 : -1.0;
+    std::vector<double> u((size_t)n), v((size_t)n);
+    for (int k = 0; k < n; k++) { u[(size_t)k] = P(k, ua); v[(size_t)k] = sgn * P(k, va); }
+    auto cross = [&](int a, int b, int c) { return (u[(size_t)b] - u[(size_t)a]) * (v[(size_t)c] - v[(size_t)a]) - (v[(size_t)b] - v[(size_t)a]) * (u[(size_t)c] - u[(size_t)a]); };
+    bool convex = true;
+    for (int k = 0; k < n && convex; k++) if (cross((k + n - 1) % n, k, (k + 1) % n) < 0.0) convex = false;
+    if (convex) { fan(); return; }
+    std::vector<int> ring((size_t)n);
+    for (int k = 0; k < n; k++) ring[(size_t)k] = k;
+    auto inside = [&](int a, int b, int c, int q) {     // strictly inside or on the boundary of the (counter-clockwise) triangle, corners excluded by the caller
+        return cross(a, b, q) >= 0.0 && cross(b, c, q) >= 0.0 && cross(c, a, q) >= 0.0;
+    };
+    int guard = 0;
+    while (ring.size() > 3 && guard++ < 4 * n * n) {
+        bool clipped = false;
+        const int m = (int)ring.size();
+        for (int k = 0; k < m; k++) {
+            const int a = ring[(size_t)((k + m - 1) % m)], b = ring[(size_t)k], c = ring[(size_t)((k + 1) % m)];
+            if (cross(a, b, c) <= 0.0) continue;         // reflex or flat corner: not an ear
+            bool empty = true;
+            for (int q : ring) if (q != a && q != b && q != c && inside(a, b, c, q)) { empty = false; break; }
+            if (!empty) continue;
+            out.push_back(a); out.push_back(b); out.push_back(c);
+            ring.erase(ring.begin() + k);
+            clipped = true;
+            break;
+        }
+        if (!clipped) {                                   // self-intersecting or collinear leftovers: close with a fan of what remains
+            for (size_t k = 1; k + 1 < ring.size(); k++) { out.push_back(ring[0]); out.push_back(ring[k]); out.push_back(ring[k + 1]); }
+            return;
+        }
+    }
+    if (ring.size() == 3) { out.push_back(ring[0]); out.push_back(ring[1]); out.push_back(ring[2]); }
+}
+
+
 std::string dirname_of(const std::string &path) {
     size_t i = path.find_last_of("/\\");
     return i == std::string::npos ? std::string(".") : path.substr(0, i);
@@ -158,8 +212,14 @@ ObjResult read_obj(HostScene &scene, const std::string &obj_path, bool want_mate
                 else { m.uvs.push_back(0.f); m.uvs.push_back(0.f); }   // rtcommon.h:701-705
                 dd[k] = id; return id;
             };
-            for (size_t k = 1; k + 1 < face.size(); k++) {   // fan triangulation
-                m.idx.push_back(index_of(face[0])); m.idx.push_back(index_of(face[k])); m.idx.push_back(index_of(face[k + 1]));
+            // aiProcess_Triangulate (rtcommon.h:650-653).  A CONVEX polygon is a fan from its first corner -- what Assimp's triangulation step gives
+            // a convex quad, and the same surface as any other triangulation of a planar polygon.  A polygon with a reflex corner is ear-clipped
+            // in the plane of its Newell normal (round 6; a fan would cover area outside it): Assimp 3.3.0 clips ears too, though not necessarily
+            // in this order -- the surface is the same, the triangle set may differ (the library is a binary the reference links; not restated).
+            std::vector<int> order;
+            triangulate_polygon(pos, face, order);
+            for (size_t k = 0; k + 2 < order.size(); k += 3) {
+                m.idx.push_back(index_of(face[(size_t)order[k]])); m.idx.push_back(index_of(face[(size_t)order[k + 1]])); m.idx.push_back(index_of(face[(size_t)order[k + 2]]));
             }
         } else if (!line.compare(0, 6, "usemtl")) {
             std::istringstream ss(line.substr(6)); std::string name; ss >> name;

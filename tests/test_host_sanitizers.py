@@ -115,6 +115,22 @@ def test_block_deal_under_asan_and_ubsan(tmp_path):
         assert r.returncode == 0 and r.stdout.startswith("ok:"), (r.stdout[-500:], r.stderr[-3000:])
 
 
+def test_concave_polygons_are_ear_clipped(tmp_path):
+    """aiProcess_Triangulate (rtcommon.h:650-653): the OBJ reader turns a convex polygon into a fan and ear-clips one with a reflex corner
+    (round 6: a fan of an L- or arrow-shaped face covers area outside it).  tools/host_fuzz/polygon_check.cpp writes L, arrow, U, star and
+    convex faces in a tilted plane, both windings, loads them through the reader under ASan + UBSan and checks n - 2 triangles, the
+    polygon's area, the polygon's winding."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "polygon_check")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+           os.path.join(ROOT, "tools", "host_fuzz", "polygon_check.cpp")] + SOURCES[1:]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-2000:])
+
+
 def test_jpeg_refusals_found_by_the_harness(tmp_path):
     """The two refusals decode_jpeg.cpp makes beyond the reference's stb_image v2.16 (round 5): sampling factors that are not integer
     ratios (its resamplers -- and ours -- would read past the end of a component's plane) and a frame header asking for more pixels
