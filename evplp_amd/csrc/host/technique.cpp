@@ -49,8 +49,8 @@ void check(evplp_group *g, int rc, const char *what) {
 }
 // What the `device` block says about the RUN (the rest of it configures the group, create_group):
 //   "deal": "cost" | "roundRobin" -- row blocks dealt by the cost a calibration frame clocks (evplp_group_calibrate / _rebalance), or block b to
-//           rank b % N.  Default: by cost when the run has more than one rank, a VPL / VSL gather, and at least four iterations (the
-//           calibration frame is one more); results do not depend on it.
+//           rank b % N.  Default: by cost when the run has more than one rank, a VPL / VSL gather, and enough iterations for the calibration
+//           frame -- one more frame -- to pay for itself (5 from six ranks on, 25 from three, 100 at two); results do not depend on it.
 //   "exchangeEvery": k -- the strips are all-gathered (every GPU holds the frame) in every k-th iteration's composite; 0 = never inside the
 //           loop.  Default 0: this loop is headless -- nothing looks at the assembled frame between the frames that are WRITTEN
 //           (rtcomphoton.h:1079-1102, 1124-1132), and those always exchange; 1 is what the reference's per-iteration runFinalProgram to
@@ -403,7 +403,10 @@ private:
         // kernels, un-jittered, then the deal.  Nothing of it reaches the images: the rebalance clears the accumulators, the loop below traces
         // the same light paths again, the jitter sequence and the progressive state have not moved.  Its time is part of the run's.
         const bool can_deal = S == 1 && evplp_group_size(h) > 1 && do_vpl_splat && !lvc && do_deferred && do_light_tracing;
-        if (can_deal && (run_opts.deal == 1 || (run_opts.deal < 0 && num_max_iteration >= 4))) {
+        // (default: when the calibration frame pays for itself.  It costs one frame -- clocking a fraction of the VPLs deals worse than round robin,
+        // measured -- and a dealt frame is ~1 % / ~4 % / ~20 % shorter than a round-robin one at 2 / 4 / 8 ranks, profiles/r06_strip_projection.json)
+        const int ranks = evplp_group_size(h), pays_from = ranks >= 6 ? 5 : ranks >= 3 ? 25 : 100;
+        if (can_deal && (run_opts.deal == 1 || (run_opts.deal < 0 && num_max_iteration >= pays_from))) {
             float j0[2] = { 0.f, 0.f };
             evplp_frame_params fp = params(scene, rng_offset, j0);
             check(h, evplp_group_calibrate(h, 1), "calibrate");

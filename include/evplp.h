@@ -425,7 +425,7 @@ int evplp_group_block_owners(evplp_group *g, int32_t *owner_rank, int32_t capaci
  * the blocks by cost (evplp_deal_blocks, capacity = strip_capacity_pct of the equal share), gives every rank its table (evplp_set_blocks)
  * and switches the calibration off.  The all-gather of the strips then moves max-blocks-per-rank x strip_rows rows per rank.  Returns
  * EVPLP_ERR_INVALID when no cost was clocked (no calibration, or no gather ran).  As below, accumulators are cleared: calibrate on a frame
- * in front of an accumulating run (the technique loop does when "device": {"deal": "cost"}).
+ * in front of an accumulating run (the technique loop does: "device": {"deal": "cost"}, or by default when the run is long enough).
  * EVPLP_PARTITION_BANDS: waits for the ranks, takes every rank's device time of the passes it ran since the last rebalance (HIP events of
  * primary rays, gathers, photon splat, path tracer), treats it as spread evenly over the rank's rows, and moves the band boundaries (multiples
  * of 16 rows, within the bands' capacity of twice the equal share) to where every rank would have had the same cost.  The accumulators are
@@ -505,8 +505,8 @@ int evplp_synth_scene_ex(const char *out_dir, const char *name, int32_t target_t
  * Build-only keys of a technique block: "bvhBuilder": "sah" | "sbvh" | "lbvh" | "gpu" (evplp_bvh_builder); "deterministic": bool (photon bins accumulated in record
  * order); "device": {"gpus": N, "virtual": bool, "stripRows": R, "rccl": bool, "deal": "cost" | "roundRobin", "exchangeEvery": k,
  * "stripCapacityPct": p, "splitLightPaths": bool, "cutScratchGB": g, "vslMaskGB": g} -- run on an evplp_group of N row-strip ranks (GPUs device .. device+N-1; "virtual": all ranks on `device`; "rccl": a
- * single rank goes through RCCL too; "deal": row blocks dealt by the cost a calibration frame clocks -- the default from two ranks and four
- * iterations on -- or block b to rank b % N; "exchangeEvery": the strips are all-gathered in every k-th iteration's composite, 0 = only for
+ * single rank goes through RCCL too; "deal": row blocks dealt by the cost a calibration frame clocks -- the default when that extra frame pays for
+ * itself: from 5 iterations at six ranks and more, 25 at three to five, 100 at two -- or block b to rank b % N; "exchangeEvery": the strips are all-gathered in every k-th iteration's composite, 0 = only for
  * the frames that are written -- the default: the loop is headless; 1 = the reference's per-iteration draw; "splitLightPaths": evplp_group_config.split_light_paths, absent = the cost model; "cutScratchGB" /
  * "vslMaskGB": evplp_config.cut_scratch_bytes / vsl_mask_bytes).
  * "device": {"gpus": N, "partition": "iterations"} (photonfam / lvcphotonfam, frameMode accumulate): the N GPUs share out the ITERATIONS of the

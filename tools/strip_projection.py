@@ -24,6 +24,7 @@ ap.add_argument("--n", default="")
 ap.add_argument("--deals", default="roundRobin,cost")
 ap.add_argument("--capacity-pct", type=int, default=150)
 ap.add_argument("--wall", action="store_true", help="also time every rank's FRAMES by the wall clock with light tracing overlapped (as the technique loop and bench.py run them): frame_wall_ms")
+ap.add_argument("--cal-fraction", type=int, default=1, help="the calibration frame gathers 1 / this many of the VPL light paths (the technique loop: 8)")
 ap.add_argument("--rounds", type=int, default=1, help="calibrate + deal this many times (every round clocks the blocks under the previous round's deal)")
 ap.add_argument("--split-light-paths", default="auto", choices=["auto", "on", "off"], help="as evplp_group_config.split_light_paths (auto: evplp_group_split_model)")
 args = ap.parse_args()
@@ -77,6 +78,8 @@ def run_rank(cfg, n, rows, r, blocks=None, calibrate=False, cap_rows=0):
             lt = c.pass_stats(ev.PASS_LIGHT_TRACE)["ms"]
             c.primary(jitter)
             fp = ev.frame_params(**kw, jitter=jitter, rng_seed=it)
+            if calibrate and args.cal_fraction > 1 and cfg["gather"]:
+                fp.num_vpl_light_paths = max(nv // args.cal_fraction, min(nv, 64))
             if cfg["gather"] == "vpl":
                 c.gather_vpl(fp)
             elif cfg["gather"] == "vsl":
